@@ -1,0 +1,95 @@
+"""ctypes binding of libfxhip.so (the C ABI declared in include/fxhip.h).
+
+There is NO fallback: if the shared library is missing or a symbol is absent this module raises at
+import, and every op raises ``RuntimeError(fx_last_error_string())`` on a non-zero return code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libfxhip.so")
+
+P = C.c_void_p
+I = C.c_int
+L = C.c_long
+F = C.c_float
+U64 = C.c_ulonglong
+
+# name -> (restype, argtypes) ; mirrors include/fxhip.h one to one
+PROTOTYPES = {
+    "fx_last_error_string": (C.c_char_p, []),
+    "fx_version": (I, []),
+    "fx_gather_rows": (I, [P, P, P, I, I, L, L, P, L, P]),
+    "fx_gemm_workspace_bytes": (L, [I, I, I]),
+    "fx_gemm_f32": (I, [I, P, P, P, P, I, I, I, L, L, L, I, P, L, P]),
+    "fx_linear_dw_adam_f32": (I, [P, P, P, P, P, I, I, I, L, L, L, P, P]),
+    "fx_colsum": (I, [P, P, I, I, L, P]),
+    "fx_bn_act_fwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, L, L, I, I, I, F, U64, U64, P, P]),
+    "fx_bn_act_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, L, L, L, L, I, I, F, I, P]),
+    "fx_sigmoid": (I, [P, P, L, P]),
+    "fx_reparam": (I, [P, P, P, P, P, L, U64, U64, P, P]),
+    "fx_mul": (I, [P, P, P, L, P]),
+    "fx_fill_normal": (I, [P, L, U64, U64, P, P]),
+    "fx_mse_masked": (I, [P, P, P, P, I, L, L, P, F, P]),
+    "fx_ce_masked": (I, [P, P, P, P, I, I, L, L, P, F, P]),
+    "fx_cox_ph": (I, [P, P, P, P, P, I, L, L, P, F, P]),
+    "fx_triplet": (I, [P, P, P, P, P, P, P, I, I, L, F, P, F, P]),
+    "fx_mmd_workspace_floats": (L, [I, I]),
+    "fx_mmd_rows": (I, [P, P, P, P, I, I, I, L, P, F, P]),
+    "fx_recon_blocks": (I, [L]),
+    "fx_recon_sigmoid": (I, [P, P, P, P, P, L, P, F, P]),
+    "fx_mmd_finalize": (I, [P, P, I, I, P, I, F, F, I, P]),
+    "fx_total_loss": (I, [P, I, I, P, P, P, P, P]),
+    "fx_step_begin": (I, [P, F, I, P]),
+    "fx_sumsq_blocks": (I, [L]),
+    "fx_sumsq": (I, [P, P, L, P]),
+    "fx_hadamard_sum": (I, [P, P, P, L, P]),
+    "fx_clip_finalize": (I, [P, P, I, F, P]),
+    "fx_adam_flat": (I, [P, P, P, P, L, P, P]),
+}
+
+# functions whose int return value is a size/count, not an error code
+_QUERIES = {"fx_version", "fx_gemm_workspace_bytes", "fx_mmd_workspace_floats", "fx_recon_blocks", "fx_sumsq_blocks",
+            "fx_last_error_string"}
+
+
+class FxError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m flexynesis_amd.csrc.build` "
+            "(or __graft_entry__.build()).  flexynesis_amd has no CPU/PyTorch fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def last_error() -> str:
+    return (lib.fx_last_error_string() or b"").decode()
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        raise FxError(f"{what or 'libfxhip'} failed (rc={rc}): {last_error()}")
+
+
+def call(name: str, *args):
+    """Call an error-code-returning entry point and raise on failure."""
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise FxError(f"{name} failed (rc={rc}): {last_error()}")
+
+
+def exported_symbols():
+    return sorted(PROTOTYPES)

@@ -1,0 +1,144 @@
+"""Architecture description derived from (config, dataset) exactly the way the reference model
+constructors derive it (reference models/direct_pred.py:30-105, models/supervised_vae.py:42-130,
+models/triplet_encoder.py:36-123) plus the reference ``state_dict`` layout (the on-disk ABI read by
+reference inference.py:378-379)."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+MODEL_KINDS = ("DirectPred", "supervised_vae", "MultiTripletNetwork")
+
+
+@dataclass
+class ArchSpec:
+    model: str
+    layers: List[Tuple[str, int]]            # (layer name, n_features) in dataset.dat.keys() order
+    latent_dim: int
+    hidden_dim_factor: float
+    supervisor_hidden_dim: int
+    variables: List[Tuple[str, str, int]]    # (name, "numerical"|"categorical", n_out)
+    surv_event_var: Optional[str] = None
+    surv_time_var: Optional[str] = None
+    use_loss_weighting: bool = True
+
+    # -- derived sizes ---------------------------------------------------------------------------
+    def hidden(self, i: int) -> int:
+        # int(F*factor) (direct_pred.py:78-80) then max(.,2) (modules.py:124 / supervised_vae.py:92)
+        return max(int(self.layers[i][1] * self.hidden_dim_factor), 2)
+
+    @property
+    def sup_hidden(self) -> int:
+        return max(int(self.supervisor_hidden_dim), 2)
+
+    @property
+    def n_layers(self) -> int:
+        return len(self.layers)
+
+    @property
+    def extra_loss(self) -> Optional[str]:
+        return {"DirectPred": None, "supervised_vae": "mmd_loss", "MultiTripletNetwork": "triplet_loss"}[self.model]
+
+    def loss_names(self) -> List[str]:
+        """Insertion order of the reference's ``losses`` dict in training_step
+        (supervised_vae.py:318, triplet_encoder.py:309, direct_pred.py:241-253)."""
+        names = [v[0] for v in self.variables]
+        return ([self.extra_loss] if self.extra_loss else []) + names
+
+    def logvar_names(self) -> List[str]:
+        """Order of the ``log_vars`` ParameterDict (direct_pred.py:60-64, supervised_vae.py:78-82)."""
+        if not self.use_loss_weighting:
+            return []
+        names = [v[0] for v in self.variables]
+        return names + ([self.extra_loss] if self.extra_loss else [])
+
+    @property
+    def weighted(self) -> bool:
+        return self.use_loss_weighting and len(self.loss_names()) > 1   # direct_pred.py:213
+
+    def param_count(self) -> int:
+        return sum(int(np.prod(s)) if s else 1 for k, s in self.state_shapes().items() if not is_buffer_key(k))
+
+    # -- state_dict manifest ---------------------------------------------------------------------
+    def state_shapes(self) -> Dict[str, Tuple[int, ...]]:
+        out: Dict[str, Tuple[int, ...]] = {}
+        n, L, S = self.n_layers, self.latent_dim, self.sup_hidden
+
+        def bn(prefix, c):
+            out[prefix + ".weight"] = (c,)
+            out[prefix + ".bias"] = (c,)
+            out[prefix + ".running_mean"] = (c,)
+            out[prefix + ".running_var"] = (c,)
+            out[prefix + ".num_batches_tracked"] = ()
+
+        def mlp(prefix, fin, h, o):
+            out[prefix + ".layer_1.weight"] = (h, fin)
+            out[prefix + ".layer_1.bias"] = (h,)
+            out[prefix + ".layer_out.weight"] = (o, h)
+            if o > 1:                                   # modules.py:126-130: scalar heads are bias-free
+                out[prefix + ".layer_out.bias"] = (o,)
+            bn(prefix + ".batchnorm", h)
+
+        for name in self.logvar_names():
+            out["log_vars." + name] = (1,)
+        if self.model in ("DirectPred", "MultiTripletNetwork"):
+            for i, (_, F) in enumerate(self.layers):
+                mlp(f"encoders.{i}", F, self.hidden(i), L)
+            if n > 1:
+                out["fusion_block.weight"] = (L, n * L)
+                out["fusion_block.bias"] = (L,)
+        else:
+            for i, (_, F) in enumerate(self.layers):
+                H, p = self.hidden(i), f"encoders.{i}"
+                out[p + ".hidden_layers.0.weight"] = (H, F)
+                out[p + ".hidden_layers.0.bias"] = (H,)
+                bn(p + ".hidden_layers.2", H)
+                for fc in ("FC_mean", "FC_var"):
+                    out[f"{p}.{fc}.weight"] = (L, H)
+                    out[f"{p}.{fc}.bias"] = (L,)
+            for fc in ("FC_mean", "FC_log_var"):
+                out[fc + ".weight"] = (L, n * L)
+                out[fc + ".bias"] = (L,)
+            for i, (_, F) in enumerate(self.layers):
+                H, p = self.hidden(i), f"decoders.{i}"
+                out[p + ".hidden_layers.0.weight"] = (H, L)
+                out[p + ".hidden_layers.0.bias"] = (H,)
+                bn(p + ".hidden_layers.2", H)
+                out[p + ".FC_output.weight"] = (F, H)
+                out[p + ".FC_output.bias"] = (F,)
+        for (v, _, C) in self.variables:
+            mlp("MLPs." + v, L, S, C)
+        return out
+
+
+def is_buffer_key(key: str) -> bool:
+    return key.endswith(("running_mean", "running_var", "num_batches_tracked"))
+
+
+def spec_from_dataset(model: str, config: dict, dataset, target_variables, batch_variables=None,
+                      surv_event_var=None, surv_time_var=None, use_loss_weighting=True) -> ArchSpec:
+    """Same derivations as the reference constructors.  ``dataset`` is only read for ``.dat.keys()``,
+    ``.features[layer]``, ``.ann[var]`` and ``.variable_types`` (also satisfied by the SimpleNamespace of
+    reference inference.py:116-122)."""
+    if model not in MODEL_KINDS:
+        raise ValueError(f"unknown model class {model!r}")
+    targets = list(target_variables)
+    if surv_event_var is not None and surv_time_var is not None:
+        targets = targets + [surv_event_var]          # direct_pred.py:48-49
+    variables = targets + list(batch_variables) if batch_variables else targets
+    layers = [(name, len(dataset.features[name])) for name in dataset.dat.keys()]   # direct_pred.py:68-71
+    var_specs = []
+    for v in variables:
+        if dataset.variable_types[v] == "numerical":
+            var_specs.append((v, "numerical", 1))
+        else:
+            ann = dataset.ann[v]
+            arr = ann.detach().cpu().numpy() if hasattr(ann, "detach") else np.asarray(ann)
+            var_specs.append((v, "categorical", int(len(np.unique(arr)))))   # direct_pred.py:100 (NaN counts)
+    if model == "MultiTripletNetwork" and dataset.variable_types[targets[0]] == "numerical":
+        raise ValueError("The first target variable", targets[0], " must be a categorical variable")
+    return ArchSpec(model, layers, int(config["latent_dim"]), float(config["hidden_dim_factor"]),
+                    int(config["supervisor_hidden_dim"]), var_specs, surv_event_var, surv_time_var,
+                    bool(use_loss_weighting))

@@ -1,0 +1,179 @@
+// Optimiser-side kernels: step bookkeeping, global grad-norm (clip_grad_norm_(1.0), reference
+// main.py:216-217), flat-arena Adam (torch.optim.Adam defaults, reference direct_pred.py:143),
+// device-resident cohort gather (replaces MultiOmicDataset.__getitem__ + default_collate + the
+// per-batch H2D copy, reference data.py:980-995 / main.py:289-298), and the library's error plumbing.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "fx_common.h"
+
+// ---- error plumbing (thread-local so concurrent host threads on different streams stay re-entrant) --
+static thread_local char g_err[512] = "";
+void fx_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+int fx_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    fx_set_error("%s: %s", what, hipGetErrorString(e));
+    return -(int)e;
+  }
+  return 0;
+}
+
+// ---- step control ----------------------------------------------------------------------------------
+__global__ void fx_step_begin_kernel(float* ctrl, float lr, int n_batches) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float t = ctrl[FXC_STEP] + 1.0f;
+  ctrl[FXC_STEP] = t;
+  ctrl[FXC_LR] = lr;
+  ctrl[FXC_BC1] = (float)(1.0 - pow((double)FX_BETA1, (double)t));
+  ctrl[FXC_BC2_SQRT] = (float)sqrt(1.0 - pow((double)FX_BETA2, (double)t));
+  ctrl[FXC_CLIP_COEF] = 1.0f;
+  ctrl[FXC_GNORM] = 0.0f;
+  if (n_batches > 0) ctrl[FXC_BATCH_CURSOR] = (float)(((long)t - 1) % n_batches);
+}
+
+// ---- sum of squares into double-precision slots ------------------------------------------------------
+__global__ __launch_bounds__(256) void fx_sumsq_kernel(double* __restrict__ slots, const float* __restrict__ x, long n) {
+  __shared__ double sm[16];
+  double acc = 0.0;
+  const long n4 = n >> 2;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = x4[i];
+    acc += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+  }
+  if (blockIdx.x == 0)
+    for (long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) acc += (double)x[i] * x[i];
+  acc = fx_block_sum_d(acc, sm);
+  if (threadIdx.x == 0) slots[blockIdx.x] = acc;
+}
+
+// slot[0] = sum_ij G1[ij] * G2[ij]   (Gram identity: |dY^T X|_F^2 = <X X^T, dY dY^T>)
+__global__ __launch_bounds__(256) void fx_hadamard_sum_kernel(double* __restrict__ slot, const float* __restrict__ g1,
+                                                              const float* __restrict__ g2, long n) {
+  __shared__ double sm[16];
+  double acc = 0.0;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) acc += (double)g1[i] * (double)g2[i];
+  acc = fx_block_sum_d(acc, sm);
+  if (threadIdx.x == 0) slot[0] = acc;
+}
+
+__global__ __launch_bounds__(256) void fx_clip_finalize_kernel(float* ctrl, const double* __restrict__ slots, int n_slots,
+                                                               float max_norm) {
+  __shared__ double sm[16];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n_slots; i += blockDim.x) acc += slots[i];
+  acc = fx_block_sum_d(acc, sm);
+  if (threadIdx.x == 0) {
+    const float total = (float)sqrt(acc);
+    ctrl[FXC_GNORM] = total;
+    float coef = 1.0f;
+    if (max_norm > 0.f) {
+      coef = max_norm / (total + 1e-6f);
+      coef = coef > 1.0f ? 1.0f : coef;
+    }
+    ctrl[FXC_CLIP_COEF] = coef;
+  }
+}
+
+// ---- Adam over a flat arena (all small parameters of a model live in one contiguous buffer) ----------
+__global__ __launch_bounds__(256) void fx_adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                           float* __restrict__ m, float* __restrict__ v, long n,
+                                                           const float* __restrict__ ctrl) {
+  const float lr = ctrl[FXC_LR], bc1 = ctrl[FXC_BC1], bc2s = ctrl[FXC_BC2_SQRT], coef = ctrl[FXC_CLIP_COEF];
+  const float step_size = lr / bc1;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gr = g[i] * coef;
+    const float m2 = m[i] + (gr - m[i]) * (1.0f - FX_BETA1);
+    const float v2 = v[i] * FX_BETA2 + (1.0f - FX_BETA2) * gr * gr;
+    const float denom = sqrtf(v2) / bc2s + FX_ADAM_EPS;
+    p[i] = p[i] - step_size * (m2 / denom);
+    m[i] = m2;
+    v[i] = v2;
+  }
+}
+
+// ---- cohort gather: dst[r, :] = src[idx[r], :]  (16-byte coalesced row copies) -------------------------
+__global__ __launch_bounds__(256) void fx_gather_rows_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                             const long* __restrict__ idx, int n_rows, int n_cols,
+                                                             long ld_src, long ld_dst, const float* __restrict__ ctrl,
+                                                             long cursor_stride, int vec) {
+  if (ctrl) idx += (long)ctrl[FXC_BATCH_CURSOR] * cursor_stride;
+  const int r = blockIdx.y;
+  const long s = idx[r];
+  const float* sp = src + s * ld_src;
+  float* dp = dst + (long)r * ld_dst;
+  if (vec) {
+    const int n4 = n_cols >> 2;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n4; c += gridDim.x * blockDim.x)
+      reinterpret_cast<float4*>(dp)[c] = reinterpret_cast<const float4*>(sp)[c];
+  } else {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n_cols; c += gridDim.x * blockDim.x) dp[c] = sp[c];
+  }
+}
+
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+extern "C" {
+
+const char* fx_last_error_string(void) { return g_err; }
+int fx_version(void) { return 100; }  // 0.1.0
+
+int fx_step_begin(float* ctrl, float lr, int n_batches, hipStream_t stream) {
+  FX_REQUIRE(ctrl != nullptr, "fx_step_begin: null ctrl");
+  hipLaunchKernelGGL(fx_step_begin_kernel, dim3(1), dim3(64), 0, stream, ctrl, lr, n_batches);
+  return fx_check_launch("fx_step_begin");
+}
+
+int fx_sumsq_blocks(long n) {
+  long b = (n / 4 + 256L * 8 - 1) / (256L * 8);
+  return (int)(b > 512 ? 512 : (b < 1 ? 1 : b));
+}
+
+// writes fx_sumsq_blocks(n) partial sums into slots[0..)
+int fx_sumsq(double* slots, const float* x, long n, hipStream_t stream) {
+  FX_REQUIRE(slots && x && n > 0, "fx_sumsq: bad args");
+  FX_REQUIRE(aligned16(x), "fx_sumsq: x must be 16-byte aligned");
+  hipLaunchKernelGGL(fx_sumsq_kernel, dim3(fx_sumsq_blocks(n)), dim3(256), 0, stream, slots, x, n);
+  return fx_check_launch("fx_sumsq");
+}
+
+int fx_hadamard_sum(double* slot, const float* g1, const float* g2, long n, hipStream_t stream) {
+  FX_REQUIRE(slot && g1 && g2 && n > 0, "fx_hadamard_sum: bad args");
+  hipLaunchKernelGGL(fx_hadamard_sum_kernel, dim3(1), dim3(256), 0, stream, slot, g1, g2, n);
+  return fx_check_launch("fx_hadamard_sum");
+}
+
+int fx_clip_finalize(float* ctrl, const double* slots, int n_slots, float max_norm, hipStream_t stream) {
+  FX_REQUIRE(ctrl && slots && n_slots > 0, "fx_clip_finalize: bad args");
+  hipLaunchKernelGGL(fx_clip_finalize_kernel, dim3(1), dim3(256), 0, stream, ctrl, slots, n_slots, max_norm);
+  return fx_check_launch("fx_clip_finalize");
+}
+
+int fx_adam_flat(float* p, const float* g, float* m, float* v, long n, const float* ctrl, hipStream_t stream) {
+  FX_REQUIRE(p && g && m && v && ctrl && n > 0, "fx_adam_flat: bad args");
+  long b = (n + 255) / 256;
+  if (b > 4096) b = 4096;
+  hipLaunchKernelGGL(fx_adam_flat_kernel, dim3((unsigned)b), dim3(256), 0, stream, p, g, m, v, n, ctrl);
+  return fx_check_launch("fx_adam_flat");
+}
+
+int fx_gather_rows(float* dst, const float* src, const long* idx, int n_rows, int n_cols, long ld_src, long ld_dst,
+                   const float* ctrl_cursor, long cursor_stride, hipStream_t stream) {
+  FX_REQUIRE(dst && src && idx && n_rows > 0 && n_cols > 0, "fx_gather_rows: bad args");
+  const int vec = aligned16(dst) && aligned16(src) && (ld_src % 4 == 0) && (ld_dst % 4 == 0) && (n_cols % 4 == 0);
+  int bx = ((vec ? n_cols / 4 : n_cols) + 255) / 256;
+  if (bx > 64) bx = 64;
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(fx_gather_rows_kernel, dim3(bx, n_rows), dim3(256), 0, stream, dst, src, idx, n_rows, n_cols, ld_src,
+                     ld_dst, ctrl_cursor, cursor_stride, vec);
+  return fx_check_launch("fx_gather_rows");
+}
+
+}  // extern "C"

@@ -1,0 +1,636 @@
+"""MI355X training engine for the flexynesis hot path.
+
+``ParamStore``  owns one model instance's parameters on one GPU: every "small" parameter (biases,
+                BatchNorm affine, latent/fusion/head weights, log_vars) lives in ONE flat fp32 arena
+                with matching grad / Adam-m / Adam-v arenas, so the optimiser is a single launch; each
+                wide omics weight (>= ``big_threshold`` elements, e.g. layer_1.weight [5000,20000])
+                has its own W/m/v (and, only when gradients must be materialised, dW).
+``StepPlan``    the hand-derived forward + backward + optimiser schedule of one model for one batch
+                size, recorded once as a tape of C-ABI launches (ops.TapeRecorder) and then re-issued
+                (or hipGraph-replayed) every step.  Replaces, per step, the reference's
+                training_step -> zero_grad -> backward -> clip_grad_norm_(1.0) -> Adam.step
+                (models/direct_pred.py:225-260, main.py:212-225) and validation_step (:262-294).
+``Engine``      epoch loop over a device-resident cohort: seeded on-device shuffling, drop_last,
+                validation, early stopping -- the counterpart of trainer.fit/validate inside
+                HyperparameterTuning.objective (main.py:228-333).
+
+Two gradient modes:
+  fused=True   (engine fast path) wide-layer dW is never written: its squared norm comes from the Gram
+               identity |dY^T X|_F^2 = <X X^T, dY dY^T>, then dW tiles are produced on the MFMA and
+               consumed by Adam in registers (fx_linear_dw_adam_f32): 24 B/param of HBM traffic.
+  fused=False  (drop-in path: loss.backward() semantics) every gradient is materialised in the grad
+               arenas so an external optimiser / Lightning loop can consume ``param.grad``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+from .arch import ArchSpec, is_buffer_key
+from .ops import ACT_LEAKY, ACT_NONE, ACT_RELU, TapeRecorder, Workspace
+
+DROPOUT_P = 0.1          # nn.Dropout(p=0.1), reference modules.py:132
+MMD_PRIOR = 200          # torch.randn(200, latent_dim), reference supervised_vae.py:545
+CLIP_MAX_NORM = 1.0      # gradient_clip_val=1.0, reference main.py:216
+TRIPLET_MARGIN = 1.0
+
+
+def _align4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+class ParamStore:
+    def __init__(self, spec: ArchSpec, device, big_threshold: int = 1 << 20, materialize_big_grads: bool = True):
+        self.spec = spec
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("flexynesis_amd.ParamStore needs a GPU device (no CPU path)")
+        self.shapes = spec.state_shapes()
+        self.param_keys = [k for k in self.shapes if not is_buffer_key(k)]
+        self.buffer_keys = [k for k in self.shapes if is_buffer_key(k) and not k.endswith("num_batches_tracked")]
+        self.nbt_keys = [k for k in self.shapes if k.endswith("num_batches_tracked")]
+        self.big_keys = [k for k in self.param_keys if len(self.shapes[k]) == 2
+                         and int(np.prod(self.shapes[k])) >= big_threshold]
+        self.small_keys = [k for k in self.param_keys if k not in self.big_keys]
+        # small arena
+        self.off: Dict[str, Tuple[int, int]] = {}
+        o = 0
+        for k in self.small_keys:
+            n = int(np.prod(self.shapes[k])) if self.shapes[k] else 1
+            self.off[k] = (o, n)
+            o += _align4(n)
+        self.n_small = max(o, 4)
+        f = dict(dtype=torch.float32, device=self.device)
+        self.P = torch.zeros(self.n_small, **f)
+        self.G = torch.zeros(self.n_small, **f)
+        self.M = torch.zeros(self.n_small, **f)
+        self.V = torch.zeros(self.n_small, **f)
+        # buffers arena (running_mean / running_var)
+        self.boff: Dict[str, Tuple[int, int]] = {}
+        o = 0
+        for k in self.buffer_keys:
+            n = int(np.prod(self.shapes[k]))
+            self.boff[k] = (o, n)
+            o += _align4(n)
+        self.Bf = torch.zeros(max(o, 4), **f)
+        self.nbt: Dict[str, int] = {k: 0 for k in self.nbt_keys}
+        # wide weights
+        self.big: Dict[str, Dict[str, Optional[torch.Tensor]]] = {}
+        for k in self.big_keys:
+            shp = self.shapes[k]
+            self.big[k] = {"W": torch.zeros(shp, **f), "M": torch.zeros(shp, **f), "V": torch.zeros(shp, **f),
+                           "G": torch.zeros(shp, **f) if materialize_big_grads else None}
+        self.ctrl = torch.zeros(ops.CTRL_FLOATS, **f)
+        self.ctrl[ops.CTRL_CLIP_COEF] = 1.0
+        self.reset_parameters()
+
+    # -- views ------------------------------------------------------------------------------------
+    def _view(self, arena, key):
+        o, n = self.off[key]
+        return arena[o:o + n].view(self.shapes[key])
+
+    def p(self, key) -> torch.Tensor:
+        return self.big[key]["W"] if key in self.big else self._view(self.P, key)
+
+    def g(self, key) -> Optional[torch.Tensor]:
+        return self.big[key]["G"] if key in self.big else self._view(self.G, key)
+
+    def m(self, key):
+        return self.big[key]["M"] if key in self.big else self._view(self.M, key)
+
+    def v(self, key):
+        return self.big[key]["V"] if key in self.big else self._view(self.V, key)
+
+    def b(self, key) -> torch.Tensor:
+        o, n = self.boff[key]
+        return self.Bf[o:o + n].view(self.shapes[key])
+
+    def ensure_big_grads(self):
+        for k, d in self.big.items():
+            if d["G"] is None:
+                d["G"] = torch.zeros_like(d["W"])
+
+    # -- init / (de)serialisation ------------------------------------------------------------------
+    @torch.no_grad()
+    def reset_parameters(self, seed: Optional[int] = None):
+        """Same init *distributions* as the reference modules (modules.py:26-41,76-89,125-130):
+        nn.Linear default (kaiming_uniform a=sqrt(5) == U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weight and
+        bias) for MLP / fusion layers, xavier_uniform weights for Encoder/Decoder Linear layers,
+        BatchNorm weight 1 / bias 0 / running stats 0,1, log_vars 0.  Drawn on the device."""
+        gen = torch.Generator(device=self.device)
+        gen.manual_seed(int(seed) if seed is not None else int(torch.initial_seed() % (2 ** 31)))
+        for k in self.param_keys:
+            t, shp = self.p(k), self.shapes[k]
+            if k.startswith("log_vars."):
+                t.zero_()
+            elif ".batchnorm." in k or ".hidden_layers.2." in k:
+                t.fill_(1.0) if k.endswith("weight") else t.zero_()
+            elif k.endswith(".weight"):
+                fan_out, fan_in = shp
+                xavier = (k.startswith(("encoders.", "decoders.")) and
+                          (".hidden_layers." in k or ".FC_" in k))
+                bound = math.sqrt(6.0 / (fan_in + fan_out)) if xavier else 1.0 / math.sqrt(fan_in)
+                t.uniform_(-bound, bound, generator=gen)
+            else:  # Linear bias: U(-1/sqrt(fan_in), 1/sqrt(fan_in)) with the fan_in of its weight
+                fan_in = self.shapes[k[:-4] + "weight"][1]
+                bound = 1.0 / math.sqrt(fan_in)
+                t.uniform_(-bound, bound, generator=gen)
+        for k in self.buffer_keys:
+            self.b(k).fill_(1.0) if k.endswith("running_var") else self.b(k).zero_()
+        for k in self.nbt:
+            self.nbt[k] = 0
+        self.reset_optimizer()
+
+    @torch.no_grad()
+    def reset_optimizer(self):
+        self.M.zero_(); self.V.zero_(); self.G.zero_()
+        for d in self.big.values():
+            d["M"].zero_(); d["V"].zero_()
+            if d["G"] is not None:
+                d["G"].zero_()
+        self.ctrl.zero_()
+        self.ctrl[ops.CTRL_CLIP_COEF] = 1.0
+
+    @torch.no_grad()
+    def load_state(self, state: Dict[str, torch.Tensor], strict: bool = True):
+        missing = [k for k in self.shapes if k not in state]
+        extra = [k for k in state if k not in self.shapes]
+        if strict and (missing or extra):
+            raise KeyError(f"state_dict mismatch: missing {missing}, unexpected {extra}")
+        for k, val in state.items():
+            if k not in self.shapes:
+                continue
+            val = torch.as_tensor(val)
+            if tuple(val.shape) != tuple(self.shapes[k]):
+                raise ValueError(f"{k}: shape {tuple(val.shape)} != {self.shapes[k]}")
+            if k in self.nbt:
+                self.nbt[k] = int(val)
+            elif is_buffer_key(k):
+                self.b(k).copy_(val.to(torch.float32))
+            else:
+                self.p(k).copy_(val.to(torch.float32))
+
+    @torch.no_grad()
+    def state_dict(self, device="cpu") -> Dict[str, torch.Tensor]:
+        out = {}
+        for k in self.shapes:
+            if k in self.nbt:
+                out[k] = torch.tensor(self.nbt[k], dtype=torch.int64)
+            elif is_buffer_key(k):
+                out[k] = self.b(k).detach().to(device).clone()
+            else:
+                out[k] = self.p(k).detach().to(device).clone()
+        return out
+
+    @torch.no_grad()
+    def load_optimizer(self, t: int, m: Dict[str, torch.Tensor], v: Dict[str, torch.Tensor]):
+        self.ctrl[ops.CTRL_STEP] = float(t)
+        for k, val in m.items():
+            self.m(k).copy_(torch.as_tensor(val).to(torch.float32))
+        for k, val in v.items():
+            self.v(k).copy_(torch.as_tensor(val).to(torch.float32))
+
+    def n_params(self) -> int:
+        return sum(int(np.prod(self.shapes[k])) if self.shapes[k] else 1 for k in self.param_keys)
+
+
+class StepPlan:
+    """Forward/backward/optimiser tapes for one (model, batch size)."""
+
+    def __init__(self, store: ParamStore, B: int, train: bool = True, fused: bool = True, clip: bool = True,
+                 supplied_draws: bool = False, seed: int = 0, cohort=None, n_batches: int = 0,
+                 epoch_acc: bool = False):
+        self.store, self.spec, self.B, self.train = store, store.spec, int(B), train
+        self.fused = bool(fused) and train
+        self.clip = clip
+        self.supplied = supplied_draws
+        self.seed = int(seed)
+        self.dev = store.device
+        self.ws = Workspace(self.dev)
+        self.cohort = cohort
+        self.n_batches = int(n_batches)
+        spec = self.spec
+        if not self.fused and train:
+            store.ensure_big_grads()
+        self.passes = 3 if spec.model == "MultiTripletNetwork" else 1
+        self.R = self.B * self.passes                     # rows through the encoders
+        f = dict(dtype=torch.float32, device=self.dev)
+        self._f = f
+        self.draws: Dict[str, torch.Tensor] = {}
+        self.buf: Dict[str, torch.Tensor] = {}
+        n_terms = len(spec.loss_names())
+        self.loss_vec = torch.zeros(n_terms + 1, **f)     # raw named losses..., total
+        self.epoch_acc = torch.zeros(n_terms + 2, **f) if epoch_acc else None
+        self.idx = torch.zeros(max(self.R, 1) * max(self.n_batches, 1), dtype=torch.int64, device=self.dev)
+        self.X = [torch.zeros(self.R, F, **f) for _, F in spec.layers]
+        self.y: Dict[str, torch.Tensor] = {}
+        for (v, _, _) in spec.variables:
+            self.y[v] = torch.zeros(self.B, **f)
+        if spec.surv_time_var:
+            self.y[spec.surv_time_var] = torch.zeros(self.B, **f)
+        self._rng_ctr = 0
+        self.big_jobs: List[Tuple[str, torch.Tensor, torch.Tensor]] = []   # (weight key, dY, X) for fused dW+Adam
+        self.t_gather, self.t_fwd, self.t_bwd, self.t_opt = TapeRecorder(), TapeRecorder(), TapeRecorder(), TapeRecorder()
+        self._build()
+        self.graph = None
+
+    # ---------------------------------------------------------------------------------------------
+    def _new(self, name, *shape):
+        t = torch.zeros(*shape, **self._f)
+        self.buf[name] = t
+        return t
+
+    def _rng(self):
+        self._rng_ctr += 1
+        return self.seed, (self._rng_ctr << 32)
+
+    def _draw(self, name, *shape):
+        """Supplied-randomness slot (parity mode): a static buffer the caller fills."""
+        t = torch.ones(*shape, **self._f)
+        self.draws[name] = t
+        return t
+
+    def _logvar(self, name):
+        return self.store.p("log_vars." + name).view(-1) if (self.train and self.spec.weighted) else None
+
+    # ---- blocks ----------------------------------------------------------------------------------
+    def _mlp_fwd(self, rec, prefix, x, out, rows, passes, tag_names):
+        """Linear -> BN -> ReLU -> Dropout -> Linear   (reference modules.py:145-149)."""
+        st, H = self.store, self.store.shapes[prefix + ".layer_1.weight"][0]
+        y1 = self._new(prefix + "/y1", rows, H)
+        a1 = self._new(prefix + "/a1", rows, H)
+        sm = self._new(prefix + "/save_mean", passes, H)
+        si = self._new(prefix + "/save_invstd", passes, H)
+        ops.linear_fwd(rec, y1, x, st.p(prefix + ".layer_1.weight"), st.p(prefix + ".layer_1.bias"), self.ws)
+        Bp = rows // passes
+        for p in range(passes):
+            sl = slice(p * Bp, (p + 1) * Bp)
+            mask = self._draw(tag_names[p], Bp, H) if (self.supplied and self.train) else None
+            seed, off = self._rng()
+            ops.bn_act_fwd(rec, a1[sl], y1[sl], st.p(prefix + ".batchnorm.weight"), st.p(prefix + ".batchnorm.bias"),
+                           st.b(prefix + ".batchnorm.running_mean"), st.b(prefix + ".batchnorm.running_var"),
+                           sm[p], si[p], ACT_NONE, ACT_RELU, self.train, DROPOUT_P if self.train else 0.0,
+                           mask=mask, seed=seed, offset=off, ctrl=st.ctrl)
+        bias_key = prefix + ".layer_out.bias"
+        ops.linear_fwd(rec, out, a1, st.p(prefix + ".layer_out.weight"),
+                       st.p(bias_key) if bias_key in st.shapes else None, self.ws)
+
+    def _mlp_bwd(self, rec, prefix, x, dout, rows, passes, dx=None, dx_accumulate=False):
+        st, H = self.store, self.store.shapes[prefix + ".layer_1.weight"][0]
+        y1, a1 = self.buf[prefix + "/y1"], self.buf[prefix + "/a1"]
+        sm, si = self.buf[prefix + "/save_mean"], self.buf[prefix + "/save_invstd"]
+        da1 = self._new(prefix + "/da1", rows, H)           # also holds dy1 (BN backward runs in place)
+        self._weight_grad(rec, prefix + ".layer_out.weight", dout, a1)
+        if prefix + ".layer_out.bias" in st.shapes:
+            ops.colsum(rec, st.g(prefix + ".layer_out.bias"), dout)
+        ops.linear_bwd_x(rec, da1, dout, st.p(prefix + ".layer_out.weight"), self.ws)
+        Bp = rows // passes
+        for p in range(passes):
+            sl = slice(p * Bp, (p + 1) * Bp)
+            ops.bn_act_bwd(rec, da1[sl], st.g(prefix + ".batchnorm.weight"), st.g(prefix + ".batchnorm.bias"),
+                           st.g(prefix + ".layer_1.bias"), da1[sl], y1[sl], a1[sl], st.p(prefix + ".batchnorm.weight"),
+                           sm[p], si[p], ACT_NONE, ACT_RELU, DROPOUT_P, accumulate=p > 0)
+        self._weight_grad(rec, prefix + ".layer_1.weight", da1, x)
+        if dx is not None:
+            ops.linear_bwd_x(rec, dx, da1, st.p(prefix + ".layer_1.weight"), self.ws, accumulate=dx_accumulate)
+
+    def _hidden_fwd(self, rec, prefix, x, rows):
+        """Linear -> LeakyReLU(0.2) -> BN   (reference modules.py:25-34 / :75-84)."""
+        st, H = self.store, self.store.shapes[prefix + ".hidden_layers.0.weight"][0]
+        y = self._new(prefix + "/y", rows, H)
+        h = self._new(prefix + "/h", rows, H)
+        sm = self._new(prefix + "/save_mean", 1, H)
+        si = self._new(prefix + "/save_invstd", 1, H)
+        ops.linear_fwd(rec, y, x, st.p(prefix + ".hidden_layers.0.weight"), st.p(prefix + ".hidden_layers.0.bias"), self.ws)
+        ops.bn_act_fwd(rec, h, y, st.p(prefix + ".hidden_layers.2.weight"), st.p(prefix + ".hidden_layers.2.bias"),
+                       st.b(prefix + ".hidden_layers.2.running_mean"), st.b(prefix + ".hidden_layers.2.running_var"),
+                       sm[0], si[0], ACT_LEAKY, ACT_NONE, self.train, 0.0)
+        return h
+
+    def _hidden_bwd(self, rec, prefix, x, dh, dx=None, dx_accumulate=False):
+        st = self.store
+        y = self.buf[prefix + "/y"]
+        sm, si = self.buf[prefix + "/save_mean"], self.buf[prefix + "/save_invstd"]
+        ops.bn_act_bwd(rec, dh, st.g(prefix + ".hidden_layers.2.weight"), st.g(prefix + ".hidden_layers.2.bias"),
+                       st.g(prefix + ".hidden_layers.0.bias"), dh, y, None, st.p(prefix + ".hidden_layers.2.weight"),
+                       sm[0], si[0], ACT_LEAKY, ACT_NONE, 0.0)
+        self._weight_grad(rec, prefix + ".hidden_layers.0.weight", dh, x)
+        if dx is not None:
+            ops.linear_bwd_x(rec, dx, dh, st.p(prefix + ".hidden_layers.0.weight"), self.ws, accumulate=dx_accumulate)
+
+    def _weight_grad(self, rec, key, dy, x):
+        """dW = dY^T X: materialised, or deferred to the fused dW+clip+Adam kernel for wide layers."""
+        if self.fused and key in self.store.big:
+            self.big_jobs.append((key, dy, x))
+        else:
+            ops.linear_bwd_w(rec, self.store.g(key), dy, x, self.ws)
+
+    def _head_losses(self, rec_f, emb):
+        """Supervisor heads + their losses (value and output-gradient in one kernel each)."""
+        spec, st, B = self.spec, self.store, self.B
+        names = spec.loss_names()
+        for (v, kind, C) in spec.variables:
+            o = self._new(f"MLPs.{v}/out", B, C)
+            self._mlp_fwd(rec_f, "MLPs." + v, emb, o, B, 1, ["MLPs." + v])
+        for (v, kind, C) in spec.variables:
+            o = self.buf[f"MLPs.{v}/out"]
+            do = self._new(f"MLPs.{v}/dout", B, C)
+            li = self.loss_vec[names.index(v):names.index(v) + 1]
+            lv = self._logvar(v)
+            if v == spec.surv_event_var:
+                ops.cox_ph(rec_f, li, do, o, self.y[spec.surv_time_var], self.y[v], lv)
+            elif kind == "numerical":
+                ops.mse_masked(rec_f, li, do, o, self.y[v], lv)
+            else:
+                ops.ce_masked(rec_f, li, do, o, self.y[v], lv)
+
+    def _head_bwd(self, rec_b, emb, demb, first_accumulate=False):
+        acc = first_accumulate
+        for (v, kind, C) in self.spec.variables:
+            self._mlp_bwd(rec_b, "MLPs." + v, emb, self.buf[f"MLPs.{v}/dout"], self.B, 1, dx=demb, dx_accumulate=acc)
+            acc = True
+
+    def _total(self, rec_f):
+        spec, st = self.spec, self.store
+        names = spec.loss_names()
+        weighted = self.train and spec.weighted
+        losses = [self.loss_vec[i:i + 1] for i in range(len(names))]
+        lvs = [st.p("log_vars." + n).view(-1) for n in names] if weighted else []
+        dls = [st.g("log_vars." + n).view(-1) for n in names] if weighted else []
+        ops.total_loss(rec_f, self.loss_vec[len(names):], losses, lvs, dls, weighted, self.epoch_acc)
+
+    # ---- model schedules ---------------------------------------------------------------------------
+    def _build(self):
+        spec = self.spec
+        rg = self.t_gather
+        if self.cohort is not None:
+            cur = self.store.ctrl if self.n_batches > 0 else None
+            for i, (name, _) in enumerate(spec.layers):
+                ops.gather_rows(rg, self.X[i], self.cohort.dat[name], self.idx, cur, self.R)
+            for k, t in self.y.items():      # labels of the anchors = first B indices of each batch row block
+                ops.gather_rows(rg, t, self.cohort.ann[k], self.idx, cur, self.R)
+        if spec.model == "supervised_vae":
+            self._build_svae()
+        else:
+            self._build_mlp_family()
+        if self.train:
+            self._build_optimizer()
+
+    def _build_mlp_family(self):
+        """DirectPred (direct_pred.py:107-133, :225-260) and MultiTripletNetwork
+        (triplet_encoder.py:125-166, :276-330; anchor/positive/negative stacked as 3B rows)."""
+        spec, st, B, R, n, L = self.spec, self.store, self.B, self.R, self.spec.n_layers, self.spec.latent_dim
+        rf, rb = self.t_fwd, self.t_bwd
+        trip = spec.model == "MultiTripletNetwork"
+        tags = ["@a", "@p", "@n"] if trip else [""]
+        ecat = self._new("ecat", R, n * L)
+        for i in range(n):
+            self._mlp_fwd(rf, f"encoders.{i}", self.X[i], ecat[:, i * L:(i + 1) * L], R, self.passes,
+                          [f"encoders.{i}{t}" for t in tags])
+        if n > 1:
+            emb = self._new("emb", R, L)
+            ops.linear_fwd(rf, emb, ecat, st.p("fusion_block.weight"), st.p("fusion_block.bias"), self.ws)
+        else:
+            emb = ecat
+        self.embeddings = emb[:B]
+        demb = self._new("demb", R, L)
+        if trip:
+            names = spec.loss_names()
+            ops.triplet(rf, self.loss_vec[0:1], demb[:B], demb[B:2 * B], demb[2 * B:], emb[:B], emb[B:2 * B],
+                        emb[2 * B:], TRIPLET_MARGIN, self._logvar("triplet_loss"))
+        self._head_losses(rf, emb[:B])
+        self._total(rf)
+        if not self.train:
+            return
+        # ---- backward
+        self._head_bwd(rb, emb[:B], demb[:B], first_accumulate=trip)
+        if n > 1:
+            decat = self._new("decat", R, n * L)
+            self._weight_grad(rb, "fusion_block.weight", demb, ecat)
+            ops.colsum(rb, st.g("fusion_block.bias"), demb)
+            ops.linear_bwd_x(rb, decat, demb, st.p("fusion_block.weight"), self.ws)
+        else:
+            decat = demb
+        for i in range(n):
+            self._mlp_bwd(rb, f"encoders.{i}", self.X[i], decat[:, i * L:(i + 1) * L], R, self.passes)
+
+    def _build_svae(self):
+        """supervised_vae (supervised_vae.py:132-200, :291-336, :494-550)."""
+        spec, st, B, n, L = self.spec, self.store, self.B, self.spec.n_layers, self.spec.latent_dim
+        rf, rb = self.t_fwd, self.t_bwd
+        mcat, vcat = self._new("mcat", B, n * L), self._new("vcat", B, n * L)
+        hs = []
+        for i in range(n):
+            p = f"encoders.{i}"
+            h = self._hidden_fwd(rf, p, self.X[i], B)
+            hs.append(h)
+            ops.linear_fwd(rf, mcat[:, i * L:(i + 1) * L], h, st.p(p + ".FC_mean.weight"), st.p(p + ".FC_mean.bias"), self.ws)
+            ops.linear_fwd(rf, vcat[:, i * L:(i + 1) * L], h, st.p(p + ".FC_var.weight"), st.p(p + ".FC_var.bias"), self.ws)
+        mean, logv, z = self._new("mean", B, L), self._new("log_var", B, L), self._new("z", B, L)
+        ops.linear_fwd(rf, mean, mcat, st.p("FC_mean.weight"), st.p("FC_mean.bias"), self.ws)
+        ops.linear_fwd(rf, logv, vcat, st.p("FC_log_var.weight"), st.p("FC_log_var.bias"), self.ws)
+        eps = self._draw("eps", B, L) if self.supplied else None
+        eps_used = self._new("eps_used", B, L)
+        seed, off = self._rng()
+        ops.reparam(rf, z, mean, logv, eps=eps, eps_out=eps_used, seed=seed, offset=off, ctrl=st.ctrl)
+        self.embeddings = z
+        self.mean = mean
+        dz = self._new("dz", B, L)
+        lv_mmd = self._logvar("mmd_loss")
+        hd, logits = [], []
+        row_sums = self._new("mmd_rows", 2 * (MMD_PRIOR + B))
+        rec_part = self._new("recon_part", 1024)
+        # dz must start from zero each step: the first head's data-grad GEMM overwrites it (accumulate=False),
+        # so heads go FIRST in the backward tape and the MMD rows kernel (+=) is emitted after them.
+        for i in range(n):
+            p = f"decoders.{i}"
+            F = spec.layers[i][1]
+            h = self._hidden_fwd(rf, p, z, B)
+            hd.append(h)
+            lg = self._new(p + "/logits", B, F)
+            logits.append(lg)
+            ops.linear_fwd(rf, lg, h, st.p(p + ".FC_output.weight"), st.p(p + ".FC_output.bias"), self.ws)
+        self.xhat = [self._new(f"xhat.{i}", B, spec.layers[i][1]) for i in range(n)] if not self.train else None
+        priors = []
+        for i in range(n):
+            if self.supplied:
+                pr = self._draw(f"prior.{i}", MMD_PRIOR, L)
+            else:
+                pr = self._new(f"prior.{i}", MMD_PRIOR, L)
+                seed, off = self._rng()
+                ops.fill_normal(rf, pr, seed, off, ctrl=st.ctrl)
+            priors.append(pr)
+        self._head_losses(rf, z)
+        if self.train:
+            self._head_bwd(rf, z, dz, first_accumulate=False)      # emitted into the forward tape: see note above
+        for i in range(n):
+            F = spec.layers[i][1]
+            dlg = logits[i] if self.train else None                  # dlogits overwrite logits in place
+            nblk = int(ops.lib.fx_recon_blocks(B * F))
+            ops.mmd_rows(rf, row_sums, dz if self.train else None, priors[i], z, lv_mmd, 1.0 / n)
+            ops.recon_sigmoid(rf, rec_part, dlg, self.xhat[i] if self.xhat else None, logits[i], self.X[i], lv_mmd, 1.0 / n)
+            ops.mmd_finalize(rf, self.loss_vec[0:1], row_sums, MMD_PRIOR, B, rec_part, nblk, float(B * F), 1.0 / n, i > 0)
+        self._total(rf)
+        if not self.train:
+            return
+        # ---- backward through decoders (dlogits live in logits[i]) -> dz, then latent, then encoders
+        for i in range(n):
+            p = f"decoders.{i}"
+            dh = self._new(p + "/dh", B, st.shapes[p + ".hidden_layers.0.weight"][0])
+            self._weight_grad(rb, p + ".FC_output.weight", logits[i], hd[i])
+            ops.colsum(rb, st.g(p + ".FC_output.bias"), logits[i])
+            ops.linear_bwd_x(rb, dh, logits[i], st.p(p + ".FC_output.weight"), self.ws)
+            self._hidden_bwd(rb, p, z, dh, dx=dz, dx_accumulate=True)
+        # z = mean + log_var * eps
+        dlv = self._new("dlog_var", B, L)
+        ops.mul(rb, dlv, dz, eps_used)
+        dmcat, dvcat = self._new("dmcat", B, n * L), self._new("dvcat", B, n * L)
+        self._weight_grad(rb, "FC_mean.weight", dz, mcat)
+        ops.colsum(rb, st.g("FC_mean.bias"), dz)
+        ops.linear_bwd_x(rb, dmcat, dz, st.p("FC_mean.weight"), self.ws)
+        self._weight_grad(rb, "FC_log_var.weight", dlv, vcat)
+        ops.colsum(rb, st.g("FC_log_var.bias"), dlv)
+        ops.linear_bwd_x(rb, dvcat, dlv, st.p("FC_log_var.weight"), self.ws)
+        for i in range(n):
+            p = f"encoders.{i}"
+            dm, dv = dmcat[:, i * L:(i + 1) * L], dvcat[:, i * L:(i + 1) * L]
+            dh = self._new(p + "/dh", B, st.shapes[p + ".hidden_layers.0.weight"][0])
+            self._weight_grad(rb, p + ".FC_mean.weight", dm, hs[i])
+            ops.colsum(rb, st.g(p + ".FC_mean.bias"), dm)
+            self._weight_grad(rb, p + ".FC_var.weight", dv, hs[i])
+            ops.colsum(rb, st.g(p + ".FC_var.bias"), dv)
+            ops.linear_bwd_x(rb, dh, dm, st.p(p + ".FC_mean.weight"), self.ws)
+            ops.linear_bwd_x(rb, dh, dv, st.p(p + ".FC_var.weight"), self.ws, accumulate=True)
+            self._hidden_bwd(rb, p, self.X[i], dh)
+
+    def _build_optimizer(self):
+        """clip_grad_norm_(1.0) + Adam over every parameter (main.py:216-217, direct_pred.py:143)."""
+        st, ro = self.store, self.t_opt
+        nsmall = ops.sumsq_blocks(st.n_small)
+        big_slots = 0
+        plan = []
+        for k in st.big_keys:
+            if self.fused:
+                big_slots += 1
+            else:
+                big_slots += ops.sumsq_blocks(st.big[k]["W"].numel())
+        self.slots = torch.zeros(nsmall + big_slots, dtype=torch.float64, device=self.dev)
+        ops.sumsq(ro, self.slots, st.G)
+        o = nsmall
+        if self.fused:
+            jobs = {k: (dy, x) for k, dy, x in self.big_jobs}
+            gram_cache: Dict[int, torch.Tensor] = {}
+            for k in st.big_keys:
+                dy, x = jobs[k]
+                R = dy.shape[0]
+                gx = gram_cache.get(x.data_ptr())
+                if gx is None:
+                    gx = self._new(f"gram_x/{k}", R, R)
+                    ops.gemm(ro, ops.GEMM_NT, gx, x, x, None, self.ws)
+                    gram_cache[x.data_ptr()] = gx
+                gd = self._new(f"gram_dy/{k}", R, R)
+                ops.gemm(ro, ops.GEMM_NT, gd, dy, dy, None, self.ws)
+                ops.hadamard_sum(ro, self.slots[o:o + 1], gx, gd)
+                o += 1
+        else:
+            for k in st.big_keys:
+                g = st.big[k]["G"]
+                ops.sumsq(ro, self.slots[o:], g.view(-1))
+                o += ops.sumsq_blocks(g.numel())
+        ops.clip_finalize(ro, st.ctrl, self.slots, self.slots.numel(), CLIP_MAX_NORM if self.clip else 0.0)
+        ops.adam_flat(ro, st.P, st.G, st.M, st.V, st.ctrl)
+        for k in st.big_keys:
+            d = st.big[k]
+            if self.fused:
+                dy, x = jobs[k]
+                ops.linear_dw_adam(ro, d["W"], d["M"], d["V"], dy, x, st.ctrl)
+            else:
+                ops.adam_flat(ro, d["W"].view(-1), d["G"].view(-1), d["M"].view(-1), d["V"].view(-1), st.ctrl)
+
+    # ---- execution ----------------------------------------------------------------------------------
+    def set_batch(self, x_list=None, y=None, parts=None):
+        """Direct mode: copy a collated batch (reference DataLoader output) into the static buffers."""
+        B = self.B
+        if parts is not None:      # triplet: (anchor, positive, negative) lists
+            for j, xs in enumerate(parts):
+                for i, x in enumerate(xs):
+                    self.X[i][j * B:(j + 1) * B].copy_(x, non_blocking=True)
+        elif x_list is not None:
+            for i, x in enumerate(x_list):
+                self.X[i].copy_(x, non_blocking=True)
+        if y is not None:
+            for k, t in self.y.items():
+                t.copy_(torch.as_tensor(y[k]).to(torch.float32), non_blocking=True)
+
+    def set_draws(self, draws: Dict[str, torch.Tensor]):
+        for k, t in self.draws.items():
+            if k in draws:
+                t.copy_(draws[k].to(torch.float32), non_blocking=True)
+
+    def bump_nbt(self):
+        for k in self.store.nbt:
+            self.store.nbt[k] += self.passes if k.startswith("encoders.") and self.passes > 1 else 1
+
+    def forward(self):
+        self.t_fwd.run()
+
+    def backward(self):
+        self.t_bwd.run()
+
+    def optimizer_step(self, lr: float):
+        ops.step_begin(ops.IMMEDIATE, self.store.ctrl, lr, 0)
+        self.t_opt.run()
+
+    def train_step(self, lr: float, gather: bool = False):
+        """One full optimisation step (eager launch of the recorded tapes)."""
+        ops.step_begin(ops.IMMEDIATE, self.store.ctrl, lr, self.n_batches)
+        if gather:
+            self.t_gather.run()
+        self.t_fwd.run()
+        self.t_bwd.run()
+        self.t_opt.run()
+        self.bump_nbt()
+
+    def capture(self, lr: float, gather: bool = True):
+        """Capture the whole step (cursor advance, gather, fwd, bwd, clip, Adam) into one hipGraph."""
+        torch.cuda.synchronize()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self._step_for_capture(lr, gather)          # warm-up outside capture (lazy module loads)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        # undo the warm-up step's side effects on the step counter only (parameters moved one step; callers
+        # capture before training starts or accept the extra step)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._step_for_capture(lr, gather)
+        self.graph = g
+        return g
+
+    def _step_for_capture(self, lr, gather):
+        rec = ops.IMMEDIATE
+        ops.step_begin(rec, self.store.ctrl, lr, self.n_batches)
+        if gather:
+            self.t_gather.run()
+        self.t_fwd.run()
+        self.t_bwd.run()
+        self.t_opt.run()
+
+    def replay(self):
+        self.graph.replay()
+        self.bump_nbt()
+
+    def n_launches(self):
+        return len(self.t_gather) + len(self.t_fwd) + len(self.t_bwd) + len(self.t_opt) + 1
+
+    def losses(self) -> Dict[str, float]:
+        vals = self.loss_vec.detach().cpu().tolist()
+        names = self.spec.loss_names()
+        out = {n: vals[i] for i, n in enumerate(names)}
+        out["total"] = vals[len(names)]
+        return out

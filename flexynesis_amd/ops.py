@@ -1,0 +1,290 @@
+"""Thin tensor-level wrappers over the libfxhip C ABI.
+
+Every op is *emitted* to a ``Recorder``: ``ImmediateRecorder`` launches right away on torch's current
+HIP stream; ``TapeRecorder`` stores the resolved (function, raw-pointer arguments) pairs so that a whole
+training step can be re-issued with almost no host work -- or captured once into a hipGraph
+(engine.py).  Tensors must be fp32 CUDA(=HIP) tensors with unit inner stride; there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import torch
+
+from . import _lib
+from ._lib import lib, FxError
+
+ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+CTRL_FLOATS = 64
+CTRL_STEP, CTRL_LR, CTRL_CLIP_COEF, CTRL_GNORM, CTRL_CURSOR = 0, 1, 4, 5, 8
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk2d(t: torch.Tensor, name: str):
+    if not (t.is_cuda and t.dtype == torch.float32):
+        raise FxError(f"{name}: expected an fp32 tensor on the GPU, got {t.dtype} on {t.device} "
+                      "(flexynesis_amd has no CPU fallback)")
+    if t.dim() != 2 or (t.stride(1) != 1 and t.shape[1] != 1):
+        raise FxError(f"{name}: expected a 2-D row-major view, got shape {tuple(t.shape)} strides {t.stride()}")
+
+
+def _ld(t: torch.Tensor) -> int:
+    """Leading dimension (elements) of a 2-D row-major view; size-1 dims carry arbitrary strides in torch."""
+    if t.dim() == 1:
+        return 1
+    return t.stride(0) if (t.shape[0] > 1 and t.stride(0) >= t.shape[1]) else max(t.shape[1], 1)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class ImmediateRecorder:
+    """Launch each op immediately on the current stream."""
+
+    def emit(self, name: str, *args):
+        rc = getattr(lib, name)(*args, _stream())
+        if rc != 0:
+            raise FxError(f"{name} failed (rc={rc}): {_lib.last_error()}")
+
+
+class TapeRecorder:
+    """Record ops; ``run()`` re-issues them on the current stream."""
+
+    def __init__(self):
+        self.calls: List[tuple] = []
+        self.keepalive: List[object] = []
+
+    def emit(self, name: str, *args):
+        self.calls.append((getattr(lib, name), name, args))
+
+    def keep(self, *objs):
+        self.keepalive.extend(objs)
+
+    def run(self):
+        s = _stream()
+        for fn, name, args in self.calls:
+            rc = fn(*args, s)
+            if rc != 0:
+                raise FxError(f"{name} failed (rc={rc}): {_lib.last_error()}")
+
+    def __len__(self):
+        return len(self.calls)
+
+
+IMMEDIATE = ImmediateRecorder()
+
+
+class Workspace:
+    """Split-K scratch shared by all GEMMs of one stream-ordered plan."""
+
+    def __init__(self, device, nbytes: int = 0):
+        self.device = device
+        self.buf = torch.empty(max(nbytes, 16) // 4 + 4, dtype=torch.float32, device=device)
+
+    def reserve(self, nbytes: int):
+        if nbytes > self.buf.numel() * 4:
+            self.buf = torch.empty(nbytes // 4 + 4, dtype=torch.float32, device=self.device)
+
+    @property
+    def nbytes(self):
+        return self.buf.numel() * 4
+
+
+def gemm_ws_bytes(M, N, K) -> int:
+    return int(lib.fx_gemm_workspace_bytes(M, N, K))
+
+
+def gemm(rec, layout: int, Cm: torch.Tensor, A: torch.Tensor, Bm: torch.Tensor, bias: Optional[torch.Tensor],
+         ws: Optional[Workspace], accumulate: bool = False):
+    """layout NT: C[M,N] = A[M,K] B[N,K]^T ; NN: C = A[M,K] B[K,N] ; TN: C = A[K,M]^T B[K,N]."""
+    for t, n in ((Cm, "C"), (A, "A"), (Bm, "B")):
+        _chk2d(t, "gemm." + n)
+    M, N = Cm.shape
+    if layout == GEMM_NT:
+        K = A.shape[1]
+        ok = A.shape == (M, K) and Bm.shape == (N, K)
+    elif layout == GEMM_NN:
+        K = A.shape[1]
+        ok = A.shape == (M, K) and Bm.shape == (K, N)
+    else:
+        K = A.shape[0]
+        ok = A.shape == (K, M) and Bm.shape == (K, N)
+    if not ok:
+        raise FxError(f"gemm layout {layout}: shape mismatch C{tuple(Cm.shape)} A{tuple(A.shape)} B{tuple(Bm.shape)}")
+    need = gemm_ws_bytes(M, N, K)
+    wptr, wbytes = None, 0
+    if need and ws is not None:
+        ws.reserve(need)
+        wptr, wbytes = ws.buf.data_ptr(), ws.nbytes
+    rec.emit("fx_gemm_f32", layout, Cm.data_ptr(), A.data_ptr(), Bm.data_ptr(), _ptr(bias), M, N, K,
+             _ld(A), _ld(Bm), _ld(Cm), int(accumulate), wptr, wbytes)
+
+
+def linear_fwd(rec, y, x, W, b, ws):
+    gemm(rec, GEMM_NT, y, x, W, b, ws)
+
+
+def linear_bwd_x(rec, dx, dy, W, ws, accumulate=False):
+    gemm(rec, GEMM_NN, dx, dy, W, None, ws, accumulate)
+
+
+def linear_bwd_w(rec, dW, dy, x, ws, accumulate=False):
+    gemm(rec, GEMM_TN, dW, dy, x, None, ws, accumulate)
+
+
+def linear_dw_adam(rec, W, m, v, dy, x, ctrl):
+    for t, n in ((W, "W"), (m, "m"), (v, "v"), (dy, "dY"), (x, "X")):
+        _chk2d(t, "linear_dw_adam." + n)
+    B, n_out = dy.shape
+    k_in = x.shape[1]
+    if W.shape != (n_out, k_in) or x.shape[0] != B or m.shape != W.shape or v.shape != W.shape:
+        raise FxError("linear_dw_adam: shape mismatch")
+    if not (_ld(m) == _ld(W) == _ld(v)):
+        raise FxError("linear_dw_adam: W/m/v must share a leading dimension")
+    rec.emit("fx_linear_dw_adam_f32", W.data_ptr(), m.data_ptr(), v.data_ptr(), dy.data_ptr(), x.data_ptr(),
+             B, n_out, k_in, _ld(dy), _ld(x), _ld(W), ctrl.data_ptr())
+
+
+def colsum(rec, out, x):
+    _chk2d(x, "colsum.x")
+    rec.emit("fx_colsum", out.data_ptr(), x.data_ptr(), x.shape[0], x.shape[1], _ld(x))
+
+
+def bn_act_fwd(rec, out, x, gamma, beta, rmean, rvar, save_mean, save_invstd, pre_act, post_act, train,
+               drop_p=0.0, mask=None, mask_out=None, seed=0, offset=0, ctrl=None):
+    _chk2d(out, "bn.out")
+    _chk2d(x, "bn.x")
+    B, Cc = x.shape
+    if mask is not None and (mask.shape != x.shape or not mask.is_contiguous()):
+        raise FxError("bn_act_fwd: mask must be a contiguous [B,C] tensor")
+    rec.emit("fx_bn_act_fwd", out.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(),
+             rvar.data_ptr(), _ptr(save_mean), _ptr(save_invstd), _ptr(mask), _ptr(mask_out), B, Cc,
+             _ld(x), _ld(out), pre_act, post_act, int(train), float(drop_p), int(seed), int(offset),
+             _ptr(ctrl))
+
+
+def bn_act_bwd(rec, dx, dgamma, dbeta, dbias, dout, x, out, gamma, save_mean, save_invstd, pre_act, post_act,
+               drop_p=0.0, accumulate=False):
+    for t, n in ((dx, "dx"), (dout, "dout"), (x, "x")):
+        _chk2d(t, "bn_bwd." + n)
+    B, Cc = x.shape
+    rec.emit("fx_bn_act_bwd", dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dbias), dout.data_ptr(),
+             x.data_ptr(), _ptr(out), gamma.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(), B, Cc,
+             _ld(x), _ld(out) if out is not None else 0, _ld(dout), _ld(dx), pre_act, post_act,
+             float(drop_p), int(accumulate))
+
+
+def gather_rows(rec, dst, src, idx, ctrl_cursor=None, cursor_stride=0):
+    """dst[r,:] = src[idx[r],:]; 1-D src (labels) is treated as [N,1]."""
+    if src.dim() == 1:
+        src2, dst2 = src.unsqueeze(1), dst.unsqueeze(1) if dst.dim() == 1 else dst
+    else:
+        src2, dst2 = src, dst
+    if idx.dtype != torch.int64 or not idx.is_cuda:
+        raise FxError("gather_rows: idx must be an int64 GPU tensor")
+    n_rows = dst2.shape[0]
+    rec.emit("fx_gather_rows", dst2.data_ptr(), src2.data_ptr(), idx.data_ptr(), n_rows, src2.shape[1],
+             _ld(src2), _ld(dst2), _ptr(ctrl_cursor), int(cursor_stride))
+
+
+def mse_masked(rec, loss_out, dyhat, yhat, y, logvar=None, extra_scale=1.0):
+    rec.emit("fx_mse_masked", loss_out.data_ptr(), dyhat.data_ptr(), yhat.data_ptr(), y.data_ptr(), yhat.shape[0],
+             _ld(yhat), _ld(dyhat), _ptr(logvar), float(extra_scale))
+
+
+def ce_masked(rec, loss_out, dlogits, logits, y, logvar=None, extra_scale=1.0):
+    rec.emit("fx_ce_masked", loss_out.data_ptr(), dlogits.data_ptr(), logits.data_ptr(), y.data_ptr(),
+             logits.shape[0], logits.shape[1], _ld(logits), _ld(dlogits), _ptr(logvar), float(extra_scale))
+
+
+def cox_ph(rec, loss_out, dout, out, durations, events, logvar=None, extra_scale=1.0):
+    rec.emit("fx_cox_ph", loss_out.data_ptr(), dout.data_ptr(), out.data_ptr(), durations.data_ptr(),
+             events.data_ptr(), out.shape[0], _ld(out), _ld(dout), _ptr(logvar), float(extra_scale))
+
+
+def triplet(rec, loss_out, da, dp, dn, a, p, n, margin=1.0, logvar=None, extra_scale=1.0):
+    for t in (da, dp, dn, a, p, n):
+        if _ld(t) != _ld(a):
+            raise FxError("triplet: all operands must share a leading dimension")
+    rec.emit("fx_triplet", loss_out.data_ptr(), da.data_ptr(), dp.data_ptr(), dn.data_ptr(), a.data_ptr(),
+             p.data_ptr(), n.data_ptr(), a.shape[0], a.shape[1], _ld(a), float(margin), _ptr(logvar),
+             float(extra_scale))
+
+
+def mmd_rows(rec, row_sums, dz, prior, z, logvar=None, extra_scale=1.0):
+    if not prior.is_contiguous():
+        raise FxError("mmd_rows: prior must be contiguous")
+    rec.emit("fx_mmd_rows", row_sums.data_ptr(), _ptr(dz), prior.data_ptr(), z.data_ptr(), prior.shape[0], z.shape[0],
+             z.shape[1], _ld(z), _ptr(logvar), float(extra_scale))
+
+
+def recon_sigmoid(rec, partial, dlogits, xhat_out, logits, x, logvar=None, extra_scale=1.0):
+    if not (logits.is_contiguous() and x.is_contiguous()):
+        raise FxError("recon_sigmoid: logits and x must be contiguous")
+    rec.emit("fx_recon_sigmoid", partial.data_ptr(), _ptr(dlogits), _ptr(xhat_out), logits.data_ptr(), x.data_ptr(),
+             logits.numel(), _ptr(logvar), float(extra_scale))
+
+
+def mmd_finalize(rec, loss_acc, row_sums, P, B, recon_partial, n_partial, n_recon, extra_scale, accumulate):
+    rec.emit("fx_mmd_finalize", loss_acc.data_ptr(), row_sums.data_ptr(), P, B, _ptr(recon_partial), n_partial,
+             float(n_recon), float(extra_scale), int(accumulate))
+
+
+def total_loss(rec, total_out, losses, logvars, dlogvars, weighted, epoch_acc=None):
+    n = len(losses)
+    arr = C.c_void_p * n
+    la = arr(*[t.data_ptr() for t in losses])
+    lv = arr(*[t.data_ptr() for t in logvars]) if weighted else None
+    dl = arr(*[(t.data_ptr() if t is not None else None) for t in dlogvars]) if weighted else None
+    if hasattr(rec, "keep"):
+        rec.keep(la, lv, dl)
+    rec.emit("fx_total_loss", total_out.data_ptr(), n, int(weighted), C.cast(la, C.c_void_p),
+             C.cast(lv, C.c_void_p) if lv is not None else None, C.cast(dl, C.c_void_p) if dl is not None else None,
+             _ptr(epoch_acc))
+
+
+def step_begin(rec, ctrl, lr, n_batches=0):
+    rec.emit("fx_step_begin", ctrl.data_ptr(), float(lr), int(n_batches))
+
+
+def sumsq_blocks(n) -> int:
+    return int(lib.fx_sumsq_blocks(n))
+
+
+def sumsq(rec, slots, x):
+    rec.emit("fx_sumsq", slots.data_ptr(), x.data_ptr(), x.numel())
+
+
+def hadamard_sum(rec, slot, g1, g2):
+    rec.emit("fx_hadamard_sum", slot.data_ptr(), g1.data_ptr(), g2.data_ptr(), g1.numel())
+
+
+def clip_finalize(rec, ctrl, slots, n_slots, max_norm):
+    rec.emit("fx_clip_finalize", ctrl.data_ptr(), slots.data_ptr(), int(n_slots), float(max_norm))
+
+
+def adam_flat(rec, p, g, m, v, ctrl):
+    rec.emit("fx_adam_flat", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), ctrl.data_ptr())
+
+
+def sigmoid(rec, y, x):
+    rec.emit("fx_sigmoid", y.data_ptr(), x.data_ptr(), x.numel())
+
+
+def reparam(rec, z, mean, log_var, eps=None, eps_out=None, seed=0, offset=0, ctrl=None):
+    rec.emit("fx_reparam", z.data_ptr(), _ptr(eps_out), mean.data_ptr(), log_var.data_ptr(), _ptr(eps), z.numel(),
+             int(seed), int(offset), _ptr(ctrl))
+
+
+def mul(rec, y, a, b):
+    rec.emit("fx_mul", y.data_ptr(), a.data_ptr(), b.data_ptr(), y.numel())
+
+
+def fill_normal(rec, y, seed, offset, ctrl=None):
+    rec.emit("fx_fill_normal", y.data_ptr(), y.numel(), int(seed), int(offset), _ptr(ctrl))

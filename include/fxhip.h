@@ -1,0 +1,120 @@
+/* libfxhip -- C ABI of the MI355X (gfx950) kernels behind the flexynesis training hot path.
+ *
+ * The reference (BIMSBbioinfo/flexynesis v1.1.14) has NO native/FFI interface: its hot path is a
+ * chain of ATen ops dispatched from nn.Modules.  Each entry point below
+ * therefore replaces a group of reference ops; the reference file:line it stands in for is cited.
+ * The reference-side binding a maintainer would add (ctypes) is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - every function returns int: 0 = ok, FX_EINVAL (-22) = bad argument, other <0 = -(hipError_t);
+ *    fx_last_error_string() describes the last failure of the calling thread.  Never throws/aborts.
+ *  - all tensor pointers are DEVICE pointers owned by the caller (e.g. the torch allocator); the
+ *    library never allocates or frees device memory.  Scratch is passed in (see *_workspace_* queries).
+ *  - every launcher takes the hipStream_t LAST, is asynchronous and stream-ordered; there is no global
+ *    mutable state besides the thread-local error string, so calls are re-entrant across host threads.
+ *  - matrices are fp32 row-major with an explicit leading dimension (elements); weights use torch's
+ *    [out_features, in_features] layout; "B" is the batch (rows = samples, reference data.py:550).
+ *  - randomness is EITHER a supplied tensor (parity mode) OR a Philox4x32-10 (seed, offset) pair; when a
+ *    step-control block ``ctrl`` is passed too, its step counter is folded into the offset on the device.
+ */
+#ifndef FXHIP_H
+#define FXHIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* fx_stream_t; /* == hipStream_t */
+
+#define FX_EINVAL (-22)
+
+/* step-control block: 64 floats in device memory, see flexynesis_amd/csrc/fx_common.h (enum FxCtrl) */
+#define FX_CTRL_FLOATS 64
+#define FX_CTRL_STEP 0
+#define FX_CTRL_LR 1
+#define FX_CTRL_CLIP_COEF 4
+#define FX_CTRL_GNORM 5
+#define FX_CTRL_BATCH_CURSOR 8
+
+/* activation codes for fx_bn_act_* */
+#define FX_ACT_NONE 0
+#define FX_ACT_LEAKY 1 /* LeakyReLU(0.2) applied BEFORE BatchNorm (Encoder/Decoder, modules.py:25-34) */
+#define FX_ACT_RELU 2  /* ReLU (+ optional dropout) applied AFTER BatchNorm (MLP, modules.py:145-148) */
+
+/* GEMM layouts for fx_gemm_f32 */
+#define FX_GEMM_NT 0 /* C[M,N] = A[M,K] . B[N,K]^T  : nn.Linear forward (modules.py:54,101,145,149)     */
+#define FX_GEMM_NN 1 /* C[M,N] = A[M,K] . B[K,N]    : autograd grad-input  (dX = dY . W)                 */
+#define FX_GEMM_TN 2 /* C[M,N] = A[K,M]^T . B[K,N]  : autograd grad-weight (dW = dY^T . X)               */
+
+const char* fx_last_error_string(void);
+int fx_version(void);
+
+/* ---- data: replaces MultiOmicDataset.__getitem__ + default_collate + per-batch H2D
+ *      (data.py:980-995, main.py:289-298).  dst[r,:] = src[idx[r],:]; idx int64 on device.
+ *      ctrl_cursor != NULL: idx is a [n_batches, cursor_stride] table and the row block
+ *      idx + ctrl[FX_CTRL_BATCH_CURSOR] * cursor_stride is used (lets a captured hipGraph walk the epoch's permutation without new arguments). */
+int fx_gather_rows(float* dst, const float* src, const long* idx, int n_rows, int n_cols, long ld_src, long ld_dst,
+                   const float* ctrl_cursor, long cursor_stride, fx_stream_t stream);
+
+/* ---- Linear layers (nn.Linear fwd / autograd bwd: modules.py:125-130,145,149; direct_pred.py:87-93) */
+long fx_gemm_workspace_bytes(int M, int N, int K);
+int fx_gemm_f32(int layout, float* C, const float* A, const float* B, const float* bias, int M, int N, int K, long lda,
+                long ldb, long ldc, int accumulate, void* workspace, long workspace_bytes, fx_stream_t stream);
+/* fused dW = dY^T.X  ->  clip  ->  Adam on W,m,v  (loss.backward + clip_grad_norm_ + Adam.step for one
+ * weight: main.py:216-217, direct_pred.py:143).  dW is never materialised. */
+int fx_linear_dw_adam_f32(float* W, float* adam_m, float* adam_v, const float* dY, const float* X, int batch, int n_out,
+                          int k_in, long lddy, long ldx, long ldw, const float* ctrl, fx_stream_t stream);
+int fx_colsum(float* out, const float* x, int B, int C, long ldx, fx_stream_t stream); /* bias gradients */
+
+/* ---- BatchNorm1d (+LeakyReLU before | +ReLU+Dropout after), train & eval (modules.py:25-34,145-148) */
+int fx_bn_act_fwd(float* out, const float* x, const float* gamma, const float* beta, float* running_mean,
+                  float* running_var, float* save_mean, float* save_invstd, const float* mask, float* mask_out, int B,
+                  int C, long ldx, long ldo, int pre_act, int post_act, int train, float drop_p, unsigned long long seed,
+                  unsigned long long offset, const float* ctrl, fx_stream_t stream);
+int fx_bn_act_bwd(float* dx, float* dgamma, float* dbeta, float* dbias, const float* dout, const float* x,
+                  const float* out, const float* gamma, const float* save_mean, const float* save_invstd, int B, int C,
+                  long ldx, long ldo, long lddo, long lddx, int pre_act, int post_act, float drop_p, int accumulate,
+                  fx_stream_t stream);
+
+/* ---- elementwise pieces of supervised_vae (supervised_vae.py:187-200; modules.py:101-102) */
+int fx_sigmoid(float* y, const float* x, long n, fx_stream_t stream);
+int fx_reparam(float* z, float* eps_out, const float* mean, const float* log_var, const float* eps, long n,
+               unsigned long long seed, unsigned long long offset, const float* ctrl, fx_stream_t stream);
+int fx_mul(float* y, const float* a, const float* b, long n, fx_stream_t stream);
+int fx_fill_normal(float* y, long n, unsigned long long seed, unsigned long long offset, const float* ctrl,
+                   fx_stream_t stream);
+
+/* ---- losses: raw value -> loss_out[0]; gradient of exp(-log_var)*extra_scale*loss -> grad output
+ *      (log_var may be NULL = unweighted).  compute_loss direct_pred.py:146-190; cox modules.py:265-305;
+ *      triplet triplet_encoder.py:178-194; MMD supervised_vae.py:494-550; total direct_pred.py:192-223 */
+int fx_mse_masked(float* loss_out, float* dyhat, const float* yhat, const float* y, int B, long ld, long ldd,
+                  const float* logvar, float extra_scale, fx_stream_t stream);
+int fx_ce_masked(float* loss_out, float* dlogits, const float* logits, const float* y, int B, int C, long ld, long ldd,
+                 const float* logvar, float extra_scale, fx_stream_t stream);
+int fx_cox_ph(float* loss_out, float* dout, const float* out, const float* durations, const float* events, int B, long ld,
+              long ldd, const float* logvar, float extra_scale, fx_stream_t stream);
+int fx_triplet(float* loss_out, float* da, float* dp, float* dn, const float* a, const float* p, const float* n, int B,
+               int L, long ld, float margin, const float* logvar, float extra_scale, fx_stream_t stream);
+long fx_mmd_workspace_floats(int P, int B);
+int fx_mmd_rows(float* row_sums, float* dz, const float* prior, const float* z, int P, int B, int L, long ldz,
+                const float* logvar, float extra_scale, fx_stream_t stream);
+int fx_recon_blocks(long n);
+int fx_recon_sigmoid(float* partial, float* dlogits, float* xhat_out, const float* logits, const float* x, long n,
+                     const float* logvar, float extra_scale, fx_stream_t stream);
+int fx_mmd_finalize(float* loss_acc, const float* row_sums, int P, int B, const float* recon_partial, int n_partial,
+                    float n_recon, float extra_scale, int accumulate, fx_stream_t stream);
+int fx_total_loss(float* total_out, int n, int weighted, const float* const* losses, const float* const* logvars,
+                  float* const* dlogvars, float* epoch_acc, fx_stream_t stream);
+
+/* ---- optimiser: Lightning's clip_grad_norm_(1.0) + torch.optim.Adam(lr) (main.py:212-225, direct_pred.py:143) */
+int fx_step_begin(float* ctrl, float lr, int n_batches, fx_stream_t stream);
+int fx_sumsq_blocks(long n);
+int fx_sumsq(double* slots, const float* x, long n, fx_stream_t stream);
+int fx_hadamard_sum(double* slot, const float* g1, const float* g2, long n, fx_stream_t stream);
+int fx_clip_finalize(float* ctrl, const double* slots, int n_slots, float max_norm, fx_stream_t stream);
+int fx_adam_flat(float* p, const float* g, float* m, float* v, long n, const float* ctrl, fx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FXHIP_H */

@@ -1,0 +1,428 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called through the C ABI,
+against (a) the committed golden vectors generated from the reference and (b) the CPU oracle
+(oracle/restate.py) on seeded inputs at larger shapes.  Nothing here reads /root/reference."""
+import numpy as np
+import pytest
+import torch
+
+from golden_io import Golden, MODEL_CASES
+
+pytestmark = pytest.mark.gpu
+
+LOSS_RTOL = 1e-4        # BASELINE.json north_star: losses within 1e-4 relative on identical inputs
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def close(a, b, rtol, atol, what=""):
+    a = torch.as_tensor(a).detach().double().cpu().reshape(-1)
+    b = torch.as_tensor(b).detach().double().cpu().reshape(-1)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs()
+    tol = (torch.as_tensor(atol).double().reshape(-1) if torch.is_tensor(atol) else atol) + rtol * b.abs()
+    bad = err > tol
+    assert not bool(bad.any()), (f"{what}: {int(bad.sum())}/{a.numel()} off, max err {err.max().item():.3e} "
+                                 f"(ref max {b.abs().max().item():.3e})")
+
+
+def noise_atol(grad, grad_norm, lr, default):
+    """See tests/test_oracle_pinning.py::shadow_atol: exactly-zero-gradient entries are rounding noise
+    that Adam amplifies to +-lr; they are implementation-defined in the reference too."""
+    if grad is None:
+        return default
+    noise = grad.abs() < 1e-6 * float(grad_norm)
+    return torch.where(noise, torch.tensor(2.1 * lr), torch.tensor(float(default)))
+
+
+def arch_from_golden(g):
+    from flexynesis_amd.arch import ArchSpec
+    s = g.spec
+    return ArchSpec(s.model, list(s.layers), s.latent_dim, s.hidden_dim_factor, s.supervisor_hidden_dim,
+                    list(s.variables), s.surv_event_var, s.surv_time_var, s.use_loss_weighting)
+
+
+def feed(plan, spec, batch, draws):
+    dev = plan.dev
+    if spec.model == "MultiTripletNetwork":
+        plan.set_batch(parts=[[x.to(dev) for x in batch[k]] for k in ("anchor", "positive", "negative")],
+                       y={k: v.to(dev) for k, v in batch["y"].items()})
+    else:
+        plan.set_batch(x_list=[x.to(dev) for x in batch["x"]], y={k: v.to(dev) for k, v in batch["y"].items()})
+    plan.set_draws({k: v.to(dev) for k, v in draws.items()})
+
+
+def golden_opt(g, s):
+    return (0, {}, {}) if s < 0 else (s + 1, g.exp(s, "m"), g.exp(s, "v"))
+
+
+# ---------------------------------------------------------------------------------------------------
+# kernels vs plain fp32/fp64 torch references at awkward shapes
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(128, 5000, 2000), (128, 64, 5000), (7, 3, 5), (33, 130, 70), (384, 100, 96),
+                                   (128, 1, 16), (1, 16, 64), (130, 257, 1000)])
+def test_gemm_layouts(M, N, K):
+    from flexynesis_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(M, K, generator=g).to(dev)
+    Bt = torch.randn(N, K, generator=g).to(dev)      # NT operand
+    bias = torch.randn(N, generator=g).to(dev)
+    ws = ops.Workspace(dev)
+    C = torch.full((M, N), float("nan"), device=dev)
+    ops.gemm(ops.IMMEDIATE, ops.GEMM_NT, C, A, Bt, bias, ws)
+    ref = (A.double() @ Bt.double().t() + bias.double())
+    scale = (A.double().abs() @ Bt.double().abs().t()).max().item()
+    assert (C.double() - ref).abs().max().item() <= 2e-6 * scale + 1e-6, "NT"
+    Bn = Bt.t().contiguous()                          # [K,N]
+    C2 = torch.full((M, N), float("nan"), device=dev)
+    ops.gemm(ops.IMMEDIATE, ops.GEMM_NN, C2, A, Bn, None, ws)
+    assert (C2.double() - A.double() @ Bn.double()).abs().max().item() <= 2e-6 * scale + 1e-6, "NN"
+    At = A.t().contiguous()                           # [K,M]
+    C3 = torch.full((M, N), float("nan"), device=dev)
+    ops.gemm(ops.IMMEDIATE, ops.GEMM_TN, C3, At, Bn, None, ws)
+    assert (C3.double() - A.double() @ Bn.double()).abs().max().item() <= 2e-6 * scale + 1e-6, "TN"
+    # accumulate + strided output view
+    big = torch.zeros(M, N + 9, device=dev)
+    view = big[:, 4:4 + N]
+    view.fill_(1.0)
+    ops.gemm(ops.IMMEDIATE, ops.GEMM_NT, view, A, Bt, None, ws, accumulate=True)
+    assert (view.double() - (A.double() @ Bt.double().t() + 1.0)).abs().max().item() <= 2e-6 * scale + 1e-5, "acc"
+    assert float(big[:, :4].abs().max()) == 0.0 and float(big[:, 4 + N:].abs().max()) == 0.0, "out-of-view write"
+
+
+def test_gemm_transpose_detecting():
+    """A = I with an asymmetric B catches row/column swaps in the MFMA C-layout (guide rule 16)."""
+    from flexynesis_amd import ops
+    dev = _dev()
+    n = 96
+    A = torch.eye(n, device=dev)
+    Bm = (torch.arange(n * n, device=dev, dtype=torch.float32).reshape(n, n) / 7.0)
+    C = torch.zeros(n, n, device=dev)
+    ops.gemm(ops.IMMEDIATE, ops.GEMM_NN, C, A, Bm, None, ops.Workspace(dev))
+    assert torch.equal(C, Bm)
+    ops.gemm(ops.IMMEDIATE, ops.GEMM_NT, C, A, Bm, None, ops.Workspace(dev))
+    assert torch.equal(C, Bm.t())
+
+
+@pytest.mark.parametrize("B,C,pre,post", [(8, 16, 0, 2), (128, 5000, 0, 2), (10, 33, 1, 0), (128, 1250, 1, 0)])
+def test_bn_act_fwd_bwd_vs_torch(B, C, pre, post):
+    from flexynesis_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(B + C)
+    x = torch.randn(B, C, generator=g, dtype=torch.float64)
+    gamma = torch.rand(C, generator=g, dtype=torch.float64) + 0.5
+    beta = torch.randn(C, generator=g, dtype=torch.float64) * 0.1
+    rm0 = torch.randn(C, generator=g, dtype=torch.float64) * 0.1
+    rv0 = torch.rand(C, generator=g, dtype=torch.float64) + 0.5
+    mask = (torch.rand(B, C, generator=g) < 0.9).double()
+    dout = torch.randn(B, C, generator=g, dtype=torch.float64)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    h = torch.where(xr > 0, xr, 0.2 * xr) if pre == 1 else xr
+    mean, var = h.mean(0), h.var(0, unbiased=False)
+    yb = (h - mean) / torch.sqrt(var + 1e-5) * gr + br
+    out_ref = torch.relu(yb) * (mask / 0.9) if post == 2 else yb
+    out_ref.backward(dout)
+    f32 = lambda t: t.float().to(dev).contiguous()
+    out, dx = torch.empty(B, C, device=dev), torch.empty(B, C, device=dev)
+    rm, rv = f32(rm0), f32(rv0)
+    sm, si = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    dg, db, dbias = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty(C, device=dev)
+    xd, gd, bd = f32(x), f32(gamma), f32(beta)
+    ops.bn_act_fwd(ops.IMMEDIATE, out, xd, gd, bd, rm, rv, sm, si, pre, post, True, 0.1 if post == 2 else 0.0,
+                   mask=f32(mask) if post == 2 else None)
+    close(out, out_ref, 1e-4, 1e-5, "bn fwd")
+    close(rm, 0.9 * rm0 + 0.1 * mean, 1e-5, 1e-6, "running_mean")
+    close(rv, 0.9 * rv0 + 0.1 * h.var(0, unbiased=True), 1e-5, 1e-6, "running_var")
+    ops.bn_act_bwd(ops.IMMEDIATE, dx, dg, db, dbias, f32(dout), xd, out if post == 2 else None, gd, sm, si, pre, post,
+                   0.1 if post == 2 else 0.0)
+    close(dx, xr.grad, 2e-4, 2e-5, "bn dx")
+    close(dg, gr.grad, 2e-4, 2e-4, "bn dgamma")
+    close(db, br.grad, 2e-4, 2e-4, "bn dbeta")
+    close(dbias, xr.grad.sum(0), 1e-3, 2e-4, "dbias")
+    # eval mode
+    ops.bn_act_fwd(ops.IMMEDIATE, out, xd, gd, bd, f32(rm0), f32(rv0), None, None, pre, post, False)
+    ev = (h.detach() - rm0) / torch.sqrt(rv0 + 1e-5) * gamma + beta
+    close(out, torch.relu(ev) if post == 2 else ev, 1e-4, 1e-5, "bn eval")
+
+
+def test_loss_kernels_vs_function_goldens():
+    """mse / ce / cox / triplet / mmd / total against values produced by the reference's own functions."""
+    from flexynesis_amd import ops
+    dev = _dev()
+    g = Golden("functions")
+    d = lambda t: t.float().to(dev).contiguous()
+    one = lambda: torch.zeros(1, device=dev)
+    for tag in ("plain", "with_nan", "all_censored", "none_valid", "single_valid", "large_batch"):
+        c = g.sub(f"cox/{tag}")
+        o = d(c["outputs"])
+        lo, do = one(), torch.full_like(o, float("nan"))
+        ops.cox_ph(ops.IMMEDIATE, lo, do, o, d(c["durations"]), d(c["events"]))
+        close(lo, c["loss"], 1e-5, 1e-6, f"cox {tag}")
+        close(do, c["grad"], 1e-4, 1e-7, f"cox grad {tag}")
+    for tag in ("mse/plain", "mse/with_nan", "mse/all_missing"):
+        c = g.sub(tag)
+        yh = d(c["yhat"])
+        lo, dy = one(), torch.full_like(yh, float("nan"))
+        ops.mse_masked(ops.IMMEDIATE, lo, dy, yh, d(c["y"]))
+        close(lo, c["loss"], 1e-5, 1e-7, tag)
+        close(dy, c["grad"], 1e-4, 1e-7, tag + " grad")
+    for tag in ("ce/plain", "ce/with_missing", "ce/all_missing"):
+        c = g.sub(tag)
+        lg = d(c["yhat"])
+        lo, dl = one(), torch.full_like(lg, float("nan"))
+        ops.ce_masked(ops.IMMEDIATE, lo, dl, lg, d(c["y"]))
+        close(lo, c["loss"], 1e-5, 1e-7, tag)
+        close(dl, c["grad"], 1e-4, 1e-7, tag + " grad")
+    t = g.sub("triplet")
+    a, p, n = d(t["a"]), d(t["p"]), d(t["n"])
+    lo, da, dp, dn = one(), torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
+    ops.triplet(ops.IMMEDIATE, lo, da, dp, dn, a, p, n)
+    close(lo, t["loss"], 1e-5, 1e-7, "triplet")
+    close(da, t["grad_a"], 1e-4, 1e-7); close(dp, t["grad_p"], 1e-4, 1e-7); close(dn, t["grad_n"], 1e-4, 1e-7)
+    m = g.sub("mmd")
+    z, x, xh, prior = d(m["z"]), d(m["x"]), m["xhat"], d(m["prior"])
+    logits = d(torch.log(xh / (1 - xh)))           # xhat = sigmoid(logits)
+    P, B = prior.shape[0], z.shape[0]
+    rows, dz = torch.zeros(2 * (P + B), device=dev), torch.zeros_like(z)
+    part, dlg, lo = torch.zeros(1024, device=dev), torch.empty_like(logits), one()
+    ops.mmd_rows(ops.IMMEDIATE, rows, dz, prior, z)
+    nblk = int(ops.lib.fx_recon_blocks(logits.numel()))
+    ops.recon_sigmoid(ops.IMMEDIATE, part, dlg, None, logits, x)
+    ops.mmd_finalize(ops.IMMEDIATE, lo, rows, P, B, part, nblk, float(logits.numel()), 1.0, False)
+    close(lo, m["loss"], 1e-5, 1e-6, "mmd loss")
+    close(dz, m["grad_z"], 1e-4, 1e-8, "mmd dz")
+    close(dlg, m["grad_xhat"] * (xh * (1 - xh)), 2e-4, 1e-8, "recon dlogits")
+    tot = g.sub("total")
+    l1, l2 = d(tot["l1"].reshape(1)), d(tot["l2"].reshape(1))
+    s1, s2 = torch.tensor([0.3], device=dev), torch.tensor([-0.2], device=dev)
+    d1, d2, out = one(), one(), one()
+    ops.total_loss(ops.IMMEDIATE, out, [l1, l2], [s1, s2], [d1, d2], True)
+    close(out, tot["weighted"], 1e-6, 1e-7, "weighted total")
+    close(d1, 1 - np.exp(-0.3) * float(tot["l1"]), 1e-5, 1e-7, "dlogvar")
+    ops.total_loss(ops.IMMEDIATE, out, [l1], [], [], False)
+    close(out, tot["single"], 1e-6, 1e-7, "single total")
+
+
+def test_fused_dw_adam_matches_materialised():
+    """fx_linear_dw_adam_f32 == (dW GEMM, then flat Adam) on the same inputs."""
+    from flexynesis_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    B, n_out, k_in = 128, 300, 1100
+    dy, x = torch.randn(B, n_out, generator=g).to(dev), torch.randn(B, k_in, generator=g).to(dev)
+    W0 = torch.randn(n_out, k_in, generator=g).to(dev)
+    m0, v0 = torch.randn(n_out, k_in, generator=g).to(dev) * 0.01, torch.rand(n_out, k_in, generator=g).to(dev) * 1e-3
+    ctrl = torch.zeros(64, device=dev)
+    ctrl[0] = 4.0
+    ops.step_begin(ops.IMMEDIATE, ctrl, 1e-3)
+    ctrl[4] = 0.37
+    W1, m1, v1 = W0.clone(), m0.clone(), v0.clone()
+    ops.linear_dw_adam(ops.IMMEDIATE, W1, m1, v1, dy, x, ctrl)
+    dW = torch.empty_like(W0)
+    ops.linear_bwd_w(ops.IMMEDIATE, dW, dy, x, ops.Workspace(dev))
+    W2, m2, v2 = W0.clone(), m0.clone(), v0.clone()
+    ops.adam_flat(ops.IMMEDIATE, W2.view(-1), dW.view(-1), m2.view(-1), v2.view(-1), ctrl)
+    assert torch.equal(W1, W2) and torch.equal(m1, m2) and torch.equal(v1, v2)
+    # and both equal the textbook update in fp64
+    gd = (dy.double().t() @ x.double()) * 0.37
+    t = 5
+    mm = 0.9 * m0.double() + 0.1 * gd
+    vv = 0.999 * v0.double() + 0.001 * gd * gd
+    ref = W0.double() - (1e-3 / (1 - 0.9 ** t)) * mm / (vv.sqrt() / np.sqrt(1 - 0.999 ** t) + 1e-8)
+    close(W1, ref, 1e-5, 1e-6, "fused adam vs fp64")
+
+
+def test_gram_norm_identity():
+    """|dY^T X|_F^2 via the Gram identity equals the norm of the materialised gradient."""
+    from flexynesis_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(6)
+    B, H, F = 128, 700, 3000
+    dy, x = (torch.randn(B, H, generator=g) * 0.01).to(dev), torch.randn(B, F, generator=g).to(dev)
+    ws = ops.Workspace(dev)
+    gx, gd = torch.empty(B, B, device=dev), torch.empty(B, B, device=dev)
+    ops.gemm(ops.IMMEDIATE, ops.GEMM_NT, gx, x, x, None, ws)
+    ops.gemm(ops.IMMEDIATE, ops.GEMM_NT, gd, dy, dy, None, ws)
+    slot = torch.zeros(1, dtype=torch.float64, device=dev)
+    ops.hadamard_sum(ops.IMMEDIATE, slot, gx, gd)
+    ref = float(((dy.double().t() @ x.double()) ** 2).sum())
+    assert abs(float(slot) - ref) <= 2e-6 * ref
+
+
+def test_gather_rows_and_cursor():
+    from flexynesis_amd import ops
+    dev = _dev()
+    src = torch.randn(50, 36, device=dev)
+    idx = torch.randint(0, 50, (3 * 8,), device=dev)
+    dst = torch.empty(8, 36, device=dev)
+    ops.gather_rows(ops.IMMEDIATE, dst, src, idx)
+    assert torch.equal(dst, src[idx[:8]])
+    ctrl = torch.zeros(64, device=dev)
+    ctrl[8] = 2.0
+    ops.gather_rows(ops.IMMEDIATE, dst, src, idx, ctrl, 8)
+    assert torch.equal(dst, src[idx[16:24]])
+    lab = torch.randn(50, device=dev)
+    out = torch.empty(8, device=dev)
+    ops.gather_rows(ops.IMMEDIATE, out, lab, idx)
+    assert torch.equal(out, lab[idx[:8]])
+
+
+def test_bad_arguments_raise():
+    from flexynesis_amd import ops
+    from flexynesis_amd._lib import FxError
+    dev = _dev()
+    with pytest.raises(FxError):
+        ops.gemm(ops.IMMEDIATE, ops.GEMM_NT, torch.zeros(4, 4, device=dev), torch.zeros(4, 5, device=dev),
+                 torch.zeros(3, 5, device=dev), None, None)
+    with pytest.raises(FxError):
+        ops.gemm(ops.IMMEDIATE, ops.GEMM_NT, torch.zeros(4, 4), torch.zeros(4, 5), torch.zeros(4, 5), None, None)
+    with pytest.raises(FxError):
+        ops.cox_ph(ops.IMMEDIATE, torch.zeros(1, device=dev), torch.zeros(2000, 1, device=dev),
+                   torch.zeros(2000, 1, device=dev), torch.zeros(2000, device=dev), torch.zeros(2000, device=dev))
+
+
+# ---------------------------------------------------------------------------------------------------
+# whole training steps vs the reference goldens
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("case", MODEL_CASES)
+def test_train_step_matches_reference_golden(case, fused):
+    """Per-step parity: every step starts from the reference's previous state + Adam moments."""
+    from flexynesis_amd.engine import ParamStore, StepPlan
+    g = Golden(case)
+    spec = arch_from_golden(g)
+    B = next(iter(g.batch(0)["y"].values())).shape[0]
+    # big_threshold small enough that the wide first layers take the fused dW+Adam path
+    store = ParamStore(spec, _dev(), big_threshold=512)
+    plan = StepPlan(store, B, train=True, fused=fused, supplied_draws=True)
+    for s in range(g.n_steps):
+        store.load_state(g.state0() if s == 0 else g.exp(s - 1, "state"))
+        store.reset_optimizer()
+        t, m, v = golden_opt(g, s - 1)
+        store.load_optimizer(t, m, v)
+        feed(plan, g.spec, g.batch(s), g.draws(s))
+        plan.train_step(g.lr)
+        got = plan.losses()
+        for k, val in g.exp(s, "loss").items():
+            close(got[k], val, LOSS_RTOL, 1e-6, f"{case} step{s} loss {k}")
+        exp_grads, gn = g.exp(s, "grad"), g.get(f"exp/{s}/grad_norm")
+        close(store.ctrl[5], gn, 1e-4, 1e-7, "grad norm")
+        if not fused:
+            for k, val in exp_grads.items():
+                close(store.g(k), val, 1e-3, 2e-6, f"{case} step{s} grad {k}")
+        st = store.state_dict()
+        for k, val in g.exp(s, "state").items():
+            close(st[k], val, 2e-4, noise_atol(exp_grads.get(k), gn, g.lr, 3e-6), f"{case} step{s} state {k}")
+        for k, val in g.exp(s, "m").items():
+            close(store.m(k), val, 1e-3, 3e-7, f"{case} step{s} exp_avg {k}")
+        for k, val in g.exp(s, "v").items():
+            close(store.v(k), val, 2e-3, 1e-9, f"{case} step{s} exp_avg_sq {k}")
+
+
+@pytest.mark.parametrize("case", MODEL_CASES)
+def test_free_running_trajectory_and_validation(case):
+    from flexynesis_amd.engine import ParamStore, StepPlan
+    g = Golden(case)
+    spec = arch_from_golden(g)
+    B = next(iter(g.batch(0)["y"].values())).shape[0]
+    store = ParamStore(spec, _dev(), big_threshold=512)
+    store.load_state(g.state0())
+    plan = StepPlan(store, B, train=True, fused=True, supplied_draws=True)
+    for s in range(g.n_steps):
+        feed(plan, g.spec, g.batch(s), g.draws(s))
+        plan.train_step(g.lr)
+        got = plan.losses()
+        for k, val in g.exp(s, "loss").items():
+            close(got[k], val, 2e-4, 2e-6, f"{case} free-run step{s} loss {k}")
+    # num_batches_tracked bookkeeping (triplet encoders see 3 BN passes per step, triplet_encoder.py:153-155)
+    final = g.exp(g.n_steps - 1, "state")
+    sd = store.state_dict()
+    for k in sd:
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == int(final[k]), k
+    # validation_step arithmetic (eval-mode BN/dropout, unweighted sum) from the reference's final state
+    store.load_state(final)
+    ev = StepPlan(store, B, train=False, supplied_draws=True)
+    feed(ev, g.spec, g.batch(0), g.sub("draws/val"))
+    ev.forward()
+    got = ev.losses()
+    for k, val in g.sub("exp/val/loss").items():
+        close(got[k], val, LOSS_RTOL, 1e-6, f"{case} val {k}")
+
+
+# ---------------------------------------------------------------------------------------------------
+# HIP engine vs the CPU oracle at larger, BASELINE-shaped sizes
+# ---------------------------------------------------------------------------------------------------
+def _oracle_spec(aspec):
+    from oracle.restate import Spec
+    return Spec(aspec.model, list(aspec.layers), aspec.latent_dim, aspec.hidden_dim_factor,
+                aspec.supervisor_hidden_dim, list(aspec.variables), aspec.surv_event_var, aspec.surv_time_var,
+                aspec.use_loss_weighting)
+
+
+@pytest.mark.parametrize("model,layers,B", [
+    ("DirectPred", [("gex", 5000)], 32),                                   # BASELINE cfg1 shape
+    ("DirectPred", [("gex", 4000), ("cnv", 3000)], 128),                   # cfg2 family (scaled to oracle-seconds)
+    ("supervised_vae", [("gex", 2000), ("cnv", 1600)], 64),                # cfg3 family
+    ("MultiTripletNetwork", [("gex", 1500), ("cnv", 1200), ("meth", 900)], 32),   # cfg4 family
+])
+def test_engine_vs_oracle_three_steps(model, layers, B):
+    from flexynesis_amd.arch import ArchSpec
+    from flexynesis_amd.engine import ParamStore, StepPlan
+    from oracle import restate as O
+    dev = _dev()
+    if model == "DirectPred" and len(layers) == 1:
+        variables = [("y", "numerical", 1)]
+        surv = (None, None)
+    elif model == "DirectPred":
+        variables = [("y", "numerical", 1), ("c", "categorical", 4)]
+        surv = (None, None)
+    elif model == "supervised_vae":
+        variables = [("c", "categorical", 4), ("event", "numerical", 1)]
+        surv = ("event", "time")
+    else:
+        variables = [("c", "categorical", 4), ("y", "numerical", 1)]
+        surv = (None, None)
+    aspec = ArchSpec(model, layers, 64, 0.25, 16, variables, surv[0], surv[1], True)
+    ospec = _oracle_spec(aspec)
+    dat, ann = O.synthetic_cohort(layers, 512, seed=1234)
+    st = O.init_state(ospec, seed=3)
+    store = ParamStore(aspec, dev)
+    store.load_state(st)
+    plan = StepPlan(store, B, train=True, fused=True, supplied_draws=True)
+    gen = torch.Generator().manual_seed(99)
+    opt, lr = {}, 1e-3
+    for step in range(3):
+        idx = torch.randperm(512, generator=gen)
+        y = {k: ann[k][idx[:B]] for k in plan.y}
+        draws = {}
+        for name, t in plan.draws.items():
+            if name == "eps" or name.startswith("prior."):
+                draws[name] = torch.randn(t.shape, generator=gen)
+            else:
+                draws[name] = (torch.rand(t.shape, generator=gen) < 0.9).float()
+        if model == "MultiTripletNetwork":
+            parts = [[dat[n][idx[j * B:(j + 1) * B]] for n, _ in layers] for j in range(3)]
+            batch = {"anchor": parts[0], "positive": parts[1], "negative": parts[2], "y": y}
+            plan.set_batch(parts=[[x.to(dev) for x in p] for p in parts], y={k: v.to(dev) for k, v in y.items()})
+        else:
+            xs = [dat[n][idx[:B]] for n, _ in layers]
+            batch = {"x": xs, "y": y}
+            plan.set_batch(x_list=[x.to(dev) for x in xs], y={k: v.to(dev) for k, v in y.items()})
+        plan.set_draws({k: v.to(dev) for k, v in draws.items()})
+        plan.train_step(lr)
+        st, opt, info = O.train_step(ospec, st, opt, batch, draws, lr)
+        got = plan.losses()
+        for k, v in info["losses"].items():
+            close(got[k], v, LOSS_RTOL, 1e-6, f"{model} step{step} loss {k}")
+        # torch-CPU's fp32 vector_norm over millions of elements is itself ~2e-4 off the exact value
+        # (measured: engine 22.892700 == fp64 oracle 22.892700, fp32 oracle 22.88873),
+        # so the global norm is gated at 5e-4 against the fp32 oracle; the losses carry the 1e-4 gate.
+        close(store.ctrl[5], info["grad_norm"], 5e-4, 1e-7, "grad_norm")
+    # after 3 steps the wide weights must still agree element-wise
+    sd = store.state_dict()
+    for k in store.big_keys:
+        close(sd[k], st[k], 1e-3, 2e-5, f"{model} {k} after 3 steps")
