@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""Headline benchmark: training samples/sec of the DirectPred hot path on synthetic
+2-omics x 20k-feature cohorts (BASELINE.json configs[1]) on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one full optimisation step of the hot path on one batch of B=128 samples already resident in
+HBM: cursor advance, on-device batch gather, forward, losses, backward, global-norm clip, Adam -- all
+hand-written HIP kernels replayed from one hipGraph.  Multi-GPU: one process per GPU, each rank trains
+its own independent trial on its own cohort replica (trial sharding, SURVEY.md section 8e: no data-path
+collective); value = total samples of all ranks / max-over-ranks wall time ("weak" scaling).
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel fx_linear_dw_adam_f32, HIP-event timed)
+and `cpu_baseline` (the oracle's CPU training loop timed on this box's host cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+CONFIGS = {
+    # BASELINE.json configs[1]: DirectPred, 2 omics (gex+cnv, 20000 feat each), intermediate fusion
+    "cfg2": dict(model="DirectPred", layers=[("gex", 20000), ("cnv", 20000)],
+                 variables=[("y", "numerical", 1)], surv=(None, None), n_samples=2048),
+    # configs[0] plumbing case (reference's CPU-runnable shape)
+    "cfg1": dict(model="DirectPred", layers=[("gex", 5000)], variables=[("y", "numerical", 1)], surv=(None, None),
+                 n_samples=500),
+    "cfg3": dict(model="supervised_vae", layers=[("gex", 20000), ("cnv", 20000)],
+                 variables=[("c", "categorical", 4), ("event", "numerical", 1)], surv=("event", "time"),
+                 n_samples=2048),
+    "cfg4": dict(model="MultiTripletNetwork", layers=[("gex", 30000), ("cnv", 30000), ("meth", 30000)],
+                 variables=[("c", "categorical", 4)], surv=(None, None), n_samples=2048),
+}
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+DOMINANT = "fx_linear_dw_adam_f32"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-graph", action="store_true", help="launch the recorded tapes eagerly instead of a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=0, help="CPU baseline steps (0 = auto, about 10-30 s)")
+    ap.add_argument("--lr", type=float, default=1e-3)
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from flexynesis_amd import ops
+    from flexynesis_amd.arch import ArchSpec
+    from flexynesis_amd.data import synthetic_cohort
+    from flexynesis_amd.engine import ParamStore, StepPlan
+
+    cfg = CONFIGS[a.config]
+    B = a.batch
+    spec = ArchSpec(cfg["model"], cfg["layers"], 64, 0.25, 16, cfg["variables"], cfg["surv"][0], cfg["surv"][1], True)
+    cohort = synthetic_cohort(cfg["layers"], cfg["n_samples"], dev, seed=1234 + rank)
+    n_train = cfg["n_samples"] - int(cfg["n_samples"] * 0.2)           # 80/20 split, reference main.py:272-276
+    rows_per_batch = B * (3 if cfg["model"] == "MultiTripletNetwork" else 1)
+    n_batches = max(n_train // rows_per_batch, 1)                      # drop_last=True, reference main.py:294
+    torch.manual_seed(1000 + rank)
+    store = ParamStore(spec, dev, materialize_big_grads=False)
+    plan = StepPlan(store, B, train=True, fused=True, supplied_draws=False, seed=17 + rank, cohort=cohort,
+                    n_batches=n_batches, epoch_acc=True)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(4321 + rank)
+
+    def reshuffle():
+        """shuffle=True: a fresh permutation of the training split per epoch, drawn on the device."""
+        perm = torch.randperm(n_train, generator=gen, device=dev)
+        plan.idx.copy_(perm[:n_batches * rows_per_batch])
+
+    reshuffle()
+    use_graph = not a.no_graph
+    if use_graph:
+        plan.capture(a.lr)
+        step = plan.replay
+    else:
+        step = lambda: plan.train_step(a.lr, gather=True)
+
+    def run(k):
+        for i in range(k):
+            if int(i) % n_batches == 0:
+                reshuffle()
+            step()
+
+    run(a.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(a.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    losses = plan.losses()
+    finite = all(v == v and abs(v) != float("inf") for v in losses.values())
+
+    # ---- dominant-kernel timing with HIP events on the launch stream (eager re-issue of the same tapes)
+    roof = None
+    if rank == 0:
+        sink = []
+        for i in range(min(a.steps, 20)):
+            ops.step_begin(ops.IMMEDIATE, store.ctrl, a.lr, n_batches)
+            plan.t_gather.run()
+            plan.t_fwd.run()
+            plan.t_bwd.run()
+            plan.t_opt.run_timed({DOMINANT}, sink)
+        torch.cuda.synchronize()
+        if sink:
+            ms = [e0.elapsed_time(e1) for _, e0, e1 in sink]
+            avg_ms = sum(ms) / len(ms)
+            big_elems = [store.big[k]["W"].numel() for k in store.big_keys]
+            bytes_per_launch = 24.0 * sum(big_elems) / len(big_elems)   # read+write of W, m, v (fp32)
+            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": DOMINANT, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(ms),
+                    "algorithmic_bytes_per_launch": bytes_per_launch}
+    P = store.n_params()
+    sumF = sum(F for _, F in cfg["layers"])
+    k_reads = 3 if cfg["model"] == "MultiTripletNetwork" else 1
+    bytes_step = 28.0 * P + 4.0 * k_reads * B * sumF
+    ms_per_step = 1e3 * elapsed / a.steps
+    value = world * a.steps * B / elapsed
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        try:
+            from oracle import cpu_baseline, restate as O
+            ospec = O.Spec(cfg["model"], cfg["layers"], 64, 0.25, 16, cfg["variables"], cfg["surv"][0], cfg["surv"][1], True)
+            threads = min(os.cpu_count() or 1, 64)
+            steps = a.cpu_steps or (6 if a.config != "cfg1" else 100)
+            r = cpu_baseline.time_training(ospec, cfg["n_samples"], B, steps=steps, warmup=1, threads=threads, lr=a.lr)
+            cpu = {"value": round(r["samples_per_s"], 2), "unit": "samples/s", "cores": r["threads"], "kind": "port",
+                   "sample": f"{r['steps']} optimisation steps (after 1 warm-up) of the same {a.config} workload, "
+                             f"B={B}, torch-CPU fp32 'highest', {r['ms_per_step']:.0f} ms/step"}
+        except Exception as e:  # the baseline is reported, never required
+            cpu = {"value": None, "unit": "samples/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
+
+    if rank == 0:
+        out = {
+            "metric": "training samples/sec (2-omics x 20k-feat DirectPred)" if a.config == "cfg2"
+            else f"training samples/sec ({a.config})",
+            "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.config}: {cfg['model']} {len(cfg['layers'])} omics x "
+                                   f"{cfg['layers'][0][1]} features, N={cfg['n_samples']}, B={B}, latent 64, "
+                                   f"hidden_dim_factor 0.25, lr {a.lr}, clip 1.0 + Adam, "
+                                   f"{'hipGraph replay' if use_graph else 'eager tapes'}",
+                       "params": P, "global_batch": B * world, "parallelism": f"{world} independent trials (trial sharding)",
+                       "launches_per_step": plan.n_launches(), "algorithmic_bytes_per_step": bytes_step,
+                       "step_hbm_frac_of_8TBs": round(bytes_step / (ms_per_step * 1e-3) / 8e12, 4),
+                       "loss_finite": finite, "last_losses": {k: round(v, 6) for k, v in losses.items()}},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -73,6 +73,22 @@ class TapeRecorder:
             if rc != 0:
                 raise FxError(f"{name} failed (rc={rc}): {_lib.last_error()}")
 
+    def run_timed(self, names, sink):
+        """Like run(), but brackets every launch whose entry-point name is in ``names`` with a pair of
+        HIP events recorded on the launch stream; (name, start, end) tuples are appended to ``sink``."""
+        s = _stream()
+        for fn, name, args in self.calls:
+            if name in names:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = fn(*args, s)
+                e1.record()
+                sink.append((name, e0, e1))
+            else:
+                rc = fn(*args, s)
+            if rc != 0:
+                raise FxError(f"{name} failed (rc={rc}): {_lib.last_error()}")
+
     def __len__(self):
         return len(self.calls)
 
@@ -89,6 +105,8 @@ class Workspace:
 
     def reserve(self, nbytes: int):
         if nbytes > self.buf.numel() * 4:
+            # tapes recorded earlier hold raw pointers into the previous buffer: keep it alive
+            self._retired = getattr(self, "_retired", []) + [self.buf]
             self.buf = torch.empty(nbytes // 4 + 4, dtype=torch.float32, device=self.device)
 
     @property
