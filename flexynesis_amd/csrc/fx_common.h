@@ -31,6 +31,7 @@ enum FxCtrl {
   FXC_SUMSQ = 6,     // reserved
   FXC_LOSS_TOTAL = 7,
   FXC_BATCH_CURSOR = 8,  // float index of the current batch in the permutation buffer
+  FXC_CURSOR_BASE = 9,   // step count at which the current fit() started (cursor = (t-1-base) mod n_batches)
   FXC_SIZE = 64
 };
 

@@ -35,7 +35,7 @@ __global__ void fx_step_begin_kernel(float* ctrl, float lr, int n_batches) {
   ctrl[FXC_BC2_SQRT] = (float)sqrt(1.0 - pow((double)FX_BETA2, (double)t));
   ctrl[FXC_CLIP_COEF] = 1.0f;
   ctrl[FXC_GNORM] = 0.0f;
-  if (n_batches > 0) ctrl[FXC_BATCH_CURSOR] = (float)(((long)t - 1) % n_batches);
+  if (n_batches > 0) ctrl[FXC_BATCH_CURSOR] = (float)(((long)t - 1 - (long)ctrl[FXC_CURSOR_BASE]) % n_batches);
 }
 
 // ---- sum of squares into double-precision slots ------------------------------------------------------

@@ -595,17 +595,19 @@ class StepPlan:
         self.t_opt.run()
         self.bump_nbt()
 
-    def capture(self, lr: float, gather: bool = True):
-        """Capture the whole step (cursor advance, gather, fwd, bwd, clip, Adam) into one hipGraph."""
+    def capture(self, lr: float, gather: bool = True, warmup: bool = True):
+        """Capture the whole step (cursor advance, gather, fwd, bwd, clip, Adam) into one hipGraph.
+        ``warmup=True`` first runs one REAL step eagerly on a side stream (loads the code objects);
+        pass ``warmup=False`` when an eager step has already been run (fit() does: its first step is eager)."""
         torch.cuda.synchronize()
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            self._step_for_capture(lr, gather)          # warm-up outside capture (lazy module loads)
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        # undo the warm-up step's side effects on the step counter only (parameters moved one step; callers
-        # capture before training starts or accept the extra step)
+        if warmup:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self._step_for_capture(lr, gather)
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            self.bump_nbt()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self._step_for_capture(lr, gather)

@@ -1,0 +1,306 @@
+"""Shared machinery of the three hot-path model classes.
+
+The classes keep the reference's LightningModule-style API surface (constructor kwargs, attributes,
+``forward`` / ``training_step`` / ``validation_step`` / ``configure_optimizers`` / ``predict`` /
+``transform``; reference models/direct_pred.py:30-415) but every step runs as a
+recorded tape of HIP kernels (engine.StepPlan).  Parameters are ordinary ``nn.Parameter``s held by
+torch ``nn.Linear`` / ``nn.BatchNorm1d`` containers with the reference's names; once the model is on a
+GPU they are re-pointed into the engine's flat arenas (``ParamStore``), so ``state_dict`` /
+``load_state_dict`` / ``parameters()`` / ``requires_grad`` keep working while the kernels see contiguous
+arenas.
+"""
+from __future__ import annotations
+
+import copy
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import ops
+from ..arch import ArchSpec, is_buffer_key, spec_from_dataset
+from ..engine import ParamStore, StepPlan
+
+try:  # subclass the real LightningModule when the package exists (it is absent in the build image)
+    import lightning as _pl
+    _Base = _pl.LightningModule
+except Exception:  # pragma: no cover - exercised in this image
+    class _Base(nn.Module):
+        """Duck-typed stand-in for lightning.LightningModule: nn.Module + log_dict/log + .device."""
+
+        def log_dict(self, d, *a, **k):
+            self._logged = {k_: (float(v.detach().reshape(-1)[0]) if torch.is_tensor(v) else float(v))
+                            for k_, v in d.items()}
+
+        def log(self, name, value, *a, **k):
+            self._logged = getattr(self, "_logged", {})
+            self._logged[name] = float(value)
+
+        @property
+        def device(self):
+            try:
+                return next(self.parameters()).device
+            except StopIteration:
+                return torch.device("cpu")
+
+
+def resolve_device(device_type) -> torch.device:
+    """'gpu' / 'cuda' / 'cuda:N' / None / 'auto' -> a HIP device (ROCm reports as torch.cuda, same strings as
+    reference utils.py:2198-2238).  There is no CPU execution path."""
+    if device_type in (None, "auto", "gpu", "cuda"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("flexynesis_amd needs an AMD GPU visible to PyTorch-ROCm (no CPU fallback)")
+        return torch.device("cuda", torch.cuda.current_device())
+    d = torch.device(device_type)
+    if d.type != "cuda":
+        raise RuntimeError(f"flexynesis_amd has no '{d.type}' execution path; use the reference for CPU/MPS runs")
+    return d
+
+
+class _PlanLoss(torch.autograd.Function):
+    """Connects a recorded StepPlan to autograd: forward has already run the forward tape; backward runs
+    the backward tape (hand-written HIP kernels, gradients materialised in the arenas) and hands a copy
+    of each gradient to autograd so that ``loss.backward()`` / Lightning / torch optimisers work."""
+
+    @staticmethod
+    def forward(ctx, model, plan, *params):
+        ctx.model, ctx.plan = model, plan
+        n = len(plan.spec.loss_names())
+        return plan.loss_vec[n:n + 1].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        model, plan = ctx.model, ctx.plan
+        plan.backward()
+        scale = gout.reshape(-1)[0]
+        grads = []
+        weighted = plan.spec.weighted
+        for key, p in model._param_items():
+            if not p.requires_grad:
+                grads.append(None)
+                continue
+            if key.startswith("log_vars.") and not weighted:
+                grads.append(None)          # reference: log_vars get no grad with a single loss term
+                continue
+            grads.append(model._store.g(key).clone() * scale)
+        return (None, None, *grads)
+
+
+class FxModel(_Base):
+    MODEL = None  # "DirectPred" | "supervised_vae" | "MultiTripletNetwork"
+
+    def __init__(self, config, dataset, target_variables, batch_variables=None, surv_event_var=None,
+                 surv_time_var=None, use_loss_weighting=True, device_type=None):
+        super().__init__()
+        self.config = config
+        self.target_variables = list(target_variables)
+        self.surv_event_var = surv_event_var
+        self.surv_time_var = surv_time_var
+        if surv_event_var is not None and surv_time_var is not None:
+            self.target_variables = self.target_variables + [surv_event_var]
+        self.batch_variables = batch_variables
+        self.variables = self.target_variables + list(batch_variables) if batch_variables else self.target_variables
+        self.feature_importances = {}
+        self.use_loss_weighting = use_loss_weighting
+        self.device_type = device_type
+        self.variable_types = dataset.variable_types
+        self.ann = dataset.ann
+        self.layers = list(dataset.dat.keys())
+        self.input_dims = [len(dataset.features[l]) for l in self.layers]
+        self.spec: ArchSpec = spec_from_dataset(self.MODEL, config, dataset, target_variables, batch_variables,
+                                                surv_event_var, surv_time_var, use_loss_weighting)
+        if self.use_loss_weighting:
+            self.log_vars = nn.ParameterDict({n: nn.Parameter(torch.zeros(1)) for n in self.spec.logvar_names()})
+        self._build_modules()
+        self._store: Optional[ParamStore] = None
+        self._plans: Dict[tuple, StepPlan] = {}
+        self._seed = int(torch.initial_seed() % (2 ** 31))
+        keys = [k for k, _ in self.state_dict().items()]
+        want = list(self.spec.state_shapes().keys())
+        assert sorted(keys) == sorted(want), (set(keys) ^ set(want))
+
+    # -- module construction is subclass-specific -------------------------------------------------------
+    def _build_modules(self):
+        raise NotImplementedError
+
+    # -- arena binding ------------------------------------------------------------------------------------
+    def _param_items(self):
+        return list(self.named_parameters())
+
+    def _bind(self, device=None) -> ParamStore:
+        """Move parameters/buffers into the engine arenas on ``device`` (idempotent)."""
+        dev = resolve_device(device if device is not None else self.device_type)
+        if self._store is not None and self._store.device == dev:
+            return self._store
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        store = ParamStore(self.spec, dev, materialize_big_grads=False)
+        store.load_state(sd)
+        for k, p in self.named_parameters():
+            p.data = store.p(k)
+        for k, b in self.named_buffers():
+            if not k.endswith("num_batches_tracked"):
+                b.data = store.b(k)
+            else:
+                b.data = b.data.to(dev)
+        self._store, self._plans = store, {}
+        return store
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        # .to()/.cuda()/.cpu() replace parameter storage: the arenas are stale after any such move
+        self._store, self._plans = None, {}
+        return out
+
+    def __deepcopy__(self, memo):
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k in ("_store", "_plans"):
+                continue
+            setattr(new, k, copy.deepcopy(v, memo))
+        new._store, new._plans = None, {}
+        # cloned parameters may still alias one cloned arena; give each its own storage
+        for p in new.parameters():
+            p.data = p.data.clone()
+        for b in new.buffers():
+            b.data = b.data.clone()
+        return new
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_store"], st["_plans"] = None, {}
+        return st
+
+    def _sync_nbt(self):
+        if self._store is None:
+            return
+        for k, b in self.named_buffers():
+            if k.endswith("num_batches_tracked"):
+                b.fill_(self._store.nbt[k])
+
+    def _plan(self, B: int, train: bool, fused: bool = False) -> StepPlan:
+        store = self._bind()
+        for k, b in self.named_buffers():           # pick up externally loaded counters
+            if k.endswith("num_batches_tracked"):
+                store.nbt[k] = int(b)
+        key = (int(B), bool(train), bool(fused))
+        if key not in self._plans:
+            self._plans[key] = StepPlan(store, B, train=train, fused=fused, supplied_draws=False,
+                                        seed=self._seed + len(self._plans))
+        return self._plans[key]
+
+    # -- batch plumbing -------------------------------------------------------------------------------------
+    def _feed(self, plan: StepPlan, batch):
+        dev = plan.dev
+        if self.MODEL == "MultiTripletNetwork":
+            anchor, pos, neg, y = batch[0], batch[1], batch[2], batch[3]
+            parts = [[torch.as_tensor(d[l]).to(dev, torch.float32) for l in self.layers] for d in (anchor, pos, neg)]
+            plan.set_batch(parts=parts, y={k: torch.as_tensor(v).to(dev) for k, v in y.items() if k in plan.y})
+        else:
+            dat, y = batch[0], batch[1]
+            xs = [torch.as_tensor(dat[l]).to(dev, torch.float32) for l in dat.keys()]
+            plan.set_batch(x_list=xs, y={k: torch.as_tensor(v).to(dev) for k, v in y.items() if k in plan.y})
+
+    @staticmethod
+    def _batch_size(batch):
+        first = batch[0]
+        return int(next(iter(first.values())).shape[0])
+
+    def _named_losses(self, plan, total_name):
+        vals = plan.loss_vec.detach().clone()
+        names = self.spec.loss_names()
+        d = {n: vals[i] for i, n in enumerate(names)}
+        d[total_name] = vals[len(names)]
+        return d
+
+    # -- LightningModule protocol ------------------------------------------------------------------------------
+    def configure_optimizers(self):
+        """Adam(lr) as the reference (models/direct_pred.py:135-144); it updates the arena views in place."""
+        return torch.optim.Adam(self.parameters(), lr=self.config["lr"])
+
+    def training_step(self, train_batch, batch_idx, log=True):
+        plan = self._plan(self._batch_size(train_batch), train=True, fused=False)
+        self._feed(plan, train_batch)
+        plan.forward()
+        plan.bump_nbt()
+        self._sync_nbt()
+        params = [p for _, p in self._param_items()]
+        total = _PlanLoss.apply(self, plan, *params)
+        if not self.spec.weighted:
+            total = total.reshape(())        # the reference's unweighted total is 0-dim, the weighted one is [1]
+        if log:
+            self.log_dict(self._named_losses(plan, "train_loss"), on_step=False, on_epoch=True, prog_bar=True)
+        return total
+
+    def validation_step(self, val_batch, batch_idx, log=True):
+        was_training = self.training
+        plan = self._plan(self._batch_size(val_batch), train=False)
+        self._feed(plan, val_batch)
+        plan.forward()
+        losses = self._named_losses(plan, "val_loss")
+        if log:
+            self.log_dict(losses, on_step=False, on_epoch=True, prog_bar=True)
+        if was_training:
+            self.train()
+        return losses["val_loss"]
+
+    # -- inference helpers ----------------------------------------------------------------------------------------
+    def _eval_batches(self, dataset, batch_size=64):
+        n = len(dataset)
+        for s in range(0, n, batch_size):
+            idx = list(range(s, min(s + batch_size, n)))
+            dat = {l: torch.stack([torch.as_tensor(dataset.dat[l][i]) for i in idx]) for l in dataset.dat.keys()}
+            yield idx, dat
+
+    def _run_eval(self, dat):
+        B = int(next(iter(dat.values())).shape[0])
+        plan = self._plan(B, train=False)
+        if self.MODEL == "MultiTripletNetwork":
+            xs = [torch.as_tensor(dat[l]).to(plan.dev, torch.float32) for l in self.layers]
+            plan.set_batch(parts=[xs, xs, xs], y=None)
+        else:
+            plan.set_batch(x_list=[torch.as_tensor(dat[l]).to(plan.dev, torch.float32) for l in dat.keys()], y=None)
+        for t in plan.y.values():          # labels are irrelevant for predictions: mark them missing
+            t.fill_(float("nan"))
+        plan.forward()
+        return plan
+
+    def predict(self, dataset):
+        """{var: np.ndarray} -- softmax probabilities for categorical heads, raw outputs for numerical
+        (reference models/direct_pred.py:296-351), batches of 64, eval mode."""
+        self.eval()
+        preds = {v: [] for v in self.variables}
+        for _, dat in self._eval_batches(dataset, 64):
+            plan = self._run_eval(dat)
+            for v in self.variables:
+                o = plan.buf[f"MLPs.{v}/out"].detach()
+                if dataset.variable_types[v] == "categorical":
+                    o = torch.softmax(o, dim=1)
+                preds[v].extend(o.cpu().numpy())
+        return {v: np.array(a) for v, a in preds.items()}
+
+    def transform(self, dataset):
+        """Latent embeddings as a DataFrame E0..E{L-1} indexed by sample (reference direct_pred.py:353-415)."""
+        import pandas as pd
+        self.eval()
+        chunks = []
+        for _, dat in self._eval_batches(dataset, 64):
+            plan = self._run_eval(dat)
+            chunks.append(plan.embeddings.detach().cpu().clone())
+        emb = torch.cat(chunks, 0).numpy()
+        return pd.DataFrame(emb, index=list(dataset.samples), columns=[f"E{i}" for i in range(emb.shape[1])])
+
+    def compute_feature_importance(self, *a, **k):
+        raise NotImplementedError(
+            "Captum attributions (reference direct_pred.py:418-590) are outside the hot path this package "
+            "implements; load the trained state_dict into the reference model to run them")
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        if self._store is not None:
+            for k, b in self.named_buffers():
+                if k.endswith("num_batches_tracked"):
+                    self._store.nbt[k] = int(b)
+        return out

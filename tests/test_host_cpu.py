@@ -1,0 +1,242 @@
+"""CPU-only tests (no GPU, no compute calls into the HIP kernels): the C-ABI library loads and exports
+every symbol include/fxhip.h declares, the host-side mirror of the reference interface (architecture
+derivation, state_dict layout, dataset contract, model-class attribute surface, triplet sampling rules)
+and the multi-process trial sharding on the gloo backend (world_size 2)."""
+import copy
+import os
+import pickle
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from golden_io import Golden, MODEL_CASES
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    import ctypes
+    from flexynesis_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "fxhip.h")).read()
+    declared = set(re.findall(r"\b(fx_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/fxhip.h but not exported by libfxhip.so"
+    assert _lib.lib.fx_version() >= 100
+    # argument validation happens before any launch, so it is testable without a GPU
+    assert _lib.lib.fx_gemm_f32(7, None, None, None, None, 1, 1, 1, 1, 1, 1, 0, None, 0, None) == -22
+    assert b"layout" in _lib.lib.fx_last_error_string()
+    assert _lib.lib.fx_cox_ph(None, None, None, None, None, 5, 1, 1, None, 1.0, None) == -22
+    assert _lib.lib.fx_gemm_workspace_bytes(128, 5000, 20000) > 0
+    assert _lib.lib.fx_gemm_workspace_bytes(5000, 20000, 128) == 0
+
+
+def test_no_product_module_imports_the_oracle():
+    pkg = os.path.join(ROOT, "flexynesis_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
+                assert "/root/reference" not in src, f
+
+
+@pytest.mark.parametrize("case", MODEL_CASES)
+def test_arch_state_layout_matches_reference_state_dict(case):
+    from flexynesis_amd.arch import ArchSpec
+    g = Golden(case)
+    s = g.spec
+    a = ArchSpec(s.model, list(s.layers), s.latent_dim, s.hidden_dim_factor, s.supervisor_hidden_dim,
+                 list(s.variables), s.surv_event_var, s.surv_time_var, s.use_loss_weighting)
+    ref = {k: tuple(v.shape) for k, v in g.state0().items()}
+    assert a.state_shapes() == ref
+    assert a.loss_names() == [k for k in _loss_order(g)]
+
+
+def _loss_order(g):
+    names = [k for k in g.exp(0, "loss") if k != "total"]
+    spec = g.spec
+    return spec.loss_names() if set(names) == set(spec.loss_names()) else names
+
+
+def _toy_dataset(n=24, missing_label=False):
+    from flexynesis_amd.data import MultiOmicDataset
+    g = torch.Generator().manual_seed(0)
+    dat = {"gex": torch.randn(n, 40, generator=g), "cnv": torch.randn(n, 24, generator=g)}
+    c = (torch.arange(n) % 3).float()
+    if missing_label:
+        c[5] = float("nan")
+    ann = {"y": torch.randn(n, generator=g), "c": c, "event": (torch.rand(n, generator=g) < 0.5).float(),
+           "time": torch.rand(n, generator=g) * 5}
+    vt = {"y": "numerical", "c": "categorical", "event": "numerical", "time": "numerical"}
+    feats = {k: [f"{k}_{i}" for i in range(v.shape[1])] for k, v in dat.items()}
+    return MultiOmicDataset(dat, ann, vt, feats, [f"s{i}" for i in range(n)], {"c": {0: "a", 1: "b", 2: "c"}})
+
+
+def test_dataset_contract():
+    ds = _toy_dataset()
+    dat, ann, sid = ds[3]
+    assert set(dat) == {"gex", "cnv"} and dat["gex"].shape == (40,) and sid == "s3"
+    assert set(ann) == {"y", "c", "event", "time"}
+    sub = ds.subset([1, 5, 7])
+    assert len(sub) == 3 and sub.samples == ["s1", "s5", "s7"] and torch.equal(sub.dat["cnv"][1], ds.dat["cnv"][5])
+    assert ds.get_dataset_stats()["sample_count"] == 24
+    from torch.utils.data import DataLoader
+    b = next(iter(DataLoader(ds, batch_size=8)))
+    assert b[0]["gex"].shape == (8, 40) and b[1]["y"].shape == (8,) and len(b[2]) == 8
+
+
+def test_triplet_dataset_index_semantics_match_reference_golden():
+    """label -> indices map incl. the "NA" group, valid anchors (reference data.py:1102-1151; golden from
+    the reference's own TripletMultiOmicDataset)."""
+    from flexynesis_amd.data import MultiOmicDataset, TripletMultiOmicDataset
+    g = Golden("functions")
+    lab = g.get("tripletds/labels")
+    ds = MultiOmicDataset({"gex": torch.randn(len(lab), 4)}, {"c": lab}, {"c": "categorical"},
+                          {"gex": list("abcd")}, [f"s{i}" for i in range(len(lab))], {})
+    t = TripletMultiOmicDataset(ds, "c")
+    assert t.valid_indices == g.get("tripletds/valid_indices").tolist()
+    ref = g.sub("tripletds/idx")
+    assert {str(k) for k in t.label_to_indices} == set(ref)
+    for k, idx in t.label_to_indices.items():
+        assert idx.tolist() == ref[str(k)].tolist()
+    np.random.seed(0)
+    import random
+    random.seed(0)
+    for i in range(len(t)):
+        a, p, n = t.sample_indices(i)
+        la, lp, ln = float(lab[a]), float(lab[p]), float(lab[n])
+        assert a != p and la == lp and (np.isnan(ln) or ln != la)
+        anchor, pos, neg, y = t[i]
+        assert set(anchor) == {"gex"} and "c" in y
+
+
+@pytest.mark.parametrize("name,targets", [("DirectPred", ["y", "c"]), ("supervised_vae", ["c"]),
+                                          ("MultiTripletNetwork", ["c", "y"])])
+def test_model_class_api_surface(name, targets):
+    import flexynesis_amd.models as M
+    cls = getattr(M, name)
+    ds = _toy_dataset(missing_label=True)
+    cfg = {"latent_dim": 8, "hidden_dim_factor": 0.25, "lr": 1e-3, "supervisor_hidden_dim": 4, "epochs": 2,
+           "batch_size": 8}
+    m = cls(cfg, ds, targets, surv_event_var="event", surv_time_var="time")
+    assert cls.__name__ == name
+    assert m.target_variables == targets + ["event"] and m.variables == m.target_variables
+    assert m.config is cfg and m.surv_event_var == "event" and m.feature_importances == {}
+    assert m.layers == ["gex", "cnv"] and m.input_dims == [40, 24]
+    assert len(list(m.encoders)) == 2 and set(m.MLPs.keys()) == set(m.variables)
+    # NaN counts as a class in len(np.unique(ann)) (reference direct_pred.py:100)
+    assert m.MLPs["c"].layer_out.weight.shape[0] == 4
+    assert m.MLPs["event"].layer_out.bias is None and m.MLPs["event"].layer_out.weight.shape == (1, 4)
+    if name == "MultiTripletNetwork":
+        assert m.main_var == "c" and "log_vars.triplet_loss" in m.state_dict()
+    if name == "supervised_vae":
+        assert "log_vars.mmd_loss" in m.state_dict() and len(m.decoders) == 2
+    sd = m.state_dict()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == m.spec.state_shapes()
+    m2 = copy.deepcopy(m)
+    m3 = pickle.loads(pickle.dumps(m))
+    for other in (m2, m3):
+        for k, v in other.state_dict().items():
+            assert torch.equal(v, sd[k])
+    m2.load_state_dict(sd)
+    opt = m.configure_optimizers()
+    assert isinstance(opt, torch.optim.Adam) and opt.defaults["lr"] == 1e-3
+    # freezing as FineTuner does (reference main.py:532-539)
+    for p in m.encoders.parameters():
+        p.requires_grad = False
+    assert not any(p.requires_grad for p in m.encoders.parameters())
+    with pytest.raises(RuntimeError):        # no CPU execution path: fails loudly instead of falling back
+        m.training_step(({"gex": ds.dat["gex"][:8], "cnv": ds.dat["cnv"][:8]}, {k: v[:8] for k, v in ds.ann.items()},
+                         ds.samples[:8]), 0) if name != "MultiTripletNetwork" else m._bind()
+
+
+def test_triplet_requires_categorical_main_variable():
+    import flexynesis_amd.models as M
+    cfg = {"latent_dim": 8, "hidden_dim_factor": 0.25, "lr": 1e-3, "supervisor_hidden_dim": 4, "epochs": 2, "batch_size": 8}
+    with pytest.raises(ValueError):
+        M.MultiTripletNetwork(cfg, _toy_dataset(), ["y"])
+
+
+def test_split_and_search_space_are_deterministic():
+    from flexynesis_amd.fit import split_indices
+    from flexynesis_amd.trials import assign_trials, draw_search_space, trial_cost
+    tr, va = split_indices(2048, 0.2, 7)
+    assert len(va) == 409 and len(tr) == 1639 and sorted(tr + va) == list(range(2048))
+    assert split_indices(2048, 0.2, 7) == (tr, va)
+    ps = draw_search_space(64, seed=0)
+    assert ps == draw_search_space(64, seed=0) and len(ps) == 64
+    assert all(16 <= p["latent_dim"] <= 128 and 0.2 <= p["hidden_dim_factor"] <= 0.5 and p["batch_size"] in (32, 64, 128)
+               and 1e-4 <= p["lr"] <= 1e-2 for p in ps)
+    costs = [trial_cost(p, 40000, 1639) for p in ps]
+    a = assign_trials(costs, 8)
+    assert sorted(sum(a, [])) == list(range(64))
+    loads = [sum(costs[i] for i in r) for r in a]
+    assert max(loads) / (sum(loads) / 8) < 1.15          # LPT keeps the tail imbalance small
+
+
+# ---- multi-process (gloo, world_size 2) -----------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from flexynesis_amd import trials
+    dat = ann = None
+    if rank == 0:
+        g = torch.Generator().manual_seed(1)
+        dat = {"zeta": torch.randn(16, 6, generator=g), "alpha": torch.randn(16, 3, generator=g)}   # non-sorted order
+        ann = {"y": torch.randn(16, generator=g)}
+    dat, ann = trials.broadcast_cohort(dat, ann, "cpu")
+    params = trials.draw_search_space(7, seed=3)
+    shapes = {"w": (2, 3), "bn.num_batches_tracked": ()}
+
+    def trial_fn(tid, p):
+        if tid == 4:
+            raise RuntimeError("boom")            # a failing trial must not hang the gather
+        if tid == 5:
+            return float("nan"), 1, None           # non-finite -> +inf
+        val = 10.0 - tid if tid != 2 else 0.5      # trial 2 wins
+        state = {"w": torch.full((2, 3), float(tid)), "bn.num_batches_tracked": torch.tensor(tid * 3)}
+        return val, p["epochs"], state
+
+    table, best, state = trials.run_sweep(params, trial_fn, costs=[1.0] * 7, device="cpu", state_shapes=shapes)
+    out.put((rank, list(dat.keys()), float(dat["zeta"].sum()), table.tolist(), best,
+             state["w"].tolist(), int(state["bn.num_batches_tracked"])))
+    dist.destroy_process_group()
+
+
+def test_trial_sharding_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    r0, r1 = res
+    assert r0[1] == r1[1] == ["zeta", "alpha"]            # rank 0's layer ORDER, not a re-sorted one
+    assert r0[2] == r1[2]                                  # same cohort everywhere
+    assert r0[3] == r1[3]                                  # identical result table on every rank
+    table = np.array(r0[3])
+    assert table[:, 0].tolist() == list(range(7))
+    assert np.isinf(table[4, 1]) and table[4, 3] == 1.0 and np.isinf(table[5, 1])
+    assert r0[4] == r1[4] == 2 and table[2, 1] == 0.5
+    assert r0[5] == r1[5] == [[2.0] * 3] * 2 and r0[6] == r1[6] == 6   # winner's weights reached both ranks
