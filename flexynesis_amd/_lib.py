@@ -26,6 +26,11 @@ PROTOTYPES = {
     "fx_gemm_f32": (I, [I, P, P, P, P, I, I, I, L, L, L, I, P, L, P]),
     "fx_linear_dw_adam_f32": (I, [P, P, P, P, P, I, I, I, L, L, L, P, P]),
     "fx_colsum": (I, [P, P, I, I, L, P]),
+    "fx_split_bf16": (I, [P, P, P, I, I, L, L, P]),
+    "fx_split_bf16_t": (I, [P, P, P, I, I, L, L, P]),
+    "fx_linear_fwd_bf16x3_workspace_bytes": (L, [I, I, I]),
+    "fx_linear_fwd_bf16x3": (I, [P, P, P, P, P, I, I, I, L, L, L, P, L, P]),
+    "fx_linear_dw_adam_bf16x3": (I, [P, P, P, P, P, P, P, I, I, I, L, L, L, P, P]),
     "fx_bn_act_fwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, L, L, I, I, I, F, U64, U64, P, P]),
     "fx_bn_act_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, L, L, L, L, I, I, F, I, P]),
     "fx_sigmoid": (I, [P, P, L, P]),
@@ -51,7 +56,7 @@ PROTOTYPES = {
 }
 
 # functions whose int return value is a size/count, not an error code
-_QUERIES = {"fx_version", "fx_gemm_workspace_bytes", "fx_mmd_workspace_floats", "fx_recon_blocks", "fx_sumsq_blocks",
+_QUERIES = {"fx_version", "fx_gemm_workspace_bytes", "fx_linear_fwd_bf16x3_workspace_bytes", "fx_mmd_workspace_floats", "fx_recon_blocks", "fx_sumsq_blocks",
             "fx_last_error_string"}
 
 

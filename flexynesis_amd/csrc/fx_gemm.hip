@@ -24,6 +24,7 @@
 // [B,K] activation operand, which then stays in that XCD's 4 MiB L2.  Partial sums go to fp32 slabs
 // and are combined in a fixed order by fx_reduce_slabs (deterministic; no float atomics).
 #include "fx_common.h"
+#include "fx_reduce.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -221,21 +222,6 @@ __global__ __launch_bounds__(256) void fx_gemm_f32_kernel(GemmArgs g) {
         }
       }
     }
-  }
-}
-
-// C[m,n] (+)= sum_z slab[z][m][n] + bias[n]
-__global__ void fx_reduce_slabs_kernel(float* __restrict__ C, const float* __restrict__ slabs, const float* __restrict__ bias,
-                                       int M, int N, long ldc, int splitk, long slab_stride, int accumulate) {
-  const long total = (long)M * N;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int m = (int)(i / N), n = (int)(i % N);
-    float s = 0.f;
-    for (int z = 0; z < splitk; ++z) s += slabs[(long)z * slab_stride + i];
-    if (bias) s += bias[n];
-    float* dst = C + (long)m * ldc + n;
-    if (accumulate) s += *dst;
-    *dst = s;
   }
 }
 

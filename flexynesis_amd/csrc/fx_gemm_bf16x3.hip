@@ -1,0 +1,408 @@
+// Split-bf16 ("bf16x3") MFMA GEMMs for the WIDE layers of the flexynesis hot path (gfx950 / CDNA4).
+//
+// Why: the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at 1/16 of the bf16 rate, which makes the
+// wide forward GEMM (B x 20000 x 5000) compute-bound and leaves the fused dW+Adam kernel MFMA-limited
+// (profiles/r01_a_*).  Here every fp32 operand x is split into two bf16 terms, x ~= hi + lo
+// (hi = rne_bf16(x), lo = rne_bf16(x - hi), 16 significand bits together), and each product is
+// evaluated as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 3/16 of the
+// fp32-MFMA cost, per-product relative error <= ~2^-16 (random sign); measured per-step loss error vs the
+// fp32 CPU oracle <= 5e-7 (scripts/precision_study.py).  Master weights, Adam moments, accumulation and
+// everything narrow stay fp32.
+//
+//   fx_split_bf16 / fx_split_bf16_t   fp32 [R,C] -> (hi, lo) bf16 [R,Cp] or transposed [C,Rp], zero padded
+//   fx_linear_fwd_bf16x3              Y[M,N] = X[M,K] . W[N,K]^T  X pre-split (re-read by every column
+//                                     tile, from L2), W fp32 streamed ONCE from HBM and split in registers
+//   fx_linear_dw_adam_bf16x3          W[N,K] -= Adam(clip * dY^T X): both operands pre-split + transposed
+//                                     (dYT [N,Bp], XT [K,Bp]); W/m/v streamed once (24 B/param)
+//
+// Structure: tile 128 x 64 x 32, 4 waves (each 64x32 = two 32x32 MFMA blocks), LDS double buffer
+// (2 x 24 KB -> 3 workgroups/CU), global loads prefetched TWO tiles ahead in named registers, one barrier
+// per K-step.  ALL global accesses are raw buffer loads/stores through SRSRC descriptors: the hardware
+// range check zero-fills out-of-range rows and drops out-of-range stores, so there is not a single
+// per-lane branch around a memory instruction (a "load or zero" select makes hipcc branch around every
+// load and drain vmcnt(0) each time -- measured 4x slower; cdna guide section 5 trap (c)).
+// LDS rows are 64 B (32 bf16); the 16-byte chunk index is XOR-swizzled with (row>>2)&3 so the 16-lane
+// groups of ds_read_b128 hit 16 distinct 4-bank slots (conflict-free) without padding.
+#include "fx_common.h"
+#include "fx_reduce.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define TM 128
+#define TN 64
+#define TK 32
+#define STAGE_ELEMS (2 * TM * TK + 2 * TN * TK)
+
+enum { XEPI_STORE = 0, XEPI_ADAM = 1 };
+
+struct XGemmArgs {
+  const __bf16* Ahi;  // [M, K] k-contiguous, ld = lda (bf16 elements, multiple of 8), K multiple of 32 (zero padded)
+  const __bf16* Alo;
+  const float* Bf;    // B as fp32 [N, Ktrue] (split in-kernel) -- or null when pre-split
+  const __bf16* Bhi;  // B pre-split [N, K]
+  const __bf16* Blo;
+  float* C;
+  int M, N, K, Ktrue;
+  long lda, ldb, ldc;
+  int splitk, kchunk;
+  long slab_stride;
+  float* adam_m;
+  float* adam_v;
+  const float* ctrl;
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * TK + ((chunk ^ ((row >> 2) & 3)) << 3); }
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t fx_rsrc(const void* p, long bytes) {
+  const unsigned n = bytes > 0xFFFFFFF0L ? 0xFFFFFFF0u : (unsigned)bytes;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, n, 0x00020000);
+}
+__device__ __forceinline__ u32x4 bld128(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+}
+__device__ __forceinline__ float bld32f(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+__device__ __forceinline__ void bst32f(float v, __amdgpu_buffer_rsrc_t r, unsigned off) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
+}
+
+// split 4 fp32 (as raw u32x4) into 4 hi + 4 lo bf16 and store them 8 bytes each
+__device__ __forceinline__ void split_store4(const u32x4 raw, __bf16* hi_dst, __bf16* lo_dst) {
+  // NB: bit_cast the WHOLE vector; __builtin_bit_cast(float, raw[j]) on a vector element is miscompiled by
+  // hipcc 7.2 (every j reads element 0 and the load is narrowed to one dword).
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const f32x4 f = __builtin_bit_cast(f32x4, raw);
+  bf16x4 h, l;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float v = f[j];
+    h[j] = (__bf16)v;
+    l[j] = (__bf16)(v - (float)h[j]);
+  }
+  *reinterpret_cast<bf16x4*>(hi_dst) = h;
+  *reinterpret_cast<bf16x4*>(lo_dst) = l;
+}
+
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+
+template <bool B_F32, int EPI>
+__global__ __launch_bounds__(256, EPI == XEPI_STORE ? 3 : 2) void fx_gemm_bf16x3_kernel(XGemmArgs g) {
+  __shared__ __attribute__((aligned(16))) __bf16 smem[2 * STAGE_ELEMS];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid & 1, wc = wid >> 1;
+  const int tiles_m = (g.M + TM - 1) / TM;
+  int lin = blockIdx.x;
+  const int z = lin % g.splitk;
+  lin /= g.splitk;
+  const int tm = lin % tiles_m, tn = lin / tiles_m;
+  const int m0 = tm * TM, n0 = tn * TN;
+  const int k_begin = z * g.kchunk;
+  const int k_end = min(g.K, k_begin + g.kchunk);
+  const int nk = (k_end > k_begin) ? (k_end - k_begin) / TK : 0;  // K, kchunk are multiples of TK
+
+  // ---- buffer descriptors: rows >= M (or >= N) fall beyond num_records and read as zero
+  const __amdgpu_buffer_rsrc_t rAh = fx_rsrc(g.Ahi, (long)g.M * g.lda * 2), rAl = fx_rsrc(g.Alo, (long)g.M * g.lda * 2);
+  const __amdgpu_buffer_rsrc_t rB0 = B_F32 ? fx_rsrc(g.Bf, (long)g.N * g.ldb * 4) : fx_rsrc(g.Bhi, (long)g.N * g.ldb * 2);
+  const __amdgpu_buffer_rsrc_t rB1 = B_F32 ? rB0 : fx_rsrc(g.Blo, (long)g.N * g.ldb * 2);
+
+  // ---- per-thread constant addressing (bytes) and LDS destinations (elements)
+  const int a_row0 = tid >> 2, a_c = tid & 3, a_row1 = a_row0 + 64;
+  const unsigned a_off0 = (unsigned)(((long)(m0 + a_row0) * g.lda + 8 * a_c) * 2);
+  const unsigned a_off1 = (unsigned)(((long)(m0 + a_row1) * g.lda + 8 * a_c) * 2);
+  const int a_lds0 = swz(a_row0, a_c), a_lds1 = swz(a_row1, a_c);
+  unsigned b_off0, b_off1;
+  int b_lds0, b_lds1;
+  if (B_F32) {  // 64 rows x 8 float4 per row; thread handles (n = tid>>3, k4 = tid&7) and n + 32
+    const int n = tid >> 3, k4 = tid & 7;
+    b_off0 = (unsigned)(((long)(n0 + n) * g.ldb + 4 * k4) * 4);
+    b_off1 = (unsigned)(((long)(n0 + n + 32) * g.ldb + 4 * k4) * 4);
+    b_lds0 = swz(n, k4 >> 1) + ((k4 & 1) << 2);
+    b_lds1 = swz(n + 32, k4 >> 1) + ((k4 & 1) << 2);
+  } else {      // 64 rows x 4 chunks: one 16-byte chunk of hi and of lo per thread
+    const int row = tid >> 2, c = tid & 3;
+    b_off0 = b_off1 = (unsigned)(((long)(n0 + row) * g.ldb + 8 * c) * 2);
+    b_lds0 = b_lds1 = swz(row, c);
+  }
+  const unsigned a_kb = (unsigned)k_begin * 2u, b_kb = (unsigned)k_begin * (B_F32 ? 4u : 2u);
+  const unsigned a_step = TK * 2u, b_step = TK * (B_F32 ? 4u : 2u);
+
+  // ---- two register stages (named: no arrays, no references -> nothing can land in scratch)
+  u32x4 s0_ah0, s0_ah1, s0_al0, s0_al1, s0_b0, s0_b1;
+  u32x4 s1_ah0, s1_ah1, s1_al0, s1_al1, s1_b0, s1_b1;
+
+#define LOAD_STAGE(P, kt)                                              \
+  {                                                                    \
+    const unsigned ka = a_kb + (unsigned)(kt) * a_step;                \
+    const unsigned kb = b_kb + (unsigned)(kt) * b_step;                \
+    P##_ah0 = bld128(rAh, a_off0 + ka);                                \
+    P##_al0 = bld128(rAl, a_off0 + ka);                                \
+    P##_ah1 = bld128(rAh, a_off1 + ka);                                \
+    P##_al1 = bld128(rAl, a_off1 + ka);                                \
+    P##_b0 = bld128(rB0, b_off0 + kb);                                 \
+    P##_b1 = bld128(B_F32 ? rB0 : rB1, b_off1 + kb);                   \
+  }
+#define STASH_STAGE(P, buf)                                            \
+  {                                                                    \
+    __bf16* base = smem + (buf) * STAGE_ELEMS;                         \
+    *reinterpret_cast<u32x4*>(base + a_lds0) = P##_ah0;                \
+    *reinterpret_cast<u32x4*>(base + TM * TK + a_lds0) = P##_al0;      \
+    *reinterpret_cast<u32x4*>(base + a_lds1) = P##_ah1;                \
+    *reinterpret_cast<u32x4*>(base + TM * TK + a_lds1) = P##_al1;      \
+    __bf16* bh = base + 2 * TM * TK;                                   \
+    __bf16* bl = bh + TN * TK;                                         \
+    if (B_F32) {                                                       \
+      split_store4(P##_b0, bh + b_lds0, bl + b_lds0);                  \
+      split_store4(P##_b1, bh + b_lds1, bl + b_lds1);                  \
+    } else {                                                           \
+      *reinterpret_cast<u32x4*>(bh + b_lds0) = P##_b0;                 \
+      *reinterpret_cast<u32x4*>(bl + b_lds1) = P##_b1;                 \
+    }                                                                  \
+  }
+
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+  const int arow = wr * 64 + (lane & 31), brow = wc * 32 + (lane & 31), kh = lane >> 5;
+  const int fa0 = swz(arow, kh), fa1 = swz(arow, 2 + kh);          // k16-step 0 / 1 chunk of the A rows
+  const int fa0b = swz(arow + 32, kh), fa1b = swz(arow + 32, 2 + kh);
+  const int fb0 = swz(brow, kh), fb1 = swz(brow, 2 + kh);
+
+#define COMPUTE(buf)                                                                         \
+  {                                                                                          \
+    const __bf16* Ah = smem + (buf) * STAGE_ELEMS;                                           \
+    const __bf16* Al = Ah + TM * TK;                                                         \
+    const __bf16* Bh = Ah + 2 * TM * TK;                                                     \
+    const __bf16* Bl = Bh + TN * TK;                                                         \
+    {                                                                                        \
+      const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(Ah + fa0);                         \
+      const bf16x8 al0 = *reinterpret_cast<const bf16x8*>(Al + fa0);                         \
+      const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(Ah + fa0b);                        \
+      const bf16x8 al1 = *reinterpret_cast<const bf16x8*>(Al + fa0b);                        \
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Bh + fb0);                          \
+      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Bl + fb0);                          \
+      acc0 = MFMA_BF16(al0, bh, acc0); acc1 = MFMA_BF16(al1, bh, acc1);                      \
+      acc0 = MFMA_BF16(ah0, bl, acc0); acc1 = MFMA_BF16(ah1, bl, acc1);                      \
+      acc0 = MFMA_BF16(ah0, bh, acc0); acc1 = MFMA_BF16(ah1, bh, acc1);                      \
+    }                                                                                        \
+    {                                                                                        \
+      const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(Ah + fa1);                         \
+      const bf16x8 al0 = *reinterpret_cast<const bf16x8*>(Al + fa1);                         \
+      const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(Ah + fa1b);                        \
+      const bf16x8 al1 = *reinterpret_cast<const bf16x8*>(Al + fa1b);                        \
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Bh + fb1);                          \
+      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Bl + fb1);                          \
+      acc0 = MFMA_BF16(al0, bh, acc0); acc1 = MFMA_BF16(al1, bh, acc1);                      \
+      acc0 = MFMA_BF16(ah0, bl, acc0); acc1 = MFMA_BF16(ah1, bl, acc1);                      \
+      acc0 = MFMA_BF16(ah0, bh, acc0); acc1 = MFMA_BF16(ah1, bh, acc1);                      \
+    }                                                                                        \
+  }
+
+  // Out-of-range tiles (kt >= nk) are never loaded: the loop conditions are workgroup-uniform scalars.
+  if (nk > 0) LOAD_STAGE(s0, 0);
+  if (nk > 1) LOAD_STAGE(s1, 1);
+  if (nk > 0) STASH_STAGE(s0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt += 2) {
+    if (kt + 2 < nk) LOAD_STAGE(s0, kt + 2);
+    COMPUTE(0);
+    if (kt + 1 < nk) STASH_STAGE(s1, 1);
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    if (kt + 3 < nk) LOAD_STAGE(s1, kt + 3);
+    COMPUTE(1);
+    if (kt + 2 < nk) STASH_STAGE(s0, 0);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  // Buffer stores drop rows >= M by the range check; columns >= N are pushed out of range explicitly.
+  const int n = n0 + wc * 32 + (lane & 31);
+  const unsigned oob = (n < g.N) ? 0u : 0xFFFFFFF0u;     // OR-ed into the byte offset: always >= num_records
+  if (EPI == XEPI_STORE) {
+    const __amdgpu_buffer_rsrc_t rC = fx_rsrc(g.C + (long)z * g.slab_stride, (long)g.M * g.ldc * 4);
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      const int mbase = m0 + wr * 64 + blk * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mbase + (r & 3) + 8 * (r >> 2);
+        const unsigned off = (unsigned)(((long)m * g.ldc + n) * 4) | oob;
+        bst32f(blk == 0 ? acc0[r] : acc1[r], rC, off);
+      }
+    }
+  } else {
+    const long bytes = (long)g.M * g.ldc * 4;
+    const __amdgpu_buffer_rsrc_t rP = fx_rsrc(g.C, bytes), rM = fx_rsrc(g.adam_m, bytes), rV = fx_rsrc(g.adam_v, bytes);
+    const float lr = g.ctrl[FXC_LR], bc1 = g.ctrl[FXC_BC1], bc2s = g.ctrl[FXC_BC2_SQRT];
+    const float coef = g.ctrl[FXC_CLIP_COEF];
+    const float step_size = lr / bc1;
+    // W/m/v are streamed exactly once: 3 x 16 independent dword loads per 32x32 block are issued back to
+    // back (each half-wave covers one full 128-byte line of a weight row), then updated and written back.
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      const int mbase = m0 + wr * 64 + blk * 32 + 4 * (lane >> 5);
+      float pv[16], mv[16], vv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mbase + (r & 3) + 8 * (r >> 2);
+        const unsigned off = (unsigned)(((long)m * g.ldc + n) * 4) | oob;
+        pv[r] = bld32f(rP, off);
+        mv[r] = bld32f(rM, off);
+        vv[r] = bld32f(rV, off);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mbase + (r & 3) + 8 * (r >> 2);
+        const unsigned off = (unsigned)(((long)m * g.ldc + n) * 4) | oob;
+        const float gr = (blk == 0 ? acc0[r] : acc1[r]) * coef;
+        const float m2 = mv[r] + (gr - mv[r]) * (1.0f - FX_BETA1);
+        const float v2 = vv[r] * FX_BETA2 + (1.0f - FX_BETA2) * gr * gr;
+        const float denom = sqrtf(v2) / bc2s + FX_ADAM_EPS;
+        bst32f(pv[r] - step_size * (m2 / denom), rP, off);
+        bst32f(m2, rM, off);
+        bst32f(v2, rV, off);
+      }
+    }
+  }
+}
+
+// ---- operand splitting ----------------------------------------------------------------------------------
+// hi/lo [R, ldo] from x [R, C]; columns C..Cp-1 are written as zeros (Cp = C rounded up to 32 <= ldo)
+__global__ __launch_bounds__(256) void fx_split_bf16_kernel(__bf16* __restrict__ hi, __bf16* __restrict__ lo,
+                                                            const float* __restrict__ x, int R, int C, int Cp, long ldx,
+                                                            long ldo) {
+  const int r = blockIdx.y;
+  const __amdgpu_buffer_rsrc_t rx = fx_rsrc(x + (long)r * ldx, (long)C * 4);
+  for (int c4 = blockIdx.x * blockDim.x + threadIdx.x; c4 < Cp / 4; c4 += gridDim.x * blockDim.x) {
+    const u32x4 raw = bld128(rx, (unsigned)c4 * 16u);      // out-of-range columns read as 0
+    split_store4(raw, hi + (long)r * ldo + 4 * c4, lo + (long)r * ldo + 4 * c4);
+  }
+}
+
+// transposed: hiT/loT [C, ldo] with hiT[c][r] = hi(x[r][c]); rows r in R..Rp-1 zero (Rp = R rounded up to 32)
+__global__ __launch_bounds__(256) void fx_split_bf16_t_kernel(__bf16* __restrict__ hiT, __bf16* __restrict__ loT,
+                                                              const float* __restrict__ x, int R, int C, int Rp, long ldx,
+                                                              long ldo) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    const bool ok = r < R && c < C;
+    const float v = x[(long)min(r, R - 1) * ldx + min(c, C - 1)];
+    tile[ty + 8 * i][tx] = ok ? v : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (c < C && r < Rp) {
+      const float v = tile[tx][ty + 8 * i];
+      const __bf16 h = (__bf16)v;
+      hiT[(long)c * ldo + r] = h;
+      loT[(long)c * ldo + r] = (__bf16)(v - (float)h);
+    }
+  }
+}
+
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+static int pick_splitk_x(int M, int N, int K) {
+  const long tiles = (long)((M + TM - 1) / TM) * ((N + TN - 1) / TN);
+  if (tiles >= 512 || K <= 4 * TK) return 1;
+  int s = (int)((1024 + tiles - 1) / tiles);
+  const int maxs = (K + 8 * TK - 1) / (8 * TK);
+  if (s > maxs) s = maxs;
+  if (s > 64) s = 64;
+  if (s >= 8) s = (s / 8) * 8;
+  return s < 1 ? 1 : s;
+}
+
+extern "C" {
+
+int fx_split_bf16(void* hi, void* lo, const float* x, int R, int C, long ldx, long ldo, hipStream_t stream) {
+  FX_REQUIRE(hi && lo && x && R > 0 && C > 0, "fx_split_bf16: bad args");
+  const int Cp = (C + 31) / 32 * 32;
+  FX_REQUIRE(ldo >= Cp && ldo % 8 == 0 && aligned16(hi) && aligned16(lo), "fx_split_bf16: ldo %ld must be >= %d, %%8", ldo, Cp);
+  int bx = (Cp / 4 + 255) / 256;
+  if (bx > 32) bx = 32;
+  hipLaunchKernelGGL(fx_split_bf16_kernel, dim3(bx, R), dim3(256), 0, stream, (__bf16*)hi, (__bf16*)lo, x, R, C, Cp, ldx, ldo);
+  return fx_check_launch("fx_split_bf16");
+}
+
+int fx_split_bf16_t(void* hiT, void* loT, const float* x, int R, int C, long ldx, long ldo, hipStream_t stream) {
+  FX_REQUIRE(hiT && loT && x && R > 0 && C > 0, "fx_split_bf16_t: bad args");
+  const int Rp = (R + 31) / 32 * 32;
+  FX_REQUIRE(ldo >= Rp && ldo % 8 == 0 && aligned16(hiT) && aligned16(loT), "fx_split_bf16_t: ldo %ld must be >= %d, %%8", ldo, Rp);
+  hipLaunchKernelGGL(fx_split_bf16_t_kernel, dim3((C + 31) / 32, Rp / 32), dim3(256), 0, stream, (__bf16*)hiT, (__bf16*)loT,
+                     x, R, C, Rp, ldx, ldo);
+  return fx_check_launch("fx_split_bf16_t");
+}
+
+long fx_linear_fwd_bf16x3_workspace_bytes(int M, int N, int K) {
+  const int Kp = (K + TK - 1) / TK * TK;
+  const int s = pick_splitk_x(M, N, Kp);
+  return (long)s * M * N * (long)sizeof(float);  // always goes through slabs (bias is added by the reduce)
+}
+
+// Y[M,N] = X[M,K] . W[N,K]^T + bias ; X given as split bf16 (xhi/xlo [M, ldx], zero padded to K%32==0)
+int fx_linear_fwd_bf16x3(float* Y, const void* xhi, const void* xlo, const float* W, const float* bias, int M, int N, int K,
+                         long ldx, long ldw, long ldy, void* workspace, long workspace_bytes, hipStream_t stream) {
+  FX_REQUIRE(Y && xhi && xlo && W && M > 0 && N > 0 && K > 0, "fx_linear_fwd_bf16x3: bad args");
+  const int Kp = (K + TK - 1) / TK * TK;
+  FX_REQUIRE(ldx >= Kp && ldx % 8 == 0 && aligned16(xhi) && aligned16(xlo),
+             "fx_linear_fwd_bf16x3: X split must be padded to %d (ld %ld)", Kp, ldx);
+  FX_REQUIRE((long)N * ldw * 4 < 0xFFFFFFF0L && (long)M * ldx * 2 < 0xFFFFFFF0L, "fx_linear_fwd_bf16x3: operand exceeds 4 GiB");
+  const int s = pick_splitk_x(M, N, Kp);
+  FX_REQUIRE(workspace && workspace_bytes >= (long)s * M * N * (long)sizeof(float), "fx_linear_fwd_bf16x3: workspace too small");
+  XGemmArgs g{};
+  g.Ahi = (const __bf16*)xhi; g.Alo = (const __bf16*)xlo;
+  g.Bf = W;
+  g.C = (float*)workspace;
+  g.M = M; g.N = N; g.K = Kp; g.Ktrue = K;
+  g.lda = ldx; g.ldb = ldw; g.ldc = N;
+  g.splitk = s;
+  g.kchunk = ((Kp / TK + s - 1) / s) * TK;
+  g.slab_stride = (long)M * N;
+  const long nblk = (long)((M + TM - 1) / TM) * ((N + TN - 1) / TN) * s;
+  FX_REQUIRE(nblk < (1L << 31), "fx_linear_fwd_bf16x3: grid too large");
+  hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<true, XEPI_STORE>), dim3((unsigned)nblk), dim3(256), 0, stream, g);
+  int rc = fx_check_launch("fx_linear_fwd_bf16x3");
+  if (rc) return rc;
+  const long total = (long)M * N;
+  const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+  hipLaunchKernelGGL(fx_reduce_slabs_kernel, dim3(blocks), dim3(256), 0, stream, Y, (const float*)workspace, bias, M, N, ldy,
+                     s, g.slab_stride, 0);
+  return fx_check_launch("fx_reduce_slabs");
+}
+
+int fx_linear_dw_adam_bf16x3(float* W, float* adam_m, float* adam_v, const void* dyT_hi, const void* dyT_lo,
+                             const void* xT_hi, const void* xT_lo, int batch_padded, int n_out, int k_in, long lddy,
+                             long ldx, long ldw, const float* ctrl, hipStream_t stream) {
+  FX_REQUIRE(W && adam_m && adam_v && dyT_hi && dyT_lo && xT_hi && xT_lo && ctrl, "fx_linear_dw_adam_bf16x3: null pointer");
+  FX_REQUIRE(batch_padded > 0 && batch_padded % TK == 0, "fx_linear_dw_adam_bf16x3: padded batch %d must be a multiple of %d",
+             batch_padded, TK);
+  FX_REQUIRE(lddy % 8 == 0 && ldx % 8 == 0 && aligned16(dyT_hi) && aligned16(dyT_lo) && aligned16(xT_hi) && aligned16(xT_lo),
+             "fx_linear_dw_adam_bf16x3: operands must be 16-byte aligned with ld %% 8 == 0");
+  FX_REQUIRE((long)n_out * ldw * 4 < 0xFFFFFFF0L, "fx_linear_dw_adam_bf16x3: weight exceeds 4 GiB");
+  XGemmArgs g{};
+  g.Ahi = (const __bf16*)dyT_hi; g.Alo = (const __bf16*)dyT_lo;
+  g.Bhi = (const __bf16*)xT_hi; g.Blo = (const __bf16*)xT_lo;
+  g.C = W;
+  g.M = n_out; g.N = k_in; g.K = batch_padded; g.Ktrue = batch_padded;
+  g.lda = lddy; g.ldb = ldx; g.ldc = ldw;
+  g.splitk = 1; g.kchunk = batch_padded;
+  g.adam_m = adam_m; g.adam_v = adam_v; g.ctrl = ctrl;
+  const long nblk = (long)((n_out + TM - 1) / TM) * ((k_in + TN - 1) / TN);
+  FX_REQUIRE(nblk < (1L << 31), "fx_linear_dw_adam_bf16x3: grid too large");
+  hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<false, XEPI_ADAM>), dim3((unsigned)nblk), dim3(256), 0, stream, g);
+  return fx_check_launch("fx_linear_dw_adam_bf16x3");
+}
+
+}  // extern "C"

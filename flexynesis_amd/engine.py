@@ -203,7 +203,7 @@ class StepPlan:
 
     def __init__(self, store: ParamStore, B: int, train: bool = True, fused: bool = True, clip: bool = True,
                  supplied_draws: bool = False, seed: int = 0, cohort=None, n_batches: int = 0,
-                 epoch_acc: bool = False):
+                 epoch_acc: bool = False, precision: str = "bf16x3"):
         self.store, self.spec, self.B, self.train = store, store.spec, int(B), train
         self.fused = bool(fused) and train
         self.clip = clip
@@ -211,6 +211,10 @@ class StepPlan:
         self.seed = int(seed)
         self.dev = store.device
         self.ws = Workspace(self.dev)
+        if precision not in ("f32", "bf16x3"):
+            raise ValueError(f"precision must be 'f32' or 'bf16x3', got {precision!r}")
+        self.precision = precision
+        self._split_cache: Dict[tuple, tuple] = {}
         self.cohort = cohort
         self.n_batches = int(n_batches)
         spec = self.spec
@@ -265,7 +269,7 @@ class StepPlan:
         a1 = self._new(prefix + "/a1", rows, H)
         sm = self._new(prefix + "/save_mean", passes, H)
         si = self._new(prefix + "/save_invstd", passes, H)
-        ops.linear_fwd(rec, y1, x, st.p(prefix + ".layer_1.weight"), st.p(prefix + ".layer_1.bias"), self.ws)
+        self._lin_fwd(rec, y1, x, prefix + ".layer_1.weight", prefix + ".layer_1.bias")
         Bp = rows // passes
         for p in range(passes):
             sl = slice(p * Bp, (p + 1) * Bp)
@@ -305,7 +309,7 @@ class StepPlan:
         h = self._new(prefix + "/h", rows, H)
         sm = self._new(prefix + "/save_mean", 1, H)
         si = self._new(prefix + "/save_invstd", 1, H)
-        ops.linear_fwd(rec, y, x, st.p(prefix + ".hidden_layers.0.weight"), st.p(prefix + ".hidden_layers.0.bias"), self.ws)
+        self._lin_fwd(rec, y, x, prefix + ".hidden_layers.0.weight", prefix + ".hidden_layers.0.bias")
         ops.bn_act_fwd(rec, h, y, st.p(prefix + ".hidden_layers.2.weight"), st.p(prefix + ".hidden_layers.2.bias"),
                        st.b(prefix + ".hidden_layers.2.running_mean"), st.b(prefix + ".hidden_layers.2.running_var"),
                        sm[0], si[0], ACT_LEAKY, ACT_NONE, self.train, 0.0)
@@ -321,6 +325,19 @@ class StepPlan:
         self._weight_grad(rec, prefix + ".hidden_layers.0.weight", dh, x)
         if dx is not None:
             ops.linear_bwd_x(rec, dx, dh, st.p(prefix + ".hidden_layers.0.weight"), self.ws, accumulate=dx_accumulate)
+
+    def _lin_fwd(self, rec, y, x, wkey, bkey):
+        """nn.Linear forward; wide weights take the split-bf16 MFMA path when precision == 'bf16x3'."""
+        st = self.store
+        if self.precision == "bf16x3" and wkey in st.big:
+            sp = self._split_cache.get(("fwd", x.data_ptr()))
+            if sp is None:
+                sp = ops.new_split(x.shape[0], x.shape[1], self.dev)
+                self._split_cache[("fwd", x.data_ptr())] = sp
+                ops.split_bf16(rec, sp[0], sp[1], x)
+            ops.linear_fwd_bf16x3(rec, y, sp[0], sp[1], st.p(wkey), st.p(bkey), self.ws)
+        else:
+            ops.linear_fwd(rec, y, x, st.p(wkey), st.p(bkey), self.ws)
 
     def _weight_grad(self, rec, key, dy, x):
         """dW = dY^T X: materialised, or deferred to the fused dW+clip+Adam kernel for wide layers."""
@@ -453,7 +470,7 @@ class StepPlan:
             hd.append(h)
             lg = self._new(p + "/logits", B, F)
             logits.append(lg)
-            ops.linear_fwd(rf, lg, h, st.p(p + ".FC_output.weight"), st.p(p + ".FC_output.bias"), self.ws)
+            self._lin_fwd(rf, lg, h, p + ".FC_output.weight", p + ".FC_output.bias")
         self.xhat = [self._new(f"xhat.{i}", B, spec.layers[i][1]) for i in range(n)] if not self.train else None
         priors = []
         for i in range(n):
@@ -545,7 +562,19 @@ class StepPlan:
         ops.adam_flat(ro, st.P, st.G, st.M, st.V, st.ctrl)
         for k in st.big_keys:
             d = st.big[k]
-            if self.fused:
+            if self.fused and self.precision == "bf16x3":
+                dy, x = jobs[k]
+                xt = self._split_cache.get(("T", x.data_ptr()))
+                if xt is None:
+                    xt = ops.new_split(x.shape[1], x.shape[0], self.dev)
+                    self._split_cache[("T", x.data_ptr())] = xt
+                    ops.split_bf16_t(ro, xt[0], xt[1], x)
+                dyt = ops.new_split(dy.shape[1], dy.shape[0], self.dev)
+                self.buf[f"dyT/{k}"] = dyt[0]
+                self.buf[f"dyT_lo/{k}"] = dyt[1]
+                ops.split_bf16_t(ro, dyt[0], dyt[1], dy)
+                ops.linear_dw_adam_bf16x3(ro, d["W"], d["M"], d["V"], dyt[0], dyt[1], xt[0], xt[1], st.ctrl)
+            elif self.fused:
                 dy, x = jobs[k]
                 ops.linear_dw_adam(ro, d["W"], d["M"], d["V"], dy, x, st.ctrl)
             else:

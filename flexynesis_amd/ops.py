@@ -169,6 +169,62 @@ def linear_dw_adam(rec, W, m, v, dy, x, ctrl):
              B, n_out, k_in, _ld(dy), _ld(x), _ld(W), ctrl.data_ptr())
 
 
+def pad32(n: int) -> int:
+    return (int(n) + 31) // 32 * 32
+
+
+def new_split(rows: int, cols: int, device):
+    """(hi, lo) bf16 buffers [rows, pad32(cols)] for fx_split_bf16 / fx_split_bf16_t outputs."""
+    return (torch.zeros(rows, pad32(cols), dtype=torch.bfloat16, device=device),
+            torch.zeros(rows, pad32(cols), dtype=torch.bfloat16, device=device))
+
+
+def split_bf16(rec, hi, lo, x):
+    """hi/lo [R, pad32(C)] <- x [R, C]  (x ~= hi + lo)."""
+    _chk2d(x, "split_bf16.x")
+    R, Cc = x.shape
+    if hi.shape != (R, pad32(Cc)) or lo.shape != hi.shape or hi.dtype != torch.bfloat16:
+        raise FxError(f"split_bf16: hi/lo must be bf16 [{R},{pad32(Cc)}]")
+    rec.emit("fx_split_bf16", hi.data_ptr(), lo.data_ptr(), x.data_ptr(), R, Cc, _ld(x), _ld(hi))
+
+
+def split_bf16_t(rec, hiT, loT, x):
+    """hiT/loT [C, pad32(R)] <- x[R, C] transposed (contraction dimension becomes contiguous)."""
+    _chk2d(x, "split_bf16_t.x")
+    R, Cc = x.shape
+    if hiT.shape != (Cc, pad32(R)) or loT.shape != hiT.shape or hiT.dtype != torch.bfloat16:
+        raise FxError(f"split_bf16_t: hiT/loT must be bf16 [{Cc},{pad32(R)}]")
+    rec.emit("fx_split_bf16_t", hiT.data_ptr(), loT.data_ptr(), x.data_ptr(), R, Cc, _ld(x), _ld(hiT))
+
+
+def linear_fwd_bf16x3(rec, y, xhi, xlo, W, b, ws):
+    """y[M,N] = x W^T + b with x pre-split (xhi/xlo [M, pad32(K)]) and W [N,K] fp32 split in-kernel."""
+    _chk2d(y, "linear_fwd_bf16x3.y")
+    _chk2d(W, "linear_fwd_bf16x3.W")
+    M, N = y.shape
+    K = W.shape[1]
+    if W.shape[0] != N or xhi.shape != (M, pad32(K)) or xlo.shape != xhi.shape:
+        raise FxError("linear_fwd_bf16x3: shape mismatch")
+    need = int(lib.fx_linear_fwd_bf16x3_workspace_bytes(M, N, K))
+    ws.reserve(need)
+    rec.emit("fx_linear_fwd_bf16x3", y.data_ptr(), xhi.data_ptr(), xlo.data_ptr(), W.data_ptr(), _ptr(b), M, N, K,
+             _ld(xhi), _ld(W), _ld(y), ws.buf.data_ptr(), ws.nbytes)
+
+
+def linear_dw_adam_bf16x3(rec, W, m, v, dyT_hi, dyT_lo, xT_hi, xT_lo, ctrl):
+    """W[N,K] <- Adam(clip * dY^T X) with dY^T [N, Bp] and X^T [K, Bp] pre-split."""
+    for t, n in ((W, "W"), (m, "m"), (v, "v")):
+        _chk2d(t, "linear_dw_adam_bf16x3." + n)
+    N, K = W.shape
+    Bp = dyT_hi.shape[1]
+    if dyT_hi.shape != (N, Bp) or xT_hi.shape != (K, Bp) or dyT_lo.shape != dyT_hi.shape or xT_lo.shape != xT_hi.shape:
+        raise FxError("linear_dw_adam_bf16x3: shape mismatch")
+    if not (_ld(m) == _ld(W) == _ld(v)):
+        raise FxError("linear_dw_adam_bf16x3: W/m/v must share a leading dimension")
+    rec.emit("fx_linear_dw_adam_bf16x3", W.data_ptr(), m.data_ptr(), v.data_ptr(), dyT_hi.data_ptr(), dyT_lo.data_ptr(),
+             xT_hi.data_ptr(), xT_lo.data_ptr(), Bp, N, K, _ld(dyT_hi), _ld(xT_hi), _ld(W), ctrl.data_ptr())
+
+
 def colsum(rec, out, x):
     _chk2d(x, "colsum.x")
     rec.emit("fx_colsum", out.data_ptr(), x.data_ptr(), x.shape[0], x.shape[1], _ld(x))

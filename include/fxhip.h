@@ -66,6 +66,20 @@ int fx_linear_dw_adam_f32(float* W, float* adam_m, float* adam_v, const float* d
                           int k_in, long lddy, long ldx, long ldw, const float* ctrl, fx_stream_t stream);
 int fx_colsum(float* out, const float* x, int B, int C, long ldx, fx_stream_t stream); /* bias gradients */
 
+/* ---- split-bf16 ("bf16x3") variants for the WIDE layers: x ~= hi + lo in bf16, products evaluated as
+ *      hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 accumulation (3/16 of the fp32-MFMA cost, ~2^-16
+ *      per-product error).  hi/lo buffers are bf16 (2 bytes/element), zero padded to a multiple of 32 in
+ *      the contracted dimension, ld a multiple of 8.  Same reference ops as fx_gemm_f32 NT /
+ *      fx_linear_dw_adam_f32 above. */
+int fx_split_bf16(void* hi, void* lo, const float* x, int R, int C, long ldx, long ldo, fx_stream_t stream);
+int fx_split_bf16_t(void* hiT, void* loT, const float* x, int R, int C, long ldx, long ldo, fx_stream_t stream);
+long fx_linear_fwd_bf16x3_workspace_bytes(int M, int N, int K);
+int fx_linear_fwd_bf16x3(float* Y, const void* xhi, const void* xlo, const float* W, const float* bias, int M, int N, int K,
+                         long ldx, long ldw, long ldy, void* workspace, long workspace_bytes, fx_stream_t stream);
+int fx_linear_dw_adam_bf16x3(float* W, float* adam_m, float* adam_v, const void* dyT_hi, const void* dyT_lo,
+                             const void* xT_hi, const void* xT_lo, int batch_padded, int n_out, int k_in, long lddy,
+                             long ldx, long ldw, const float* ctrl, fx_stream_t stream);
+
 /* ---- BatchNorm1d (+LeakyReLU before | +ReLU+Dropout after), train & eval (modules.py:25-34,145-148) */
 int fx_bn_act_fwd(float* out, const float* x, const float* gamma, const float* beta, float* running_mean,
                   float* running_var, float* save_mean, float* save_invstd, const float* mask, float* mask_out, int B,
