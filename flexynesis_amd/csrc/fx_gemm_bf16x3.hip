@@ -15,26 +15,28 @@
 //   fx_linear_dw_adam_bf16x3          W[N,K] -= Adam(clip * dY^T X): both operands pre-split + transposed
 //                                     (dYT [N,Bp], XT [K,Bp]); W/m/v streamed once (24 B/param)
 //
-// Structure: tile 128 x 64 x 32, 4 waves (each 64x32 = two 32x32 MFMA blocks), LDS double buffer
-// (2 x 24 KB -> 3 workgroups/CU), global loads prefetched TWO tiles ahead in named registers, one barrier
-// per K-step.  ALL global accesses are raw buffer loads/stores through SRSRC descriptors: the hardware
-// range check zero-fills out-of-range rows and drops out-of-range stores, so there is not a single
-// per-lane branch around a memory instruction (a "load or zero" select makes hipcc branch around every
-// load and drain vmcnt(0) each time -- measured 4x slower; cdna guide section 5 trap (c)).
-// LDS rows are 64 B (32 bf16); the 16-byte chunk index is XOR-swizzled with (row>>2)&3 so the 16-lane
-// groups of ds_read_b128 hit 16 distinct 4-bank slots (conflict-free) without padding.
+// Structure: tile 128 x (32*WN) x 32 with 2*WN waves (each 64x32 = two 32x32 MFMA blocks); WN = 4
+// (128x128, 512 threads) halves the L2->LDS re-reads of the shared activation operand, which an ablation
+// showed to cost 36 % of the 128x64 forward kernel.  LDS double buffer, global loads prefetched TWO tiles
+// ahead in named registers, one barrier per K-step.  ALL global accesses are raw buffer loads/stores
+// through SRSRC descriptors: the hardware range check zero-fills out-of-range rows and drops out-of-range
+// stores, so there is no per-lane branch around a memory instruction (a "load or zero" select makes hipcc
+// branch around every load and drain vmcnt(0) each time -- measured 4x slower; cdna guide section 5 trap
+// (c)).  LDS rows are 64 B (32 bf16); the 16-byte chunk index is XOR-swizzled with (row>>2)&3 so the
+// 16-lane groups of ds_read_b128 hit 16 distinct 4-bank slots (conflict-free) without padding.
+#include <stdlib.h>
+
 #include "fx_common.h"
 #include "fx_reduce.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define TM 128
-#define TN 64
 #define TK 32
-#define STAGE_ELEMS (2 * TM * TK + 2 * TN * TK)
 
 enum { XEPI_STORE = 0, XEPI_ADAM = 1 };
 
@@ -60,21 +62,25 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t fx_rsrc(const void* p, long by
   const unsigned n = bytes > 0xFFFFFFF0L ? 0xFFFFFFF0u : (unsigned)bytes;
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, n, 0x00020000);
 }
+// AUX = cache-policy bits of the buffer instruction: 0 = default, 2 = nt (data streamed exactly once should
+// not displace the L2-resident activation operand).
+template <int AUX = 0>
 __device__ __forceinline__ u32x4 bld128(__amdgpu_buffer_rsrc_t r, unsigned off) {
-  return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+  return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, AUX);
 }
+template <int AUX = 0>
 __device__ __forceinline__ float bld32f(__amdgpu_buffer_rsrc_t r, unsigned off) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, AUX));
 }
+template <int AUX = 0>
 __device__ __forceinline__ void bst32f(float v, __amdgpu_buffer_rsrc_t r, unsigned off) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, AUX);
 }
 
 // split 4 fp32 (as raw u32x4) into 4 hi + 4 lo bf16 and store them 8 bytes each
 __device__ __forceinline__ void split_store4(const u32x4 raw, __bf16* hi_dst, __bf16* lo_dst) {
   // NB: bit_cast the WHOLE vector; __builtin_bit_cast(float, raw[j]) on a vector element is miscompiled by
   // hipcc 7.2 (every j reads element 0 and the load is narrowed to one dword).
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
   const f32x4 f = __builtin_bit_cast(f32x4, raw);
   bf16x4 h, l;
 #pragma unroll
@@ -89,8 +95,12 @@ __device__ __forceinline__ void split_store4(const u32x4 raw, __bf16* hi_dst, __
 
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 
-template <bool B_F32, int EPI>
-__global__ __launch_bounds__(256, EPI == XEPI_STORE ? 3 : 2) void fx_gemm_bf16x3_kernel(XGemmArgs g) {
+// WN = number of 32-column wave slices (2 -> 128x64 tile / 256 threads, 4 -> 128x128 tile / 512 threads)
+template <bool B_F32, int EPI, int NT, int WN>
+__global__ __launch_bounds__(128 * WN) void fx_gemm_bf16x3_kernel(XGemmArgs g) {
+  constexpr int TN = 32 * WN, T = 128 * WN;
+  constexpr int STAGE_ELEMS = 2 * TM * TK + 2 * TN * TK;
+  constexpr bool A2 = (T == 256);  // two A chunks per array per thread (else one)
   __shared__ __attribute__((aligned(16))) __bf16 smem[2 * STAGE_ELEMS];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid & 1, wc = wid >> 1;
@@ -110,19 +120,19 @@ __global__ __launch_bounds__(256, EPI == XEPI_STORE ? 3 : 2) void fx_gemm_bf16x3
   const __amdgpu_buffer_rsrc_t rB1 = B_F32 ? rB0 : fx_rsrc(g.Blo, (long)g.N * g.ldb * 2);
 
   // ---- per-thread constant addressing (bytes) and LDS destinations (elements)
-  const int a_row0 = tid >> 2, a_c = tid & 3, a_row1 = a_row0 + 64;
+  const int a_row0 = tid >> 2, a_c = tid & 3, a_row1 = a_row0 + 64;  // a_row1 only used when A2
   const unsigned a_off0 = (unsigned)(((long)(m0 + a_row0) * g.lda + 8 * a_c) * 2);
   const unsigned a_off1 = (unsigned)(((long)(m0 + a_row1) * g.lda + 8 * a_c) * 2);
   const int a_lds0 = swz(a_row0, a_c), a_lds1 = swz(a_row1, a_c);
   unsigned b_off0, b_off1;
   int b_lds0, b_lds1;
-  if (B_F32) {  // 64 rows x 8 float4 per row; thread handles (n = tid>>3, k4 = tid&7) and n + 32
+  if (B_F32) {  // TN rows x 8 float4 per row; thread handles (n = tid>>3, k4 = tid&7) and n + TN/2
     const int n = tid >> 3, k4 = tid & 7;
     b_off0 = (unsigned)(((long)(n0 + n) * g.ldb + 4 * k4) * 4);
-    b_off1 = (unsigned)(((long)(n0 + n + 32) * g.ldb + 4 * k4) * 4);
+    b_off1 = (unsigned)(((long)(n0 + n + TN / 2) * g.ldb + 4 * k4) * 4);
     b_lds0 = swz(n, k4 >> 1) + ((k4 & 1) << 2);
-    b_lds1 = swz(n + 32, k4 >> 1) + ((k4 & 1) << 2);
-  } else {      // 64 rows x 4 chunks: one 16-byte chunk of hi and of lo per thread
+    b_lds1 = swz(n + TN / 2, k4 >> 1) + ((k4 & 1) << 2);
+  } else {      // TN rows x 4 chunks: one 16-byte chunk of hi and of lo per thread
     const int row = tid >> 2, c = tid & 3;
     b_off0 = b_off1 = (unsigned)(((long)(n0 + row) * g.ldb + 8 * c) * 2);
     b_lds0 = b_lds1 = swz(row, c);
@@ -140,18 +150,22 @@ __global__ __launch_bounds__(256, EPI == XEPI_STORE ? 3 : 2) void fx_gemm_bf16x3
     const unsigned kb = b_kb + (unsigned)(kt) * b_step;                \
     P##_ah0 = bld128(rAh, a_off0 + ka);                                \
     P##_al0 = bld128(rAl, a_off0 + ka);                                \
-    P##_ah1 = bld128(rAh, a_off1 + ka);                                \
-    P##_al1 = bld128(rAl, a_off1 + ka);                                \
-    P##_b0 = bld128(rB0, b_off0 + kb);                                 \
-    P##_b1 = bld128(B_F32 ? rB0 : rB1, b_off1 + kb);                   \
+    if (A2) {                                                          \
+      P##_ah1 = bld128(rAh, a_off1 + ka);                              \
+      P##_al1 = bld128(rAl, a_off1 + ka);                              \
+    }                                                                  \
+    P##_b0 = bld128<B_F32 ? NT : 0>(rB0, b_off0 + kb);                 \
+    P##_b1 = bld128<B_F32 ? NT : 0>(B_F32 ? rB0 : rB1, b_off1 + kb);   \
   }
 #define STASH_STAGE(P, buf)                                            \
   {                                                                    \
     __bf16* base = smem + (buf) * STAGE_ELEMS;                         \
     *reinterpret_cast<u32x4*>(base + a_lds0) = P##_ah0;                \
     *reinterpret_cast<u32x4*>(base + TM * TK + a_lds0) = P##_al0;      \
-    *reinterpret_cast<u32x4*>(base + a_lds1) = P##_ah1;                \
-    *reinterpret_cast<u32x4*>(base + TM * TK + a_lds1) = P##_al1;      \
+    if (A2) {                                                          \
+      *reinterpret_cast<u32x4*>(base + a_lds1) = P##_ah1;              \
+      *reinterpret_cast<u32x4*>(base + TM * TK + a_lds1) = P##_al1;    \
+    }                                                                  \
     __bf16* bh = base + 2 * TM * TK;                                   \
     __bf16* bl = bh + TN * TK;                                         \
     if (B_F32) {                                                       \
@@ -202,20 +216,24 @@ __global__ __launch_bounds__(256, EPI == XEPI_STORE ? 3 : 2) void fx_gemm_bf16x3
     }                                                                                        \
   }
 
-  // Out-of-range tiles (kt >= nk) are never loaded: the loop conditions are workgroup-uniform scalars.
-  if (nk > 0) LOAD_STAGE(s0, 0);
-  if (nk > 1) LOAD_STAGE(s1, 1);
-  if (nk > 0) STASH_STAGE(s0, 0);
+  // The loads and LDS stashes inside the loop are UNCONDITIONAL: a branch around LOAD_STAGE makes hipcc's
+  // waitcnt insertion assume the not-taken path at the join, i.e. it emits vmcnt(0/1) before the stash and
+  // drains the tile that was just requested -- prefetch depth 2 silently becomes depth 1 (seen in the .s).
+  // Tiles past this workgroup's K-slice are therefore fetched (at most 3, harmless: the buffer range check
+  // returns zeros beyond the tensor) and stashed into a buffer that is never computed on.
+  LOAD_STAGE(s0, 0);
+  LOAD_STAGE(s1, 1);
+  STASH_STAGE(s0, 0);
   __syncthreads();
   for (int kt = 0; kt < nk; kt += 2) {
-    if (kt + 2 < nk) LOAD_STAGE(s0, kt + 2);
+    LOAD_STAGE(s0, kt + 2);
     COMPUTE(0);
-    if (kt + 1 < nk) STASH_STAGE(s1, 1);
+    STASH_STAGE(s1, 1);
     __syncthreads();
     if (kt + 1 >= nk) break;
-    if (kt + 3 < nk) LOAD_STAGE(s1, kt + 3);
+    LOAD_STAGE(s1, kt + 3);
     COMPUTE(1);
-    if (kt + 2 < nk) STASH_STAGE(s0, 0);
+    STASH_STAGE(s0, 0);
     __syncthreads();
   }
 
@@ -241,31 +259,83 @@ __global__ __launch_bounds__(256, EPI == XEPI_STORE ? 3 : 2) void fx_gemm_bf16x3
     const float lr = g.ctrl[FXC_LR], bc1 = g.ctrl[FXC_BC1], bc2s = g.ctrl[FXC_BC2_SQRT];
     const float coef = g.ctrl[FXC_CLIP_COEF];
     const float step_size = lr / bc1;
-    // W/m/v are streamed exactly once: 3 x 16 independent dword loads per 32x32 block are issued back to
-    // back (each half-wave covers one full 128-byte line of a weight row), then updated and written back.
+    if ((g.N & 3) == 0 && (g.ldc & 3) == 0) {
+      // Row-contiguous 16-byte streaming of W/m/v: the dW tile is transposed through LDS (the operand
+      // buffers are free after the K loop) so that consecutive lanes own consecutive float4 of a weight row --
+      // each wave touches 2 rows x 512 B instead of 32 scattered 128-byte segments (the HBM probe in
+      // scripts/membench.hip: 5.9 vs 4.9 TB/s) with 4x fewer memory instructions.
+      float* ct = reinterpret_cast<float*>(smem);                       // [TM][TN] fp32
 #pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-      const int mbase = m0 + wr * 64 + blk * 32 + 4 * (lane >> 5);
-      float pv[16], mv[16], vv[16];
+      for (int blk = 0; blk < 2; ++blk) {
+        const int rbase = wr * 64 + blk * 32 + 4 * (lane >> 5);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mbase + (r & 3) + 8 * (r >> 2);
-        const unsigned off = (unsigned)(((long)m * g.ldc + n) * 4) | oob;
-        pv[r] = bld32f(rP, off);
-        mv[r] = bld32f(rM, off);
-        vv[r] = bld32f(rV, off);
+        for (int r = 0; r < 16; ++r)
+          ct[(rbase + (r & 3) + 8 * (r >> 2)) * TN + wc * 32 + (lane & 31)] = (blk == 0 ? acc0[r] : acc1[r]);
       }
+      __syncthreads();
+      constexpr int UPR = TN / 4;                                       // float4 units per tile row
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mbase + (r & 3) + 8 * (r >> 2);
-        const unsigned off = (unsigned)(((long)m * g.ldc + n) * 4) | oob;
-        const float gr = (blk == 0 ? acc0[r] : acc1[r]) * coef;
-        const float m2 = mv[r] + (gr - mv[r]) * (1.0f - FX_BETA1);
-        const float v2 = vv[r] * FX_BETA2 + (1.0f - FX_BETA2) * gr * gr;
-        const float denom = sqrtf(v2) / bc2s + FX_ADAM_EPS;
-        bst32f(pv[r] - step_size * (m2 / denom), rP, off);
-        bst32f(m2, rM, off);
-        bst32f(v2, rV, off);
+      for (int half = 0; half < 2; ++half) {
+        u32x4 p4[4], m4[4], v4[4];
+        unsigned off[4];
+        int lidx[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int u = tid + T * (half * 4 + i), row = u / UPR, c4 = u % UPR;
+          const int gn = n0 + 4 * c4;
+          lidx[i] = row * TN + 4 * c4;
+          off[i] = (unsigned)(((long)(m0 + row) * g.ldc + gn) * 4) | ((gn < g.N) ? 0u : 0xFFFFFFF0u);
+          p4[i] = bld128<NT>(rP, off[i]);
+          m4[i] = bld128<NT>(rM, off[i]);
+          v4[i] = bld128<NT>(rV, off[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f32x4 g4 = *reinterpret_cast<const f32x4*>(ct + lidx[i]);
+          const f32x4 pf = __builtin_bit_cast(f32x4, p4[i]), mf = __builtin_bit_cast(f32x4, m4[i]);
+          const f32x4 vf = __builtin_bit_cast(f32x4, v4[i]);
+          f32x4 po, mo, vo;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float gr = g4[j] * coef;
+            const float m2 = mf[j] + (gr - mf[j]) * (1.0f - FX_BETA1);
+            const float v2 = vf[j] * FX_BETA2 + (1.0f - FX_BETA2) * gr * gr;
+            const float denom = sqrtf(v2) / bc2s + FX_ADAM_EPS;
+            po[j] = pf[j] - step_size * (m2 / denom);
+            mo[j] = m2;
+            vo[j] = v2;
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, po), rP, off[i], 0, NT);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mo), rM, off[i], 0, NT);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vo), rV, off[i], 0, NT);
+        }
+      }
+    } else {
+      // generic path (weight width not a multiple of 4): dword accesses in the MFMA C/D layout
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+        const int mbase = m0 + wr * 64 + blk * 32 + 4 * (lane >> 5);
+        float pv[16], mv[16], vv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mbase + (r & 3) + 8 * (r >> 2);
+          const unsigned off = (unsigned)(((long)m * g.ldc + n) * 4) | oob;
+          pv[r] = bld32f<NT>(rP, off);
+          mv[r] = bld32f<NT>(rM, off);
+          vv[r] = bld32f<NT>(rV, off);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mbase + (r & 3) + 8 * (r >> 2);
+          const unsigned off = (unsigned)(((long)m * g.ldc + n) * 4) | oob;
+          const float gr = (blk == 0 ? acc0[r] : acc1[r]) * coef;
+          const float m2 = mv[r] + (gr - mv[r]) * (1.0f - FX_BETA1);
+          const float v2 = vv[r] * FX_BETA2 + (1.0f - FX_BETA2) * gr * gr;
+          const float denom = sqrtf(v2) / bc2s + FX_ADAM_EPS;
+          bst32f<NT>(pv[r] - step_size * (m2 / denom), rP, off);
+          bst32f<NT>(m2, rM, off);
+          bst32f<NT>(v2, rV, off);
+        }
       }
     }
   }
@@ -313,14 +383,28 @@ __global__ __launch_bounds__(256) void fx_split_bf16_t_kernel(__bf16* __restrict
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-static int pick_splitk_x(int M, int N, int K) {
-  const long tiles = (long)((M + TM - 1) / TM) * ((N + TN - 1) / TN);
-  if (tiles >= 512 || K <= 4 * TK) return 1;
-  int s = (int)((1024 + tiles - 1) / tiles);
-  const int maxs = (K + 8 * TK - 1) / (8 * TK);
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+// wave-column count of the forward kernel: 4 (128x128 tile) unless overridden for experiments
+static int fwd_wn() { return env_int("FX_FWD_WN", 4) == 2 ? 2 : 4; }
+static int adam_wn() { return env_int("FX_ADAM_WN", 4) == 2 ? 2 : 4; }
+
+// split-K so that the grid fills the chip about once: 256 CUs x (3 workgroups of 256 threads | 2 of 512)
+static int pick_splitk_x(int M, int N, int K, int wn) {
+  const int forced = env_int("FX_SPLITK", 0);
+  if (forced > 0) return forced;
+  const int tn = 32 * wn;
+  const long tiles = (long)((M + TM - 1) / TM) * ((N + tn - 1) / tn);
+  const long slots = wn == 2 ? 768 : 512;
+  if (tiles >= slots / 2 || K <= 8 * TK) return 1;
+  int s = (int)(slots / tiles);
+  const int maxs = (K + 8 * TK - 1) / (8 * TK);  // keep >= 8 K-steps per slice
   if (s > maxs) s = maxs;
   if (s > 64) s = 64;
-  if (s >= 8) s = (s / 8) * 8;
+  if (wn == 2 && s >= 8) s = (s / 8) * 8;  // K-slice <-> XCD affinity (workgroup id mod 8)
   return s < 1 ? 1 : s;
 }
 
@@ -347,7 +431,8 @@ int fx_split_bf16_t(void* hiT, void* loT, const float* x, int R, int C, long ldx
 
 long fx_linear_fwd_bf16x3_workspace_bytes(int M, int N, int K) {
   const int Kp = (K + TK - 1) / TK * TK;
-  const int s = pick_splitk_x(M, N, Kp);
+  int s = pick_splitk_x(M, N, Kp, 2), s4 = pick_splitk_x(M, N, Kp, 4);
+  if (s4 > s) s = s4;
   return (long)s * M * N * (long)sizeof(float);  // always goes through slabs (bias is added by the reduce)
 }
 
@@ -359,7 +444,8 @@ int fx_linear_fwd_bf16x3(float* Y, const void* xhi, const void* xlo, const float
   FX_REQUIRE(ldx >= Kp && ldx % 8 == 0 && aligned16(xhi) && aligned16(xlo),
              "fx_linear_fwd_bf16x3: X split must be padded to %d (ld %ld)", Kp, ldx);
   FX_REQUIRE((long)N * ldw * 4 < 0xFFFFFFF0L && (long)M * ldx * 2 < 0xFFFFFFF0L, "fx_linear_fwd_bf16x3: operand exceeds 4 GiB");
-  const int s = pick_splitk_x(M, N, Kp);
+  const int wn = fwd_wn(), tn = 32 * wn;
+  const int s = pick_splitk_x(M, N, Kp, wn);
   FX_REQUIRE(workspace && workspace_bytes >= (long)s * M * N * (long)sizeof(float), "fx_linear_fwd_bf16x3: workspace too small");
   XGemmArgs g{};
   g.Ahi = (const __bf16*)xhi; g.Alo = (const __bf16*)xlo;
@@ -370,9 +456,16 @@ int fx_linear_fwd_bf16x3(float* Y, const void* xhi, const void* xlo, const float
   g.splitk = s;
   g.kchunk = ((Kp / TK + s - 1) / s) * TK;
   g.slab_stride = (long)M * N;
-  const long nblk = (long)((M + TM - 1) / TM) * ((N + TN - 1) / TN) * s;
+  const long nblk = (long)((M + TM - 1) / TM) * ((N + tn - 1) / tn) * s;
   FX_REQUIRE(nblk < (1L << 31), "fx_linear_fwd_bf16x3: grid too large");
-  hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<true, XEPI_STORE>), dim3((unsigned)nblk), dim3(256), 0, stream, g);
+  const int nt = env_int("FX_NT_FWD", 0);
+  if (wn == 4) {
+    if (nt) hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<true, XEPI_STORE, 2, 4>), dim3((unsigned)nblk), dim3(512), 0, stream, g);
+    else hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<true, XEPI_STORE, 0, 4>), dim3((unsigned)nblk), dim3(512), 0, stream, g);
+  } else {
+    if (nt) hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<true, XEPI_STORE, 2, 2>), dim3((unsigned)nblk), dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<true, XEPI_STORE, 0, 2>), dim3((unsigned)nblk), dim3(256), 0, stream, g);
+  }
   int rc = fx_check_launch("fx_linear_fwd_bf16x3");
   if (rc) return rc;
   const long total = (long)M * N;
@@ -399,9 +492,17 @@ int fx_linear_dw_adam_bf16x3(float* W, float* adam_m, float* adam_v, const void*
   g.lda = lddy; g.ldb = ldx; g.ldc = ldw;
   g.splitk = 1; g.kchunk = batch_padded;
   g.adam_m = adam_m; g.adam_v = adam_v; g.ctrl = ctrl;
-  const long nblk = (long)((n_out + TM - 1) / TM) * ((k_in + TN - 1) / TN);
+  const int wn = adam_wn(), tn = 32 * wn;
+  const long nblk = (long)((n_out + TM - 1) / TM) * ((k_in + tn - 1) / tn);
   FX_REQUIRE(nblk < (1L << 31), "fx_linear_dw_adam_bf16x3: grid too large");
-  hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<false, XEPI_ADAM>), dim3((unsigned)nblk), dim3(256), 0, stream, g);
+  const int nt = env_int("FX_NT_ADAM", 1);
+  if (wn == 4) {
+    if (nt) hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<false, XEPI_ADAM, 2, 4>), dim3((unsigned)nblk), dim3(512), 0, stream, g);
+    else hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<false, XEPI_ADAM, 0, 4>), dim3((unsigned)nblk), dim3(512), 0, stream, g);
+  } else {
+    if (nt) hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<false, XEPI_ADAM, 2, 2>), dim3((unsigned)nblk), dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<false, XEPI_ADAM, 0, 2>), dim3((unsigned)nblk), dim3(256), 0, stream, g);
+  }
   return fx_check_launch("fx_linear_dw_adam_bf16x3");
 }
 
