@@ -150,8 +150,19 @@ def main():
             big_elems = [store.big[k]["W"].numel() for k in store.big_keys]
             bytes_per_launch = 24.0 * sum(big_elems) / len(big_elems)   # read+write of W, m, v (fp32)
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), collected
+            # in separate rocprofv3 --pmc passes of this same command and committed under profiles/.
+            traffic = None
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_cfg2.json")))
+                if a.config == "cfg2" and B == 128 and a.precision == "bf16x3":
+                    for kname, d in pm["kernels"].items():
+                        if kname.startswith("fx_gemm_bf16x3_kernel<false, 1"):
+                            traffic = d["hbm_bytes_per_launch_corrected"]
+            except Exception:
+                traffic = None
             roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(ms),
                     "algorithmic_bytes_per_launch": bytes_per_launch}
     P = store.n_params()
