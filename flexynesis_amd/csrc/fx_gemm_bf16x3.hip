@@ -443,7 +443,7 @@ int fx_linear_fwd_bf16x3(float* Y, const void* xhi, const void* xlo, const float
   const int Kp = (K + TK - 1) / TK * TK;
   FX_REQUIRE(ldx >= Kp && ldx % 8 == 0 && aligned16(xhi) && aligned16(xlo),
              "fx_linear_fwd_bf16x3: X split must be padded to %d (ld %ld)", Kp, ldx);
-  FX_REQUIRE((long)N * ldw * 4 < 0xFFFFFFF0L && (long)M * ldx * 2 < 0xFFFFFFF0L, "fx_linear_fwd_bf16x3: operand exceeds 4 GiB");
+  FX_REQUIRE((long)N * ldw * 4 < 0xF0000000L && (long)M * ldx * 2 < 0xF0000000L, "fx_linear_fwd_bf16x3: operand exceeds 4 GiB");
   const int wn = fwd_wn(), tn = 32 * wn;
   const int s = pick_splitk_x(M, N, Kp, wn);
   FX_REQUIRE(workspace && workspace_bytes >= (long)s * M * N * (long)sizeof(float), "fx_linear_fwd_bf16x3: workspace too small");
@@ -483,7 +483,7 @@ int fx_linear_dw_adam_bf16x3(float* W, float* adam_m, float* adam_v, const void*
              batch_padded, TK);
   FX_REQUIRE(lddy % 8 == 0 && ldx % 8 == 0 && aligned16(dyT_hi) && aligned16(dyT_lo) && aligned16(xT_hi) && aligned16(xT_lo),
              "fx_linear_dw_adam_bf16x3: operands must be 16-byte aligned with ld %% 8 == 0");
-  FX_REQUIRE((long)n_out * ldw * 4 < 0xFFFFFFF0L, "fx_linear_dw_adam_bf16x3: weight exceeds 4 GiB");
+  FX_REQUIRE((long)n_out * ldw * 4 < 0xF0000000L && (long)k_in * ldx * 2 < 0xF0000000L, "fx_linear_dw_adam_bf16x3: weight exceeds 4 GiB");
   XGemmArgs g{};
   g.Ahi = (const __bf16*)dyT_hi; g.Alo = (const __bf16*)dyT_lo;
   g.Bhi = (const __bf16*)xT_hi; g.Blo = (const __bf16*)xT_lo;
