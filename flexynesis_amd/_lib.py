@@ -26,6 +26,14 @@ PROTOTYPES = {
     "fx_gemm_f32": (I, [I, P, P, P, P, I, I, I, L, L, L, I, P, L, P]),
     "fx_linear_dw_adam_f32": (I, [P, P, P, P, P, I, I, I, L, L, L, P, P]),
     "fx_colsum": (I, [P, P, I, I, L, P]),
+    "fx_gemm_splitk": (I, [I, I, I]),
+    "fx_gemm_f32_slabs": (I, [I, P, P, P, I, I, I, L, L, P]),
+    "fx_linear_fwd_bf16x3_splitk": (I, [I, I, I]),
+    "fx_linear_fwd_bf16x3_slabs": (I, [P, L, P, P, P, I, I, I, L, L, P]),
+    "fx_bn_act_fwd_slabs": (I, [P, P, P, I, L, P, P, P, P, P, P, P, P, I, I, L, L, I, I, I, F, U64, U64, P, P]),
+    "fx_gram_hadamard_blocks": (I, [L]),
+    "fx_gram_hadamard": (I, [P, P, I, P, I, L, P]),
+    "fx_gather_split": (I, [P, P, P, P, P, P, P, I, I, L, L, L, L, P, L, P]),
     "fx_split_bf16": (I, [P, P, P, I, I, L, L, P]),
     "fx_split_bf16_t": (I, [P, P, P, I, I, L, L, P]),
     "fx_linear_fwd_bf16x3_workspace_bytes": (L, [I, I, I]),
@@ -56,7 +64,7 @@ PROTOTYPES = {
 }
 
 # functions whose int return value is a size/count, not an error code
-_QUERIES = {"fx_version", "fx_gemm_workspace_bytes", "fx_linear_fwd_bf16x3_workspace_bytes", "fx_mmd_workspace_floats", "fx_recon_blocks", "fx_sumsq_blocks",
+_QUERIES = {"fx_version", "fx_gemm_splitk", "fx_linear_fwd_bf16x3_splitk", "fx_gram_hadamard_blocks", "fx_gemm_workspace_bytes", "fx_linear_fwd_bf16x3_workspace_bytes", "fx_mmd_workspace_floats", "fx_recon_blocks", "fx_sumsq_blocks",
             "fx_last_error_string"}
 
 

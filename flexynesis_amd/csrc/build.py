@@ -5,7 +5,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["fx_gemm.hip", "fx_gemm_bf16x3.hip", "fx_norm_act.hip", "fx_losses.hip", "fx_optim.hip"]
+SOURCES = ["fx_gemm.hip", "fx_gemm_bf16x3.hip", "fx_norm_act.hip", "fx_fused_small.hip", "fx_losses.hip", "fx_optim.hip"]
 OUT = os.path.join(HERE, "libfxhip.so")
 
 
@@ -13,7 +13,7 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = SOURCES + ["fx_common.h", "fx_reduce.h", "build.py"]
+    deps = SOURCES + ["fx_common.h", "fx_reduce.h", "fx_small.h", "build.py"]
     return any(os.path.getmtime(os.path.join(HERE, s)) > t for s in deps)
 
 

@@ -352,4 +352,23 @@ int fx_linear_dw_adam_f32(float* W, float* adam_m, float* adam_v, const float* d
   return gemm_dispatch(0, 0, g, EPI_ADAM, stream);
 }
 
+int fx_gemm_splitk(int M, int N, int K) { return pick_splitk(M, N, K); }
+
+// Same contraction as fx_gemm_f32 but the split-K partial sums are LEFT in `slabs` ([fx_gemm_splitk(M,N,K)][M][N],
+// contiguous) for a consumer that folds the reduction into its own pass (fx_gram_hadamard, fx_bn_act_fwd_slabs).
+int fx_gemm_f32_slabs(int layout, float* slabs, const float* A, const float* B, int M, int N, int K, long lda, long ldb,
+                      hipStream_t stream) {
+  FX_REQUIRE(layout >= 0 && layout <= 2, "fx_gemm_f32_slabs: layout %d", layout);
+  FX_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && slabs, "fx_gemm_f32_slabs: bad shape/pointer");
+  const int a_kc = layout != 2, b_kc = layout == 0;
+  GemmArgs g{};
+  g.A = A; g.B = B; g.C = slabs;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = N;
+  const int s = pick_splitk(M, N, K);
+  g.splitk = s;
+  g.kchunk = ((K + s - 1) / s + BK - 1) / BK * BK;
+  g.slab_stride = (long)M * N;
+  return gemm_dispatch(a_kc, b_kc, g, EPI_STORE, stream);
+}
+
 }  // extern "C"

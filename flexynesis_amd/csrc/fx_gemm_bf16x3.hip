@@ -436,10 +436,34 @@ long fx_linear_fwd_bf16x3_workspace_bytes(int M, int N, int K) {
   return (long)s * M * N * (long)sizeof(float);  // always goes through slabs (bias is added by the reduce)
 }
 
+int fx_linear_fwd_bf16x3_splitk(int M, int N, int K) {
+  return pick_splitk_x(M, N, (K + TK - 1) / TK * TK, fwd_wn());
+}
+
+static int fwd_bf16x3_impl(float* Y, const void* xhi, const void* xlo, const float* W, const float* bias, int M, int N,
+                           int K, long ldx, long ldw, long ldy, void* workspace, long workspace_bytes, bool reduce,
+                           hipStream_t stream);
+
 // Y[M,N] = X[M,K] . W[N,K]^T + bias ; X given as split bf16 (xhi/xlo [M, ldx], zero padded to K%32==0)
 int fx_linear_fwd_bf16x3(float* Y, const void* xhi, const void* xlo, const float* W, const float* bias, int M, int N, int K,
                          long ldx, long ldw, long ldy, void* workspace, long workspace_bytes, hipStream_t stream) {
-  FX_REQUIRE(Y && xhi && xlo && W && M > 0 && N > 0 && K > 0, "fx_linear_fwd_bf16x3: bad args");
+  FX_REQUIRE(Y != nullptr, "fx_linear_fwd_bf16x3: null output");
+  return fwd_bf16x3_impl(Y, xhi, xlo, W, bias, M, N, K, ldx, ldw, ldy, workspace, workspace_bytes, true, stream);
+}
+
+// Same, but the fx_linear_fwd_bf16x3_splitk(M,N,K) partial-sum slabs ([s][M][N]) are left in `slabs` (no bias) for
+// a consumer that reduces them in its own pass (fx_bn_act_fwd_slabs).
+int fx_linear_fwd_bf16x3_slabs(float* slabs, long slabs_bytes, const void* xhi, const void* xlo, const float* W, int M,
+                               int N, int K, long ldx, long ldw, hipStream_t stream) {
+  return fwd_bf16x3_impl(nullptr, xhi, xlo, W, nullptr, M, N, K, ldx, ldw, N, slabs, slabs_bytes, false, stream);
+}
+
+}  // extern "C"
+
+static int fwd_bf16x3_impl(float* Y, const void* xhi, const void* xlo, const float* W, const float* bias, int M, int N,
+                           int K, long ldx, long ldw, long ldy, void* workspace, long workspace_bytes, bool reduce,
+                           hipStream_t stream) {
+  FX_REQUIRE(xhi && xlo && W && M > 0 && N > 0 && K > 0, "fx_linear_fwd_bf16x3: bad args");
   const int Kp = (K + TK - 1) / TK * TK;
   FX_REQUIRE(ldx >= Kp && ldx % 8 == 0 && aligned16(xhi) && aligned16(xlo),
              "fx_linear_fwd_bf16x3: X split must be padded to %d (ld %ld)", Kp, ldx);
@@ -467,13 +491,15 @@ int fx_linear_fwd_bf16x3(float* Y, const void* xhi, const void* xlo, const float
     else hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<true, XEPI_STORE, 0, 2>), dim3((unsigned)nblk), dim3(256), 0, stream, g);
   }
   int rc = fx_check_launch("fx_linear_fwd_bf16x3");
-  if (rc) return rc;
+  if (rc || !reduce) return rc;
   const long total = (long)M * N;
   const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
   hipLaunchKernelGGL(fx_reduce_slabs_kernel, dim3(blocks), dim3(256), 0, stream, Y, (const float*)workspace, bias, M, N, ldy,
                      s, g.slab_stride, 0);
   return fx_check_launch("fx_reduce_slabs");
 }
+
+extern "C" {
 
 int fx_linear_dw_adam_bf16x3(float* W, float* adam_m, float* adam_v, const void* dyT_hi, const void* dyT_lo,
                              const void* xT_hi, const void* xT_lo, int batch_padded, int n_out, int k_in, long lddy,

@@ -7,6 +7,7 @@
 // and the per-column batch statistics are wavefront/LDS reductions (no atomics, fixed order).
 // Statistics are two-pass (mean, then sum (x-mean)^2), like the reference's CPU batch_norm.
 #include "fx_common.h"
+#include "fx_small.h"
 
 enum { ACT_NONE = 0, ACT_LEAKY = 1, ACT_RELU = 2 };
 #define LEAKY_SLOPE 0.2f
@@ -235,6 +236,11 @@ int fx_bn_act_fwd(float* out, const float* x, const float* gamma, const float* b
   FX_REQUIRE(!train || (save_mean && save_invstd), "fx_bn_act_fwd: train mode needs save_mean/save_invstd");
   FX_REQUIRE(!(train && B < 2), "fx_bn_act_fwd: BatchNorm1d training needs more than 1 value per channel");
   FX_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "fx_bn_act_fwd: drop_p %f", (double)drop_p);
+  if (B <= FX_BN_R16_MAX_B && mask_out == nullptr) {   // whole column in registers: one pass over x
+    BnFwd16 r{out, nullptr, x, nullptr, 0, 0, nullptr, gamma, beta, running_mean, running_var, save_mean, save_invstd, mask,
+              B, C, ldx, ldo, pre_act, post_act, train, drop_p, seed, offset, ctrl};
+    return fx_launch_bn_fwd_r16(r, stream);
+  }
   BnFwdArgs a{out, x, gamma, beta, running_mean, running_var, save_mean, save_invstd, mask, mask_out, B, C, ldx, ldo,
               pre_act, post_act, train, drop_p, seed, offset, ctrl};
   hipLaunchKernelGGL(fx_bn_fwd_kernel, dim3((C + COLS - 1) / COLS), dim3(256), 0, stream, a);
@@ -246,6 +252,11 @@ int fx_bn_act_bwd(float* dx, float* dgamma, float* dbeta, float* dbias, const fl
                   long lddo, long lddx, int pre_act, int post_act, float drop_p, int accumulate, hipStream_t stream) {
   FX_REQUIRE(dx && dgamma && dbeta && dout && x && gamma && save_mean && save_invstd, "fx_bn_act_bwd: null pointer");
   FX_REQUIRE(post_act != ACT_RELU || out, "fx_bn_act_bwd: ReLU gating needs the saved block output");
+  if (B <= FX_BN_R16_MAX_B) {
+    BnBwd16 r{dx, dgamma, dbeta, dbias, dout, x, out, gamma, save_mean, save_invstd, B, C, ldx, ldo, lddo, lddx,
+              pre_act, post_act, drop_p, accumulate};
+    return fx_launch_bn_bwd_r16(r, stream);
+  }
   BnBwdArgs a{dx, dgamma, dbeta, dbias, dout, x, out, gamma, save_mean, save_invstd, B, C, ldx, ldo, lddo, lddx,
               pre_act, post_act, drop_p, accumulate};
   hipLaunchKernelGGL(fx_bn_bwd_kernel, dim3((C + COLS - 1) / COLS), dim3(256), 0, stream, a);

@@ -203,14 +203,20 @@ class StepPlan:
 
     def __init__(self, store: ParamStore, B: int, train: bool = True, fused: bool = True, clip: bool = True,
                  supplied_draws: bool = False, seed: int = 0, cohort=None, n_batches: int = 0,
-                 epoch_acc: bool = False, precision: str = "bf16x3"):
+                 epoch_acc: bool = False, precision: str = "bf16x3", branches: bool = True):
         self.store, self.spec, self.B, self.train = store, store.spec, int(B), train
         self.fused = bool(fused) and train
         self.clip = clip
         self.supplied = supplied_draws
         self.seed = int(seed)
         self.dev = store.device
-        self.ws = Workspace(self.dev)
+        self._ws = [Workspace(self.dev)]
+        self._branch = 0
+        self.branches = bool(branches)          # per-modality chains as parallel hipGraph branches
+        self.bn_slabs = False                   # fold the wide layer's split-K reduce into BatchNorm (measured: no gain)
+        self._gram_x: Dict[int, tuple] = {}
+        self._jobs: Dict[str, tuple] = {}
+        self._slot_o = 0
         if precision not in ("f32", "bf16x3"):
             raise ValueError(f"precision must be 'f32' or 'bf16x3', got {precision!r}")
         self.precision = precision
@@ -269,16 +275,22 @@ class StepPlan:
         a1 = self._new(prefix + "/a1", rows, H)
         sm = self._new(prefix + "/save_mean", passes, H)
         si = self._new(prefix + "/save_invstd", passes, H)
-        self._lin_fwd(rec, y1, x, prefix + ".layer_1.weight", prefix + ".layer_1.bias")
         Bp = rows // passes
+        slabs = self._lin_fwd(rec, y1, x, prefix + ".layer_1.weight", prefix + ".layer_1.bias",
+                              want_slabs=self.bn_slabs and Bp <= 128)
         for p in range(passes):
             sl = slice(p * Bp, (p + 1) * Bp)
             mask = self._draw(tag_names[p], Bp, H) if (self.supplied and self.train) else None
             seed, off = self._rng()
-            ops.bn_act_fwd(rec, a1[sl], y1[sl], st.p(prefix + ".batchnorm.weight"), st.p(prefix + ".batchnorm.bias"),
-                           st.b(prefix + ".batchnorm.running_mean"), st.b(prefix + ".batchnorm.running_var"),
-                           sm[p], si[p], ACT_NONE, ACT_RELU, self.train, DROPOUT_P if self.train else 0.0,
-                           mask=mask, seed=seed, offset=off, ctrl=st.ctrl)
+            bn = (st.p(prefix + ".batchnorm.weight"), st.p(prefix + ".batchnorm.bias"),
+                  st.b(prefix + ".batchnorm.running_mean"), st.b(prefix + ".batchnorm.running_var"), sm[p], si[p],
+                  ACT_NONE, ACT_RELU, self.train, DROPOUT_P if self.train else 0.0)
+            if slabs is not None:      # split-K reduction + bias folded into the BatchNorm pass
+                sbuf, ns = slabs
+                ops.bn_act_fwd_slabs(rec, a1[sl], y1[sl], sbuf.view(-1)[p * Bp * H:], ns, rows * H,
+                                     st.p(prefix + ".layer_1.bias"), *bn, mask=mask, seed=seed, offset=off, ctrl=st.ctrl)
+            else:
+                ops.bn_act_fwd(rec, a1[sl], y1[sl], *bn, mask=mask, seed=seed, offset=off, ctrl=st.ctrl)
         bias_key = prefix + ".layer_out.bias"
         ops.linear_fwd(rec, out, a1, st.p(prefix + ".layer_out.weight"),
                        st.p(bias_key) if bias_key in st.shapes else None, self.ws)
@@ -309,10 +321,15 @@ class StepPlan:
         h = self._new(prefix + "/h", rows, H)
         sm = self._new(prefix + "/save_mean", 1, H)
         si = self._new(prefix + "/save_invstd", 1, H)
-        self._lin_fwd(rec, y, x, prefix + ".hidden_layers.0.weight", prefix + ".hidden_layers.0.bias")
-        ops.bn_act_fwd(rec, h, y, st.p(prefix + ".hidden_layers.2.weight"), st.p(prefix + ".hidden_layers.2.bias"),
-                       st.b(prefix + ".hidden_layers.2.running_mean"), st.b(prefix + ".hidden_layers.2.running_var"),
-                       sm[0], si[0], ACT_LEAKY, ACT_NONE, self.train, 0.0)
+        slabs = self._lin_fwd(rec, y, x, prefix + ".hidden_layers.0.weight", prefix + ".hidden_layers.0.bias",
+                              want_slabs=self.bn_slabs and rows <= 128)
+        bn = (st.p(prefix + ".hidden_layers.2.weight"), st.p(prefix + ".hidden_layers.2.bias"),
+              st.b(prefix + ".hidden_layers.2.running_mean"), st.b(prefix + ".hidden_layers.2.running_var"),
+              sm[0], si[0], ACT_LEAKY, ACT_NONE, self.train, 0.0)
+        if slabs is not None:
+            ops.bn_act_fwd_slabs(rec, h, y, slabs[0], slabs[1], rows * H, st.p(prefix + ".hidden_layers.0.bias"), *bn)
+        else:
+            ops.bn_act_fwd(rec, h, y, *bn)
         return h
 
     def _hidden_bwd(self, rec, prefix, x, dh, dx=None, dx_accumulate=False):
@@ -326,8 +343,11 @@ class StepPlan:
         if dx is not None:
             ops.linear_bwd_x(rec, dx, dh, st.p(prefix + ".hidden_layers.0.weight"), self.ws, accumulate=dx_accumulate)
 
-    def _lin_fwd(self, rec, y, x, wkey, bkey):
-        """nn.Linear forward; wide weights take the split-bf16 MFMA path when precision == 'bf16x3'."""
+    def _lin_fwd(self, rec, y, x, wkey, bkey, want_slabs=False):
+        """nn.Linear forward; wide weights take the split-bf16 MFMA path when precision == 'bf16x3'.
+        With ``want_slabs`` the wide path leaves its split-K partial sums unreduced and returns
+        (slab buffer, n_slabs) so that the following BatchNorm kernel folds reduction + bias into its own pass
+        (``y`` is then written by that kernel)."""
         st = self.store
         if self.precision == "bf16x3" and wkey in st.big:
             sp = self._split_cache.get(("fwd", x.data_ptr()))
@@ -335,16 +355,60 @@ class StepPlan:
                 sp = ops.new_split(x.shape[0], x.shape[1], self.dev)
                 self._split_cache[("fwd", x.data_ptr())] = sp
                 ops.split_bf16(rec, sp[0], sp[1], x)
+            if self.fused and self.train:
+                self._gram_x_for(rec, x)
+            if want_slabs:
+                M, N = y.shape
+                ns = int(ops.lib.fx_linear_fwd_bf16x3_splitk(M, N, x.shape[1]))
+                sbuf = self._new(f"slabs/{wkey}", ns, M * N)
+                ops.linear_fwd_bf16x3_slabs(rec, sbuf, sp[0], sp[1], st.p(wkey))
+                return sbuf, ns
             ops.linear_fwd_bf16x3(rec, y, sp[0], sp[1], st.p(wkey), st.p(bkey), self.ws)
         else:
             ops.linear_fwd(rec, y, x, st.p(wkey), st.p(bkey), self.ws)
+        return None
 
     def _weight_grad(self, rec, key, dy, x):
         """dW = dY^T X: materialised, or deferred to the fused dW+clip+Adam kernel for wide layers."""
         if self.fused and key in self.store.big:
-            self.big_jobs.append((key, dy, x))
+            # wide layer on the engine path: nothing is materialised.  Here (inside the modality's backward
+            # branch) only the pieces the optimiser tape needs are prepared:
+            #   |dW|_F^2 = <X X^T, dY dY^T>  -> partial sums into the norm slots (Gram identity)
+            #   split-bf16 transposed operands dY^T, X^T for the fused dW+clip+Adam kernel
+            R = dy.shape[0]
+            gx = self._gram_x_for(rec, x)
+            nd = int(ops.lib.fx_gemm_splitk(R, R, dy.shape[1]))
+            gd = self._new(f"gram_dy/{key}", nd, R * R)
+            ops.gemm_slabs(rec, ops.GEMM_NT, gd, dy, dy, R, R)
+            nb = ops.gram_hadamard_blocks(R * R)
+            ops.gram_hadamard(rec, self.slots[self._slot_o:self._slot_o + nb], gx[0], gx[1], gd, nd, R * R)
+            self._slot_o += nb
+            xt = dyt = None
+            if self.precision == "bf16x3":
+                xt = self._split_cache.get(("T", x.data_ptr()))
+                if xt is None:
+                    xt = ops.new_split(x.shape[1], x.shape[0], self.dev)
+                    self._split_cache[("T", x.data_ptr())] = xt
+                    ops.split_bf16_t(rec, xt[0], xt[1], x)
+                dyt = ops.new_split(dy.shape[1], dy.shape[0], self.dev)
+                self.buf[f"dyT/{key}"], self.buf[f"dyT_lo/{key}"] = dyt
+                ops.split_bf16_t(rec, dyt[0], dyt[1], dy)
+            self._jobs[key] = (dy, x, dyt, xt)
         else:
             ops.linear_bwd_w(rec, self.store.g(key), dy, x, self.ws)
+
+    def _gram_x_for(self, rec, x):
+        """X X^T split-K slabs (depends on the batch only): emitted once per operand, in whatever branch asks
+        first -- the forward branch of the modality when possible, so it hides under the other modality's
+        HBM-bound forward kernel."""
+        gx = self._gram_x.get(x.data_ptr())
+        if gx is None:
+            R = x.shape[0]
+            nx = int(ops.lib.fx_gemm_splitk(R, R, x.shape[1]))
+            gx = (self._new(f"gram_x/{x.data_ptr()}", nx, R * R), nx)
+            ops.gemm_slabs(rec, ops.GEMM_NT, gx[0], x, x, R, R)
+            self._gram_x[x.data_ptr()] = gx
+        return gx
 
     def _head_losses(self, rec_f, emb):
         """Supervisor heads + their losses (value and output-gradient in one kernel each)."""
@@ -386,10 +450,20 @@ class StepPlan:
         rg = self.t_gather
         if self.cohort is not None:
             cur = self.store.ctrl if self.n_batches > 0 else None
-            for i, (name, _) in enumerate(spec.layers):
-                ops.gather_rows(rg, self.X[i], self.cohort.dat[name], self.idx, cur, self.R)
+            first_w = "encoders.{}.hidden_layers.0.weight" if spec.model == "supervised_vae" else "encoders.{}.layer_1.weight"
+            for i, (name, F) in enumerate(spec.layers):
+                if self.precision == "bf16x3" and first_w.format(i) in self.store.big:
+                    # one pass: gather + fp32 copy + the bf16 splits the wide-layer kernels consume
+                    sp, spt = ops.new_split(self.R, F, self.dev), ops.new_split(F, self.R, self.dev)
+                    self._split_cache[("fwd", self.X[i].data_ptr())] = sp
+                    self._split_cache[("T", self.X[i].data_ptr())] = spt
+                    ops.gather_split(rg, self.X[i], sp[0], sp[1], spt[0], spt[1], self.cohort.dat[name], self.idx, cur, self.R)
+                else:
+                    ops.gather_rows(rg, self.X[i], self.cohort.dat[name], self.idx, cur, self.R)
             for k, t in self.y.items():      # labels of the anchors = first B indices of each batch row block
                 ops.gather_rows(rg, t, self.cohort.ann[k], self.idx, cur, self.R)
+        if self.train:
+            self._alloc_slots()
         if spec.model == "supervised_vae":
             self._build_svae()
         else:
@@ -405,9 +479,12 @@ class StepPlan:
         trip = spec.model == "MultiTripletNetwork"
         tags = ["@a", "@p", "@n"] if trip else [""]
         ecat = self._new("ecat", R, n * L)
-        for i in range(n):
-            self._mlp_fwd(rf, f"encoders.{i}", self.X[i], ecat[:, i * L:(i + 1) * L], R, self.passes,
-                          [f"encoders.{i}{t}" for t in tags])
+        with rf.parallel(n if self.branches else 1) as par:      # one graph branch per modality
+            for i in range(n):
+                self._enter_branch(par, i)
+                self._mlp_fwd(rf, f"encoders.{i}", self.X[i], ecat[:, i * L:(i + 1) * L], R, self.passes,
+                              [f"encoders.{i}{t}" for t in tags])
+        self._branch = 0
         if n > 1:
             emb = self._new("emb", R, L)
             ops.linear_fwd(rf, emb, ecat, st.p("fusion_block.weight"), st.p("fusion_block.bias"), self.ws)
@@ -432,8 +509,23 @@ class StepPlan:
             ops.linear_bwd_x(rb, decat, demb, st.p("fusion_block.weight"), self.ws)
         else:
             decat = demb
-        for i in range(n):
-            self._mlp_bwd(rb, f"encoders.{i}", self.X[i], decat[:, i * L:(i + 1) * L], R, self.passes)
+        with rb.parallel(n if self.branches else 1) as par:
+            for i in range(n):
+                self._enter_branch(par, i)
+                self._mlp_bwd(rb, f"encoders.{i}", self.X[i], decat[:, i * L:(i + 1) * L], R, self.passes)
+        self._branch = 0
+
+    def _enter_branch(self, par, i):
+        """Route subsequent emits to graph branch i (with its own split-K scratch)."""
+        b = i if self.branches else 0
+        par.branch(b)
+        self._branch = b
+        while len(self._ws) <= b:
+            self._ws.append(Workspace(self.dev))
+
+    @property
+    def ws(self):
+        return self._ws[self._branch]
 
     def _build_svae(self):
         """supervised_vae (supervised_vae.py:132-200, :291-336, :494-550)."""
@@ -527,58 +619,36 @@ class StepPlan:
     def _build_optimizer(self):
         """clip_grad_norm_(1.0) + Adam over every parameter (main.py:216-217, direct_pred.py:143)."""
         st, ro = self.store, self.t_opt
-        nsmall = ops.sumsq_blocks(st.n_small)
-        big_slots = 0
-        plan = []
-        for k in st.big_keys:
-            if self.fused:
-                big_slots += 1
-            else:
-                big_slots += ops.sumsq_blocks(st.big[k]["W"].numel())
-        self.slots = torch.zeros(nsmall + big_slots, dtype=torch.float64, device=self.dev)
-        ops.sumsq(ro, self.slots, st.G)
-        o = nsmall
-        if self.fused:
-            jobs = {k: (dy, x) for k, dy, x in self.big_jobs}
-            gram_cache: Dict[int, torch.Tensor] = {}
-            for k in st.big_keys:
-                dy, x = jobs[k]
-                R = dy.shape[0]
-                gx = gram_cache.get(x.data_ptr())
-                if gx is None:
-                    gx = self._new(f"gram_x/{k}", R, R)
-                    ops.gemm(ro, ops.GEMM_NT, gx, x, x, None, self.ws)
-                    gram_cache[x.data_ptr()] = gx
-                gd = self._new(f"gram_dy/{k}", R, R)
-                ops.gemm(ro, ops.GEMM_NT, gd, dy, dy, None, self.ws)
-                ops.hadamard_sum(ro, self.slots[o:o + 1], gx, gd)
-                o += 1
-        else:
+        o = self._slot_o
+        if not self.fused:
             for k in st.big_keys:
                 g = st.big[k]["G"]
                 ops.sumsq(ro, self.slots[o:], g.view(-1))
                 o += ops.sumsq_blocks(g.numel())
+        ops.sumsq(ro, self.slots[o:], st.G)
+        o += ops.sumsq_blocks(st.n_small)
+        assert o <= self.slots.numel(), (o, self.slots.numel())
         ops.clip_finalize(ro, st.ctrl, self.slots, self.slots.numel(), CLIP_MAX_NORM if self.clip else 0.0)
         ops.adam_flat(ro, st.P, st.G, st.M, st.V, st.ctrl)
         for k in st.big_keys:
             d = st.big[k]
             if self.fused and self.precision == "bf16x3":
-                dy, x = jobs[k]
-                xt = self._split_cache.get(("T", x.data_ptr()))
-                if xt is None:
-                    xt = ops.new_split(x.shape[1], x.shape[0], self.dev)
-                    self._split_cache[("T", x.data_ptr())] = xt
-                    ops.split_bf16_t(ro, xt[0], xt[1], x)
-                dyt = ops.new_split(dy.shape[1], dy.shape[0], self.dev)
-                self.buf[f"dyT/{k}"] = dyt[0]
-                self.buf[f"dyT_lo/{k}"] = dyt[1]
-                ops.split_bf16_t(ro, dyt[0], dyt[1], dy)
+                dy, x, dyt, xt = self._jobs[k]
                 ops.linear_dw_adam_bf16x3(ro, d["W"], d["M"], d["V"], dyt[0], dyt[1], xt[0], xt[1], st.ctrl)
             elif self.fused:
-                dy, x = jobs[k]
+                dy, x, _, _ = self._jobs[k]
                 ops.linear_dw_adam(ro, d["W"], d["M"], d["V"], dy, x, st.ctrl)
             else:
                 ops.adam_flat(ro, d["W"].view(-1), d["G"].view(-1), d["M"].view(-1), d["V"].view(-1), st.ctrl)
+
+    def _alloc_slots(self):
+        """fp64 partial sums of the squared grad norm: Gram blocks per wide weight (fused) or Sum g^2 blocks of the
+        materialised wide grads, plus the small-arena blocks.  Unused slots stay 0."""
+        st = self.store
+        n = ops.sumsq_blocks(st.n_small)
+        for k in st.big_keys:
+            n += ops.gram_hadamard_blocks(self.R * self.R) if self.fused else ops.sumsq_blocks(st.big[k]["W"].numel())
+        self.slots = torch.zeros(n, dtype=torch.float64, device=self.dev)
 
     # ---- execution ----------------------------------------------------------------------------------
     def set_batch(self, x_list=None, y=None, parts=None):

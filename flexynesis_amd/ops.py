@@ -53,41 +53,100 @@ class ImmediateRecorder:
             raise FxError(f"{name} failed (rc={rc}): {_lib.last_error()}")
 
 
+class _Branches:
+    """Context helper returned by TapeRecorder.parallel(n)."""
+
+    def __init__(self, tape, n):
+        self.tape, self.n = tape, n
+
+    def __enter__(self):
+        self.tape.segments.append([[] for _ in range(self.n)])
+        self.tape._cur = 0
+        return self
+
+    def __exit__(self, *exc):
+        self.tape.segments.append([[]])
+        self.tape._cur = 0
+        return False
+
+    def branch(self, i):
+        self.tape._cur = i
+        return self
+
+
 class TapeRecorder:
-    """Record ops; ``run()`` re-issues them on the current stream."""
+    """Record ops; ``run()`` re-issues them.  A tape is a list of SEGMENTS; a segment holds one or more
+    independent BRANCHES (``with tape.parallel(n) as par: par.branch(i); ...``).  Branches of a segment are issued
+    on separate HIP streams (fork/join with stream waits), so under hipGraph capture they become parallel
+    graph branches: the narrow per-modality chains overlap each other and the other modality's HBM-bound
+    wide-layer kernel instead of queueing behind it."""
 
     def __init__(self):
-        self.calls: List[tuple] = []
+        self.segments: List[List[List[tuple]]] = [[[]]]
+        self._cur = 0
         self.keepalive: List[object] = []
+        self._side: List[torch.cuda.Stream] = []
+
+    @property
+    def calls(self):
+        return [c for seg in self.segments for br in seg for c in br]
 
     def emit(self, name: str, *args):
-        self.calls.append((getattr(lib, name), name, args))
+        self.segments[-1][self._cur].append((getattr(lib, name), name, args))
+
+    def parallel(self, n: int) -> _Branches:
+        return _Branches(self, n)
 
     def keep(self, *objs):
         self.keepalive.extend(objs)
 
-    def run(self):
+    @staticmethod
+    def _issue(branch, hook=None):
         s = _stream()
-        for fn, name, args in self.calls:
-            rc = fn(*args, s)
-            if rc != 0:
-                raise FxError(f"{name} failed (rc={rc}): {_lib.last_error()}")
-
-    def run_timed(self, names, sink):
-        """Like run(), but brackets every launch whose entry-point name is in ``names`` with a pair of
-        HIP events recorded on the launch stream; (name, start, end) tuples are appended to ``sink``."""
-        s = _stream()
-        for fn, name, args in self.calls:
-            if name in names:
+        for fn, name, args in branch:
+            if hook is not None and hook(name):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 rc = fn(*args, s)
                 e1.record()
-                sink.append((name, e0, e1))
+                hook.sink.append((name, e0, e1))
             else:
                 rc = fn(*args, s)
             if rc != 0:
                 raise FxError(f"{name} failed (rc={rc}): {_lib.last_error()}")
+
+    def _run(self, hook=None):
+        for seg in self.segments:
+            live = [br for br in seg if br]
+            if not live:
+                continue
+            if len(live) == 1:
+                self._issue(live[0], hook)
+                continue
+            main = torch.cuda.current_stream()
+            while len(self._side) < len(live) - 1:
+                self._side.append(torch.cuda.Stream())
+            for br, st in zip(live[1:], self._side):
+                st.wait_stream(main)          # fork point: recorded BEFORE any branch work is queued on main
+            self._issue(live[0], hook)
+            for br, st in zip(live[1:], self._side):
+                with torch.cuda.stream(st):
+                    self._issue(br, hook)
+            for st in self._side[:len(live) - 1]:
+                main.wait_stream(st)          # join
+
+    def run(self):
+        self._run(None)
+
+    def run_timed(self, names, sink):
+        """Like run(), but brackets every launch whose entry-point name is in ``names`` with a pair of
+        HIP events recorded on the launch stream; (name, start, end) tuples are appended to ``sink``."""
+        class _Hook:
+            def __call__(self, n):
+                return n in names
+        h = _Hook()
+        h.sink = sink
+        self._run(h)
 
     def __len__(self):
         return len(self.calls)
@@ -223,6 +282,60 @@ def linear_dw_adam_bf16x3(rec, W, m, v, dyT_hi, dyT_lo, xT_hi, xT_lo, ctrl):
         raise FxError("linear_dw_adam_bf16x3: W/m/v must share a leading dimension")
     rec.emit("fx_linear_dw_adam_bf16x3", W.data_ptr(), m.data_ptr(), v.data_ptr(), dyT_hi.data_ptr(), dyT_lo.data_ptr(),
              xT_hi.data_ptr(), xT_lo.data_ptr(), Bp, N, K, _ld(dyT_hi), _ld(xT_hi), _ld(W), ctrl.data_ptr())
+
+
+def gemm_slabs(rec, layout, slabs, A, Bm, M, N):
+    """Contraction whose split-K partial sums stay in ``slabs`` [splitk, M, N]; returns splitk."""
+    _chk2d(A, "gemm_slabs.A")
+    _chk2d(Bm, "gemm_slabs.B")
+    K = A.shape[0] if layout == GEMM_TN else A.shape[1]
+    s = int(lib.fx_gemm_splitk(M, N, K))
+    if slabs.numel() < s * M * N:
+        raise FxError("gemm_slabs: slab buffer too small")
+    rec.emit("fx_gemm_f32_slabs", layout, slabs.data_ptr(), A.data_ptr(), Bm.data_ptr(), M, N, K, _ld(A), _ld(Bm))
+    return s
+
+
+def linear_fwd_bf16x3_slabs(rec, slabs, xhi, xlo, W):
+    """Wide forward contraction, partial sums left in ``slabs`` [splitk, M, N]; returns splitk."""
+    _chk2d(W, "linear_fwd_bf16x3_slabs.W")
+    M, (N, K) = xhi.shape[0], W.shape
+    s = int(lib.fx_linear_fwd_bf16x3_splitk(M, N, K))
+    if slabs.numel() < s * M * N or xhi.shape != (M, pad32(K)):
+        raise FxError("linear_fwd_bf16x3_slabs: bad buffer shapes")
+    rec.emit("fx_linear_fwd_bf16x3_slabs", slabs.data_ptr(), slabs.numel() * 4, xhi.data_ptr(), xlo.data_ptr(),
+             W.data_ptr(), M, N, K, _ld(xhi), _ld(W))
+    return s
+
+
+def bn_act_fwd_slabs(rec, out, x_out, slabs, nslabs, slab_stride, lin_bias, gamma, beta, rmean, rvar, save_mean,
+                     save_invstd, pre_act, post_act, train, drop_p=0.0, mask=None, seed=0, offset=0, ctrl=None):
+    """BatchNorm block fed by split-K slabs [nslabs, B, C]; also materialises x = sum(slabs)+bias in x_out."""
+    _chk2d(out, "bn_slabs.out")
+    B, Cc = out.shape
+    rec.emit("fx_bn_act_fwd_slabs", out.data_ptr(), _ptr(x_out), slabs.data_ptr(), int(nslabs), int(slab_stride),
+             _ptr(lin_bias),
+             gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(), _ptr(save_mean), _ptr(save_invstd),
+             _ptr(mask), B, Cc, _ld(x_out) if x_out is not None else Cc, _ld(out), pre_act, post_act, int(train),
+             float(drop_p), int(seed), int(offset), _ptr(ctrl))
+
+
+def gram_hadamard_blocks(n) -> int:
+    return int(lib.fx_gram_hadamard_blocks(n))
+
+
+def gram_hadamard(rec, slots, slabs_x, nx, slabs_d, nd, n):
+    rec.emit("fx_gram_hadamard", slots.data_ptr(), slabs_x.data_ptr(), int(nx), slabs_d.data_ptr(), int(nd), int(n))
+
+
+def gather_split(rec, x, hi, lo, hiT, loT, src, idx, ctrl_cursor=None, cursor_stride=0):
+    """x[r,:] = src[idx[r],:] plus its bf16 splits (row-major [R,pad32(F)] and transposed [F,pad32(R)])."""
+    R, Fc = hi.shape[0], src.shape[1]
+    if hi.shape != (R, pad32(Fc)) or hiT.shape != (Fc, pad32(R)) or idx.dtype != torch.int64:
+        raise FxError("gather_split: bad buffer shapes")
+    rec.emit("fx_gather_split", _ptr(x), hi.data_ptr(), lo.data_ptr(), hiT.data_ptr(), loT.data_ptr(), src.data_ptr(),
+             idx.data_ptr(), R, Fc, _ld(src), _ld(x) if x is not None else Fc, _ld(hi), _ld(hiT), _ptr(ctrl_cursor),
+             int(cursor_stride))
 
 
 def colsum(rec, out, x):

@@ -80,6 +80,27 @@ int fx_linear_dw_adam_bf16x3(float* W, float* adam_m, float* adam_v, const void*
                              const void* xT_hi, const void* xT_lo, int batch_padded, int n_out, int k_in, long lddy,
                              long ldx, long ldw, const float* ctrl, fx_stream_t stream);
 
+/* ---- launch-fusion variants (same reference ops, fewer passes): GEMMs that leave their split-K partial sums in
+ *      slabs [splitk][M][N] for a consumer that reduces them in its own pass; Gram-norm Hadamard sum straight
+ *      from two slab sets; cohort gather fused with the bf16 splits the wide-layer kernels consume. */
+int fx_gemm_splitk(int M, int N, int K);
+int fx_gemm_f32_slabs(int layout, float* slabs, const float* A, const float* B, int M, int N, int K, long lda, long ldb,
+                      fx_stream_t stream);
+int fx_linear_fwd_bf16x3_splitk(int M, int N, int K);
+int fx_linear_fwd_bf16x3_slabs(float* slabs, long slabs_bytes, const void* xhi, const void* xlo, const float* W, int M,
+                               int N, int K, long ldx, long ldw, fx_stream_t stream);
+int fx_bn_act_fwd_slabs(float* out, float* x_out, const float* slabs, int nslabs, long slab_stride, const float* lin_bias,
+                        const float* gamma, const float* beta, float* running_mean, float* running_var, float* save_mean,
+                        float* save_invstd, const float* mask, int B, int C, long ldx, long ldo, int pre_act, int post_act,
+                        int train, float drop_p, unsigned long long seed, unsigned long long offset, const float* ctrl,
+                        fx_stream_t stream);
+int fx_gram_hadamard_blocks(long n);
+int fx_gram_hadamard(double* slots, const float* slabs_x, int nslabs_x, const float* slabs_d, int nslabs_d, long n,
+                     fx_stream_t stream);
+int fx_gather_split(float* x, void* hi, void* lo, void* hiT, void* loT, const float* src, const long* idx, int n_rows,
+                    int n_cols, long ld_src, long ldx, long ldo, long ldt, const float* ctrl_cursor, long cursor_stride,
+                    fx_stream_t stream);
+
 /* ---- BatchNorm1d (+LeakyReLU before | +ReLU+Dropout after), train & eval (modules.py:25-34,145-148) */
 int fx_bn_act_fwd(float* out, const float* x, const float* gamma, const float* beta, float* running_mean,
                   float* running_var, float* save_mean, float* save_invstd, const float* mask, float* mask_out, int B,
