@@ -12,7 +12,7 @@ hand-written HIP kernels replayed from one hipGraph.  Multi-GPU: one process per
 its own independent trial on its own cohort replica (trial sharding, SURVEY.md section 8e: no data-path
 collective); value = total samples of all ranks / max-over-ranks wall time ("weak" scaling).
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel fx_linear_dw_adam_f32, HIP-event timed)
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel fx_linear_dw_adam_bf16x3, HIP-event timed)
 and `cpu_baseline` (the oracle's CPU training loop timed on this box's host cores, N=1 only).
 """
 import argparse

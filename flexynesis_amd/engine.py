@@ -357,6 +357,12 @@ class StepPlan:
                 ops.split_bf16(rec, sp[0], sp[1], x)
             if self.fused and self.train:
                 self._gram_x_for(rec, x)
+            # Stagger the HBM-bound wide kernels of the parallel modality branches: two of them side by side
+            # take as long as back to back, but back to back lets modality i's narrow post-chain (reduce, BN,
+            # layer_out) run underneath modality i+1's wide kernel instead of after both.
+            stagger = self.branches and isinstance(rec, TapeRecorder) and len(rec.segments[-1]) > 1
+            if stagger and getattr(self, "_last_wide_ev", None) is not None:
+                rec.wait_event(self._last_wide_ev)
             if want_slabs:
                 M, N = y.shape
                 ns = int(ops.lib.fx_linear_fwd_bf16x3_splitk(M, N, x.shape[1]))
@@ -364,6 +370,9 @@ class StepPlan:
                 ops.linear_fwd_bf16x3_slabs(rec, sbuf, sp[0], sp[1], st.p(wkey))
                 return sbuf, ns
             ops.linear_fwd_bf16x3(rec, y, sp[0], sp[1], st.p(wkey), st.p(bkey), self.ws)
+            if stagger:
+                self._last_wide_ev = torch.cuda.Event()
+                rec.record_event(self._last_wide_ev)
         else:
             ops.linear_fwd(rec, y, x, st.p(wkey), st.p(bkey), self.ws)
         return None
@@ -451,7 +460,10 @@ class StepPlan:
         if self.cohort is not None:
             cur = self.store.ctrl if self.n_batches > 0 else None
             first_w = "encoders.{}.hidden_layers.0.weight" if spec.model == "supervised_vae" else "encoders.{}.layer_1.weight"
+            gpar = rg.parallel(len(spec.layers) if self.branches else 1)
+            gpar.__enter__()
             for i, (name, F) in enumerate(spec.layers):
+                gpar.branch(i if self.branches else 0)
                 if self.precision == "bf16x3" and first_w.format(i) in self.store.big:
                     # one pass: gather + fp32 copy + the bf16 splits the wide-layer kernels consume
                     sp, spt = ops.new_split(self.R, F, self.dev), ops.new_split(F, self.R, self.dev)
@@ -460,8 +472,10 @@ class StepPlan:
                     ops.gather_split(rg, self.X[i], sp[0], sp[1], spt[0], spt[1], self.cohort.dat[name], self.idx, cur, self.R)
                 else:
                     ops.gather_rows(rg, self.X[i], self.cohort.dat[name], self.idx, cur, self.R)
+            gpar.branch(0)
             for k, t in self.y.items():      # labels of the anchors = first B indices of each batch row block
                 ops.gather_rows(rg, t, self.cohort.ann[k], self.idx, cur, self.R)
+            gpar.__exit__(None, None, None)
         if self.train:
             self._alloc_slots()
         if spec.model == "supervised_vae":
@@ -520,6 +534,8 @@ class StepPlan:
         b = i if self.branches else 0
         par.branch(b)
         self._branch = b
+        if i == 0:
+            self._last_wide_ev = None
         while len(self._ws) <= b:
             self._ws.append(Workspace(self.dev))
 

@@ -89,13 +89,20 @@ class TapeRecorder:
 
     @property
     def calls(self):
-        return [c for seg in self.segments for br in seg for c in br]
+        return [c for seg in self.segments for br in seg for c in br if c[0] is not None]
 
     def emit(self, name: str, *args):
         self.segments[-1][self._cur].append((getattr(lib, name), name, args))
 
     def parallel(self, n: int) -> _Branches:
         return _Branches(self, n)
+
+    def record_event(self, ev):
+        """Mark a point in the current branch that a later-issued branch of the same segment can wait for."""
+        self.segments[-1][self._cur].append((None, "__record__", (ev,)))
+
+    def wait_event(self, ev):
+        self.segments[-1][self._cur].append((None, "__wait__", (ev,)))
 
     def keep(self, *objs):
         self.keepalive.extend(objs)
@@ -104,6 +111,13 @@ class TapeRecorder:
     def _issue(branch, hook=None):
         s = _stream()
         for fn, name, args in branch:
+            if fn is None:      # cross-branch ordering inside a parallel segment (HIP events; graph edges under capture)
+                ev = args[0]
+                if name == "__record__":
+                    ev.record(torch.cuda.current_stream())
+                else:
+                    torch.cuda.current_stream().wait_event(ev)
+                continue
             if hook is not None and hook(name):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()

@@ -520,3 +520,74 @@ def test_train_step_exact_fp32_mode(case):
     exp_grads, gn = g.exp(0, "grad"), g.get("exp/0/grad_norm")
     for k, val in g.exp(0, "state").items():
         close(st[k], val, 2e-4, noise_atol(exp_grads.get(k), gn, g.lr, 3e-6), f"{case} f32 state {k}")
+
+
+# ---------------------------------------------------------------------------------------------------
+# launch-fusion kernels (fx_fused_small.hip)
+# ---------------------------------------------------------------------------------------------------
+def test_gather_split_matches_gather_plus_splits():
+    from flexynesis_amd import ops
+    dev = _dev()
+    src = torch.randn(300, 1000, device=dev)
+    R, F = 100, 1000                                    # R not a multiple of 32: padded rows must be zero
+    idx = torch.randint(0, 300, (3 * R,), device=dev)
+    ctrl = torch.zeros(64, device=dev)
+    ctrl[8] = 1.0
+    x = torch.empty(R, F, device=dev)
+    sp, spt = ops.new_split(R, F, dev), ops.new_split(F, R, dev)
+    for t in (*sp, *spt):
+        t.fill_(7.0)
+    ops.gather_split(ops.IMMEDIATE, x, sp[0], sp[1], spt[0], spt[1], src, idx, ctrl, R)
+    ref = src[idx[R:2 * R]]
+    assert torch.equal(x, ref)
+    hi, lo = ops.new_split(R, F, dev)
+    ops.split_bf16(ops.IMMEDIATE, hi, lo, ref)
+    assert torch.equal(sp[0], hi) and torch.equal(sp[1], lo)
+    hit, lot = ops.new_split(F, R, dev)
+    ops.split_bf16_t(ops.IMMEDIATE, hit, lot, ref)
+    assert torch.equal(spt[0], hit) and torch.equal(spt[1], lot)
+    assert float(spt[0][:, R:].float().abs().sum()) == 0.0 and float(sp[0][:, F:].float().abs().sum()) == 0.0
+
+
+def test_gram_hadamard_from_slabs():
+    from flexynesis_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(21)
+    B, H, F = 128, 900, 4000
+    dy, x = (torch.randn(B, H, generator=g) * 1e-2).to(dev), torch.randn(B, F, generator=g).to(dev)
+    nx, nd = int(ops.lib.fx_gemm_splitk(B, B, F)), int(ops.lib.fx_gemm_splitk(B, B, H))
+    sx, sd = torch.empty(nx, B * B, device=dev), torch.empty(nd, B * B, device=dev)
+    assert ops.gemm_slabs(ops.IMMEDIATE, ops.GEMM_NT, sx, x, x, B, B) == nx
+    ops.gemm_slabs(ops.IMMEDIATE, ops.GEMM_NT, sd, dy, dy, B, B)
+    nb = ops.gram_hadamard_blocks(B * B)
+    slots = torch.zeros(nb, dtype=torch.float64, device=dev)
+    ops.gram_hadamard(ops.IMMEDIATE, slots, sx, nx, sd, nd, B * B)
+    ref = float(((dy.double().t() @ x.double()) ** 2).sum())
+    assert abs(float(slots.sum()) - ref) <= 3e-6 * ref
+
+
+@pytest.mark.parametrize("B,C,pre,post", [(128, 5000, 0, 2), (100, 700, 1, 0)])
+def test_bn_fed_by_splitk_slabs(B, C, pre, post):
+    """fx_bn_act_fwd_slabs == reduce(slabs)+bias followed by fx_bn_act_fwd (bitwise: same arithmetic order)."""
+    from flexynesis_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(B + C)
+    ns = 5
+    slabs = torch.randn(ns, B * C, generator=g).to(dev)
+    bias, gamma, beta = (torch.randn(C, generator=g).to(dev) for _ in range(3))
+    mask = (torch.rand(B, C, generator=g) < 0.9).float().to(dev)
+    rm1, rv1, rm2, rv2 = (torch.zeros(C, device=dev), torch.ones(C, device=dev), torch.zeros(C, device=dev),
+                          torch.ones(C, device=dev))
+    x_ref = bias.clone().expand(B, C).clone()
+    for z in range(ns):
+        x_ref = x_ref + slabs[z].view(B, C)
+    out1, out2, x_out = (torch.empty(B, C, device=dev) for _ in range(3))
+    sm1, si1, sm2, si2 = (torch.empty(C, device=dev) for _ in range(4))
+    drop = 0.1 if post == 2 else 0.0
+    ops.bn_act_fwd(ops.IMMEDIATE, out1, x_ref, gamma, beta, rm1, rv1, sm1, si1, pre, post, True, drop,
+                   mask=mask if post == 2 else None)
+    ops.bn_act_fwd_slabs(ops.IMMEDIATE, out2, x_out, slabs, ns, B * C, bias, gamma, beta, rm2, rv2, sm2, si2, pre, post,
+                         True, drop, mask=mask if post == 2 else None)
+    close(x_out, x_ref, 1e-6, 1e-6, "slab sum")
+    close(out2, out1, 1e-5, 1e-5, "bn from slabs")
+    close(rv2, rv1, 1e-5, 1e-6, "running_var")
