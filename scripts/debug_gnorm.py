@@ -5,7 +5,7 @@ from flexynesis_amd.arch import ArchSpec
 from flexynesis_amd.engine import ParamStore, StepPlan
 from oracle import restate as O
 dev = torch.device("cuda:0")
-layers=[("gex",5000)]; B=32
+layers=[(os.environ.get("L","gex"),int(os.environ.get("F","5000")))]; B=int(os.environ.get("B","32"))
 variables=[("y","numerical",1)]
 aspec=ArchSpec("DirectPred",layers,64,0.25,16,variables,None,None,True)
 ospec=O.Spec("DirectPred",layers,64,0.25,16,variables,None,None,True)

@@ -367,6 +367,8 @@ def _oracle_spec(aspec):
 @pytest.mark.parametrize("model,layers,B", [
     ("DirectPred", [("gex", 5000)], 32),                                   # BASELINE cfg1 shape
     ("DirectPred", [("gex", 4000), ("cnv", 3000)], 128),                   # cfg2 family (scaled to oracle-seconds)
+    ("DirectPred", [("all", 7000)], 100),                                  # --fusion_type early: one layer "all", B % 32 != 0
+    ("DirectPred", [("gex", 3000), ("covariates", 6)], 64),                # covariates modality: hidden = max(int(6*.25), 2)
     ("supervised_vae", [("gex", 2000), ("cnv", 1600)], 64),                # cfg3 family
     ("MultiTripletNetwork", [("gex", 1500), ("cnv", 1200), ("meth", 900)], 32),   # cfg4 family
 ])
@@ -427,10 +429,13 @@ def test_engine_vs_oracle_three_steps(model, layers, B):
         got = plan.losses()
         for k, v in info["losses"].items():
             close(got[k], v, 2e-5, 1e-6, f"{model} step{step} loss {k}")      # gate is 1e-4; observed <= 5e-7
-        # torch-CPU's fp32 vector_norm over millions of elements is itself ~2e-4 off the exact value
-        # (measured: engine 22.892700 == fp64 oracle 22.892700, fp32 oracle 22.88873),
-        # so the global norm is gated at 5e-4 against the fp32 oracle.
-        close(store.ctrl[5], info["grad_norm"], 5e-4, 1e-7, "grad_norm")
+        # torch-CPU's fp32 vector_norm over millions of elements is itself 2e-4..5e-4 off the exact value
+        # (measured at [1750,7000]: engine 20.532915 == fp64 oracle 20.532911, fp32 oracle 20.52206;
+        # DESIGN.md section 3), so the global norm is checked tightly against the fp64 norm of the oracle's
+        # fp32 gradients and only loosely against the oracle's own fp32 reduction.
+        exact = sum(float((gv.double() ** 2).sum()) for gv in info["grads"].values()) ** 0.5
+        close(store.ctrl[5], exact, 2e-5, 1e-7, "grad_norm vs fp64 norm of the oracle's gradients")
+        close(store.ctrl[5], info["grad_norm"], 1e-3, 1e-7, "grad_norm")
         sd = store.state_dict()
         for k in store.big_keys:      # wide weights after this step, element-wise
             # Adam's update is ~lr * sign(g) while v is young, so an element whose gradient is below the
