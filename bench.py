@@ -7,8 +7,8 @@
            --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" = one full optimisation step of the hot path on one batch of B=128 samples already resident in
-HBM: cursor advance, on-device batch gather, forward, losses, backward, global-norm clip, Adam -- all
-hand-written HIP kernels replayed from one hipGraph.  Multi-GPU: one process per GPU, each rank trains
+HBM: cursor advance, on-device batch assembly (of the NEXT step's batch, double-buffered, as a parallel graph
+branch), forward, losses, backward, global-norm clip, Adam -- all hand-written HIP kernels replayed from a hipGraph.  Multi-GPU: one process per GPU, each rank trains
 its own independent trial on its own cohort replica (trial sharding, SURVEY.md section 8e: no data-path
 collective); value = total samples of all ranks / max-over-ranks wall time ("weak" scaling).
 
@@ -42,7 +42,6 @@ CONFIGS = {
                  variables=[("c", "categorical", 4)], surv=(None, None), n_samples=2048),
 }
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-DOMINANT = "fx_linear_dw_adam_f32"
 
 
 def parse():
@@ -78,7 +77,7 @@ def main():
     from flexynesis_amd import ops
     from flexynesis_amd.arch import ArchSpec
     from flexynesis_amd.data import synthetic_cohort
-    from flexynesis_amd.engine import ParamStore, StepPlan
+    from flexynesis_amd.engine import ParamStore, PipelinedStep
 
     cfg = CONFIGS[a.config]
     B = a.batch
@@ -89,8 +88,7 @@ def main():
     n_batches = max(n_train // rows_per_batch, 1)                      # drop_last=True, reference main.py:294
     torch.manual_seed(1000 + rank)
     store = ParamStore(spec, dev, materialize_big_grads=False)
-    plan = StepPlan(store, B, train=True, fused=True, supplied_draws=False, seed=17 + rank, cohort=cohort,
-                    n_batches=n_batches, epoch_acc=True, precision=a.precision)
+    pipe = PipelinedStep(store, B, cohort=cohort, n_batches=n_batches, seed=17 + rank, precision=a.precision)
     dominant = "fx_linear_dw_adam_bf16x3" if a.precision == "bf16x3" else "fx_linear_dw_adam_f32"
     gen = torch.Generator(device=dev)
     gen.manual_seed(4321 + rank)
@@ -98,20 +96,22 @@ def main():
     def reshuffle():
         """shuffle=True: a fresh permutation of the training split per epoch, drawn on the device."""
         perm = torch.randperm(n_train, generator=gen, device=dev)
-        plan.idx.copy_(perm[:n_batches * rows_per_batch])
+        pipe.idx.copy_(perm[:n_batches * rows_per_batch])
 
     reshuffle()
+    pipe.prime()                     # assemble batch 0; from here on every step assembles the batch of the next one
     use_graph = not a.no_graph
+    pipe.step(a.lr)                  # one real eager step loads the code objects (counts as neither warm-up nor timed)
     if use_graph:
-        plan.capture(a.lr)
-        step = plan.replay
+        pipe.capture(a.lr)
+        step = pipe.replay
     else:
-        step = lambda: plan.train_step(a.lr, gather=True)
+        step = lambda: pipe.step(a.lr)
 
     def run(k):
         for i in range(k):
-            if int(i) % n_batches == 0:
-                reshuffle()
+            if pipe.epoch_end_next():
+                reshuffle()          # the epoch's last step prefetches the first batch of the next permutation
             step()
 
     run(a.warmup)
@@ -130,7 +130,7 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    losses = plan.losses()
+    losses = pipe.losses()
     finite = all(v == v and abs(v) != float("inf") for v in losses.values())
 
     # ---- dominant-kernel timing with HIP events on the launch stream (eager re-issue of the same tapes)
@@ -138,11 +138,9 @@ def main():
     if rank == 0:
         sink = []
         for i in range(min(a.steps, 20)):
-            ops.step_begin(ops.IMMEDIATE, store.ctrl, a.lr, n_batches)
-            plan.t_gather.run()
-            plan.t_fwd.run()
-            plan.t_bwd.run()
-            plan.t_opt.run_timed({dominant}, sink)
+            if pipe.epoch_end_next():
+                reshuffle()
+            pipe.step(a.lr, timed=({dominant}, sink))
         torch.cuda.synchronize()
         if sink:
             ms = [e0.elapsed_time(e1) for _, e0, e1 in sink]
@@ -199,7 +197,7 @@ def main():
                                    f"hidden_dim_factor 0.25, lr {a.lr}, clip 1.0 + Adam, "
                                    f"{'hipGraph replay' if use_graph else 'eager tapes'}",
                        "params": P, "global_batch": B * world, "parallelism": f"{world} independent trials (trial sharding)",
-                       "launches_per_step": plan.n_launches(), "algorithmic_bytes_per_step": bytes_step,
+                       "launches_per_step": pipe.n_launches(), "algorithmic_bytes_per_step": bytes_step,
                        "step_hbm_frac_of_8TBs": round(bytes_step / (ms_per_step * 1e-3) / 8e12, 4),
                        "loss_finite": finite, "last_losses": {k: round(v, 6) for k, v in losses.items()}},
             "roofline": roof, "cpu_baseline": cpu,

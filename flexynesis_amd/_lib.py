@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libfxhip.so")
+# FXHIP_LIB: A/B-test another build of the SAME ABI (e.g. a previous libfxhip.so); never a fallback
+LIB_PATH = os.environ.get("FXHIP_LIB") or os.path.join(_HERE, "csrc", "libfxhip.so")
 
 P = C.c_void_p
 I = C.c_int

@@ -244,11 +244,12 @@ __global__ __launch_bounds__(256) void fx_gather_split_kernel(GatherSplit a) {
     const float v = a.src[s * a.ld_src + min(c, a.F - 1)];
     const float w = ok ? v : 0.f;
     tile[ty + 8 * i][tx] = w;
-    if (r < a.R) {          // columns F..Fp-1 of hi/lo are zero padding (ldo >= round32(F))
-      if (a.x && c < a.F) a.x[(long)r * a.ldx + c] = w;
+    if (r < a.R) {          // K-blocked [Fp/32][ldo rows][32]: this workgroup's 32x32 tile is 2 KB contiguous;
+      if (a.x && c < a.F) a.x[(long)r * a.ldx + c] = w;     // columns F..Fp-1 are zero padding
       const __bf16 h = (__bf16)w;
-      a.hi[(long)r * a.ldo + c] = h;
-      a.lo[(long)r * a.ldo + c] = (__bf16)(w - (float)h);
+      const long o = ((long)blockIdx.x * a.ldo + r) * 32 + tx;
+      a.hi[o] = h;
+      a.lo[o] = (__bf16)(w - (float)h);
     }
   }
   __syncthreads();
@@ -307,7 +308,8 @@ int fx_gather_split(float* x, void* hi, void* lo, void* hiT, void* loT, const fl
                     hipStream_t stream) {
   FX_REQUIRE(hi && lo && hiT && loT && src && idx && n_rows > 0 && n_cols > 0, "fx_gather_split: bad args");
   const int Rp = (n_rows + 31) / 32 * 32, Fp = (n_cols + 31) / 32 * 32;
-  FX_REQUIRE(ldo >= Fp && ldt >= Rp, "fx_gather_split: split buffers must be padded to multiples of 32 (ldo %ld, ldt %ld)", ldo, ldt);
+  FX_REQUIRE(ldo >= n_rows && ldo % 128 == 0 && ldt >= Rp,
+             "fx_gather_split: hi/lo are K-blocked with rows padded to 128 (got %ld), hiT/loT need ld >= %d (got %ld)", ldo, Rp, ldt);
   GatherSplit a{x, (__bf16*)hi, (__bf16*)lo, (__bf16*)hiT, (__bf16*)loT, src, idx, ctrl_cursor, cursor_stride,
                 n_rows, n_cols, ld_src, ldx, ldo, ldt};
   hipLaunchKernelGGL(fx_gather_split_kernel, dim3(Fp / 32, Rp / 32), dim3(256), 0, stream, a);

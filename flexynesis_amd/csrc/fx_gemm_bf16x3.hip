@@ -41,8 +41,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 enum { XEPI_STORE = 0, XEPI_ADAM = 1 };
 
 struct XGemmArgs {
-  const __bf16* Ahi;  // [M, K] k-contiguous, ld = lda (bf16 elements, multiple of 8), K multiple of 32 (zero padded)
-  const __bf16* Alo;
+  const __bf16* Ahi;  // a_rp == 0: [M, K] k-contiguous, ld = lda (bf16 elements, multiple of 8), K multiple of 32
+  const __bf16* Alo;  // a_rp  > 0: K-BLOCKED [K/32][a_rp rows][32] -- one 128-row K-step tile is 8 KB contiguous
+  long a_rp;
   const float* Bf;    // B as fp32 [N, Ktrue] (split in-kernel) -- or null when pre-split
   const __bf16* Bhi;  // B pre-split [N, K]
   const __bf16* Blo;
@@ -115,14 +116,19 @@ __global__ __launch_bounds__(128 * WN) void fx_gemm_bf16x3_kernel(XGemmArgs g) {
   const int nk = (k_end > k_begin) ? (k_end - k_begin) / TK : 0;  // K, kchunk are multiples of TK
 
   // ---- buffer descriptors: rows >= M (or >= N) fall beyond num_records and read as zero
-  const __amdgpu_buffer_rsrc_t rAh = fx_rsrc(g.Ahi, (long)g.M * g.lda * 2), rAl = fx_rsrc(g.Alo, (long)g.M * g.lda * 2);
+  const long a_bytes = g.a_rp ? (long)g.K * g.a_rp * 2 : (long)g.M * g.lda * 2;
+  const __amdgpu_buffer_rsrc_t rAh = fx_rsrc(g.Ahi, a_bytes), rAl = fx_rsrc(g.Alo, a_bytes);
   const __amdgpu_buffer_rsrc_t rB0 = B_F32 ? fx_rsrc(g.Bf, (long)g.N * g.ldb * 4) : fx_rsrc(g.Bhi, (long)g.N * g.ldb * 2);
   const __amdgpu_buffer_rsrc_t rB1 = B_F32 ? rB0 : fx_rsrc(g.Blo, (long)g.N * g.ldb * 2);
 
   // ---- per-thread constant addressing (bytes) and LDS destinations (elements)
   const int a_row0 = tid >> 2, a_c = tid & 3, a_row1 = a_row0 + 64;  // a_row1 only used when A2
-  const unsigned a_off0 = (unsigned)(((long)(m0 + a_row0) * g.lda + 8 * a_c) * 2);
-  const unsigned a_off1 = (unsigned)(((long)(m0 + a_row1) * g.lda + 8 * a_c) * 2);
+  // K-blocked A (the wide forward's activations): rows of a K-step tile are 64 B apart, K-steps a_rp*64 B apart.
+  // Row-major, a 128-row x 32-k tile is 128 half cache lines 2*lda bytes apart: every line is pulled from L2 twice
+  // and the forward ran at 3.3 TB/s; blocked it is 64 full lines and reaches 4.9 (scripts/fwdprobe.hip).
+  const long a_ld = g.a_rp ? TK : g.lda;
+  const unsigned a_off0 = (unsigned)(((long)(m0 + a_row0) * a_ld + 8 * a_c) * 2);
+  const unsigned a_off1 = (unsigned)(((long)(m0 + a_row1) * a_ld + 8 * a_c) * 2);
   const int a_lds0 = swz(a_row0, a_c), a_lds1 = swz(a_row1, a_c);
   unsigned b_off0, b_off1;
   int b_lds0, b_lds1;
@@ -137,8 +143,8 @@ __global__ __launch_bounds__(128 * WN) void fx_gemm_bf16x3_kernel(XGemmArgs g) {
     b_off0 = b_off1 = (unsigned)(((long)(n0 + row) * g.ldb + 8 * c) * 2);
     b_lds0 = b_lds1 = swz(row, c);
   }
-  const unsigned a_kb = (unsigned)k_begin * 2u, b_kb = (unsigned)k_begin * (B_F32 ? 4u : 2u);
-  const unsigned a_step = TK * 2u, b_step = TK * (B_F32 ? 4u : 2u);
+  const unsigned a_step = g.a_rp ? (unsigned)g.a_rp * (TK * 2u) : TK * 2u, b_step = TK * (B_F32 ? 4u : 2u);
+  const unsigned a_kb = (unsigned)(k_begin / TK) * a_step, b_kb = (unsigned)k_begin * (B_F32 ? 4u : 2u);
 
   // ---- two register stages (named: no arrays, no references -> nothing can land in scratch)
   u32x4 s0_ah0, s0_ah1, s0_al0, s0_al1, s0_b0, s0_b1;
@@ -342,15 +348,17 @@ __global__ __launch_bounds__(128 * WN) void fx_gemm_bf16x3_kernel(XGemmArgs g) {
 }
 
 // ---- operand splitting ----------------------------------------------------------------------------------
-// hi/lo [R, ldo] from x [R, C]; columns C..Cp-1 are written as zeros (Cp = C rounded up to 32 <= ldo)
+// hi/lo K-BLOCKED [Cp/32][Rp][32] from x [R, C]: element (r, c) at ((c/32)*Rp + r)*32 + c%32; columns C..Cp-1 are
+// written as zeros (Cp = C rounded up to 32); rows R..Rp-1 are never written (the caller allocates them as zeros)
 __global__ __launch_bounds__(256) void fx_split_bf16_kernel(__bf16* __restrict__ hi, __bf16* __restrict__ lo,
                                                             const float* __restrict__ x, int R, int C, int Cp, long ldx,
-                                                            long ldo) {
+                                                            long Rp) {
   const int r = blockIdx.y;
   const __amdgpu_buffer_rsrc_t rx = fx_rsrc(x + (long)r * ldx, (long)C * 4);
   for (int c4 = blockIdx.x * blockDim.x + threadIdx.x; c4 < Cp / 4; c4 += gridDim.x * blockDim.x) {
     const u32x4 raw = bld128(rx, (unsigned)c4 * 16u);      // out-of-range columns read as 0
-    split_store4(raw, hi + (long)r * ldo + 4 * c4, lo + (long)r * ldo + 4 * c4);
+    const long o = ((long)(c4 >> 3) * Rp + r) * 32 + 4 * (c4 & 7);
+    split_store4(raw, hi + o, lo + o);
   }
 }
 
@@ -410,13 +418,15 @@ static int pick_splitk_x(int M, int N, int K, int wn) {
 
 extern "C" {
 
-int fx_split_bf16(void* hi, void* lo, const float* x, int R, int C, long ldx, long ldo, hipStream_t stream) {
+int fx_split_bf16(void* hi, void* lo, const float* x, int R, int C, long ldx, long rows_padded, hipStream_t stream) {
   FX_REQUIRE(hi && lo && x && R > 0 && C > 0, "fx_split_bf16: bad args");
   const int Cp = (C + 31) / 32 * 32;
-  FX_REQUIRE(ldo >= Cp && ldo % 8 == 0 && aligned16(hi) && aligned16(lo), "fx_split_bf16: ldo %ld must be >= %d, %%8", ldo, Cp);
+  FX_REQUIRE(rows_padded >= R && rows_padded % 128 == 0 && aligned16(hi) && aligned16(lo),
+             "fx_split_bf16: rows_padded %ld must be a multiple of 128 and >= %d", rows_padded, R);
   int bx = (Cp / 4 + 255) / 256;
   if (bx > 32) bx = 32;
-  hipLaunchKernelGGL(fx_split_bf16_kernel, dim3(bx, R), dim3(256), 0, stream, (__bf16*)hi, (__bf16*)lo, x, R, C, Cp, ldx, ldo);
+  hipLaunchKernelGGL(fx_split_bf16_kernel, dim3(bx, R), dim3(256), 0, stream, (__bf16*)hi, (__bf16*)lo, x, R, C, Cp, ldx,
+                     rows_padded);
   return fx_check_launch("fx_split_bf16");
 }
 
@@ -444,7 +454,8 @@ static int fwd_bf16x3_impl(float* Y, const void* xhi, const void* xlo, const flo
                            int K, long ldx, long ldw, long ldy, void* workspace, long workspace_bytes, bool reduce,
                            hipStream_t stream);
 
-// Y[M,N] = X[M,K] . W[N,K]^T + bias ; X given as split bf16 (xhi/xlo [M, ldx], zero padded to K%32==0)
+// Y[M,N] = X[M,K] . W[N,K]^T + bias ; X given as K-BLOCKED split bf16 (fx_split_bf16 / fx_gather_split layout:
+// [ceil(K/32)][ldx rows][32], ldx = rows padded to a multiple of 128, padding zero)
 int fx_linear_fwd_bf16x3(float* Y, const void* xhi, const void* xlo, const float* W, const float* bias, int M, int N, int K,
                          long ldx, long ldw, long ldy, void* workspace, long workspace_bytes, hipStream_t stream) {
   FX_REQUIRE(Y != nullptr, "fx_linear_fwd_bf16x3: null output");
@@ -465,9 +476,9 @@ static int fwd_bf16x3_impl(float* Y, const void* xhi, const void* xlo, const flo
                            hipStream_t stream) {
   FX_REQUIRE(xhi && xlo && W && M > 0 && N > 0 && K > 0, "fx_linear_fwd_bf16x3: bad args");
   const int Kp = (K + TK - 1) / TK * TK;
-  FX_REQUIRE(ldx >= Kp && ldx % 8 == 0 && aligned16(xhi) && aligned16(xlo),
-             "fx_linear_fwd_bf16x3: X split must be padded to %d (ld %ld)", Kp, ldx);
-  FX_REQUIRE((long)N * ldw * 4 < 0xF0000000L && (long)M * ldx * 2 < 0xF0000000L, "fx_linear_fwd_bf16x3: operand exceeds 4 GiB");
+  FX_REQUIRE(ldx >= M && ldx % 128 == 0 && aligned16(xhi) && aligned16(xlo),
+             "fx_linear_fwd_bf16x3: X must be a K-blocked split with rows padded to a multiple of 128 (got %ld for M=%d)", ldx, M);
+  FX_REQUIRE((long)N * ldw * 4 < 0xF0000000L && (long)Kp * ldx * 2 < 0xF0000000L, "fx_linear_fwd_bf16x3: operand exceeds 4 GiB");
   const int wn = fwd_wn(), tn = 32 * wn;
   const int s = pick_splitk_x(M, N, Kp, wn);
   FX_REQUIRE(workspace && workspace_bytes >= (long)s * M * N * (long)sizeof(float), "fx_linear_fwd_bf16x3: workspace too small");
@@ -476,7 +487,7 @@ static int fwd_bf16x3_impl(float* Y, const void* xhi, const void* xlo, const flo
   g.Bf = W;
   g.C = (float*)workspace;
   g.M = M; g.N = N; g.K = Kp; g.Ktrue = K;
-  g.lda = ldx; g.ldb = ldw; g.ldc = N;
+  g.lda = 0; g.a_rp = ldx; g.ldb = ldw; g.ldc = N;
   g.splitk = s;
   g.kchunk = ((Kp / TK + s - 1) / s) * TK;
   g.slab_stride = (long)M * N;

@@ -203,7 +203,7 @@ class StepPlan:
 
     def __init__(self, store: ParamStore, B: int, train: bool = True, fused: bool = True, clip: bool = True,
                  supplied_draws: bool = False, seed: int = 0, cohort=None, n_batches: int = 0,
-                 epoch_acc: bool = False, precision: str = "bf16x3", branches: bool = True):
+                 epoch_acc: bool = False, precision: str = "bf16x3", branches: bool = True, share: "StepPlan" = None):
         self.store, self.spec, self.B, self.train = store, store.spec, int(B), train
         self.fused = bool(fused) and train
         self.clip = clip
@@ -234,8 +234,11 @@ class StepPlan:
         self.buf: Dict[str, torch.Tensor] = {}
         n_terms = len(spec.loss_names())
         self.loss_vec = torch.zeros(n_terms + 1, **f)     # raw named losses..., total
-        self.epoch_acc = torch.zeros(n_terms + 2, **f) if epoch_acc else None
-        self.idx = torch.zeros(max(self.R, 1) * max(self.n_batches, 1), dtype=torch.int64, device=self.dev)
+        if share is not None:      # second half of a PipelinedStep: same index table and epoch accumulators
+            self.epoch_acc, self.idx = share.epoch_acc, share.idx
+        else:
+            self.epoch_acc = torch.zeros(n_terms + 2, **f) if epoch_acc else None
+            self.idx = torch.zeros(max(self.R, 1) * max(self.n_batches, 1), dtype=torch.int64, device=self.dev)
         self.X = [torch.zeros(self.R, F, **f) for _, F in spec.layers]
         self.y: Dict[str, torch.Tensor] = {}
         for (v, _, _) in spec.variables:
@@ -352,7 +355,7 @@ class StepPlan:
         if self.precision == "bf16x3" and wkey in st.big:
             sp = self._split_cache.get(("fwd", x.data_ptr()))
             if sp is None:
-                sp = ops.new_split(x.shape[0], x.shape[1], self.dev)
+                sp = ops.new_split_kb(x.shape[0], x.shape[1], self.dev)
                 self._split_cache[("fwd", x.data_ptr())] = sp
                 ops.split_bf16(rec, sp[0], sp[1], x)
             if self.fused and self.train:
@@ -367,7 +370,7 @@ class StepPlan:
                 M, N = y.shape
                 ns = int(ops.lib.fx_linear_fwd_bf16x3_splitk(M, N, x.shape[1]))
                 sbuf = self._new(f"slabs/{wkey}", ns, M * N)
-                ops.linear_fwd_bf16x3_slabs(rec, sbuf, sp[0], sp[1], st.p(wkey))
+                ops.linear_fwd_bf16x3_slabs(rec, sbuf, sp[0], sp[1], st.p(wkey), M)
                 return sbuf, ns
             ops.linear_fwd_bf16x3(rec, y, sp[0], sp[1], st.p(wkey), st.p(bkey), self.ws)
             if stagger:
@@ -466,12 +469,15 @@ class StepPlan:
                 gpar.branch(i if self.branches else 0)
                 if self.precision == "bf16x3" and first_w.format(i) in self.store.big:
                     # one pass: gather + fp32 copy + the bf16 splits the wide-layer kernels consume
-                    sp, spt = ops.new_split(self.R, F, self.dev), ops.new_split(F, self.R, self.dev)
+                    sp, spt = ops.new_split_kb(self.R, F, self.dev), ops.new_split(F, self.R, self.dev)
                     self._split_cache[("fwd", self.X[i].data_ptr())] = sp
                     self._split_cache[("T", self.X[i].data_ptr())] = spt
-                    ops.gather_split(rg, self.X[i], sp[0], sp[1], spt[0], spt[1], self.cohort.dat[name], self.idx, cur, self.R)
+                    ops.gather_split(rg, self.X[i], sp[0], sp[1], spt[0], spt[1], self.cohort.dat[name], self.idx, cur, self.R,
+                                     n_rows=self.R)
                 else:
                     ops.gather_rows(rg, self.X[i], self.cohort.dat[name], self.idx, cur, self.R)
+                if self.fused and first_w.format(i) in self.store.big:
+                    self._gram_x_for(rg, self.X[i])      # batch-only half of the Gram norm: part of batch assembly
             gpar.branch(0)
             for k, t in self.y.items():      # labels of the anchors = first B indices of each batch row block
                 ops.gather_rows(rg, t, self.cohort.ann[k], self.idx, cur, self.R)
@@ -751,3 +757,91 @@ class StepPlan:
         out = {n: vals[i] for i, n in enumerate(names)}
         out["total"] = vals[len(names)]
         return out
+
+
+class PipelinedStep:
+    """Double-buffered optimisation steps over one device-resident cohort.
+
+    Two StepPlans share the ParamStore, the batch index table and the epoch accumulators but own separate
+    batch buffers.  Step t computes from plan t%2; concurrently with its latency-bound head/backward chain
+    (where the chip is nearly idle) the batch of step t+1 -- row gather, bf16 splits, X X^T Gram slabs -- is
+    assembled into plan (t+1)%2 on a side stream, which under hipGraph capture is a parallel graph branch.
+    The device cursor therefore runs ONE table row ahead of the step: the caller must have written the
+    index table of the NEXT epoch before it launches the last step of an epoch (`epoch_end_next()`).
+
+    This is the DataLoader-prefetch of the reference's loop (main.py:289-298, num_workers) moved onto the GPU."""
+
+    def __init__(self, store: ParamStore, B: int, *, cohort, n_batches: int, seed: int = 0,
+                 precision: str = "bf16x3", epoch_acc: bool = True):
+        kw = dict(train=True, fused=True, supplied_draws=False, seed=seed, cohort=cohort, n_batches=n_batches,
+                  epoch_acc=epoch_acc, precision=precision)
+        a = StepPlan(store, B, **kw)
+        self.plans = [a, StepPlan(store, B, share=a, **kw)]
+        self.store, self.n_batches = store, int(n_batches)
+        self.idx, self.epoch_acc = a.idx, a.epoch_acc
+        self.k = 0                       # plan holding the batch of the next step
+        self.done = 0                    # steps issued since prime()
+        self.graphs = [None, None]
+        self._pool: List[torch.cuda.Stream] = []
+
+    def prime(self):
+        """Assemble table row 0 into plan 0 and point the cursor one row ahead of the step counter."""
+        c = self.store.ctrl
+        c[9] = c[0] - 1.0                # fx_step_begin: cursor = (t - 1 - base) mod n_batches = row of step t+1
+        c[8] = 0.0
+        self.plans[0].t_gather.run()
+        self.k, self.done = 0, 0
+
+    def epoch_end_next(self) -> bool:
+        """True when the NEXT step is the last of its epoch, i.e. its prefetch reads row 0 of the next epoch's
+        table: write that table before issuing the step."""
+        return (self.done + 1) % self.n_batches == 0
+
+    def _issue(self, k, lr, timed=None):
+        cur, nxt = self.plans[k], self.plans[1 - k]
+        ops.step_begin(ops.IMMEDIATE, self.store.ctrl, lr, self.n_batches)
+        cur.t_fwd.run()
+        main = torch.cuda.current_stream()
+        used = nxt.t_gather.fork_from(main, self._pool)   # fork: batch assembly of step t+1 ...
+        cur.t_bwd.run()                                   # ... overlaps the head / backward chain of step t
+        for st in used:
+            main.wait_stream(st)                          # join before the HBM-saturating dW+Adam launches
+        if timed is None:
+            cur.t_opt.run()
+        else:
+            cur.t_opt.run_timed(*timed)
+
+    def step(self, lr: float, timed=None):
+        """One optimisation step, eager launch."""
+        self._issue(self.k, lr, timed)
+        self._advance()
+
+    def capture(self, lr: float):
+        """Capture both parities of the step into hipGraphs (no work is executed)."""
+        torch.cuda.synchronize()
+        for k in (0, 1):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._issue(k, lr)
+            self.graphs[k] = g
+
+    def replay(self):
+        self.graphs[self.k].replay()
+        self._advance()
+
+    def _advance(self):
+        self.plans[self.k].bump_nbt()
+        self.k ^= 1
+        self.done += 1
+
+    @property
+    def last(self) -> StepPlan:
+        """The plan the most recent step computed from."""
+        return self.plans[self.k ^ 1]
+
+    def losses(self):
+        return self.last.losses()
+
+    def n_launches(self):
+        p = self.plans[0]
+        return len(p.t_gather) + len(p.t_fwd) + len(p.t_bwd) + len(p.t_opt) + 1

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from .data import DeviceCohort
-from .engine import StepPlan
+from .engine import PipelinedStep, StepPlan
 
 
 @dataclass
@@ -134,34 +134,39 @@ def fit(model, dataset, train_idx: Sequence[int], val_idx: Optional[Sequence[int
     n_batches = tr.numel() // B                                  # drop_last=True (main.py:294)
     if n_batches < 1:
         raise ValueError(f"batch_size {B} exceeds the training split ({tr.numel()} samples) with drop_last=True")
-    plan = StepPlan(store, B, train=True, fused=True, supplied_draws=False, seed=int(seed) * 7919 + 13, cohort=cohort,
-                    n_batches=n_batches, epoch_acc=True)
+    pipe = PipelinedStep(store, B, cohort=cohort, n_batches=n_batches, seed=int(seed) * 7919 + 13, epoch_acc=True)
     names = spec.loss_names()
     eval_cache: Dict[int, StepPlan] = {}
     history: List[Dict[str, float]] = []
     best, wait, stopped_epoch, steps = float("inf"), 0, 0, 0
-    # the captured graph walks the index table with cursor = (t - 1 - base) mod n_batches
-    store.ctrl[9] = store.ctrl[0].clone()
-    epochs_run = 0
-    for epoch in range(int(epochs)):
+
+    def write_table():
+        """shuffle=True, drop_last=True (main.py:289-298): a fresh device permutation of the training split."""
         perm = tr[torch.randperm(tr.numel(), generator=gen, device=dev)][: n_batches * B]
         if trip:
             pos, neg = sampler.sample(perm, gen)
             table = torch.cat([perm.view(n_batches, B), pos.view(n_batches, B), neg.view(n_batches, B)], dim=1)
-            plan.idx.copy_(table.reshape(-1))
+            pipe.idx.copy_(table.reshape(-1))
         else:
-            plan.idx.copy_(perm)
-        plan.epoch_acc.zero_()
+            pipe.idx.copy_(perm)
+
+    write_table()
+    pipe.prime()                      # batch 0 is assembled now; every step assembles the batch of the next one
+    epochs_run = 0
+    for epoch in range(int(epochs)):
+        pipe.epoch_acc.zero_()
         for b in range(n_batches):
-            if use_graph and plan.graph is not None:
-                plan.replay()
+            if pipe.epoch_end_next():
+                write_table()         # the last step of an epoch prefetches row 0 of the next epoch's table
+            if use_graph and pipe.graphs[0] is not None:
+                pipe.replay()
             else:
-                plan.train_step(lr, gather=True)
+                pipe.step(lr)
                 if use_graph:
-                    plan.capture(lr, gather=True, warmup=False)
+                    pipe.capture(lr)
             steps += 1
         epochs_run = epoch + 1
-        acc = plan.epoch_acc.detach().cpu().tolist()
+        acc = pipe.epoch_acc.detach().cpu().tolist()
         rec = {n: acc[i] / max(acc[-1], 1.0) for i, n in enumerate(names)}
         rec["train_loss"] = acc[len(names)] / max(acc[-1], 1.0)
         if va is not None:

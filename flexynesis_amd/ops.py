@@ -152,6 +152,25 @@ class TapeRecorder:
     def run(self):
         self._run(None)
 
+    def fork_from(self, main, pool: List["torch.cuda.Stream"]):
+        """Issue the whole tape off the critical path: every branch goes to its own stream of ``pool``, each
+        forked DIRECTLY from ``main``; returns the streams the caller must join (``main.wait_stream``).
+        (A fork made from an already-forked stream -- i.e. ``run()`` under ``torch.cuda.stream(side)`` --
+        crashes hipGraph capture in ROCm 7.2's hipStreamEndCapture, so nested forks are never generated.)"""
+        live = [[br for br in seg if br] for seg in self.segments]
+        live = [seg for seg in live if seg]
+        if len(live) != 1:
+            raise FxError("fork_from: only tapes with a single (parallel) segment can run as a detached fork")
+        while len(pool) < len(live[0]):
+            pool.append(torch.cuda.Stream())
+        used = pool[:len(live[0])]
+        for st in used:
+            st.wait_stream(main)
+        for br, st in zip(live[0], used):
+            with torch.cuda.stream(st):
+                self._issue(br)
+        return used
+
     def run_timed(self, names, sink):
         """Like run(), but brackets every launch whose entry-point name is in ``names`` with a pair of
         HIP events recorded on the launch stream; (name, start, end) tuples are appended to ``sink``."""
@@ -247,18 +266,39 @@ def pad32(n: int) -> int:
 
 
 def new_split(rows: int, cols: int, device):
-    """(hi, lo) bf16 buffers [rows, pad32(cols)] for fx_split_bf16 / fx_split_bf16_t outputs."""
+    """(hi, lo) bf16 buffers [rows, pad32(cols)] (row-major, contraction dim contiguous) for fx_split_bf16_t."""
     return (torch.zeros(rows, pad32(cols), dtype=torch.bfloat16, device=device),
             torch.zeros(rows, pad32(cols), dtype=torch.bfloat16, device=device))
 
 
+def pad128(n: int) -> int:
+    return (n + 127) // 128 * 128
+
+
+def new_split_kb(rows: int, cols: int, device):
+    """(hi, lo) K-BLOCKED bf16 buffers [pad32(cols)/32, pad128(rows), 32] (include/fxhip.h): the X operand of the
+    wide forward.  Padding rows/columns are zero (allocated zero, never written)."""
+    shape = (pad32(cols) // 32, pad128(rows), 32)
+    return (torch.zeros(shape, dtype=torch.bfloat16, device=device), torch.zeros(shape, dtype=torch.bfloat16, device=device))
+
+
+def unblock(t: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
+    """K-blocked [Kb, Rp, 32] -> row-major [rows, cols] view-copy (tests / debugging)."""
+    return t.permute(1, 0, 2).reshape(t.shape[1], -1)[:rows, :cols]
+
+
+def _chk_kb(hi, lo, R, K, what):
+    want = (pad32(K) // 32, pad128(R), 32)
+    if tuple(hi.shape) != want or tuple(lo.shape) != want or hi.dtype != torch.bfloat16 or not hi.is_contiguous():
+        raise FxError(f"{what}: hi/lo must be contiguous K-blocked bf16 {want} (ops.new_split_kb), got {tuple(hi.shape)}")
+
+
 def split_bf16(rec, hi, lo, x):
-    """hi/lo [R, pad32(C)] <- x [R, C]  (x ~= hi + lo)."""
+    """hi/lo K-blocked (new_split_kb(R, C)) <- x [R, C]  (x ~= hi + lo)."""
     _chk2d(x, "split_bf16.x")
     R, Cc = x.shape
-    if hi.shape != (R, pad32(Cc)) or lo.shape != hi.shape or hi.dtype != torch.bfloat16:
-        raise FxError(f"split_bf16: hi/lo must be bf16 [{R},{pad32(Cc)}]")
-    rec.emit("fx_split_bf16", hi.data_ptr(), lo.data_ptr(), x.data_ptr(), R, Cc, _ld(x), _ld(hi))
+    _chk_kb(hi, lo, R, Cc, "split_bf16")
+    rec.emit("fx_split_bf16", hi.data_ptr(), lo.data_ptr(), x.data_ptr(), R, Cc, _ld(x), hi.shape[1])
 
 
 def split_bf16_t(rec, hiT, loT, x):
@@ -276,12 +316,13 @@ def linear_fwd_bf16x3(rec, y, xhi, xlo, W, b, ws):
     _chk2d(W, "linear_fwd_bf16x3.W")
     M, N = y.shape
     K = W.shape[1]
-    if W.shape[0] != N or xhi.shape != (M, pad32(K)) or xlo.shape != xhi.shape:
+    if W.shape[0] != N:
         raise FxError("linear_fwd_bf16x3: shape mismatch")
+    _chk_kb(xhi, xlo, M, K, "linear_fwd_bf16x3")
     need = int(lib.fx_linear_fwd_bf16x3_workspace_bytes(M, N, K))
     ws.reserve(need)
     rec.emit("fx_linear_fwd_bf16x3", y.data_ptr(), xhi.data_ptr(), xlo.data_ptr(), W.data_ptr(), _ptr(b), M, N, K,
-             _ld(xhi), _ld(W), _ld(y), ws.buf.data_ptr(), ws.nbytes)
+             xhi.shape[1], _ld(W), _ld(y), ws.buf.data_ptr(), ws.nbytes)
 
 
 def linear_dw_adam_bf16x3(rec, W, m, v, dyT_hi, dyT_lo, xT_hi, xT_lo, ctrl):
@@ -310,15 +351,17 @@ def gemm_slabs(rec, layout, slabs, A, Bm, M, N):
     return s
 
 
-def linear_fwd_bf16x3_slabs(rec, slabs, xhi, xlo, W):
+def linear_fwd_bf16x3_slabs(rec, slabs, xhi, xlo, W, M):
     """Wide forward contraction, partial sums left in ``slabs`` [splitk, M, N]; returns splitk."""
     _chk2d(W, "linear_fwd_bf16x3_slabs.W")
-    M, (N, K) = xhi.shape[0], W.shape
+    N, K = W.shape
+    M = int(M)
     s = int(lib.fx_linear_fwd_bf16x3_splitk(M, N, K))
-    if slabs.numel() < s * M * N or xhi.shape != (M, pad32(K)):
+    _chk_kb(xhi, xlo, M, K, "linear_fwd_bf16x3_slabs")
+    if slabs.numel() < s * M * N:
         raise FxError("linear_fwd_bf16x3_slabs: bad buffer shapes")
     rec.emit("fx_linear_fwd_bf16x3_slabs", slabs.data_ptr(), slabs.numel() * 4, xhi.data_ptr(), xlo.data_ptr(),
-             W.data_ptr(), M, N, K, _ld(xhi), _ld(W))
+             W.data_ptr(), M, N, K, xhi.shape[1], _ld(W))
     return s
 
 
@@ -342,13 +385,16 @@ def gram_hadamard(rec, slots, slabs_x, nx, slabs_d, nd, n):
     rec.emit("fx_gram_hadamard", slots.data_ptr(), slabs_x.data_ptr(), int(nx), slabs_d.data_ptr(), int(nd), int(n))
 
 
-def gather_split(rec, x, hi, lo, hiT, loT, src, idx, ctrl_cursor=None, cursor_stride=0):
-    """x[r,:] = src[idx[r],:] plus its bf16 splits (row-major [R,pad32(F)] and transposed [F,pad32(R)])."""
-    R, Fc = hi.shape[0], src.shape[1]
-    if hi.shape != (R, pad32(Fc)) or hiT.shape != (Fc, pad32(R)) or idx.dtype != torch.int64:
+def gather_split(rec, x, hi, lo, hiT, loT, src, idx, ctrl_cursor=None, cursor_stride=0, n_rows=None):
+    """x[r,:] = src[idx[r],:] plus its bf16 splits: K-blocked hi/lo (new_split_kb(R, F), the forward operand) and
+    transposed hiT/loT [F, pad32(R)] (the weight-gradient operand)."""
+    R = int(n_rows) if n_rows is not None else x.shape[0]
+    Fc = src.shape[1]
+    _chk_kb(hi, lo, R, Fc, "gather_split")
+    if hiT.shape != (Fc, pad32(R)) or idx.dtype != torch.int64:
         raise FxError("gather_split: bad buffer shapes")
     rec.emit("fx_gather_split", _ptr(x), hi.data_ptr(), lo.data_ptr(), hiT.data_ptr(), loT.data_ptr(), src.data_ptr(),
-             idx.data_ptr(), R, Fc, _ld(src), _ld(x) if x is not None else Fc, _ld(hi), _ld(hiT), _ptr(ctrl_cursor),
+             idx.data_ptr(), R, Fc, _ld(src), _ld(x) if x is not None else Fc, hi.shape[1], _ld(hiT), _ptr(ctrl_cursor),
              int(cursor_stride))
 
 

@@ -69,9 +69,16 @@ int fx_colsum(float* out, const float* x, int B, int C, long ldx, fx_stream_t st
 /* ---- split-bf16 ("bf16x3") variants for the WIDE layers: x ~= hi + lo in bf16, products evaluated as
  *      hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 accumulation (3/16 of the fp32-MFMA cost, ~2^-16
  *      per-product error).  hi/lo buffers are bf16 (2 bytes/element), zero padded to a multiple of 32 in
- *      the contracted dimension, ld a multiple of 8.  Same reference ops as fx_gemm_f32 NT /
- *      fx_linear_dw_adam_f32 above. */
-int fx_split_bf16(void* hi, void* lo, const float* x, int R, int C, long ldx, long ldo, fx_stream_t stream);
+ *      the contracted dimension.  Two layouts:
+ *        K-BLOCKED (fx_split_bf16, fx_gather_split hi/lo; the X operand of fx_linear_fwd_bf16x3*):
+ *          [ceil(C/32)][rows_padded][32], element (r, c) at ((c/32)*rows_padded + r)*32 + c%32, rows_padded a
+ *          multiple of 128 with zero padding rows -- a 128-row K-step tile is 8 KB contiguous (64 full cache
+ *          lines instead of 128 half lines; measured +22 % on the wide forward);
+ *        TRANSPOSED row-major (fx_split_bf16_t, fx_gather_split hiT/loT; operands of fx_linear_dw_adam_bf16x3):
+ *          [C][ld] with the contracted (batch) dimension contiguous, ld a multiple of 8.
+ *      Same reference ops as fx_gemm_f32 NT / fx_linear_dw_adam_f32 above.  In fx_linear_fwd_bf16x3* the `ldx`
+ *      argument is rows_padded of the K-blocked X. */
+int fx_split_bf16(void* hi, void* lo, const float* x, int R, int C, long ldx, long rows_padded, fx_stream_t stream);
 int fx_split_bf16_t(void* hiT, void* loT, const float* x, int R, int C, long ldx, long ldo, fx_stream_t stream);
 long fx_linear_fwd_bf16x3_workspace_bytes(int M, int N, int K);
 int fx_linear_fwd_bf16x3(float* Y, const void* xhi, const void* xlo, const float* W, const float* bias, int M, int N, int K,
@@ -98,8 +105,8 @@ int fx_gram_hadamard_blocks(long n);
 int fx_gram_hadamard(double* slots, const float* slabs_x, int nslabs_x, const float* slabs_d, int nslabs_d, long n,
                      fx_stream_t stream);
 int fx_gather_split(float* x, void* hi, void* lo, void* hiT, void* loT, const float* src, const long* idx, int n_rows,
-                    int n_cols, long ld_src, long ldx, long ldo, long ldt, const float* ctrl_cursor, long cursor_stride,
-                    fx_stream_t stream);
+                    int n_cols, long ld_src, long ldx, long ldo /* rows_padded of the K-blocked hi/lo */, long ldt,
+                    const float* ctrl_cursor, long cursor_stride, fx_stream_t stream);
 
 /* ---- BatchNorm1d (+LeakyReLU before | +ReLU+Dropout after), train & eval (modules.py:25-34,145-148) */
 int fx_bn_act_fwd(float* out, const float* x, const float* gamma, const float* beta, float* running_mean,

@@ -14,7 +14,7 @@ b = torch.zeros(H, device=dev)
 dY = torch.randn(B, H, device=dev, generator=g) * 1e-3
 Y = torch.empty(B, H, device=dev)
 ws = ops.Workspace(dev)
-xs = ops.new_split(B, F, dev); ops.split_bf16(ops.IMMEDIATE, xs[0], xs[1], X)
+xs = ops.new_split_kb(B, F, dev); ops.split_bf16(ops.IMMEDIATE, xs[0], xs[1], X)
 xt = ops.new_split(F, B, dev); ops.split_bf16_t(ops.IMMEDIATE, xt[0], xt[1], X)
 dyt = ops.new_split(H, B, dev); ops.split_bf16_t(ops.IMMEDIATE, dyt[0], dyt[1], dY)
 ctrl = torch.zeros(64, device=dev); ops.step_begin(ops.IMMEDIATE, ctrl, 1e-3)

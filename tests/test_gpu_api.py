@@ -235,3 +235,64 @@ def test_early_stopping_and_run_trial():
     bad = dict(params, batch_size=100000)
     val2, _, _, info2 = run_trial(M.DirectPred, bad, ds, ["y"], seed=3, device="cuda")
     assert val2 == float("inf") and "error" in info2
+
+
+@pytest.mark.parametrize("model_name", ["DirectPred", "MultiTripletNetwork"])
+def test_pipelined_step_equals_plain_step(model_name):
+    """Double-buffered batch assembly (PipelinedStep: the batch of step t+1 is gathered during step t, hipGraph
+    replay) walks the same index tables as the plain one-plan step and must produce the identical trajectory."""
+    from flexynesis_amd.arch import ArchSpec
+    from flexynesis_amd.data import synthetic_cohort
+    from flexynesis_amd.engine import ParamStore, PipelinedStep, StepPlan
+    dev = torch.device("cuda:0")
+    layers = [("gex", 1300), ("cnv", 1100)]
+    trip = model_name == "MultiTripletNetwork"
+    variables = [("c", "categorical", 4)] if trip else [("y", "numerical", 1)]
+    spec = ArchSpec(model_name, layers, 32, 0.9, 16, variables, None, None, True)      # hidden >= 2^20/F: wide path
+    cohort = synthetic_cohort(layers, 400, dev, seed=5)
+    B, nb, steps, lr = 32, 3, 8, 1e-3
+    rows = B * (3 if trip else 1)
+    g = torch.Generator().manual_seed(0)
+    tables = [torch.randint(0, 400, (nb * rows,), generator=g).to(dev) for _ in range(steps // nb + 2)]
+    torch.manual_seed(11)
+    init = ParamStore(spec, dev).state_dict()
+
+    def plain():
+        store = ParamStore(spec, dev)
+        store.load_state(init)
+        plan = StepPlan(store, B, train=True, fused=True, seed=9, cohort=cohort, n_batches=nb, epoch_acc=True)
+        store.ctrl[9] = store.ctrl[0].clone()
+        out = []
+        for s in range(steps):
+            if s % nb == 0:
+                plan.idx.copy_(tables[s // nb])
+            plan.train_step(lr, gather=True)
+            out.append(plan.losses()["total"])
+        return out, store.state_dict()
+
+    def piped(graph):
+        store = ParamStore(spec, dev)
+        store.load_state(init)
+        pipe = PipelinedStep(store, B, cohort=cohort, n_batches=nb, seed=9)
+        pipe.idx.copy_(tables[0])
+        pipe.prime()
+        out, e = [], 0
+        for s in range(steps):
+            if pipe.epoch_end_next():
+                e += 1
+                pipe.idx.copy_(tables[e])
+            if graph and pipe.graphs[0] is not None:
+                pipe.replay()
+            else:
+                pipe.step(lr)
+                if graph:
+                    pipe.capture(lr)
+            out.append(pipe.losses()["total"])
+        return out, store.state_dict()
+
+    l0, s0 = plain()
+    for graph in (False, True):
+        l1, s1 = piped(graph)
+        assert l1 == l0, (graph, l0, l1)
+        for k in s0:
+            assert torch.equal(s0[k], s1[k]), (graph, k)
