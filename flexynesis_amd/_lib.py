@@ -35,6 +35,8 @@ PROTOTYPES = {
     "fx_gram_hadamard_blocks": (I, [L]),
     "fx_gram_hadamard": (I, [P, P, I, P, I, L, P]),
     "fx_gather_split": (I, [P, P, P, P, P, P, P, I, I, L, L, L, L, P, L, P]),
+    "fx_heads_fwd": (I, [P, I, P, L, I, I, I, F, P, P]),
+    "fx_heads_bwd": (I, [P, I, P, L, P, L, I, I, I, F, P]),
     "fx_split_bf16": (I, [P, P, P, I, I, L, L, P]),
     "fx_split_bf16_t": (I, [P, P, P, I, I, L, L, P]),
     "fx_linear_fwd_bf16x3_workspace_bytes": (L, [I, I, I]),
@@ -67,6 +69,13 @@ PROTOTYPES = {
 # functions whose int return value is a size/count, not an error code
 _QUERIES = {"fx_version", "fx_gemm_splitk", "fx_linear_fwd_bf16x3_splitk", "fx_gram_hadamard_blocks", "fx_gemm_workspace_bytes", "fx_linear_fwd_bf16x3_workspace_bytes", "fx_mmd_workspace_floats", "fx_recon_blocks", "fx_sumsq_blocks",
             "fx_last_error_string"}
+
+
+class HeadDesc(C.Structure):
+    """include/fxhip.h: fx_head_desc (host struct of device pointers)."""
+    _fields_ = [(n, P) for n in ("W1", "b1", "gamma", "beta", "running_mean", "running_var", "W2", "b2", "y1", "a1",
+                                 "save_mean", "save_invstd", "out", "mask", "dout", "gW1", "gb1", "ggamma", "gbeta",
+                                 "gW2", "gb2")] + [("seed", U64), ("offset", U64), ("hidden", I), ("n_out", I)]
 
 
 class FxError(RuntimeError):

@@ -1,0 +1,454 @@
+// fx_heads.hip -- all supervisor heads of a model in ONE launch each way.
+//
+// A supervisor head is the reference's MLP(latent -> supervisor_hidden -> n_out) (modules.py:106-150:
+// Linear -> BatchNorm1d -> ReLU -> Dropout(0.1) -> Linear) applied to the [B, L] embedding
+// (direct_pred.py:126-131, supervised_vae.py:190-196, triplet_encoder.py:160-164).  Every tensor involved is tiny
+// (B <= 128 rows, L <= 128, hidden <= 32, outputs <= 32), so as separate GEMM / BatchNorm launches the heads were
+// pure launch latency: 3 forward + 5 backward dependent launches per head at ~5-8 us each on the critical path
+// between the wide forward and the dW+Adam kernels.  Here one workgroup per head does the whole forward through
+// LDS, and one workgroup does the whole backward of all heads (sequentially, so the embedding gradient is summed in
+// a fixed order: deterministic, no atomics).  Arithmetic is plain fp32 FMA with the same expressions as
+// fx_bn_act_fwd/bwd (same Philox stream for the dropout mask), so the fused and unfused paths agree to rounding.
+#include "fx_common.h"
+
+#define FX_MAX_HEADS 8
+constexpr int HB = 128;   // max rows
+constexpr int HS = 32;    // max supervisor hidden width
+constexpr int HC = 32;    // max head outputs
+constexpr int HL = 128;   // max latent width
+
+struct FxHeadDesc {       // mirrors include/fxhip.h: fx_head_desc
+  const float* W1; const float* b1; const float* gamma; const float* beta; float* rmean; float* rvar;
+  const float* W2; const float* b2;
+  float* y1; float* a1; float* save_mean; float* save_invstd; float* out;
+  const float* mask;
+  const float* dout;
+  float* gW1; float* gb1; float* ggamma; float* gbeta; float* gW2; float* gb2;
+  unsigned long long seed, offset;
+  int S, C;
+};
+
+struct HeadsArgs {
+  FxHeadDesc h[FX_MAX_HEADS];
+  int n_heads;
+  const float* x; long ldx;
+  float* dx; long lddx; int dx_accumulate;
+  int B, L, train;
+  float drop_p;
+  const float* ctrl;
+};
+
+__device__ __forceinline__ unsigned long long heads_step_offset(const float* ctrl, unsigned long long offset) {
+  return ctrl ? offset + (((unsigned long long)ctrl[FXC_STEP]) << 44) : offset;   // same layout as fx_norm_act.hip
+}
+
+// column sums over rows of a [HB][33] LDS tile: thread (col = t&31, rg = t>>5) adds rows rg, rg+8, ...; the 8 partials
+// are then added in a fixed order by every thread of the column
+__device__ __forceinline__ float heads_colsum(float partial, float (*part)[32], int col, int rg) {
+  __syncthreads();
+  part[rg][col] = partial;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += part[i][col];
+  return s;
+}
+
+// Every global read inside a loop is staged through LDS first: a single workgroup has nothing to hide memory
+// latency behind, and a dependent global load per loop iteration (~0.5 us each) made the first version of these
+// kernels slower than the eight launches they replace.
+typedef float Tile[HB][33];
+
+// NOTE on every load below: addresses are CLAMPED into range and the load is unconditional; the select happens on the
+// loaded value.  `cond ? p[i] : 0` makes hipcc wrap each load in its own exec-mask region with an s_waitcnt vmcnt(0)
+// behind it, i.e. 16 dependent round trips to memory per staging call (measured: 45 us for the forward kernel).
+// dst[rr][cc] = src[rr, col0 + cc] for rr < B, col0 + cc < ncols, else 0   (32-column chunk, coalesced, 16 loads in flight)
+__device__ __forceinline__ void heads_stage(Tile dst, const float* __restrict__ src, long ld, int B, int col0, int ncols) {
+  const int t = threadIdx.x;
+  float v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int idx = t + 256 * i, rr = idx >> 5, cc = idx & 31;
+    v[i] = src[(long)min(rr, B - 1) * ld + min(col0 + cc, ncols - 1)];
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int idx = t + 256 * i, rr = idx >> 5, cc = idx & 31;
+    dst[rr][cc] = (rr < B && col0 + cc < ncols) ? v[i] : 0.f;
+  }
+}
+template <int MAXN>
+__device__ __forceinline__ void heads_copy(float* dst, const float* __restrict__ src, int n) {
+  float v[MAXN / 256];
+#pragma unroll
+  for (int i = 0; i < MAXN / 256; ++i) v[i] = src[min((int)threadIdx.x + 256 * i, n - 1)];
+#pragma unroll
+  for (int i = 0; i < MAXN / 256; ++i)
+    if ((int)threadIdx.x + 256 * i < n) dst[threadIdx.x + 256 * i] = v[i];
+}
+
+// Dropout mask for 4 consecutive elements i0 .. i0+3 of the Philox stream used by fx_bn_act_fwd
+// (element i -> word i&3 of block i>>2): two blocks cover any alignment; selection is branch-free.
+__device__ __forceinline__ void heads_mask4(unsigned long long seed, unsigned long long off, unsigned long long i0, float keep,
+                                            float mk[4]) {
+  uint32_t b[8];
+  fx_philox4(seed, off + (i0 >> 2), b);
+  fx_philox4(seed, off + (i0 >> 2) + 1, b + 4);
+  const int sh = (int)(i0 & 3);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    uint32_t w = b[k];
+    w = sh == 1 ? b[k + 1] : w;
+    w = sh == 2 ? b[k + 2] : w;
+    w = sh == 3 ? b[k + 3] : w;
+    mk[k] = fx_u01(w) <= keep ? 1.f : 0.f;
+  }
+}
+
+// All per-column loops run over the PADDED width HS = 32 with zero-padded parameters, so they have compile-time trip
+// counts and no predicates; only global stores are predicated on the true width.
+__global__ __launch_bounds__(256) void fx_heads_fwd_kernel(HeadsArgs a) {
+  const FxHeadDesc& h = a.h[blockIdx.x];
+  __shared__ Tile xs;                       // one 32-column chunk of the embedding
+  __shared__ Tile ys;                       // layer_1 output, then the block output (columns >= S stay zero)
+  __shared__ __attribute__((aligned(16))) float W1s[HS * HL];   // TRANSPOSED [L][32], columns >= S zero
+  __shared__ float W2s[HC * HS];            // [C][32], columns >= S zero
+  __shared__ float part[8][32];
+  __shared__ float stat[5][32];             // mean, invstd, gamma, beta, layer_1 bias (zero padded)
+  const int t = threadIdx.x, r = t & 127, hf = t >> 7, col = t & 31, rg = t >> 5;
+  const int S = h.S, C = h.C, B = a.B, L = a.L;
+  const int s0 = hf * (HS / 2);
+  {   // W1s[l][s] = W1[s][l] (zero for s >= S): the 16 weights one thread needs per l are 4 x ds_read_b128
+    float v[HS * HL / 256];
+#pragma unroll
+    for (int i = 0; i < HS * HL / 256; ++i) {
+      const int idx = t + 256 * i, s_ = idx / L, l_ = idx - s_ * L;       // coalesced over the source
+      v[i] = h.W1[min(idx, S * L - 1)];
+      (void)s_; (void)l_;
+    }
+#pragma unroll
+    for (int i = 0; i < HS * HL / 256; ++i) {
+      const int idx = t + 256 * i, s_ = idx / L, l_ = idx - s_ * L;
+      if (idx < HS * L) W1s[l_ * HS + s_] = idx < S * L ? v[i] : 0.f;
+    }
+  }
+  {
+    float v[HC * HS / 256];
+#pragma unroll
+    for (int i = 0; i < HC * HS / 256; ++i) {
+      const int idx = t + 256 * i, c = idx >> 5, s_ = idx & 31;
+      v[i] = h.W2[min(c, C - 1) * S + min(s_, S - 1)];
+    }
+#pragma unroll
+    for (int i = 0; i < HC * HS / 256; ++i) {
+      const int idx = t + 256 * i, c = idx >> 5, s_ = idx & 31;
+      W2s[idx] = (c < C && s_ < S) ? v[i] : 0.f;
+    }
+  }
+  if (t < 32) {
+    const int sc = min(t, S - 1);
+    const float g_ = h.gamma[sc], b_ = h.beta[sc], b1_ = h.b1[sc];
+    stat[2][t] = t < S ? g_ : 0.f;
+    stat[3][t] = t < S ? b_ : 0.f;
+    stat[4][t] = t < S ? b1_ : 0.f;
+  }
+  __syncthreads();
+  // ---- layer_1: y1[r, s] = b1[s] + sum_l x[r, l] W1[s, l]; each thread owns one row and 16 of the 32 padded columns
+  float acc[HS / 2];
+#pragma unroll
+  for (int j = 0; j < HS / 2; ++j) acc[j] = stat[4][s0 + j];
+  for (int c0 = 0; c0 < L; c0 += 32) {
+    __syncthreads();
+    heads_stage(xs, a.x, a.ldx, B, c0, L);
+    __syncthreads();
+    const int lmax = min(32, L - c0);
+    const float4* w4 = reinterpret_cast<const float4*>(W1s + c0 * HS + s0);
+    for (int l = 0; l < lmax; ++l) {
+      const float xv = xs[r][l];
+#pragma unroll
+      for (int q = 0; q < HS / 8; ++q) {
+        const float4 wv = w4[l * (HS / 4) + q];
+        acc[4 * q + 0] = fmaf(xv, wv.x, acc[4 * q + 0]);
+        acc[4 * q + 1] = fmaf(xv, wv.y, acc[4 * q + 1]);
+        acc[4 * q + 2] = fmaf(xv, wv.z, acc[4 * q + 2]);
+        acc[4 * q + 3] = fmaf(xv, wv.w, acc[4 * q + 3]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < HS / 2; ++j) ys[r][s0 + j] = (r < B) ? acc[j] : 0.f;
+  if (r < B && h.y1) {
+#pragma unroll
+    for (int j = 0; j < HS / 2; ++j)
+      if (s0 + j < S) h.y1[(long)r * S + s0 + j] = acc[j];
+  }
+  // ---- BatchNorm statistics (two-pass, biased variance for normalisation, unbiased for running_var)
+  float mean = 0.f, invstd = 0.f;
+  __syncthreads();                                        // ys complete
+  if (a.train) {
+    float p = 0.f;
+    for (int rr = rg; rr < B; rr += 8) p += ys[rr][col];
+    mean = heads_colsum(p, part, col, rg) / (float)B;
+    float q = 0.f;
+    for (int rr = rg; rr < B; rr += 8) {
+      const float d = ys[rr][col] - mean;
+      q += d * d;
+    }
+    const float var_b = heads_colsum(q, part, col, rg) / (float)B;
+    invstd = 1.0f / sqrtf(var_b + FX_BN_EPS);
+    if (col < S && rg == 0) {
+      h.save_mean[col] = mean;
+      h.save_invstd[col] = invstd;
+      const float var_u = B > 1 ? var_b * ((float)B / (float)(B - 1)) : var_b;
+      h.rmean[col] = (1.0f - FX_BN_MOMENTUM) * h.rmean[col] + FX_BN_MOMENTUM * mean;
+      h.rvar[col] = (1.0f - FX_BN_MOMENTUM) * h.rvar[col] + FX_BN_MOMENTUM * var_u;
+    }
+  } else {
+    const int sc = min(col, S - 1);
+    mean = h.rmean[sc];
+    invstd = 1.0f / sqrtf(h.rvar[sc] + FX_BN_EPS);
+  }
+  if (rg == 0) { stat[0][col] = mean; stat[1][col] = invstd; }
+  __syncthreads();
+  // ---- normalise + ReLU + dropout (mask scaled first, then multiplied == F.dropout on CPU)
+  const bool drop = a.train && a.drop_p > 0.f;
+  const float keep_scale = 1.0f / (1.0f - a.drop_p);
+  float mk[HS / 2];
+  if (drop && h.mask) {
+#pragma unroll
+    for (int j = 0; j < HS / 2; ++j) mk[j] = h.mask[(long)min(r, B - 1) * S + min(s0 + j, S - 1)];
+  } else if (drop) {
+    const unsigned long long rng_off = heads_step_offset(a.ctrl, h.offset);
+#pragma unroll
+    for (int jb = 0; jb < HS / 8; ++jb)
+      heads_mask4(h.seed, rng_off, (unsigned long long)r * S + s0 + 4 * jb, 1.0f - a.drop_p, mk + 4 * jb);
+  } else {
+#pragma unroll
+    for (int j = 0; j < HS / 2; ++j) mk[j] = 1.f;
+  }
+  float yv[HS / 2];
+#pragma unroll
+  for (int j = 0; j < HS / 2; ++j) {
+    const int s = s0 + j;
+    float y = (ys[r][s] - stat[0][s]) * stat[1][s] * stat[2][s] + stat[3][s];
+    y = fmaxf(y, 0.f);
+    if (drop) y = y * (mk[j] * keep_scale);
+    yv[j] = (r < B) ? y : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < HS / 2; ++j) ys[r][s0 + j] = yv[j];
+  if (r < B && h.a1) {
+#pragma unroll
+    for (int j = 0; j < HS / 2; ++j)
+      if (s0 + j < S) h.a1[(long)r * S + s0 + j] = yv[j];
+  }
+  __syncthreads();
+  // ---- layer_out: out[r, c] = b2[c] + sum_s a1[r, s] W2[c, s]   (padded columns of a1 / W2 are zero)
+  const int Ch = (C + 1) >> 1;
+  for (int c = hf * Ch; c < min(C, (hf + 1) * Ch); ++c) {
+    float o = h.b2 ? h.b2[c] : 0.f;
+#pragma unroll
+    for (int s = 0; s < HS; ++s) o += ys[r][s] * W2s[c * HS + s];
+    if (r < B) h.out[(long)r * C + c] = o;
+  }
+}
+
+// Backward of every head and the sum of their embedding gradients.  One workgroup; heads are processed in order.
+__global__ __launch_bounds__(256) void fx_heads_bwd_kernel(HeadsArgs a) {
+  __shared__ Tile R1;                 // dout (columns >= C zero), later 32-column chunks of the embedding
+  __shared__ Tile R2;                 // saved block output, then x-hat, then layer_1.weight as [S][L]
+  __shared__ Tile R3;                 // grad at the BatchNorm output, then grad at the layer_1 output
+  __shared__ float W2s[HC * HS];      // [C][32], columns >= S zero
+  __shared__ float part[8][32];
+  __shared__ float stat[3][32];       // mean, invstd, gamma (zero padded)
+  const int t = threadIdx.x, r = t & 127, hf = t >> 7, col = t & 31, rg = t >> 5;
+  const int B = a.B, L = a.L;
+  const int Lh = (L + 1) >> 1, l0 = hf * Lh;
+  const int s0 = hf * (HS / 2);
+  float* W1s = &R2[0][0];             // HB*33 floats >= HS*HL
+  float accx[HL / 2];
+#pragma unroll
+  for (int j = 0; j < HL / 2; ++j) accx[j] = 0.f;
+  if (a.dx && a.dx_accumulate) {
+#pragma unroll
+    for (int j = 0; j < HL / 2; ++j) accx[j] = a.dx[(long)min(r, B - 1) * a.lddx + min(l0 + j, L - 1)];   // only in-range lanes are stored
+  }
+  const float gate_scale = 1.0f / (1.0f - a.drop_p);
+  for (int hi = 0; hi < a.n_heads; ++hi) {
+    const FxHeadDesc& h = a.h[hi];
+    const int S = h.S, C = h.C;
+    __syncthreads();
+    heads_stage(R1, h.dout, C, B, 0, C);
+    heads_stage(R2, h.a1, S, B, 0, S);
+    {
+      float v[HC * HS / 256];
+#pragma unroll
+      for (int i = 0; i < HC * HS / 256; ++i) {
+        const int idx = t + 256 * i, c = idx >> 5, s_ = idx & 31;
+        v[i] = h.W2[min(c, C - 1) * S + min(s_, S - 1)];
+      }
+#pragma unroll
+      for (int i = 0; i < HC * HS / 256; ++i) {
+        const int idx = t + 256 * i, c = idx >> 5, s_ = idx & 31;
+        W2s[idx] = (c < C && s_ < S) ? v[i] : 0.f;
+      }
+    }
+    if (t < 32) {
+      const int sc = min(t, S - 1);
+      const float m_ = h.save_mean[sc], i_ = h.save_invstd[sc], g_ = h.gamma[sc];
+      stat[0][t] = t < S ? m_ : 0.f;
+      stat[1][t] = t < S ? i_ : 0.f;
+      stat[2][t] = t < S ? g_ : 0.f;
+    }
+    __syncthreads();
+    // layer_out.weight / bias gradients (over the padded [C][32] grid; only true columns are stored)
+    for (int o = t; o < C * HS; o += 256) {
+      const int c = o >> 5, s = o & 31;
+      float g = 0.f;
+#pragma unroll 8
+      for (int rr = 0; rr < HB; ++rr) g += R1[rr][c] * R2[rr][s];      // rows >= B are zero
+      if (s < S) h.gW2[c * S + s] = g;
+    }
+    if (h.gb2 && t < C) {
+      float g = 0.f;
+#pragma unroll 8
+      for (int rr = 0; rr < HB; ++rr) g += R1[rr][t];
+      h.gb2[t] = g;
+    }
+    // grad at the BatchNorm output: (dout . W2) gated by the saved block output (ReLU and dropout in one test)
+    {
+      float d[HS / 2];
+#pragma unroll
+      for (int j = 0; j < HS / 2; ++j) d[j] = 0.f;
+      for (int c = 0; c < C; ++c) {
+        const float dv = R1[r][c];
+#pragma unroll
+        for (int j = 0; j < HS / 2; ++j) d[j] += dv * W2s[c * HS + s0 + j];
+      }
+#pragma unroll
+      for (int j = 0; j < HS / 2; ++j) R3[r][s0 + j] = (R2[r][s0 + j] > 0.f) ? d[j] * gate_scale : 0.f;
+    }
+    __syncthreads();
+    // x-hat of the saved layer_1 output (replaces the block output in R2)
+    {
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int idx = t + 256 * i, rr = idx >> 5, cc = idx & 31;
+        v[i] = h.y1[(long)min(rr, B - 1) * S + min(cc, S - 1)];
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int idx = t + 256 * i, rr = idx >> 5, cc = idx & 31;
+        R2[rr][cc] = (rr < B && cc < S) ? (v[i] - stat[0][cc]) * stat[1][cc] : 0.f;
+      }
+    }
+    __syncthreads();
+    // BatchNorm backward (same expressions as fx_bn_bwd_kernel); padded columns have gamma = 0
+    const float invstd = stat[1][col], gm = stat[2][col];
+    float s1 = 0.f, s2 = 0.f;
+    for (int rr = rg; rr < B; rr += 8) {
+      const float dy = R3[rr][col];
+      s1 += dy;
+      s2 += dy * R2[rr][col];
+    }
+    const float sum_dy = heads_colsum(s1, part, col, rg);
+    const float sum_dy_xh = heads_colsum(s2, part, col, rg);
+    float sb = 0.f;
+    {
+      const float invB = 1.0f / (float)B;
+      for (int rr = rg; rr < B; rr += 8) {
+        const float d = gm * invstd * (R3[rr][col] - invB * sum_dy - R2[rr][col] * invB * sum_dy_xh);
+        R3[rr][col] = d;        // each (row, col) is owned by exactly one thread here
+        sb += d;
+      }
+    }
+    const float sum_dx = heads_colsum(sb, part, col, rg);
+    if (col < S && rg == 0) {
+      h.ggamma[col] = sum_dy_xh;
+      h.gbeta[col] = sum_dy;
+      h.gb1[col] = sum_dx;
+    }
+    // layer_1.weight gradient: gW1[s, l] = sum_r dy1[r, s] x[r, l], 32 columns of x at a time through R1
+    for (int c0 = 0; c0 < L; c0 += 32) {
+      __syncthreads();
+      heads_stage(R1, a.x, a.ldx, B, c0, L);
+      __syncthreads();
+      for (int o = t; o < S * 32; o += 256) {
+        const int s = o >> 5, l = o & 31;
+        float g = 0.f;
+#pragma unroll 8
+        for (int rr = 0; rr < HB; ++rr) g += R3[rr][s] * R1[rr][l];
+        if (c0 + l < L) h.gW1[(long)s * L + c0 + l] = g;
+      }
+    }
+    // embedding gradient, accumulated over the heads in registers (layer_1.weight staged over the dead x-hat)
+    if (a.dx) {
+      __syncthreads();
+      heads_copy<HS * HL>(W1s, h.W1, S * L);
+      __syncthreads();
+      // branch-free as in the forward: lanes j with l0 + j >= L accumulate neighbouring weights and are never stored
+      for (int s = 0; s < S; ++s) {
+        const float d = R3[r][s];
+        const float* w = W1s + s * L + l0;
+#pragma unroll
+        for (int j = 0; j < HL / 2; ++j) accx[j] = fmaf(d, w[j], accx[j]);
+      }
+    }
+  }
+  if (a.dx && r < B) {
+#pragma unroll
+    for (int j = 0; j < HL / 2; ++j)
+      if (j < Lh && l0 + j < L) a.dx[(long)r * a.lddx + l0 + j] = accx[j];
+  }
+}
+
+extern "C" {
+
+struct fx_head_desc;   // include/fxhip.h; layout identical to FxHeadDesc
+
+static int heads_check(const FxHeadDesc* heads, int n_heads, const float* x, int B, int L, const char* who) {
+  FX_REQUIRE(heads && x && n_heads > 0 && n_heads <= FX_MAX_HEADS, "%s: bad args (1..%d heads)", who, FX_MAX_HEADS);
+  FX_REQUIRE(B > 0 && B <= HB && L > 0 && L <= HL, "%s: B=%d must be <= %d and latent=%d <= %d", who, B, HB, L, HL);
+  for (int i = 0; i < n_heads; ++i)
+    FX_REQUIRE(heads[i].S > 0 && heads[i].S <= HS && heads[i].C > 0 && heads[i].C <= HC && heads[i].W1 && heads[i].W2,
+               "%s: head %d has hidden=%d (max %d), outputs=%d (max %d)", who, i, heads[i].S, HS, heads[i].C, HC);
+  return 0;
+}
+
+int fx_heads_fwd(const void* heads_, int n_heads, const float* x, long ldx, int B, int L, int train, float drop_p,
+                 const float* ctrl, hipStream_t stream) {
+  const FxHeadDesc* heads = (const FxHeadDesc*)heads_;
+  if (int rc = heads_check(heads, n_heads, x, B, L, "fx_heads_fwd")) return rc;
+  FX_REQUIRE(!train || B > 1, "fx_heads_fwd: train mode needs B > 1");
+  HeadsArgs a{};
+  for (int i = 0; i < n_heads; ++i) {
+    a.h[i] = heads[i];
+    FX_REQUIRE(a.h[i].b1 && a.h[i].gamma && a.h[i].beta && a.h[i].rmean && a.h[i].rvar && a.h[i].out,
+               "fx_heads_fwd: head %d has a null parameter/output pointer", i);
+    FX_REQUIRE(!train || (a.h[i].save_mean && a.h[i].save_invstd && a.h[i].y1 && a.h[i].a1),
+               "fx_heads_fwd: train mode needs y1/a1/save_mean/save_invstd (head %d)", i);
+  }
+  a.n_heads = n_heads; a.x = x; a.ldx = ldx; a.B = B; a.L = L; a.train = train; a.drop_p = drop_p; a.ctrl = ctrl;
+  hipLaunchKernelGGL(fx_heads_fwd_kernel, dim3(n_heads), dim3(256), 0, stream, a);
+  return fx_check_launch("fx_heads_fwd");
+}
+
+int fx_heads_bwd(const void* heads_, int n_heads, const float* x, long ldx, float* dx, long lddx, int dx_accumulate, int B,
+                 int L, float drop_p, hipStream_t stream) {
+  const FxHeadDesc* heads = (const FxHeadDesc*)heads_;
+  if (int rc = heads_check(heads, n_heads, x, B, L, "fx_heads_bwd")) return rc;
+  HeadsArgs a{};
+  for (int i = 0; i < n_heads; ++i) {
+    a.h[i] = heads[i];
+    FX_REQUIRE(a.h[i].dout && a.h[i].a1 && a.h[i].y1 && a.h[i].save_mean && a.h[i].save_invstd && a.h[i].gamma &&
+                   a.h[i].gW1 && a.h[i].gb1 && a.h[i].ggamma && a.h[i].gbeta && a.h[i].gW2,
+               "fx_heads_bwd: head %d has a null saved-tensor / gradient pointer", i);
+  }
+  a.n_heads = n_heads; a.x = x; a.ldx = ldx; a.dx = dx; a.lddx = lddx; a.dx_accumulate = dx_accumulate;
+  a.B = B; a.L = L; a.train = 1; a.drop_p = drop_p;
+  hipLaunchKernelGGL(fx_heads_bwd_kernel, dim3(1), dim3(256), 0, stream, a);
+  return fx_check_launch("fx_heads_bwd");
+}
+
+}  // extern "C"

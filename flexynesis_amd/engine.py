@@ -24,6 +24,7 @@ Two gradient modes:
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -203,7 +204,8 @@ class StepPlan:
 
     def __init__(self, store: ParamStore, B: int, train: bool = True, fused: bool = True, clip: bool = True,
                  supplied_draws: bool = False, seed: int = 0, cohort=None, n_batches: int = 0,
-                 epoch_acc: bool = False, precision: str = "bf16x3", branches: bool = True, share: "StepPlan" = None):
+                 epoch_acc: bool = False, precision: str = "bf16x3", branches: bool = True, share: "StepPlan" = None,
+                 fuse_heads: bool = True):
         self.store, self.spec, self.B, self.train = store, store.spec, int(B), train
         self.fused = bool(fused) and train
         self.clip = clip
@@ -214,6 +216,8 @@ class StepPlan:
         self._branch = 0
         self.branches = bool(branches)          # per-modality chains as parallel hipGraph branches
         self.bn_slabs = False                   # fold the wide layer's split-K reduce into BatchNorm (measured: no gain)
+        # all supervisor heads in one launch each way (fx_heads_fwd/bwd); FX_FUSE_HEADS=0 is an A/B switch for benchmarks
+        self.fuse_heads = bool(fuse_heads) and os.environ.get("FX_FUSE_HEADS", "1") != "0"
         self._gram_x: Dict[int, tuple] = {}
         self._jobs: Dict[str, tuple] = {}
         self._slot_o = 0
@@ -426,9 +430,12 @@ class StepPlan:
         """Supervisor heads + their losses (value and output-gradient in one kernel each)."""
         spec, st, B = self.spec, self.store, self.B
         names = spec.loss_names()
-        for (v, kind, C) in spec.variables:
-            o = self._new(f"MLPs.{v}/out", B, C)
-            self._mlp_fwd(rec_f, "MLPs." + v, emb, o, B, 1, ["MLPs." + v])
+        if self._heads_fusable(emb):
+            self._heads_fwd_fused(rec_f, emb)
+        else:
+            for (v, kind, C) in spec.variables:
+                o = self._new(f"MLPs.{v}/out", B, C)
+                self._mlp_fwd(rec_f, "MLPs." + v, emb, o, B, 1, ["MLPs." + v])
         for (v, kind, C) in spec.variables:
             o = self.buf[f"MLPs.{v}/out"]
             do = self._new(f"MLPs.{v}/dout", B, C)
@@ -441,7 +448,48 @@ class StepPlan:
             else:
                 ops.ce_masked(rec_f, li, do, o, self.y[v], lv)
 
+    def _heads_fusable(self, emb) -> bool:
+        """fx_heads_fwd / fx_heads_bwd cover every search-space shape of the reference (config.py:7-15: latent <= 128,
+        supervisor hidden <= 32, batch <= 128); anything larger goes through the per-layer kernels."""
+        m, st = ops.HEADS_MAX, self.store
+        if not self.fuse_heads or self.B > m["B"] or emb.shape[1] > m["L"] or not (0 < len(self.spec.variables) <= m["heads"]):
+            return False
+        return all(st.shapes[f"MLPs.{v}.layer_1.weight"][0] <= m["hidden"] and C <= m["n_out"]
+                   for (v, _, C) in self.spec.variables)
+
+    def _heads_fwd_fused(self, rec_f, emb):
+        st, B = self.store, self.B
+        descs = []
+        for (v, kind, C) in self.spec.variables:
+            pre = "MLPs." + v
+            S = st.shapes[pre + ".layer_1.weight"][0]
+            bias_key = pre + ".layer_out.bias"
+            mask = self._draw(pre, B, S) if (self.supplied and self.train) else None
+            seed, off = self._rng()
+            descs.append(ops.head_desc(
+                W1=st.p(pre + ".layer_1.weight"), b1=st.p(pre + ".layer_1.bias"), gamma=st.p(pre + ".batchnorm.weight"),
+                beta=st.p(pre + ".batchnorm.bias"), running_mean=st.b(pre + ".batchnorm.running_mean"),
+                running_var=st.b(pre + ".batchnorm.running_var"), W2=st.p(pre + ".layer_out.weight"),
+                b2=st.p(bias_key) if bias_key in st.shapes else None, y1=self._new(pre + "/y1", B, S),
+                a1=self._new(pre + "/a1", B, S), save_mean=self._new(pre + "/save_mean", 1, S),
+                save_invstd=self._new(pre + "/save_invstd", 1, S), out=self._new(f"MLPs.{v}/out", B, C), mask=mask,
+                seed=seed, offset=off, hidden=S, n_out=C))
+        self._head_descs = descs
+        ops.heads_fwd(rec_f, descs, emb, B, emb.shape[1], self.train, DROPOUT_P if self.train else 0.0, ctrl=st.ctrl)
+
     def _head_bwd(self, rec_b, emb, demb, first_accumulate=False):
+        if getattr(self, "_head_descs", None):
+            st = self.store
+            for d, (v, kind, C) in zip(self._head_descs, self.spec.variables):
+                pre = "MLPs." + v
+                bias_key = pre + ".layer_out.bias"
+                for field, t in (("dout", self.buf[f"MLPs.{v}/dout"]), ("gW1", st.g(pre + ".layer_1.weight")),
+                                 ("gb1", st.g(pre + ".layer_1.bias")), ("ggamma", st.g(pre + ".batchnorm.weight")),
+                                 ("gbeta", st.g(pre + ".batchnorm.bias")), ("gW2", st.g(pre + ".layer_out.weight")),
+                                 ("gb2", st.g(bias_key) if bias_key in st.shapes else None)):
+                    setattr(d, field, t.data_ptr() if t is not None else None)
+            ops.heads_bwd(rec_b, self._head_descs, emb, demb, self.B, emb.shape[1], DROPOUT_P, dx_accumulate=first_accumulate)
+            return
         acc = first_accumulate
         for (v, kind, C) in self.spec.variables:
             self._mlp_bwd(rec_b, "MLPs." + v, emb, self.buf[f"MLPs.{v}/dout"], self.B, 1, dx=demb, dx_accumulate=acc)

@@ -398,6 +398,42 @@ def gather_split(rec, x, hi, lo, hiT, loT, src, idx, ctrl_cursor=None, cursor_st
              int(cursor_stride))
 
 
+HEADS_MAX = dict(B=128, L=128, hidden=32, n_out=32, heads=8)     # limits of fx_heads_fwd / fx_heads_bwd
+
+
+def head_desc(**kw):
+    """One fx_head_desc; tensors are converted to device pointers (None -> NULL)."""
+    d = _lib.HeadDesc()
+    for k, v in kw.items():
+        setattr(d, k, v.data_ptr() if torch.is_tensor(v) else v)
+    return d
+
+
+def _head_array(rec, descs):
+    arr = (_lib.HeadDesc * len(descs))(*descs)
+    if hasattr(rec, "keep"):
+        rec.keep(arr)                   # the tape re-reads the host array at every launch
+    return arr
+
+
+def heads_fwd(rec, descs, x, B, L, train, drop_p, ctrl=None):
+    """All supervisor heads forward in one launch (one workgroup per head)."""
+    _chk2d(x, "heads_fwd.x")
+    arr = _head_array(rec, descs)
+    rec.emit("fx_heads_fwd", C.addressof(arr), len(descs), x.data_ptr(), _ld(x), int(B), int(L), int(train), float(drop_p),
+             _ptr(ctrl))
+    return arr
+
+
+def heads_bwd(rec, descs, x, dx, B, L, drop_p, dx_accumulate=False):
+    """All supervisor heads backward + the summed embedding gradient in one launch."""
+    _chk2d(x, "heads_bwd.x")
+    arr = _head_array(rec, descs)
+    rec.emit("fx_heads_bwd", C.addressof(arr), len(descs), x.data_ptr(), _ld(x), _ptr(dx), _ld(dx) if dx is not None else 0,
+             int(bool(dx_accumulate)), int(B), int(L), float(drop_p))
+    return arr
+
+
 def colsum(rec, out, x):
     _chk2d(x, "colsum.x")
     rec.emit("fx_colsum", out.data_ptr(), x.data_ptr(), x.shape[0], x.shape[1], _ld(x))

@@ -108,6 +108,34 @@ int fx_gather_split(float* x, void* hi, void* lo, void* hiT, void* loT, const fl
                     int n_cols, long ld_src, long ldx, long ldo /* rows_padded of the K-blocked hi/lo */, long ldt,
                     const float* ctrl_cursor, long cursor_stride, fx_stream_t stream);
 
+/* ---- all supervisor heads in one launch each way.  A head is the reference MLP(latent -> hidden -> n_out)
+ *      (modules.py:106-150: Linear -> BatchNorm1d -> ReLU -> Dropout -> Linear) applied to the [B, L] embedding
+ *      (direct_pred.py:126-131, supervised_vae.py:190-196, triplet_encoder.py:160-164) and its autograd backward.
+ *      `heads` is a HOST array of descriptors holding DEVICE pointers (copied into the kernel arguments at launch).
+ *      Limits: B <= 128, L <= 128, hidden <= 32, n_out <= 32, <= 8 heads; larger shapes use the per-layer entry
+ *      points above.  fx_heads_fwd: y1 (layer_1 output), a1 (block output), save_*, running stats (train) and
+ *      `out`; dropout from `mask` (supplied 0/1 [B,hidden]) or Philox(seed, offset, step from ctrl), the same
+ *      stream as fx_bn_act_fwd.  fx_heads_bwd: from `dout` (the loss kernels' output gradient) every parameter
+ *      gradient of every head and dx (+)= sum over heads of the embedding gradient, heads summed in order. */
+typedef struct fx_head_desc {
+  const float* W1; const float* b1;            /* layer_1.weight [hidden, L], .bias [hidden] */
+  const float* gamma; const float* beta;       /* batchnorm.weight / .bias [hidden] */
+  float* running_mean; float* running_var;     /* updated in train mode */
+  const float* W2; const float* b2;            /* layer_out.weight [n_out, hidden], .bias [n_out] or NULL */
+  float* y1; float* a1;                        /* saved for backward: [B, hidden] each */
+  float* save_mean; float* save_invstd;        /* [hidden] */
+  float* out;                                  /* [B, n_out] */
+  const float* mask;                           /* supplied dropout mask or NULL */
+  const float* dout;                           /* backward input [B, n_out] */
+  float* gW1; float* gb1; float* ggamma; float* gbeta; float* gW2; float* gb2;   /* gradients (gb2 NULL if no bias) */
+  unsigned long long seed, offset;             /* Philox stream of this head's dropout */
+  int hidden, n_out;
+} fx_head_desc;
+int fx_heads_fwd(const fx_head_desc* heads, int n_heads, const float* x, long ldx, int B, int L, int train, float drop_p,
+                 const float* ctrl, fx_stream_t stream);
+int fx_heads_bwd(const fx_head_desc* heads, int n_heads, const float* x, long ldx, float* dx, long lddx, int dx_accumulate,
+                 int B, int L, float drop_p, fx_stream_t stream);
+
 /* ---- BatchNorm1d (+LeakyReLU before | +ReLU+Dropout after), train & eval (modules.py:25-34,145-148) */
 int fx_bn_act_fwd(float* out, const float* x, const float* gamma, const float* beta, float* running_mean,
                   float* running_var, float* save_mean, float* save_invstd, const float* mask, float* mask_out, int B,

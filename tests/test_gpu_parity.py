@@ -603,3 +603,43 @@ def test_bn_fed_by_splitk_slabs(B, C, pre, post):
     close(x_out, x_ref, 1e-6, 1e-6, "slab sum")
     close(out2, out1, 1e-5, 1e-5, "bn from slabs")
     close(rv2, rv1, 1e-5, 1e-6, "running_var")
+
+
+@pytest.mark.parametrize("B,L", [(128, 64), (100, 128), (37, 16)])
+def test_fused_heads_match_per_layer_kernels(B, L):
+    """fx_heads_fwd / fx_heads_bwd (all supervisor heads in one launch each way) against the per-layer GEMM +
+    BatchNorm kernels: same Philox dropout stream, so masks are identical and everything else agrees to rounding."""
+    from flexynesis_amd.arch import ArchSpec
+    from flexynesis_amd.engine import ParamStore, StepPlan
+    dev = _dev()
+    variables = [("y", "numerical", 1), ("c", "categorical", 5), ("event", "numerical", 1)]
+    spec = ArchSpec("DirectPred", [("gex", 300), ("cnv", 200)], L, 0.3, 24, variables, "event", "time", True)
+    torch.manual_seed(B + L)
+    init = ParamStore(spec, dev).state_dict()
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(B, 300, generator=g), torch.randn(B, 200, generator=g)]
+    y = {"y": torch.randn(B, generator=g), "c": torch.randint(0, 5, (B,), generator=g).float(),
+         "event": (torch.rand(B, generator=g) < 0.5).float(), "time": torch.rand(B, generator=g) * 10}
+    y["y"][3] = float("nan")
+    y["c"][5] = -1.0
+    res = []
+    for fuse in (True, False):
+        store = ParamStore(spec, dev, materialize_big_grads=True)
+        store.load_state(init)
+        plan = StepPlan(store, B, train=True, fused=False, seed=77, fuse_heads=fuse)
+        assert plan._heads_fusable(plan.embeddings) == fuse
+        plan.set_batch(x_list=[x.to(dev) for x in xs], y={k: v.to(dev) for k, v in y.items()})
+        plan.train_step(1e-3)
+        res.append((plan.losses(), {k: store.g(k).clone() for k in store.small_keys},
+                    store.state_dict(), plan.buf["MLPs.c/a1"].clone()))
+    (l1, g1, s1, a1), (l0, g0, s0, a0) = res
+    assert torch.equal(a1 == 0, a0 == 0), "dropout/ReLU pattern differs: the fused kernel is not on the same Philox stream"
+    for k in l0:
+        close(l1[k], l0[k], 2e-6, 1e-7, f"loss {k}")
+    gmax = max(float(v.abs().max()) for v in g0.values())
+    for k in g0:      # biases in front of a BatchNorm have a true gradient of 0: both paths hold rounding noise there
+        scale = float(g0[k].abs().max())
+        close(g1[k], g0[k], 1e-4, 2e-6 * scale + 1e-6 * gmax, f"grad {k}")
+    for k in s0:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            close(s1[k], s0[k], 1e-5, 1e-7, k)
