@@ -1,6 +1,6 @@
 """Architecture description derived from (config, dataset) exactly the way the reference model
 constructors derive it (reference models/direct_pred.py:30-105, models/supervised_vae.py:42-130,
-models/triplet_encoder.py:36-123) plus the reference ``state_dict`` layout (the on-disk ABI read by
+models/triplet_encoder.py:36-123, models/crossmodal_pred.py:31-132) plus the reference ``state_dict`` layout (the on-disk ABI read by
 reference inference.py:378-379)."""
 from __future__ import annotations
 
@@ -9,7 +9,7 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
-MODEL_KINDS = ("DirectPred", "supervised_vae", "MultiTripletNetwork")
+MODEL_KINDS = ("DirectPred", "supervised_vae", "MultiTripletNetwork", "CrossModalPred")
 
 
 @dataclass
@@ -23,8 +23,31 @@ class ArchSpec:
     surv_event_var: Optional[str] = None
     surv_time_var: Optional[str] = None
     use_loss_weighting: bool = True
+    # CrossModalPred (crossmodal_pred.py:62-65): layers that are encoded / reconstructed; None = every layer
+    input_layers: Optional[List[str]] = None
+    output_layers: Optional[List[str]] = None
 
     # -- derived sizes ---------------------------------------------------------------------------
+    @property
+    def is_vae(self) -> bool:
+        return self.model in ("supervised_vae", "CrossModalPred")
+
+    def _idx(self, names) -> List[int]:
+        order = [n for n, _ in self.layers]
+        if names is None or self.model != "CrossModalPred":
+            return list(range(len(order)))
+        return [order.index(n) for n in names]
+
+    @property
+    def enc_idx(self) -> List[int]:
+        """encoders.j reads layers[enc_idx[j]] (all layers except for CrossModalPred's input_layers)"""
+        return self._idx(self.input_layers)
+
+    @property
+    def dec_idx(self) -> List[int]:
+        """decoders.j reconstructs layers[dec_idx[j]]"""
+        return self._idx(self.output_layers)
+
     def hidden(self, i: int) -> int:
         # int(F*factor) (direct_pred.py:78-80) then max(.,2) (modules.py:124 / supervised_vae.py:92)
         return max(int(self.layers[i][1] * self.hidden_dim_factor), 2)
@@ -39,7 +62,8 @@ class ArchSpec:
 
     @property
     def extra_loss(self) -> Optional[str]:
-        return {"DirectPred": None, "supervised_vae": "mmd_loss", "MultiTripletNetwork": "triplet_loss"}[self.model]
+        return {"DirectPred": None, "supervised_vae": "mmd_loss", "MultiTripletNetwork": "triplet_loss",
+                "CrossModalPred": "mmd_loss"}[self.model]
 
     def loss_names(self) -> List[str]:
         """Insertion order of the reference's ``losses`` dict in training_step
@@ -90,8 +114,9 @@ class ArchSpec:
                 out["fusion_block.weight"] = (L, n * L)
                 out["fusion_block.bias"] = (L,)
         else:
-            for i, (_, F) in enumerate(self.layers):
-                H, p = self.hidden(i), f"encoders.{i}"
+            n = len(self.enc_idx)
+            for j, i in enumerate(self.enc_idx):
+                F, H, p = self.layers[i][1], self.hidden(i), f"encoders.{j}"
                 out[p + ".hidden_layers.0.weight"] = (H, F)
                 out[p + ".hidden_layers.0.bias"] = (H,)
                 bn(p + ".hidden_layers.2", H)
@@ -101,8 +126,8 @@ class ArchSpec:
             for fc in ("FC_mean", "FC_log_var"):
                 out[fc + ".weight"] = (L, n * L)
                 out[fc + ".bias"] = (L,)
-            for i, (_, F) in enumerate(self.layers):
-                H, p = self.hidden(i), f"decoders.{i}"
+            for j, i in enumerate(self.dec_idx):
+                F, H, p = self.layers[i][1], self.hidden(i), f"decoders.{j}"
                 out[p + ".hidden_layers.0.weight"] = (H, L)
                 out[p + ".hidden_layers.0.bias"] = (H,)
                 bn(p + ".hidden_layers.2", H)
@@ -118,7 +143,8 @@ def is_buffer_key(key: str) -> bool:
 
 
 def spec_from_dataset(model: str, config: dict, dataset, target_variables, batch_variables=None,
-                      surv_event_var=None, surv_time_var=None, use_loss_weighting=True) -> ArchSpec:
+                      surv_event_var=None, surv_time_var=None, use_loss_weighting=True, input_layers=None,
+                      output_layers=None) -> ArchSpec:
     """Same derivations as the reference constructors.  ``dataset`` is only read for ``.dat.keys()``,
     ``.features[layer]``, ``.ann[var]`` and ``.variable_types`` (also satisfied by the SimpleNamespace of
     reference inference.py:116-122)."""
@@ -139,6 +165,13 @@ def spec_from_dataset(model: str, config: dict, dataset, target_variables, batch
             var_specs.append((v, "categorical", int(len(np.unique(arr)))))   # direct_pred.py:100 (NaN counts)
     if model == "MultiTripletNetwork" and dataset.variable_types[targets[0]] == "numerical":
         raise ValueError("The first target variable", targets[0], " must be a categorical variable")
+    names = [n for n, _ in layers]
+    for lst in (input_layers, output_layers):
+        for n in (lst or []):
+            if n not in names:
+                raise KeyError(f"layer {n!r} is not in the dataset ({names})")
     return ArchSpec(model, layers, int(config["latent_dim"]), float(config["hidden_dim_factor"]),
                     int(config["supervisor_hidden_dim"]), var_specs, surv_event_var, surv_time_var,
-                    bool(use_loss_weighting))
+                    bool(use_loss_weighting),
+                    list(input_layers) if (model == "CrossModalPred" and input_layers) else None,
+                    list(output_layers) if (model == "CrossModalPred" and output_layers) else None)

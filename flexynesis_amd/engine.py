@@ -510,12 +510,14 @@ class StepPlan:
         rg = self.t_gather
         if self.cohort is not None:
             cur = self.store.ctrl if self.n_batches > 0 else None
-            first_w = "encoders.{}.hidden_layers.0.weight" if spec.model == "supervised_vae" else "encoders.{}.layer_1.weight"
+            first_w = "encoders.{}.hidden_layers.0.weight" if spec.is_vae else "encoders.{}.layer_1.weight"
+            enc_pos = {li: j for j, li in enumerate(spec.enc_idx)} if spec.is_vae else {i: i for i in range(len(spec.layers))}
             gpar = rg.parallel(len(spec.layers) if self.branches else 1)
             gpar.__enter__()
             for i, (name, F) in enumerate(spec.layers):
                 gpar.branch(i if self.branches else 0)
-                if self.precision == "bf16x3" and first_w.format(i) in self.store.big:
+                wk = first_w.format(enc_pos[i]) if i in enc_pos else None      # layers that are only reconstructed have no encoder
+                if self.precision == "bf16x3" and wk in self.store.big:
                     # one pass: gather + fp32 copy + the bf16 splits the wide-layer kernels consume
                     sp, spt = ops.new_split_kb(self.R, F, self.dev), ops.new_split(F, self.R, self.dev)
                     self._split_cache[("fwd", self.X[i].data_ptr())] = sp
@@ -524,7 +526,7 @@ class StepPlan:
                                      n_rows=self.R)
                 else:
                     ops.gather_rows(rg, self.X[i], self.cohort.dat[name], self.idx, cur, self.R)
-                if self.fused and first_w.format(i) in self.store.big:
+                if self.fused and wk in self.store.big:
                     self._gram_x_for(rg, self.X[i])      # batch-only half of the Gram norm: part of batch assembly
             gpar.branch(0)
             for k, t in self.y.items():      # labels of the anchors = first B indices of each batch row block
@@ -532,7 +534,7 @@ class StepPlan:
             gpar.__exit__(None, None, None)
         if self.train:
             self._alloc_slots()
-        if spec.model == "supervised_vae":
+        if spec.is_vae:
             self._build_svae()
         else:
             self._build_mlp_family()
@@ -598,14 +600,17 @@ class StepPlan:
         return self._ws[self._branch]
 
     def _build_svae(self):
-        """supervised_vae (supervised_vae.py:132-200, :291-336, :494-550)."""
-        spec, st, B, n, L = self.spec, self.store, self.B, self.spec.n_layers, self.spec.latent_dim
+        """supervised_vae (supervised_vae.py:132-200, :291-336, :494-550) and CrossModalPred, the same network with
+        encoders over ``input_layers`` and decoders over ``output_layers`` (crossmodal_pred.py:79-117, :293-351)."""
+        spec, st, B, L = self.spec, self.store, self.B, self.spec.latent_dim
+        enc, dec = spec.enc_idx, spec.dec_idx       # encoders.j <- X[enc[j]] ; decoders.j -> X[dec[j]]
+        n, nd = len(enc), len(dec)
         rf, rb = self.t_fwd, self.t_bwd
         mcat, vcat = self._new("mcat", B, n * L), self._new("vcat", B, n * L)
         hs = []
         for i in range(n):
             p = f"encoders.{i}"
-            h = self._hidden_fwd(rf, p, self.X[i], B)
+            h = self._hidden_fwd(rf, p, self.X[enc[i]], B)
             hs.append(h)
             ops.linear_fwd(rf, mcat[:, i * L:(i + 1) * L], h, st.p(p + ".FC_mean.weight"), st.p(p + ".FC_mean.bias"), self.ws)
             ops.linear_fwd(rf, vcat[:, i * L:(i + 1) * L], h, st.p(p + ".FC_var.weight"), st.p(p + ".FC_var.bias"), self.ws)
@@ -625,17 +630,17 @@ class StepPlan:
         rec_part = self._new("recon_part", 1024)
         # dz must start from zero each step: the first head's data-grad GEMM overwrites it (accumulate=False),
         # so heads go FIRST in the backward tape and the MMD rows kernel (+=) is emitted after them.
-        for i in range(n):
+        for i in range(nd):
             p = f"decoders.{i}"
-            F = spec.layers[i][1]
+            F = spec.layers[dec[i]][1]
             h = self._hidden_fwd(rf, p, z, B)
             hd.append(h)
             lg = self._new(p + "/logits", B, F)
             logits.append(lg)
             self._lin_fwd(rf, lg, h, p + ".FC_output.weight", p + ".FC_output.bias")
-        self.xhat = [self._new(f"xhat.{i}", B, spec.layers[i][1]) for i in range(n)] if not self.train else None
+        self.xhat = [self._new(f"xhat.{i}", B, spec.layers[dec[i]][1]) for i in range(nd)] if not self.train else None
         priors = []
-        for i in range(n):
+        for i in range(nd):
             if self.supplied:
                 pr = self._draw(f"prior.{i}", MMD_PRIOR, L)
             else:
@@ -646,18 +651,18 @@ class StepPlan:
         self._head_losses(rf, z)
         if self.train:
             self._head_bwd(rf, z, dz, first_accumulate=False)      # emitted into the forward tape: see note above
-        for i in range(n):
-            F = spec.layers[i][1]
+        for i in range(nd):       # mmd_loss = mean over the reconstructed layers (supervised_vae.py:309-313)
+            F = spec.layers[dec[i]][1]
             dlg = logits[i] if self.train else None                  # dlogits overwrite logits in place
             nblk = int(ops.lib.fx_recon_blocks(B * F))
-            ops.mmd_rows(rf, row_sums, dz if self.train else None, priors[i], z, lv_mmd, 1.0 / n)
-            ops.recon_sigmoid(rf, rec_part, dlg, self.xhat[i] if self.xhat else None, logits[i], self.X[i], lv_mmd, 1.0 / n)
-            ops.mmd_finalize(rf, self.loss_vec[0:1], row_sums, MMD_PRIOR, B, rec_part, nblk, float(B * F), 1.0 / n, i > 0)
+            ops.mmd_rows(rf, row_sums, dz if self.train else None, priors[i], z, lv_mmd, 1.0 / nd)
+            ops.recon_sigmoid(rf, rec_part, dlg, self.xhat[i] if self.xhat else None, logits[i], self.X[dec[i]], lv_mmd, 1.0 / nd)
+            ops.mmd_finalize(rf, self.loss_vec[0:1], row_sums, MMD_PRIOR, B, rec_part, nblk, float(B * F), 1.0 / nd, i > 0)
         self._total(rf)
         if not self.train:
             return
         # ---- backward through decoders (dlogits live in logits[i]) -> dz, then latent, then encoders
-        for i in range(n):
+        for i in range(nd):
             p = f"decoders.{i}"
             dh = self._new(p + "/dh", B, st.shapes[p + ".hidden_layers.0.weight"][0])
             self._weight_grad(rb, p + ".FC_output.weight", logits[i], hd[i])
@@ -684,7 +689,7 @@ class StepPlan:
             ops.colsum(rb, st.g(p + ".FC_var.bias"), dv)
             ops.linear_bwd_x(rb, dh, dm, st.p(p + ".FC_mean.weight"), self.ws)
             ops.linear_bwd_x(rb, dh, dv, st.p(p + ".FC_var.weight"), self.ws, accumulate=True)
-            self._hidden_bwd(rb, p, self.X[i], dh)
+            self._hidden_bwd(rb, p, self.X[enc[i]], dh)
 
     def _build_optimizer(self):
         """clip_grad_norm_(1.0) + Adam over every parameter (main.py:216-217, direct_pred.py:143)."""

@@ -3,5 +3,6 @@
 from .direct_pred import DirectPred
 from .supervised_vae import supervised_vae
 from .triplet_encoder import MultiTripletNetwork
+from .crossmodal_pred import CrossModalPred
 
-__all__ = ["DirectPred", "supervised_vae", "MultiTripletNetwork"]
+__all__ = ["DirectPred", "supervised_vae", "MultiTripletNetwork", "CrossModalPred"]

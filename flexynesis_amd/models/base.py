@@ -88,10 +88,10 @@ class _PlanLoss(torch.autograd.Function):
 
 
 class FxModel(_Base):
-    MODEL = None  # "DirectPred" | "supervised_vae" | "MultiTripletNetwork"
+    MODEL = None  # "DirectPred" | "supervised_vae" | "MultiTripletNetwork" | "CrossModalPred"
 
     def __init__(self, config, dataset, target_variables, batch_variables=None, surv_event_var=None,
-                 surv_time_var=None, use_loss_weighting=True, device_type=None):
+                 surv_time_var=None, use_loss_weighting=True, device_type=None, **spec_kw):
         super().__init__()
         self.config = config
         self.target_variables = list(target_variables)
@@ -109,7 +109,7 @@ class FxModel(_Base):
         self.layers = list(dataset.dat.keys())
         self.input_dims = [len(dataset.features[l]) for l in self.layers]
         self.spec: ArchSpec = spec_from_dataset(self.MODEL, config, dataset, target_variables, batch_variables,
-                                                surv_event_var, surv_time_var, use_loss_weighting)
+                                                surv_event_var, surv_time_var, use_loss_weighting, **spec_kw)
         if self.use_loss_weighting:
             self.log_vars = nn.ParameterDict({n: nn.Parameter(torch.zeros(1)) for n in self.spec.logvar_names()})
         self._build_modules()

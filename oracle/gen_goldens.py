@@ -50,6 +50,11 @@ def case_specs():
                   [("c", "categorical", 3), ("event", "numerical", 1)],
                   surv_event_var="event", surv_time_var="time"),
         n=40, B=10, steps=3, missing=True)
+    c["crossmodal_2in_2out"] = dict(               # encode (gex, cnv), reconstruct (meth, gex)
+        spec=Spec("CrossModalPred", [("gex", 48), ("cnv", 40), ("meth", 36)], 8, 0.25, 4,
+                  [("y", "numerical", 1), ("c", "categorical", 3)],
+                  input_layers=["gex", "cnv"], output_layers=["meth", "gex"]),
+        n=40, B=10, steps=3, missing=True)
     c["triplet_3omics"] = dict(
         spec=Spec("MultiTripletNetwork", [("gex", 48), ("cnv", 40), ("meth", 32)], 8, 0.25, 4,
                   [("c", "categorical", 3), ("y", "numerical", 1)]),
@@ -176,16 +181,16 @@ def gen_model_case(R, name, cfg, out):
         model.validation_step(ref_capture.reference_batch(spec, vb), 0, log=True)
     for k, v in logged[0].items():
         arrays[f"exp/val/loss/{'total' if k == 'val_loss' else k}"] = _np(v).reshape(-1)[0:1].reshape(())
-    if spec.model == "supervised_vae":
-        for i in range(len(spec.layers)):
-            arrays[f"draws/val/prior.{i}"] = _np(cap.randn[i])
+    if spec.is_vae:
+        for j in range(len(spec.dec_idx)):
+            arrays[f"draws/val/prior.{j}"] = _np(cap.randn[j])
         arrays["draws/val/eps"] = _np(cap.randn_like[0])
     if spec.model != "MultiTripletNetwork":   # triplet transform/predict need the full dataset object
         with torch.no_grad(), ref_capture.capture_rng() as cap_p:
             pred = model.predict(ds)
         with torch.no_grad(), ref_capture.capture_rng() as cap_t:
             emb = model.transform(ds)
-        if spec.model == "supervised_vae":
+        if spec.is_vae:
             # the reference's predict/transform run the full stochastic forward even in eval mode
             # (supervised_vae.py:417-419, :470): z = mean + log_var * randn_like(log_var)
             arrays["draws/predict/eps"] = _np(cap_p.randn_like[0])
@@ -327,9 +332,12 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     R = ref_shim.load()
     torch.set_num_threads(1)          # fixed reduction order for the recorded numbers
+    only = set(sys.argv[1:])                     # optional: regenerate just the named cases
     for name, cfg in case_specs().items():
-        gen_model_case(R, name, cfg, OUT)
-    gen_function_goldens(R, OUT)
+        if not only or name in only:
+            gen_model_case(R, name, cfg, OUT)
+    if not only or "functions" in only:
+        gen_function_goldens(R, OUT)
 
 
 if __name__ == "__main__":

@@ -65,11 +65,14 @@ def make_dataset(R, dat: Dict[str, torch.Tensor], ann: Dict[str, torch.Tensor], 
 
 def build_reference_model(R, spec: Spec, dataset, config: dict):
     cls = {"DirectPred": R.DirectPred, "supervised_vae": R.supervised_vae,
-           "MultiTripletNetwork": R.MultiTripletNetwork}[spec.model]
+           "MultiTripletNetwork": R.MultiTripletNetwork, "CrossModalPred": R.CrossModalPred}[spec.model]
     targets = [v[0] for v in spec.variables if v[0] != spec.surv_event_var]
+    extra = {}
+    if spec.model == "CrossModalPred":          # crossmodal_pred.py:39-40
+        extra = dict(input_layers=spec.input_layers, output_layers=spec.output_layers)
     model = cls(config, dataset, targets, batch_variables=None,
                 surv_event_var=spec.surv_event_var, surv_time_var=spec.surv_time_var,
-                use_loss_weighting=spec.use_loss_weighting, device_type="cpu")
+                use_loss_weighting=spec.use_loss_weighting, device_type="cpu", **extra)
     return model
 
 
@@ -87,8 +90,8 @@ def name_draws(spec: Spec, cap: Capture) -> Dict[str, torch.Tensor]:
                 draws[f"encoders.{i}{tag}"] = masks.pop(0)
     else:
         draws["eps"] = cap.randn_like[0]
-        for i in range(n):
-            draws[f"prior.{i}"] = cap.randn[i]
+        for j in range(len(spec.dec_idx)):      # one 200-sample prior draw per reconstructed layer
+            draws[f"prior.{j}"] = cap.randn[j]
     for (v, _, _) in spec.variables:
         draws["MLPs." + v] = masks.pop(0)
     assert not masks, "unconsumed dropout draws"

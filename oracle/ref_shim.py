@@ -120,10 +120,12 @@ def load():
     from flexynesis.models.direct_pred import DirectPred
     from flexynesis.models.supervised_vae import supervised_vae
     from flexynesis.models.triplet_encoder import MultiTripletNetwork
+    from flexynesis.models.crossmodal_pred import CrossModalPred
 
     torch.set_float32_matmul_precision("highest")
     return types.SimpleNamespace(
         MLP=MLP, Encoder=Encoder, Decoder=Decoder, cox_ph_loss=cox_ph_loss,
         MultiOmicDataset=MultiOmicDataset, TripletMultiOmicDataset=TripletMultiOmicDataset,
         DirectPred=DirectPred, supervised_vae=supervised_vae, MultiTripletNetwork=MultiTripletNetwork,
+        CrossModalPred=CrossModalPred,
     )

@@ -9,7 +9,7 @@ from oracle.restate import Spec
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 MODEL_CASES = ["directpred_2omics_multitask", "directpred_1omics_regression", "directpred_unweighted",
-               "supervised_vae_2omics", "triplet_3omics"]
+               "supervised_vae_2omics", "triplet_3omics", "crossmodal_2in_2out"]
 
 
 def _t(a):

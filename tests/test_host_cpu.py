@@ -54,7 +54,8 @@ def test_arch_state_layout_matches_reference_state_dict(case):
     g = Golden(case)
     s = g.spec
     a = ArchSpec(s.model, list(s.layers), s.latent_dim, s.hidden_dim_factor, s.supervisor_hidden_dim,
-                 list(s.variables), s.surv_event_var, s.surv_time_var, s.use_loss_weighting)
+                 list(s.variables), s.surv_event_var, s.surv_time_var, s.use_loss_weighting,
+                    s.input_layers, s.output_layers)
     ref = {k: tuple(v.shape) for k, v in g.state0().items()}
     assert a.state_shapes() == ref
     assert a.loss_names() == [k for k in _loss_order(g)]

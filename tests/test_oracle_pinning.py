@@ -101,7 +101,7 @@ def test_validation_and_predict_match_reference(case):
     if spec.model != "MultiTripletNetwork":
         cohort = g.sub("cohort")
         xs = [cohort[name] for name, _ in spec.layers]
-        svae = spec.model == "supervised_vae"
+        svae = spec.is_vae
         emb, _ = O.predict_outputs(spec, st, xs, g.get("draws/transform/eps") if svae else None)
         close(emb, g.get("exp/transform"), rtol=1e-4, atol=1e-5, what="transform")
         _, outs = O.predict_outputs(spec, st, xs, g.get("draws/predict/eps") if svae else None)
@@ -158,6 +158,8 @@ def test_live_reference_step_matches_oracle():
         O.Spec("DirectPred", [("a", 33), ("b", 21)], 5, 0.4, 3, [("c", "categorical", 4), ("y", "numerical", 1)]),
         O.Spec("supervised_vae", [("a", 30), ("b", 18)], 6, 0.3, 3, [("y", "numerical", 1)]),
         O.Spec("MultiTripletNetwork", [("a", 20), ("b", 26)], 4, 0.5, 3, [("c", "categorical", 3)]),
+        O.Spec("CrossModalPred", [("a", 30), ("b", 18), ("d", 22)], 6, 0.3, 3, [("c", "categorical", 3)],
+               input_layers=["b"], output_layers=["a", "d"]),
     ]
     for spec in specs:
         dat, ann, vt = make_cohort(spec, 30, seed=9, missing=False)
