@@ -63,7 +63,7 @@ PROTOTYPES = {
     "fx_sumsq": (I, [P, P, L, P]),
     "fx_hadamard_sum": (I, [P, P, P, L, P]),
     "fx_clip_finalize": (I, [P, P, I, F, P]),
-    "fx_adam_flat": (I, [P, P, P, P, L, P, P]),
+    "fx_adam_flat": (I, [P, P, P, P, L, P, P, P]),
 }
 
 # functions whose int return value is a size/count, not an error code

@@ -85,10 +85,12 @@ __global__ __launch_bounds__(256) void fx_clip_finalize_kernel(float* ctrl, cons
 // ---- Adam over a flat arena (all small parameters of a model live in one contiguous buffer) ----------
 __global__ __launch_bounds__(256) void fx_adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                            float* __restrict__ m, float* __restrict__ v, long n,
-                                                           const float* __restrict__ ctrl) {
+                                                           const float* __restrict__ ctrl,
+                                                           const float* __restrict__ trainable) {
   const float lr = ctrl[FXC_LR], bc1 = ctrl[FXC_BC1], bc2s = ctrl[FXC_BC2_SQRT], coef = ctrl[FXC_CLIP_COEF];
   const float step_size = lr / bc1;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    if (trainable && trainable[i] == 0.f) continue;      // requires_grad=False: not in the optimiser (FineTuner, main.py:562-566)
     const float gr = g[i] * coef;
     const float m2 = m[i] + (gr - m[i]) * (1.0f - FX_BETA1);
     const float v2 = v[i] * FX_BETA2 + (1.0f - FX_BETA2) * gr * gr;
@@ -156,11 +158,12 @@ int fx_clip_finalize(float* ctrl, const double* slots, int n_slots, float max_no
   return fx_check_launch("fx_clip_finalize");
 }
 
-int fx_adam_flat(float* p, const float* g, float* m, float* v, long n, const float* ctrl, hipStream_t stream) {
+int fx_adam_flat(float* p, const float* g, float* m, float* v, long n, const float* ctrl, const float* trainable,
+                 hipStream_t stream) {
   FX_REQUIRE(p && g && m && v && ctrl && n > 0, "fx_adam_flat: bad args");
   long b = (n + 255) / 256;
   if (b > 4096) b = 4096;
-  hipLaunchKernelGGL(fx_adam_flat_kernel, dim3((unsigned)b), dim3(256), 0, stream, p, g, m, v, n, ctrl);
+  hipLaunchKernelGGL(fx_adam_flat_kernel, dim3((unsigned)b), dim3(256), 0, stream, p, g, m, v, n, ctrl, trainable);
   return fx_check_launch("fx_adam_flat");
 }
 

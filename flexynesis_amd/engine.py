@@ -205,10 +205,17 @@ class StepPlan:
     def __init__(self, store: ParamStore, B: int, train: bool = True, fused: bool = True, clip: bool = True,
                  supplied_draws: bool = False, seed: int = 0, cohort=None, n_batches: int = 0,
                  epoch_acc: bool = False, precision: str = "bf16x3", branches: bool = True, share: "StepPlan" = None,
-                 fuse_heads: bool = True):
+                 fuse_heads: bool = True, frozen: Tuple[str, ...] = ()):
         self.store, self.spec, self.B, self.train = store, store.spec, int(B), train
         self.fused = bool(fused) and train
         self.clip = clip
+        # FineTuner (reference main.py:530-539): state_dict key prefixes with requires_grad=False, e.g. ("encoders.",)
+        # or ("MLPs.",).  Frozen parameters get no gradient work and are skipped by Adam; BatchNorm buffers of frozen
+        # blocks still update.  The reference never clips while fine-tuning (its Trainer has no gradient_clip_val).
+        self.frozen = tuple(frozen)
+        if self.frozen and clip and train:
+            raise ValueError("frozen parameter groups are the FineTuner's configuration, which trains without gradient "
+                             "clipping (reference main.py:591-600): pass clip=False")
         self.supplied = supplied_draws
         self.seed = int(seed)
         self.dev = store.device
@@ -362,7 +369,7 @@ class StepPlan:
                 sp = ops.new_split_kb(x.shape[0], x.shape[1], self.dev)
                 self._split_cache[("fwd", x.data_ptr())] = sp
                 ops.split_bf16(rec, sp[0], sp[1], x)
-            if self.fused and self.train:
+            if self.fused and self.train and self.clip and not self._is_frozen(wkey):
                 self._gram_x_for(rec, x)
             # Stagger the HBM-bound wide kernels of the parallel modality branches: two of them side by side
             # take as long as back to back, but back to back lets modality i's narrow post-chain (reduce, BN,
@@ -384,21 +391,27 @@ class StepPlan:
             ops.linear_fwd(rec, y, x, st.p(wkey), st.p(bkey), self.ws)
         return None
 
+    def _is_frozen(self, key: str) -> bool:
+        return bool(self.frozen) and key.startswith(self.frozen)
+
     def _weight_grad(self, rec, key, dy, x):
         """dW = dY^T X: materialised, or deferred to the fused dW+clip+Adam kernel for wide layers."""
+        if self._is_frozen(key):
+            return                                       # requires_grad=False: no gradient, not in the optimiser
         if self.fused and key in self.store.big:
             # wide layer on the engine path: nothing is materialised.  Here (inside the modality's backward
             # branch) only the pieces the optimiser tape needs are prepared:
             #   |dW|_F^2 = <X X^T, dY dY^T>  -> partial sums into the norm slots (Gram identity)
             #   split-bf16 transposed operands dY^T, X^T for the fused dW+clip+Adam kernel
             R = dy.shape[0]
-            gx = self._gram_x_for(rec, x)
-            nd = int(ops.lib.fx_gemm_splitk(R, R, dy.shape[1]))
-            gd = self._new(f"gram_dy/{key}", nd, R * R)
-            ops.gemm_slabs(rec, ops.GEMM_NT, gd, dy, dy, R, R)
-            nb = ops.gram_hadamard_blocks(R * R)
-            ops.gram_hadamard(rec, self.slots[self._slot_o:self._slot_o + nb], gx[0], gx[1], gd, nd, R * R)
-            self._slot_o += nb
+            if self.clip:                                # the norm is only needed for the clip coefficient
+                gx = self._gram_x_for(rec, x)
+                nd = int(ops.lib.fx_gemm_splitk(R, R, dy.shape[1]))
+                gd = self._new(f"gram_dy/{key}", nd, R * R)
+                ops.gemm_slabs(rec, ops.GEMM_NT, gd, dy, dy, R, R)
+                nb = ops.gram_hadamard_blocks(R * R)
+                ops.gram_hadamard(rec, self.slots[self._slot_o:self._slot_o + nb], gx[0], gx[1], gd, nd, R * R)
+                self._slot_o += nb
             xt = dyt = None
             if self.precision == "bf16x3":
                 xt = self._split_cache.get(("T", x.data_ptr()))
@@ -526,7 +539,7 @@ class StepPlan:
                                      n_rows=self.R)
                 else:
                     ops.gather_rows(rg, self.X[i], self.cohort.dat[name], self.idx, cur, self.R)
-                if self.fused and wk in self.store.big:
+                if self.fused and self.clip and wk in self.store.big and not self._is_frozen(wk):
                     self._gram_x_for(rg, self.X[i])      # batch-only half of the Gram norm: part of batch assembly
             gpar.branch(0)
             for k, t in self.y.items():      # labels of the anchors = first B indices of each batch row block
@@ -572,13 +585,17 @@ class StepPlan:
             return
         # ---- backward
         self._head_bwd(rb, emb[:B], demb[:B], first_accumulate=trip)
+        enc_frozen = self._is_frozen("encoders.0.layer_1.weight")
         if n > 1:
             decat = self._new("decat", R, n * L)
             self._weight_grad(rb, "fusion_block.weight", demb, ecat)
             ops.colsum(rb, st.g("fusion_block.bias"), demb)
-            ops.linear_bwd_x(rb, decat, demb, st.p("fusion_block.weight"), self.ws)
+            if not enc_frozen:
+                ops.linear_bwd_x(rb, decat, demb, st.p("fusion_block.weight"), self.ws)
         else:
             decat = demb
+        if enc_frozen:
+            return          # FineTuner "encoders": True -- nothing upstream of the fusion layer needs a gradient
         with rb.parallel(n if self.branches else 1) as par:
             for i in range(n):
                 self._enter_branch(par, i)
@@ -675,9 +692,11 @@ class StepPlan:
         dmcat, dvcat = self._new("dmcat", B, n * L), self._new("dvcat", B, n * L)
         self._weight_grad(rb, "FC_mean.weight", dz, mcat)
         ops.colsum(rb, st.g("FC_mean.bias"), dz)
-        ops.linear_bwd_x(rb, dmcat, dz, st.p("FC_mean.weight"), self.ws)
         self._weight_grad(rb, "FC_log_var.weight", dlv, vcat)
         ops.colsum(rb, st.g("FC_log_var.bias"), dlv)
+        if self._is_frozen("encoders.0.FC_mean.weight"):
+            return          # FineTuner "encoders": True -- the encoders need no gradient
+        ops.linear_bwd_x(rb, dmcat, dz, st.p("FC_mean.weight"), self.ws)
         ops.linear_bwd_x(rb, dvcat, dlv, st.p("FC_log_var.weight"), self.ws)
         for i in range(n):
             p = f"encoders.{i}"
@@ -704,8 +723,17 @@ class StepPlan:
         o += ops.sumsq_blocks(st.n_small)
         assert o <= self.slots.numel(), (o, self.slots.numel())
         ops.clip_finalize(ro, st.ctrl, self.slots, self.slots.numel(), CLIP_MAX_NORM if self.clip else 0.0)
-        ops.adam_flat(ro, st.P, st.G, st.M, st.V, st.ctrl)
+        trainable = None
+        if self.frozen:             # 0/1 mask over the small-parameter arena: frozen tensors are skipped by Adam
+            trainable = torch.ones_like(st.P)
+            for k in st.small_keys:
+                if self._is_frozen(k):
+                    st._view(trainable, k).zero_()
+            self.buf["trainable_mask"] = trainable
+        ops.adam_flat(ro, st.P, st.G, st.M, st.V, st.ctrl, trainable)
         for k in st.big_keys:
+            if self._is_frozen(k):
+                continue
             d = st.big[k]
             if self.fused and self.precision == "bf16x3":
                 dy, x, dyt, xt = self._jobs[k]
@@ -825,9 +853,9 @@ class PipelinedStep:
     This is the DataLoader-prefetch of the reference's loop (main.py:289-298, num_workers) moved onto the GPU."""
 
     def __init__(self, store: ParamStore, B: int, *, cohort, n_batches: int, seed: int = 0,
-                 precision: str = "bf16x3", epoch_acc: bool = True):
+                 precision: str = "bf16x3", epoch_acc: bool = True, clip: bool = True, frozen: Tuple[str, ...] = ()):
         kw = dict(train=True, fused=True, supplied_draws=False, seed=seed, cohort=cohort, n_batches=n_batches,
-                  epoch_acc=epoch_acc, precision=precision)
+                  epoch_acc=epoch_acc, precision=precision, clip=clip, frozen=frozen)
         a = StepPlan(store, B, **kw)
         self.plans = [a, StepPlan(store, B, share=a, **kw)]
         self.store, self.n_batches = store, int(n_batches)

@@ -111,12 +111,19 @@ def _eval_loss(model, store, cohort, idx_rows: torch.Tensor, batch_size: int, pa
 
 def fit(model, dataset, train_idx: Sequence[int], val_idx: Optional[Sequence[int]] = None, *, batch_size: int,
         epochs: int, lr: float, patience: int = 0, seed: int = 0, use_graph: bool = True, device=None,
-        verbose: bool = False) -> FitResult:
+        verbose: bool = False, clip: bool = True, frozen: Sequence[str] = (), drop_last: bool = True,
+        fresh_optimizer: bool = False) -> FitResult:
     """Train ``model`` on ``dataset[train_idx]`` and validate on ``dataset[val_idx]`` once per epoch.
     For MultiTripletNetwork the indices address the valid (non-NaN main label) anchors, like the reference's
-    ``TripletMultiOmicDataset`` (data.py:1102-1104)."""
+    ``TripletMultiOmicDataset`` (data.py:1102-1104).
+
+    Defaults = the HPO trainer (main.py:212-225, :289-298: clip 1.0, shuffle, drop_last=True).  The FineTuner's
+    trainer (main.py:530-611) is ``clip=False, drop_last=False, frozen=(...)``: state_dict key prefixes with
+    requires_grad=False are neither differentiated nor stepped, and the last partial batch of an epoch is used."""
     store = model._bind(device)
     dev = store.device
+    if fresh_optimizer:
+        store.reset_optimizer()             # a new torch.optim.Adam per fit (main.py:562-566)
     cohort = _cohort_of(dataset, dev)
     spec = model.spec
     trip = spec.model == "MultiTripletNetwork"
@@ -131,30 +138,45 @@ def fit(model, dataset, train_idx: Sequence[int], val_idx: Optional[Sequence[int
         tr = sampler.valid[tr]
         va = sampler.valid[va] if va is not None else None
     B = int(batch_size)
-    n_batches = tr.numel() // B                                  # drop_last=True (main.py:294)
-    if n_batches < 1:
+    n_batches = tr.numel() // B                                  # full batches (drop_last=True: main.py:294)
+    tail = 0 if drop_last else tr.numel() - n_batches * B        # DataLoader default keeps the partial batch (main.py:544)
+    if n_batches < 1 and tail < 1:
         raise ValueError(f"batch_size {B} exceeds the training split ({tr.numel()} samples) with drop_last=True")
-    pipe = PipelinedStep(store, B, cohort=cohort, n_batches=n_batches, seed=int(seed) * 7919 + 13, epoch_acc=True)
+    frozen = tuple(frozen)
+    plan_kw = dict(clip=bool(clip), frozen=frozen)
+    pipe = PipelinedStep(store, B, cohort=cohort, n_batches=n_batches, seed=int(seed) * 7919 + 13, epoch_acc=True,
+                         **plan_kw) if n_batches >= 1 else None
+    tail_plan = StepPlan(store, tail, train=True, fused=True, supplied_draws=False, seed=int(seed) * 7919 + 17, cohort=cohort,
+                         n_batches=0, epoch_acc=True, **plan_kw) if tail else None
     names = spec.loss_names()
     eval_cache: Dict[int, StepPlan] = {}
     history: List[Dict[str, float]] = []
     best, wait, stopped_epoch, steps = float("inf"), 0, 0, 0
+    tails: List[torch.Tensor] = []          # tail rows of the epochs whose table has been drawn, oldest first
+
+    def rows_of(perm, k):
+        if not trip:
+            return perm
+        pos, neg = sampler.sample(perm, gen)
+        return torch.cat([perm.view(-1, k), pos.view(-1, k), neg.view(-1, k)], dim=1).reshape(-1)
 
     def write_table():
-        """shuffle=True, drop_last=True (main.py:289-298): a fresh device permutation of the training split."""
-        perm = tr[torch.randperm(tr.numel(), generator=gen, device=dev)][: n_batches * B]
-        if trip:
-            pos, neg = sampler.sample(perm, gen)
-            table = torch.cat([perm.view(n_batches, B), pos.view(n_batches, B), neg.view(n_batches, B)], dim=1)
-            pipe.idx.copy_(table.reshape(-1))
-        else:
-            pipe.idx.copy_(perm)
+        """shuffle=True (main.py:289-298): a fresh device permutation of the training split."""
+        perm = tr[torch.randperm(tr.numel(), generator=gen, device=dev)]
+        if pipe is not None:
+            pipe.idx.copy_(rows_of(perm[: n_batches * B], B))
+        if tail:
+            tails.append(rows_of(perm[n_batches * B:], tail))
 
     write_table()
-    pipe.prime()                      # batch 0 is assembled now; every step assembles the batch of the next one
+    if pipe is not None:
+        pipe.prime()                  # batch 0 is assembled now; every step assembles the batch of the next one
     epochs_run = 0
     for epoch in range(int(epochs)):
-        pipe.epoch_acc.zero_()
+        if pipe is not None:
+            pipe.epoch_acc.zero_()
+        if tail_plan is not None:
+            tail_plan.epoch_acc.zero_()
         for b in range(n_batches):
             if pipe.epoch_end_next():
                 write_table()         # the last step of an epoch prefetches row 0 of the next epoch's table
@@ -165,10 +187,26 @@ def fit(model, dataset, train_idx: Sequence[int], val_idx: Optional[Sequence[int
                 if use_graph:
                     pipe.capture(lr)
             steps += 1
+        if tail_plan is not None:
+            if pipe is None:
+                write_table()
+            tail_plan.idx.copy_(tails.pop(0))
+            tail_plan.train_step(lr, gather=True)
+            store.ctrl[9] += 1.0      # the table cursor is derived from the step counter: the tail step is not a table row
+            steps += 1
         epochs_run = epoch + 1
-        acc = pipe.epoch_acc.detach().cpu().tolist()
-        rec = {n: acc[i] / max(acc[-1], 1.0) for i, n in enumerate(names)}
-        rec["train_loss"] = acc[len(names)] / max(acc[-1], 1.0)
+        # epoch means weighted by batch size, like Lightning's on_epoch reduction of the logged losses
+        acc = [0.0] * (len(names) + 1)
+        wsum = 0.0
+        for pl, bs in ((pipe, B), (tail_plan, tail)):
+            if pl is None:
+                continue
+            a = pl.epoch_acc.detach().cpu().tolist()
+            for i in range(len(names) + 1):
+                acc[i] += a[i] * bs
+            wsum += a[-1] * bs
+        rec = {n: acc[i] / max(wsum, 1.0) for i, n in enumerate(names)}
+        rec["train_loss"] = acc[len(names)] / max(wsum, 1.0)
         if va is not None:
             rec["val_loss"] = _eval_loss(model, store, cohort, va, B, passes, sampler, gen, eval_cache)
         history.append(rec)
@@ -188,6 +226,72 @@ def fit(model, dataset, train_idx: Sequence[int], val_idx: Optional[Sequence[int
     final_val = _eval_loss(model, store, cohort, va, B, passes, sampler, gen, eval_cache) if va is not None else float("nan")
     model._sync_nbt()
     return FitResult(final_val, epochs_run, stopped_epoch, history, steps)
+
+
+def kfold_indices(n: int, n_splits: int, seed: int):
+    """sklearn.model_selection.KFold(n_splits, shuffle=True) fold sizes and semantics (reference main.py:505, :517):
+    the first n % n_splits folds get one extra sample; a seeded permutation replaces sklearn's unseeded one."""
+    g = torch.Generator().manual_seed(int(seed))
+    perm = torch.randperm(n, generator=g).tolist()
+    sizes = [n // n_splits + (1 if i < n % n_splits else 0) for i in range(n_splits)]
+    folds, o = [], 0
+    for sz in sizes:
+        val = sorted(perm[o:o + sz])
+        held = set(val)
+        folds.append(([i for i in range(n) if i not in held], val))
+        o += sz
+    return folds
+
+
+FREEZE_PREFIXES = {"encoders": "encoders.", "supervisors": "MLPs."}       # apply_freeze_config, main.py:530-539
+
+
+def fine_tune(model, dataset, *, n_splits: int = 5, batch_size: int = 32, learning_rates=None, max_epoch: int = 50,
+              freeze_configs=None, seed: int = 0, device=None, use_graph: bool = True, verbose: bool = False):
+    """The reference's ``FineTuner.run_experiments`` (main.py:575-659) on the engine: for every learning rate x
+    freeze configuration, k-fold cross-validated short fits of a deep copy of ``model`` (fresh Adam, no gradient
+    clipping, partial last batch kept, early stopping with patience 3), pick the configuration with the lowest mean
+    validation loss, then continue training on all samples for the mean stopped epoch of that configuration.
+    Frozen groups cost nothing: their backward, norm and Adam work is not launched.
+
+    Returns (final_model, best, results) with ``results`` = the reference's ``val_loss_results`` records."""
+    import copy
+    lrs = list(learning_rates) if learning_rates else [model.config["lr"], model.config["lr"] / 10, model.config["lr"] / 100]
+    cfgs = list(freeze_configs) if freeze_configs else [{"encoders": True, "supervisors": False},
+                                                         {"encoders": False, "supervisors": True},
+                                                         {"encoders": False, "supervisors": False}]
+    n = len(dataset)
+    if model.spec.model == "MultiTripletNetwork":          # the FineTuner wraps the dataset in TripletMultiOmicDataset
+        n = int((~np.isnan(np.asarray(dataset.ann[model.main_var]))).sum())
+    folds = kfold_indices(n, n_splits, seed)
+    results, last = [], model
+
+    def frozen_of(cfg):
+        return tuple(FREEZE_PREFIXES[k] for k in ("encoders", "supervisors") if cfg.get(k))
+
+    for lr in lrs:
+        for cfg in cfgs:
+            losses, eps = [], []
+            for fi, (tr, va) in enumerate(folds):
+                m = copy.deepcopy(model)
+                res = fit(m, dataset, tr, va, batch_size=batch_size, epochs=max_epoch, lr=float(lr), patience=3,
+                          seed=seed * 1000 + fi, use_graph=use_graph, device=device, clip=False, frozen=frozen_of(cfg),
+                          drop_last=False, fresh_optimizer=True)
+                losses.append(res.val_loss)
+                eps.append(res.stopped_epoch)
+                last = m
+            rec = {"learning_rate": lr, "average_val_loss": float(np.mean(losses)), "freeze": cfg, "epochs": int(np.mean(eps))}
+            results.append(rec)
+            if verbose:
+                print(f"[fine_tune] lr {lr} freeze {cfg}: val_loss {rec['average_val_loss']:.5f}, epochs {rec['epochs']}", flush=True)
+    best = min(results, key=lambda r: r["average_val_loss"])
+    # main.py:647-659: the final model continues from the LAST cross-validation model, on all samples
+    final = copy.deepcopy(last)
+    if best["epochs"] > 0:
+        fit(final, dataset, list(range(n)), None, batch_size=batch_size, epochs=best["epochs"], lr=float(best["learning_rate"]),
+            seed=seed * 1000 + 999, use_graph=use_graph, device=device, clip=False, frozen=frozen_of(best["freeze"]),
+            drop_last=False, fresh_optimizer=True)
+    return final, best, results
 
 
 def split_indices(n: int, val_size: float, seed: int):

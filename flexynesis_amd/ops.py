@@ -552,8 +552,10 @@ def clip_finalize(rec, ctrl, slots, n_slots, max_norm):
     rec.emit("fx_clip_finalize", ctrl.data_ptr(), slots.data_ptr(), int(n_slots), float(max_norm))
 
 
-def adam_flat(rec, p, g, m, v, ctrl):
-    rec.emit("fx_adam_flat", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), ctrl.data_ptr())
+def adam_flat(rec, p, g, m, v, ctrl, trainable=None):
+    """``trainable``: optional 0/1 fp32 mask over the arena; elements with 0 are left untouched (frozen groups)."""
+    rec.emit("fx_adam_flat", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), ctrl.data_ptr(),
+             _ptr(trainable))
 
 
 def sigmoid(rec, y, x):

@@ -182,7 +182,9 @@ int fx_sumsq_blocks(long n);
 int fx_sumsq(double* slots, const float* x, long n, fx_stream_t stream);
 int fx_hadamard_sum(double* slot, const float* g1, const float* g2, long n, fx_stream_t stream);
 int fx_clip_finalize(float* ctrl, const double* slots, int n_slots, float max_norm, fx_stream_t stream);
-int fx_adam_flat(float* p, const float* g, float* m, float* v, long n, const float* ctrl, fx_stream_t stream);
+int fx_adam_flat(float* p, const float* g, float* m, float* v, long n, const float* ctrl,
+                 const float* trainable /* optional 0/1 per element: 0 = requires_grad False, skipped (main.py:530-539,562-566) */,
+                 fx_stream_t stream);
 
 #ifdef __cplusplus
 }

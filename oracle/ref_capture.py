@@ -106,11 +106,20 @@ def reference_batch(spec: Spec, batch):
     return ({name: x for (name, _), x in zip(spec.layers, batch["x"])}, batch["y"], samples)
 
 
-def reference_train_steps(R, spec: Spec, model, batches, lr: float):
+def reference_train_steps(R, spec: Spec, model, batches, lr: float, clip: bool = True, freeze=None):
     """zero_grad -> training_step -> backward -> clip_grad_norm_(1.0) -> Adam.step per batch,
     exactly what Lightning's automatic optimisation does with the Trainer of reference main.py:212-225.
-    Returns a list of per-step records."""
-    opt = torch.optim.Adam(model.parameters(), lr=lr)   # == model.configure_optimizers()
+    ``freeze`` ({"encoders": bool, "supervisors": bool}) + ``clip=False`` reproduce the FineTuner's setup instead
+    (main.py:530-539 requires_grad flags, :562-566 Adam over the trainable parameters, :591-600 a Trainer without
+    gradient clipping).  Returns a list of per-step records."""
+    if freeze is not None:
+        for enc in model.encoders:
+            for p in enc.parameters():
+                p.requires_grad = not freeze["encoders"]
+        for mlp in model.MLPs.values():
+            for p in mlp.parameters():
+                p.requires_grad = not freeze["supervisors"]
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=lr)
     model.train()
     recs = []
     for bi, batch in enumerate(batches):
@@ -119,7 +128,10 @@ def reference_train_steps(R, spec: Spec, model, batches, lr: float):
             loss = model.training_step(reference_batch(spec, batch), bi, log=False)
         loss.backward()
         grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
-        gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        if clip:
+            gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        else:
+            gn = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g) for g in grads.values()]))
         opt.step()
         recs.append(SimpleNamespace(
             total=loss.detach().clone(), grads=grads, grad_norm=gn.detach().clone(),

@@ -326,3 +326,32 @@ def test_crossmodal_validation_decode_and_fit():
     assert res.epochs_run == 6 and np.isfinite(res.val_loss)
     assert res.history[-1]["train_loss"] < res.history[0]["train_loss"]
     assert set(res.history[0]) >= {"mmd_loss", "y", "c", "train_loss", "val_loss"}
+
+
+def test_fit_keeps_partial_batch_and_fine_tune_runs():
+    """fit(drop_last=False) uses the partial last batch like the FineTuner's DataLoader (reference main.py:541-545);
+    fine_tune = FineTuner.run_experiments (main.py:575-659) on the engine."""
+    import flexynesis_amd.models as M
+    from flexynesis_amd.fit import fit, fine_tune
+    ds = _synthetic_ds(n=75)
+    torch.manual_seed(0)
+    cfg = {"latent_dim": 16, "hidden_dim_factor": 0.5, "lr": 3e-3, "supervisor_hidden_dim": 8, "epochs": 3, "batch_size": 16}
+    m = M.DirectPred(cfg, ds, ["y", "c"], device_type="cuda")
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    res = fit(m, ds, list(range(60)), list(range(60, 75)), batch_size=16, epochs=3, lr=3e-3, seed=2, device="cuda",
+              clip=False, frozen=("encoders.",), drop_last=False, fresh_optimizer=True)
+    assert res.steps == 3 * (60 // 16 + 1)                      # 3 full batches + the 12-sample tail, per epoch
+    after = m.state_dict()
+    for k in before:
+        if k.startswith("encoders.") and not k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            assert torch.equal(before[k].to(after[k].device), after[k]), k
+    assert not torch.equal(before["MLPs.y.layer_1.weight"].to(DEV), after["MLPs.y.layer_1.weight"])
+    assert not torch.equal(before["encoders.0.batchnorm.running_mean"].to(DEV), after["encoders.0.batchnorm.running_mean"])
+    assert int(after["encoders.0.batchnorm.num_batches_tracked"]) == res.steps
+    final, best, results = fine_tune(m, ds, n_splits=2, batch_size=16, learning_rates=[3e-3, 3e-4], max_epoch=4,
+                                     freeze_configs=[{"encoders": True, "supervisors": False},
+                                                     {"encoders": False, "supervisors": True}], seed=1, device="cuda")
+    assert len(results) == 4 and best in results and all(np.isfinite(r["average_val_loss"]) for r in results)
+    assert set(results[0]) == {"learning_rate", "average_val_loss", "freeze", "epochs"}
+    assert final is not m and set(final.state_dict()) == set(m.state_dict())
+    assert set(final.predict(ds)) == {"y", "c"}

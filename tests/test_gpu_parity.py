@@ -649,3 +649,63 @@ def test_fused_heads_match_per_layer_kernels(B, L):
     for k in s0:
         if k.endswith("running_mean") or k.endswith("running_var"):
             close(s1[k], s0[k], 1e-5, 1e-7, k)
+
+
+@pytest.mark.parametrize("model,frozen", [("DirectPred", ("encoders.",)), ("DirectPred", ("MLPs.",)),
+                                          ("supervised_vae", ("encoders.",)), ("supervised_vae", ("MLPs.",))])
+def test_finetune_step_frozen_groups_no_clip_vs_oracle(model, frozen):
+    """FineTuner step (reference main.py:530-539, :562-566, :591-600; pinned live in test_oracle_pinning.py): frozen
+    groups are bit-identical after the step, everything else matches the oracle's unclipped Adam step, BatchNorm
+    buffers of frozen blocks still move."""
+    from flexynesis_amd.arch import ArchSpec
+    from flexynesis_amd.engine import ParamStore, StepPlan
+    from oracle import restate as O
+    dev = _dev()
+    layers = [("gex", 2400), ("cnv", 1800)]
+    variables = [("y", "numerical", 1), ("c", "categorical", 4)]
+    aspec = ArchSpec(model, layers, 32, 0.5, 16, variables, None, None, True)
+    ospec = _oracle_spec(aspec)
+    dat, ann = O.synthetic_cohort(layers, 256, seed=7)
+    st0 = O.init_state(ospec, seed=5)
+    B, lr = 64, 1e-3
+    store = ParamStore(aspec, dev)
+    store.load_state(st0)
+    with pytest.raises(ValueError):
+        StepPlan(store, B, train=True, fused=True, supplied_draws=True, frozen=frozen)        # frozen + clip: not a reference setup
+    plan = StepPlan(store, B, train=True, fused=True, supplied_draws=True, clip=False, frozen=frozen)
+    names = {c[1] for c in plan.t_bwd.calls} | {c[1] for c in plan.t_opt.calls}
+    if frozen == ("encoders.",):
+        assert "fx_linear_dw_adam_bf16x3" not in names or model == "supervised_vae"      # svae decoders are still trained
+    gen = torch.Generator().manual_seed(3)
+    xs = [dat[n][:B] for n, _ in layers]
+    y = {k: ann[k][:B] for k in plan.y}
+    draws = {}
+    for name, t in plan.draws.items():
+        draws[name] = torch.randn(t.shape, generator=gen) if (name == "eps" or name.startswith("prior.")) \
+            else (torch.rand(t.shape, generator=gen) < 0.9).float()
+    plan.set_batch(x_list=[x.to(dev) for x in xs], y={k: v.to(dev) for k, v in y.items()})
+    plan.set_draws({k: v.to(dev) for k, v in draws.items()})
+    plan.train_step(lr)
+    st1, _, info = O.train_step(ospec, st0, {}, {"x": xs, "y": y}, draws, lr, clip=False, frozen=frozen)
+    got = plan.losses()
+    for k, v in info["losses"].items():
+        close(got[k], v, 2e-5, 1e-6, f"loss {k}")
+    sd = store.state_dict()
+    gn = float(info["grad_norm"])
+    moved_buffers = 0
+    for k in sd:
+        if k.endswith("num_batches_tracked"):
+            continue
+        if k.startswith(frozen) and not O.is_buffer(k):
+            assert torch.equal(sd[k].cpu(), st0[k]), f"frozen {k} changed"
+        elif O.is_buffer(k):
+            close(sd[k], st1[k], 1e-4, 1e-6, k)
+            moved_buffers += int(k.startswith(frozen) and not torch.equal(st1[k], st0[k]))
+        else:
+            g = info["grads"].get(k)
+            if k in store.big_keys:
+                bad = (sd[k].cpu().double() - st1[k].double()).abs() > 2e-5 + 1e-3 * st1[k].double().abs()
+                assert float(bad.double().mean()) <= 1e-3, k
+            else:
+                close(sd[k], st1[k], 1e-4, noise_atol(g, gn, lr, 2e-6), k)
+    assert moved_buffers > 0, "BatchNorm running statistics of the frozen blocks must still update (train mode)"

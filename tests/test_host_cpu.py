@@ -241,3 +241,14 @@ def test_trial_sharding_gloo_world2():
     assert np.isinf(table[4, 1]) and table[4, 3] == 1.0 and np.isinf(table[5, 1])
     assert r0[4] == r1[4] == 2 and table[2, 1] == 0.5
     assert r0[5] == r1[5] == [[2.0] * 3] * 2 and r0[6] == r1[6] == 6   # winner's weights reached both ranks
+
+
+def test_kfold_indices_are_a_partition_with_sklearn_fold_sizes():
+    from flexynesis_amd.fit import kfold_indices
+    folds = kfold_indices(23, 5, seed=3)
+    assert [len(v) for _, v in folds] == [5, 5, 5, 4, 4]            # sklearn KFold: first n % k folds get one extra
+    allv = sorted(i for _, v in folds for i in v)
+    assert allv == list(range(23))
+    for tr, va in folds:
+        assert sorted(tr + va) == list(range(23)) and not set(tr) & set(va)
+    assert kfold_indices(23, 5, seed=3) == folds and kfold_indices(23, 5, seed=4) != folds

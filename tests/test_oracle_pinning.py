@@ -179,3 +179,37 @@ def test_live_reference_step_matches_oracle():
                 for k, v in r.state.items():
                     close(st[k], v, rtol=1e-4, atol=shadow_atol(r.grads.get(k), r.grad_norm, 3e-3, 1, 2e-6),
                           what=f"{spec.model} {k}")
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="reference only exists in the build container")
+@pytest.mark.parametrize("freeze", [{"encoders": True, "supervisors": False}, {"encoders": False, "supervisors": True}])
+def test_live_reference_finetune_step_matches_oracle(freeze):
+    """FineTuner steps (reference main.py:530-539, :562-566, :591-600): frozen parameter groups, Adam over the
+    trainable ones, NO gradient clipping -- reference vs the restatement's train_step(clip=False, frozen=...)."""
+    from oracle import ref_capture
+    from oracle.gen_goldens import make_cohort, make_batches, perturbed_state
+    R = ref_shim.load()
+    frozen = tuple(p for p, on in (("encoders.", freeze["encoders"]), ("MLPs.", freeze["supervisors"])) if on)
+    for spec in (O.Spec("DirectPred", [("a", 33), ("b", 21)], 5, 0.4, 3, [("c", "categorical", 4), ("y", "numerical", 1)]),
+                 O.Spec("supervised_vae", [("a", 30), ("b", 18)], 6, 0.3, 3, [("y", "numerical", 1)])):
+        dat, ann, vt = make_cohort(spec, 30, seed=9, missing=False)
+        ds = ref_capture.make_dataset(R, dat, ann, vt)
+        cfg = {"latent_dim": spec.latent_dim, "hidden_dim_factor": spec.hidden_dim_factor, "lr": 3e-3,
+               "supervisor_hidden_dim": spec.supervisor_hidden_dim, "epochs": 1, "batch_size": 6}
+        model = ref_capture.build_reference_model(R, spec, ds, cfg)
+        st0 = perturbed_state(spec, seed=3)
+        model.load_state_dict(st0)
+        batches = make_batches(spec, dat, ann, 6, 2, seed=4, missing=False)
+        recs = ref_capture.reference_train_steps(R, spec, model, batches, 3e-3, clip=False, freeze=freeze)
+        st, opt = st0, {}
+        for si, (b, r) in enumerate(zip(batches, recs)):
+            st, opt, info = O.train_step(spec, st, opt, b, r.draws, 3e-3, clip=False, frozen=frozen)
+            close(info["losses"]["total"], r.total, rtol=1e-4, what=spec.model + " total")
+            assert set(info["grads"]) == set(r.grads), set(info["grads"]) ^ set(r.grads)
+            if si == 0:
+                for k, v in r.state.items():
+                    if k.startswith(frozen) and not O.is_buffer(k):
+                        assert torch.equal(st[k], st0[k]) and torch.equal(v, st0[k]), k       # frozen: bit-identical
+                    else:
+                        close(st[k], v, rtol=1e-4, atol=shadow_atol(r.grads.get(k), r.grad_norm, 3e-3, 1, 2e-6),
+                              what=f"{spec.model} {k}")
