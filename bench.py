@@ -176,7 +176,7 @@ def main():
             from oracle import cpu_baseline, restate as O
             ospec = O.Spec(cfg["model"], cfg["layers"], 64, 0.25, 16, cfg["variables"], cfg["surv"][0], cfg["surv"][1], True)
             threads = min(os.cpu_count() or 1, 64)
-            steps = a.cpu_steps or (6 if a.config != "cfg1" else 100)
+            steps = a.cpu_steps or (20 if a.config == "cfg2" else 100 if a.config == "cfg1" else 8)   # ~15 s of CPU work
             r = cpu_baseline.time_training(ospec, cfg["n_samples"], B, steps=steps, warmup=1, threads=threads, lr=a.lr)
             cpu = {"value": round(r["samples_per_s"], 2), "unit": "samples/s", "cores": r["threads"], "kind": "port",
                    "sample": f"{r['steps']} optimisation steps (after 1 warm-up) of the same {a.config} workload, "

@@ -69,6 +69,9 @@ template <int AUX = 0>
 __device__ __forceinline__ u32x4 bld128(__amdgpu_buffer_rsrc_t r, unsigned off) {
   return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, AUX);
 }
+__device__ __forceinline__ unsigned bld32u(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0);
+}
 template <int AUX = 0>
 __device__ __forceinline__ float bld32f(__amdgpu_buffer_rsrc_t r, unsigned off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, AUX));
@@ -97,8 +100,13 @@ __device__ __forceinline__ void split_store4(const u32x4 raw, __bf16* hi_dst, __
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 
 // WN = number of 32-column wave slices (2 -> 128x64 tile / 256 threads, 4 -> 128x128 tile / 512 threads)
-template <bool B_F32, int EPI, int NT, int WN>
+// B_KN: the fp32 B operand is stored [K, N] (N contiguous) instead of [N, K] -- the data-gradient contraction
+// dX = dY . W through a wide layer (W [out=K, in=N]).  Each thread then loads the 8 consecutive k of ONE column n as
+// eight coalesced dword loads (64 lanes = 256 contiguous bytes of a W row) and owns exactly one 16-byte k-chunk of
+// the [n][k] LDS tile, so the MFMA side is unchanged and no LDS transpose is needed.
+template <bool B_F32, int EPI, int NT, int WN, bool B_KN = false>
 __global__ __launch_bounds__(128 * WN) void fx_gemm_bf16x3_kernel(XGemmArgs g) {
+  static_assert(!B_KN || (B_F32 && WN == 4), "B_KN needs the fp32 B operand and the 128x128 tile");
   constexpr int TN = 32 * WN, T = 128 * WN;
   constexpr int STAGE_ELEMS = 2 * TM * TK + 2 * TN * TK;
   constexpr bool A2 = (T == 256);  // two A chunks per array per thread (else one)
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(128 * WN) void fx_gemm_bf16x3_kernel(XGemmArgs g) {
   // ---- buffer descriptors: rows >= M (or >= N) fall beyond num_records and read as zero
   const long a_bytes = g.a_rp ? (long)g.K * g.a_rp * 2 : (long)g.M * g.lda * 2;
   const __amdgpu_buffer_rsrc_t rAh = fx_rsrc(g.Ahi, a_bytes), rAl = fx_rsrc(g.Alo, a_bytes);
-  const __amdgpu_buffer_rsrc_t rB0 = B_F32 ? fx_rsrc(g.Bf, (long)g.N * g.ldb * 4) : fx_rsrc(g.Bhi, (long)g.N * g.ldb * 2);
+  const __amdgpu_buffer_rsrc_t rB0 = B_F32 ? fx_rsrc(g.Bf, (long)(B_KN ? g.Ktrue : g.N) * g.ldb * 4) : fx_rsrc(g.Bhi, (long)g.N * g.ldb * 2);
   const __amdgpu_buffer_rsrc_t rB1 = B_F32 ? rB0 : fx_rsrc(g.Blo, (long)g.N * g.ldb * 2);
 
   // ---- per-thread constant addressing (bytes) and LDS destinations (elements)
@@ -132,7 +140,13 @@ __global__ __launch_bounds__(128 * WN) void fx_gemm_bf16x3_kernel(XGemmArgs g) {
   const int a_lds0 = swz(a_row0, a_c), a_lds1 = swz(a_row1, a_c);
   unsigned b_off0, b_off1;
   int b_lds0, b_lds1;
-  if (B_F32) {  // TN rows x 8 float4 per row; thread handles (n = tid>>3, k4 = tid&7) and n + TN/2
+  if (B_KN) {   // thread (n = tid & 127, kq = tid >> 7): W[k0 + 8 kq + j][n0 + n], j = 0..7  -> LDS chunk kq of row n
+    const int n = tid & 127, kq = tid >> 7;
+    b_off0 = (unsigned)(((long)(8 * kq) * g.ldb + n0 + n) * 4);
+    b_off1 = b_off0 + (unsigned)(4 * g.ldb * 4);
+    b_lds0 = swz(n, kq);
+    b_lds1 = b_lds0 + 4;
+  } else if (B_F32) {  // TN rows x 8 float4 per row; thread handles (n = tid>>3, k4 = tid&7) and n + TN/2
     const int n = tid >> 3, k4 = tid & 7;
     b_off0 = (unsigned)(((long)(n0 + n) * g.ldb + 4 * k4) * 4);
     b_off1 = (unsigned)(((long)(n0 + n + TN / 2) * g.ldb + 4 * k4) * 4);
@@ -143,8 +157,11 @@ __global__ __launch_bounds__(128 * WN) void fx_gemm_bf16x3_kernel(XGemmArgs g) {
     b_off0 = b_off1 = (unsigned)(((long)(n0 + row) * g.ldb + 8 * c) * 2);
     b_lds0 = b_lds1 = swz(row, c);
   }
-  const unsigned a_step = g.a_rp ? (unsigned)g.a_rp * (TK * 2u) : TK * 2u, b_step = TK * (B_F32 ? 4u : 2u);
-  const unsigned a_kb = (unsigned)(k_begin / TK) * a_step, b_kb = (unsigned)k_begin * (B_F32 ? 4u : 2u);
+  const unsigned a_step = g.a_rp ? (unsigned)g.a_rp * (TK * 2u) : TK * 2u;
+  const unsigned b_step = B_KN ? (unsigned)(TK * g.ldb * 4) : TK * (B_F32 ? 4u : 2u);
+  const unsigned a_kb = (unsigned)(k_begin / TK) * a_step;
+  const unsigned b_kb = B_KN ? (unsigned)((long)k_begin * g.ldb * 4) : (unsigned)k_begin * (B_F32 ? 4u : 2u);
+  const unsigned b_row = (unsigned)(g.ldb * 4);      // B_KN: bytes between consecutive k
 
   // ---- two register stages (named: no arrays, no references -> nothing can land in scratch)
   u32x4 s0_ah0, s0_ah1, s0_al0, s0_al1, s0_b0, s0_b1;
@@ -160,8 +177,15 @@ __global__ __launch_bounds__(128 * WN) void fx_gemm_bf16x3_kernel(XGemmArgs g) {
       P##_ah1 = bld128(rAh, a_off1 + ka);                              \
       P##_al1 = bld128(rAl, a_off1 + ka);                              \
     }                                                                  \
-    P##_b0 = bld128<B_F32 ? NT : 0>(rB0, b_off0 + kb);                 \
-    P##_b1 = bld128<B_F32 ? NT : 0>(B_F32 ? rB0 : rB1, b_off1 + kb);   \
+    if (B_KN) {                                                        \
+      P##_b0 = u32x4{bld32u(rB0, b_off0 + kb), bld32u(rB0, b_off0 + kb + b_row), bld32u(rB0, b_off0 + kb + 2 * b_row),      \
+                     bld32u(rB0, b_off0 + kb + 3 * b_row)};            \
+      P##_b1 = u32x4{bld32u(rB0, b_off1 + kb), bld32u(rB0, b_off1 + kb + b_row), bld32u(rB0, b_off1 + kb + 2 * b_row),      \
+                     bld32u(rB0, b_off1 + kb + 3 * b_row)};            \
+    } else {                                                           \
+      P##_b0 = bld128<B_F32 ? NT : 0>(rB0, b_off0 + kb);               \
+      P##_b1 = bld128<B_F32 ? NT : 0>(B_F32 ? rB0 : rB1, b_off1 + kb); \
+    }                                                                  \
   }
 #define STASH_STAGE(P, buf)                                            \
   {                                                                    \
@@ -452,7 +476,7 @@ int fx_linear_fwd_bf16x3_splitk(int M, int N, int K) {
 
 static int fwd_bf16x3_impl(float* Y, const void* xhi, const void* xlo, const float* W, const float* bias, int M, int N,
                            int K, long ldx, long ldw, long ldy, void* workspace, long workspace_bytes, bool reduce,
-                           hipStream_t stream);
+                           hipStream_t stream, bool kn = false);
 
 // Y[M,N] = X[M,K] . W[N,K]^T + bias ; X given as K-BLOCKED split bf16 (fx_split_bf16 / fx_gather_split layout:
 // [ceil(K/32)][ldx rows][32], ldx = rows padded to a multiple of 128, padding zero)
@@ -469,17 +493,27 @@ int fx_linear_fwd_bf16x3_slabs(float* slabs, long slabs_bytes, const void* xhi, 
   return fwd_bf16x3_impl(nullptr, xhi, xlo, W, nullptr, M, N, K, ldx, ldw, N, slabs, slabs_bytes, false, stream);
 }
 
+// dX[M,N] = dY[M,K] . W[K,N]   (W = the layer's weight [out=K, in=N] as stored): the data gradient through a WIDE
+// layer (autograd's mm in Linear backward, e.g. the supervised_vae / CrossModalPred decoders' FC_output).  dY given
+// as a K-blocked split (fx_split_bf16 with rows_padded = lddy_rows).  Workspace: fx_linear_fwd_bf16x3_workspace_bytes.
+int fx_linear_bwd_x_bf16x3(float* dX, const void* dyhi, const void* dylo, const float* W, int M, int N, int K, long dy_rows_padded,
+                           long ldw, long lddx, void* workspace, long workspace_bytes, hipStream_t stream) {
+  FX_REQUIRE(dX != nullptr, "fx_linear_bwd_x_bf16x3: null output");
+  FX_REQUIRE(ldw >= N, "fx_linear_bwd_x_bf16x3: ldw %ld < N %d", ldw, N);
+  return fwd_bf16x3_impl(dX, dyhi, dylo, W, nullptr, M, N, K, dy_rows_padded, ldw, lddx, workspace, workspace_bytes, true, stream, true);
+}
+
 }  // extern "C"
 
 static int fwd_bf16x3_impl(float* Y, const void* xhi, const void* xlo, const float* W, const float* bias, int M, int N,
                            int K, long ldx, long ldw, long ldy, void* workspace, long workspace_bytes, bool reduce,
-                           hipStream_t stream) {
+                           hipStream_t stream, bool kn) {
   FX_REQUIRE(xhi && xlo && W && M > 0 && N > 0 && K > 0, "fx_linear_fwd_bf16x3: bad args");
   const int Kp = (K + TK - 1) / TK * TK;
   FX_REQUIRE(ldx >= M && ldx % 128 == 0 && aligned16(xhi) && aligned16(xlo),
              "fx_linear_fwd_bf16x3: X must be a K-blocked split with rows padded to a multiple of 128 (got %ld for M=%d)", ldx, M);
-  FX_REQUIRE((long)N * ldw * 4 < 0xF0000000L && (long)Kp * ldx * 2 < 0xF0000000L, "fx_linear_fwd_bf16x3: operand exceeds 4 GiB");
-  const int wn = fwd_wn(), tn = 32 * wn;
+  FX_REQUIRE((long)(kn ? K : N) * ldw * 4 < 0xF0000000L && (long)Kp * ldx * 2 < 0xF0000000L, "fx_linear_fwd_bf16x3: operand exceeds 4 GiB");
+  const int wn = kn ? 4 : fwd_wn(), tn = 32 * wn;
   const int s = pick_splitk_x(M, N, Kp, wn);
   FX_REQUIRE(workspace && workspace_bytes >= (long)s * M * N * (long)sizeof(float), "fx_linear_fwd_bf16x3: workspace too small");
   XGemmArgs g{};
@@ -494,7 +528,9 @@ static int fwd_bf16x3_impl(float* Y, const void* xhi, const void* xlo, const flo
   const long nblk = (long)((M + TM - 1) / TM) * ((N + tn - 1) / tn) * s;
   FX_REQUIRE(nblk < (1L << 31), "fx_linear_fwd_bf16x3: grid too large");
   const int nt = env_int("FX_NT_FWD", 0);
-  if (wn == 4) {
+  if (kn) {
+    hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<true, XEPI_STORE, 0, 4, true>), dim3((unsigned)nblk), dim3(512), 0, stream, g);
+  } else if (wn == 4) {
     if (nt) hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<true, XEPI_STORE, 2, 4>), dim3((unsigned)nblk), dim3(512), 0, stream, g);
     else hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<true, XEPI_STORE, 0, 4>), dim3((unsigned)nblk), dim3(512), 0, stream, g);
   } else {

@@ -325,6 +325,20 @@ def linear_fwd_bf16x3(rec, y, xhi, xlo, W, b, ws):
              xhi.shape[1], _ld(W), _ld(y), ws.buf.data_ptr(), ws.nbytes)
 
 
+def linear_bwd_x_bf16x3(rec, dx, dyhi, dylo, W, ws: Workspace):
+    """dx[M,N] = dy[M,K] W[K,N] for a wide W (dy K-blocked split, new_split_kb(M, K))."""
+    _chk2d(dx, "linear_bwd_x_bf16x3.dx")
+    _chk2d(W, "linear_bwd_x_bf16x3.W")
+    M, N = dx.shape
+    K = W.shape[0]
+    if W.shape[1] != N:
+        raise FxError("linear_bwd_x_bf16x3: shape mismatch")
+    _chk_kb(dyhi, dylo, M, K, "linear_bwd_x_bf16x3")
+    ws.reserve(int(lib.fx_linear_fwd_bf16x3_workspace_bytes(M, N, K)))
+    rec.emit("fx_linear_bwd_x_bf16x3", dx.data_ptr(), dyhi.data_ptr(), dylo.data_ptr(), W.data_ptr(), M, N, K, dyhi.shape[1],
+             _ld(W), _ld(dx), ws.buf.data_ptr(), ws.nbytes)
+
+
 def linear_dw_adam_bf16x3(rec, W, m, v, dyT_hi, dyT_lo, xT_hi, xT_lo, ctrl):
     """W[N,K] <- Adam(clip * dY^T X) with dY^T [N, Bp] and X^T [K, Bp] pre-split."""
     for t, n in ((W, "W"), (m, "m"), (v, "v")):

@@ -83,6 +83,10 @@ int fx_split_bf16_t(void* hiT, void* loT, const float* x, int R, int C, long ldx
 long fx_linear_fwd_bf16x3_workspace_bytes(int M, int N, int K);
 int fx_linear_fwd_bf16x3(float* Y, const void* xhi, const void* xlo, const float* W, const float* bias, int M, int N, int K,
                          long ldx, long ldw, long ldy, void* workspace, long workspace_bytes, fx_stream_t stream);
+/* dX[M,N] = dY[M,K] . W[K,N] with W = the weight [out = K, in = N] as stored: autograd's data-gradient mm through a WIDE
+ * layer (the decoders' FC_output of supervised_vae / CrossModalPred, modules.py:89,101).  dY as a K-blocked split. */
+int fx_linear_bwd_x_bf16x3(float* dX, const void* dyhi, const void* dylo, const float* W, int M, int N, int K,
+                           long dy_rows_padded, long ldw, long lddx, void* workspace, long workspace_bytes, fx_stream_t stream);
 int fx_linear_dw_adam_bf16x3(float* W, float* adam_m, float* adam_v, const void* dyT_hi, const void* dyT_lo,
                              const void* xT_hi, const void* xT_lo, int batch_padded, int n_out, int k_in, long lddy,
                              long ldx, long ldw, const float* ctrl, fx_stream_t stream);

@@ -709,3 +709,21 @@ def test_finetune_step_frozen_groups_no_clip_vs_oracle(model, frozen):
             else:
                 close(sd[k], st1[k], 1e-4, noise_atol(g, gn, lr, 2e-6), k)
     assert moved_buffers > 0, "BatchNorm running statistics of the frozen blocks must still update (train mode)"
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 5000, 20000), (100, 330, 1000), (37, 64, 96), (128, 1250, 5000)])
+def test_linear_bwd_x_bf16x3_vs_fp64(M, N, K):
+    """dX = dY . W with W stored [K, N] (the wide data-gradient contraction): split-bf16 kernel vs fp64."""
+    from flexynesis_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + N + K)
+    dy = torch.randn(M, K, generator=g).to(dev)
+    W = (torch.randn(K, N, generator=g) / K ** 0.5).to(dev)
+    hi, lo = ops.new_split_kb(M, K, dev)
+    ops.split_bf16(ops.IMMEDIATE, hi, lo, dy)
+    dx = torch.full((M, N), float("nan"), device=dev)
+    ops.linear_bwd_x_bf16x3(ops.IMMEDIATE, dx, hi, lo, W, ops.Workspace(dev))
+    ref = dy.double() @ W.double()
+    scale = dy.double().abs() @ W.double().abs()
+    assert ((dx.double() - ref).abs() / scale).max().item() <= 2e-5
+    assert ((dx.double() - ref).norm() / ref.norm()).item() <= 1e-5
