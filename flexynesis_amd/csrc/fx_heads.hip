@@ -118,18 +118,15 @@ __global__ __launch_bounds__(256) void fx_heads_fwd_kernel(HeadsArgs a) {
   const int t = threadIdx.x, r = t & 127, hf = t >> 7, col = t & 31, rg = t >> 5;
   const int S = h.S, C = h.C, B = a.B, L = a.L;
   const int s0 = hf * (HS / 2);
-  {   // W1s[l][s] = W1[s][l] (zero for s >= S): the 16 weights one thread needs per l are 4 x ds_read_b128
-    float v[HS * HL / 256];
+  // W1s[l][s] = W1[s][l] (zero for s >= S): the 16 weights one thread needs per l are 4 x ds_read_b128.
+  // Thread (l = t & 127, row pair t >> 7): 16 passes cover the 32 padded rows, coalesced over l, no integer division.
+  float vw1[HS / 2];
+  {
+    const int l_ = t & 127;
 #pragma unroll
-    for (int i = 0; i < HS * HL / 256; ++i) {
-      const int idx = t + 256 * i, s_ = idx / L, l_ = idx - s_ * L;       // coalesced over the source
-      v[i] = h.W1[min(idx, S * L - 1)];
-      (void)s_; (void)l_;
-    }
-#pragma unroll
-    for (int i = 0; i < HS * HL / 256; ++i) {
-      const int idx = t + 256 * i, s_ = idx / L, l_ = idx - s_ * L;
-      if (idx < HS * L) W1s[l_ * HS + s_] = idx < S * L ? v[i] : 0.f;
+    for (int i = 0; i < HS / 2; ++i) {
+      const int s_ = (t >> 7) + 2 * i;
+      vw1[i] = h.W1[(long)min(s_, S - 1) * L + min(l_, L - 1)];
     }
   }
   {
@@ -152,14 +149,39 @@ __global__ __launch_bounds__(256) void fx_heads_fwd_kernel(HeadsArgs a) {
     stat[3][t] = t < S ? b_ : 0.f;
     stat[4][t] = t < S ? b1_ : 0.f;
   }
+  {
+    const int l_ = t & 127;
+#pragma unroll
+    for (int i = 0; i < HS / 2; ++i) {
+      const int s_ = (t >> 7) + 2 * i;
+      if (l_ < L) W1s[l_ * HS + s_] = s_ < S ? vw1[i] : 0.f;
+    }
+  }
   __syncthreads();
   // ---- layer_1: y1[r, s] = b1[s] + sum_l x[r, l] W1[s, l]; each thread owns one row and 16 of the 32 padded columns
   float acc[HS / 2];
 #pragma unroll
   for (int j = 0; j < HS / 2; ++j) acc[j] = stat[4][s0 + j];
-  for (int c0 = 0; c0 < L; c0 += 32) {
+  // all chunks of the embedding are requested up front (one memory round trip instead of one per chunk)
+  float vx[HL / 32][16];
+#pragma unroll
+  for (int ch = 0; ch < HL / 32; ++ch) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int idx = t + 256 * i, rr = min(idx >> 5, B - 1), cc = min(32 * ch + (idx & 31), L - 1);
+      vx[ch][i] = a.x[(long)rr * a.ldx + cc];
+    }
+  }
+#pragma unroll
+  for (int ch = 0; ch < HL / 32; ++ch) {
+    const int c0 = 32 * ch;
+    if (c0 >= L) break;
     __syncthreads();
-    heads_stage(xs, a.x, a.ldx, B, c0, L);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int idx = t + 256 * i, rr = idx >> 5, cc = idx & 31;
+      xs[rr][cc] = (rr < B && c0 + cc < L) ? vx[ch][i] : 0.f;
+    }
     __syncthreads();
     const int lmax = min(32, L - c0);
     const float4* w4 = reinterpret_cast<const float4*>(W1s + c0 * HS + s0);
@@ -253,153 +275,207 @@ __global__ __launch_bounds__(256) void fx_heads_fwd_kernel(HeadsArgs a) {
   }
 }
 
-// Backward of every head and the sum of their embedding gradients.  One workgroup; heads are processed in order.
-__global__ __launch_bounds__(256) void fx_heads_bwd_kernel(HeadsArgs a) {
-  __shared__ Tile R1;                 // dout (columns >= C zero), later 32-column chunks of the embedding
-  __shared__ Tile R2;                 // saved block output, then x-hat, then layer_1.weight as [S][L]
-  __shared__ Tile R3;                 // grad at the BatchNorm output, then grad at the layer_1 output
-  __shared__ float W2s[HC * HS];      // [C][32], columns >= S zero
-  __shared__ float part[8][32];
-  __shared__ float stat[3][32];       // mean, invstd, gamma (zero padded)
-  const int t = threadIdx.x, r = t & 127, hf = t >> 7, col = t & 31, rg = t >> 5;
-  const int B = a.B, L = a.L;
-  const int Lh = (L + 1) >> 1, l0 = hf * Lh;
-  const int s0 = hf * (HS / 2);
-  float* W1s = &R2[0][0];             // HB*33 floats >= HS*HL
-  float accx[HL / 2];
+// Backward.  grid = n_heads + 1 workgroups:
+//   workgroups 0 .. n_heads-1 : parameter gradients of head i (layer_out, BatchNorm, layer_1)
+//   workgroup  n_heads        : the embedding gradient dx (+)= sum over heads, heads in order (fixed summation order)
+// Both kinds run the same PREFIX per head -- dout.W2 gated by the saved block output, then the BatchNorm backward --
+// which leaves dy1 (the gradient at the layer_1 output) in the LDS tile R3; recomputing ~5 us of prefix is cheaper
+// than a dependent launch.  Every global operand a phase needs is requested at the start of the head (registers), so
+// a head costs about two memory round trips instead of six.
+struct HeadsBwdLds {
+  Tile R1;                 // dout (columns >= C zero), later 32-column chunks of the embedding
+  Tile R2;                 // saved block output, then x-hat, then layer_1.weight as [S][L]
+  Tile R3;                 // grad at the BatchNorm output, then dy1
+  float W2s[HC * HS];      // [C][32], columns >= S zero
+  float part[8][32];
+  float stat[3][32];       // mean, invstd, gamma (zero padded)
+};
+
+// stages dout / a1 / W2 / statistics and leaves the gradient at the BatchNorm output in R3
+__device__ __forceinline__ void heads_bwd_prefix(HeadsBwdLds& L, const FxHeadDesc& h, int B, float gate_scale) {
+  const int t = threadIdx.x, r = t & 127, hf = t >> 7;
+  const int S = h.S, C = h.C, s0 = hf * (HS / 2);
+  // ---- request everything at once: dout, a1 (16 values each), W2 (4), statistics
+  float vd[16], va[16], vw[HC * HS / 256];
 #pragma unroll
-  for (int j = 0; j < HL / 2; ++j) accx[j] = 0.f;
-  if (a.dx && a.dx_accumulate) {
-#pragma unroll
-    for (int j = 0; j < HL / 2; ++j) accx[j] = a.dx[(long)min(r, B - 1) * a.lddx + min(l0 + j, L - 1)];   // only in-range lanes are stored
+  for (int i = 0; i < 16; ++i) {
+    const int idx = t + 256 * i, rr = min(idx >> 5, B - 1), cc = idx & 31;
+    vd[i] = h.dout[(long)rr * C + min(cc, C - 1)];
+    va[i] = h.a1[(long)rr * S + min(cc, S - 1)];
   }
+#pragma unroll
+  for (int i = 0; i < HC * HS / 256; ++i) {
+    const int idx = t + 256 * i;
+    vw[i] = h.W2[min(idx >> 5, C - 1) * S + min(idx & 31, S - 1)];
+  }
+  float m_ = 0.f, i_ = 0.f, g_ = 0.f;
+  if (t < 32) {
+    const int sc = min(t, S - 1);
+    m_ = h.save_mean[sc]; i_ = h.save_invstd[sc]; g_ = h.gamma[sc];
+  }
+  __syncthreads();                                     // previous head's readers are done with the tiles
+  if (t < 32) {
+    L.stat[0][t] = t < S ? m_ : 0.f;
+    L.stat[1][t] = t < S ? i_ : 0.f;
+    L.stat[2][t] = t < S ? g_ : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int idx = t + 256 * i, rr = idx >> 5, cc = idx & 31;
+    L.R1[rr][cc] = (rr < B && cc < C) ? vd[i] : 0.f;
+    L.R2[rr][cc] = (rr < B && cc < S) ? va[i] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < HC * HS / 256; ++i) {
+    const int idx = t + 256 * i;
+    L.W2s[idx] = ((idx >> 5) < C && (idx & 31) < S) ? vw[i] : 0.f;
+  }
+  __syncthreads();
+  // ---- grad at the BatchNorm output: (dout . W2) gated by the saved block output (ReLU and dropout in one test)
+  {
+    float d[HS / 2];
+#pragma unroll
+    for (int j = 0; j < HS / 2; ++j) d[j] = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float dv = L.R1[r][c];
+#pragma unroll
+      for (int j = 0; j < HS / 2; ++j) d[j] = fmaf(dv, L.W2s[c * HS + s0 + j], d[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < HS / 2; ++j) L.R3[r][s0 + j] = (L.R2[r][s0 + j] > 0.f) ? d[j] * gate_scale : 0.f;
+  }
+  // (the caller's layer_out gradients read R1/R2 between these two barriers -- see fx_heads_bwd_kernel)
+}
+
+__device__ __forceinline__ void heads_bwd_bn(HeadsBwdLds& L, int B, const float vy[16], float& sum_dy, float& sum_dy_xh,
+                                             float& sum_dx) {
+  const int t = threadIdx.x, col = t & 31, rg = t >> 5;
+  // x-hat of the saved layer_1 output replaces the block output in R2
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int idx = t + 256 * i, rr = idx >> 5, cc = idx & 31;
+    L.R2[rr][cc] = (rr < B) ? (vy[i] - L.stat[0][cc]) * L.stat[1][cc] : 0.f;       // padded columns: invstd = 0
+  }
+  __syncthreads();
+  // BatchNorm backward (same expressions as fx_bn_bwd_kernel); padded columns have gamma = 0
+  const float invstd = L.stat[1][col], gm = L.stat[2][col];
+  float s1 = 0.f, s2 = 0.f;
+  for (int rr = rg; rr < B; rr += 8) {
+    const float dy = L.R3[rr][col];
+    s1 += dy;
+    s2 += dy * L.R2[rr][col];
+  }
+  sum_dy = heads_colsum(s1, L.part, col, rg);
+  sum_dy_xh = heads_colsum(s2, L.part, col, rg);
+  float sb = 0.f;
+  const float invB = 1.0f / (float)B;
+  for (int rr = rg; rr < B; rr += 8) {
+    const float d = gm * invstd * (L.R3[rr][col] - invB * sum_dy - L.R2[rr][col] * invB * sum_dy_xh);
+    L.R3[rr][col] = d;          // each (row, col) is owned by exactly one thread here
+    sb += d;
+  }
+  sum_dx = heads_colsum(sb, L.part, col, rg);
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void fx_heads_bwd_kernel(HeadsArgs a) {
+  __shared__ HeadsBwdLds L;
+  const int t = threadIdx.x, r = t & 127, hf = t >> 7, col = t & 31, rg = t >> 5;
+  const int B = a.B, Ld = a.L;
   const float gate_scale = 1.0f / (1.0f - a.drop_p);
-  for (int hi = 0; hi < a.n_heads; ++hi) {
-    const FxHeadDesc& h = a.h[hi];
+  const bool dx_role = (int)blockIdx.x == a.n_heads;
+  if (!dx_role) {
+    // ================= parameter gradients of head blockIdx.x =================
+    const FxHeadDesc& h = a.h[blockIdx.x];
     const int S = h.S, C = h.C;
-    __syncthreads();
-    heads_stage(R1, h.dout, C, B, 0, C);
-    heads_stage(R2, h.a1, S, B, 0, S);
-    {
-      float v[HC * HS / 256];
+    // y1 for the x-hat and both 32-column chunks... the embedding is staged chunk by chunk below
+    float vy[16];
 #pragma unroll
-      for (int i = 0; i < HC * HS / 256; ++i) {
-        const int idx = t + 256 * i, c = idx >> 5, s_ = idx & 31;
-        v[i] = h.W2[min(c, C - 1) * S + min(s_, S - 1)];
-      }
-#pragma unroll
-      for (int i = 0; i < HC * HS / 256; ++i) {
-        const int idx = t + 256 * i, c = idx >> 5, s_ = idx & 31;
-        W2s[idx] = (c < C && s_ < S) ? v[i] : 0.f;
-      }
+    for (int i = 0; i < 16; ++i) {
+      const int idx = t + 256 * i;
+      vy[i] = h.y1[(long)min(idx >> 5, B - 1) * S + min(idx & 31, S - 1)];
     }
-    if (t < 32) {
-      const int sc = min(t, S - 1);
-      const float m_ = h.save_mean[sc], i_ = h.save_invstd[sc], g_ = h.gamma[sc];
-      stat[0][t] = t < S ? m_ : 0.f;
-      stat[1][t] = t < S ? i_ : 0.f;
-      stat[2][t] = t < S ? g_ : 0.f;
-    }
-    __syncthreads();
+    float sum_dy, sum_dy_xh, sum_dx;
+    heads_bwd_prefix(L, h, B, gate_scale);
     // layer_out.weight / bias gradients (over the padded [C][32] grid; only true columns are stored)
     for (int o = t; o < C * HS; o += 256) {
       const int c = o >> 5, s = o & 31;
       float g = 0.f;
 #pragma unroll 8
-      for (int rr = 0; rr < HB; ++rr) g += R1[rr][c] * R2[rr][s];      // rows >= B are zero
+      for (int rr = 0; rr < HB; ++rr) g = fmaf(L.R1[rr][c], L.R2[rr][s], g);      // rows >= B are zero
       if (s < S) h.gW2[c * S + s] = g;
     }
     if (h.gb2 && t < C) {
       float g = 0.f;
 #pragma unroll 8
-      for (int rr = 0; rr < HB; ++rr) g += R1[rr][t];
+      for (int rr = 0; rr < HB; ++rr) g += L.R1[rr][t];
       h.gb2[t] = g;
     }
-    // grad at the BatchNorm output: (dout . W2) gated by the saved block output (ReLU and dropout in one test)
-    {
-      float d[HS / 2];
-#pragma unroll
-      for (int j = 0; j < HS / 2; ++j) d[j] = 0.f;
-      for (int c = 0; c < C; ++c) {
-        const float dv = R1[r][c];
-#pragma unroll
-        for (int j = 0; j < HS / 2; ++j) d[j] += dv * W2s[c * HS + s0 + j];
-      }
-#pragma unroll
-      for (int j = 0; j < HS / 2; ++j) R3[r][s0 + j] = (R2[r][s0 + j] > 0.f) ? d[j] * gate_scale : 0.f;
-    }
     __syncthreads();
-    // x-hat of the saved layer_1 output (replaces the block output in R2)
-    {
-      float v[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int idx = t + 256 * i, rr = idx >> 5, cc = idx & 31;
-        v[i] = h.y1[(long)min(rr, B - 1) * S + min(cc, S - 1)];
-      }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int idx = t + 256 * i, rr = idx >> 5, cc = idx & 31;
-        R2[rr][cc] = (rr < B && cc < S) ? (v[i] - stat[0][cc]) * stat[1][cc] : 0.f;
-      }
-    }
-    __syncthreads();
-    // BatchNorm backward (same expressions as fx_bn_bwd_kernel); padded columns have gamma = 0
-    const float invstd = stat[1][col], gm = stat[2][col];
-    float s1 = 0.f, s2 = 0.f;
-    for (int rr = rg; rr < B; rr += 8) {
-      const float dy = R3[rr][col];
-      s1 += dy;
-      s2 += dy * R2[rr][col];
-    }
-    const float sum_dy = heads_colsum(s1, part, col, rg);
-    const float sum_dy_xh = heads_colsum(s2, part, col, rg);
-    float sb = 0.f;
-    {
-      const float invB = 1.0f / (float)B;
-      for (int rr = rg; rr < B; rr += 8) {
-        const float d = gm * invstd * (R3[rr][col] - invB * sum_dy - R2[rr][col] * invB * sum_dy_xh);
-        R3[rr][col] = d;        // each (row, col) is owned by exactly one thread here
-        sb += d;
-      }
-    }
-    const float sum_dx = heads_colsum(sb, part, col, rg);
+    heads_bwd_bn(L, B, vy, sum_dy, sum_dy_xh, sum_dx);
     if (col < S && rg == 0) {
       h.ggamma[col] = sum_dy_xh;
       h.gbeta[col] = sum_dy;
       h.gb1[col] = sum_dx;
     }
     // layer_1.weight gradient: gW1[s, l] = sum_r dy1[r, s] x[r, l], 32 columns of x at a time through R1
-    for (int c0 = 0; c0 < L; c0 += 32) {
+    for (int c0 = 0; c0 < Ld; c0 += 32) {
       __syncthreads();
-      heads_stage(R1, a.x, a.ldx, B, c0, L);
+      heads_stage(L.R1, a.x, a.ldx, B, c0, Ld);
       __syncthreads();
       for (int o = t; o < S * 32; o += 256) {
         const int s = o >> 5, l = o & 31;
         float g = 0.f;
 #pragma unroll 8
-        for (int rr = 0; rr < HB; ++rr) g += R3[rr][s] * R1[rr][l];
-        if (c0 + l < L) h.gW1[(long)s * L + c0 + l] = g;
+        for (int rr = 0; rr < HB; ++rr) g = fmaf(L.R3[rr][s], L.R1[rr][l], g);
+        if (c0 + l < Ld) h.gW1[(long)s * Ld + c0 + l] = g;
       }
     }
-    // embedding gradient, accumulated over the heads in registers (layer_1.weight staged over the dead x-hat)
-    if (a.dx) {
-      __syncthreads();
-      heads_copy<HS * HL>(W1s, h.W1, S * L);
-      __syncthreads();
-      // branch-free as in the forward: lanes j with l0 + j >= L accumulate neighbouring weights and are never stored
-      for (int s = 0; s < S; ++s) {
-        const float d = R3[r][s];
-        const float* w = W1s + s * L + l0;
+    return;
+  }
+  // ================= embedding gradient, accumulated over the heads in registers =================
+  if (!a.dx) return;
+  const int Lh = (Ld + 1) >> 1, l0 = hf * Lh;
+  float* W1s = &L.R2[0][0];             // HB*33 floats >= HS*HL
+  float accx[HL / 2];
 #pragma unroll
-        for (int j = 0; j < HL / 2; ++j) accx[j] = fmaf(d, w[j], accx[j]);
-      }
+  for (int j = 0; j < HL / 2; ++j) accx[j] = 0.f;
+  if (a.dx_accumulate) {
+#pragma unroll
+    for (int j = 0; j < HL / 2; ++j) accx[j] = a.dx[(long)min(r, B - 1) * a.lddx + min(l0 + j, Ld - 1)];   // only in-range lanes are stored
+  }
+  for (int hi = 0; hi < a.n_heads; ++hi) {
+    const FxHeadDesc& h = a.h[hi];
+    const int S = h.S;
+    float vy[16], vw1[HS * HL / 256];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int idx = t + 256 * i;
+      vy[i] = h.y1[(long)min(idx >> 5, B - 1) * S + min(idx & 31, S - 1)];
+    }
+#pragma unroll
+    for (int i = 0; i < HS * HL / 256; ++i) vw1[i] = h.W1[min(t + 256 * i, S * Ld - 1)];
+    float sum_dy, sum_dy_xh, sum_dx;
+    heads_bwd_prefix(L, h, B, gate_scale);
+    __syncthreads();
+    heads_bwd_bn(L, B, vy, sum_dy, sum_dy_xh, sum_dx);
+    // layer_1.weight staged over the dead x-hat; branch-free FMA loop: lanes j with l0 + j >= L accumulate neighbouring
+    // weights and are never stored
+#pragma unroll
+    for (int i = 0; i < HS * HL / 256; ++i)
+      if (t + 256 * i < S * Ld) W1s[t + 256 * i] = vw1[i];
+    __syncthreads();
+    for (int s = 0; s < S; ++s) {
+      const float d = L.R3[r][s];
+      const float* w = W1s + s * Ld + l0;
+#pragma unroll
+      for (int j = 0; j < HL / 2; ++j) accx[j] = fmaf(d, w[j], accx[j]);
     }
   }
-  if (a.dx && r < B) {
+  if (r < B) {
 #pragma unroll
     for (int j = 0; j < HL / 2; ++j)
-      if (j < Lh && l0 + j < L) a.dx[(long)r * a.lddx + l0 + j] = accx[j];
+      if (j < Lh && l0 + j < Ld) a.dx[(long)r * a.lddx + l0 + j] = accx[j];
   }
 }
 
@@ -447,7 +523,7 @@ int fx_heads_bwd(const void* heads_, int n_heads, const float* x, long ldx, floa
   }
   a.n_heads = n_heads; a.x = x; a.ldx = ldx; a.dx = dx; a.lddx = lddx; a.dx_accumulate = dx_accumulate;
   a.B = B; a.L = L; a.train = 1; a.drop_p = drop_p;
-  hipLaunchKernelGGL(fx_heads_bwd_kernel, dim3(1), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(fx_heads_bwd_kernel, dim3(n_heads + 1), dim3(256), 0, stream, a);
   return fx_check_launch("fx_heads_bwd");
 }
 

@@ -221,7 +221,7 @@ class StepPlan:
         self.dev = store.device
         self._ws = [Workspace(self.dev)]
         self._branch = 0
-        self.branches = bool(branches)          # per-modality chains as parallel hipGraph branches
+        self.branches = bool(branches) and os.environ.get("FX_BRANCHES", "1") != "0"   # per-modality chains as parallel hipGraph branches
         self.bn_slabs = False                   # fold the wide layer's split-K reduce into BatchNorm (measured: no gain)
         # all supervisor heads in one launch each way (fx_heads_fwd/bwd); FX_FUSE_HEADS=0 is an A/B switch for benchmarks
         self.fuse_heads = bool(fuse_heads) and os.environ.get("FX_FUSE_HEADS", "1") != "0"
