@@ -44,6 +44,22 @@ CONFIGS = {
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
+class _stdout_to_stderr:
+    """fd-level redirect: RCCL prints a version banner to STDOUT when its first communicator is created; rank 0's
+    stdout must carry exactly one JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,9 +86,13 @@ def main():
             sys.exit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_pg = world > 1 or bool(os.environ.get("FX_BENCH_FORCE_PG"))   # the env switch exercises the RCCL path on one GPU
+    if use_pg:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        with _stdout_to_stderr():
+            dist.init_process_group("nccl", device_id=dev)
+            dist.barrier()            # creates the communicator now (and its banner goes to stderr)
+            torch.cuda.synchronize()
 
     from flexynesis_amd import ops
     from flexynesis_amd.arch import ArchSpec
@@ -116,17 +136,17 @@ def main():
 
     run(a.warmup)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_pg:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(a.steps)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_pg:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_pg:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -203,7 +223,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 
