@@ -370,6 +370,9 @@ def _oracle_spec(aspec):
     ("DirectPred", [("gex", 4000), ("cnv", 3000)], 128),                   # cfg2 family (scaled to oracle-seconds)
     ("DirectPred", [("all", 7000)], 100),                                  # --fusion_type early: one layer "all", B % 32 != 0
     ("DirectPred", [("gex", 3000), ("covariates", 6)], 64),                # covariates modality: hidden = max(int(6*.25), 2)
+    ("DirectPred", [("gex", 4099), ("cnv", 3001)], 37),                    # odd feature counts / batch: unaligned rows everywhere
+    ("DirectPred", [("gex", 2500), ("cnv", 1800)], 200),                   # B > 128: per-layer heads / loop BatchNorm fallbacks
+    ("supervised_vae", [("gex", 2051), ("cnv", 1403)], 50),                # same for the VAE family (decoder outputs of odd width)
     ("supervised_vae", [("gex", 2000), ("cnv", 1600)], 64),                # cfg3 family
     ("MultiTripletNetwork", [("gex", 1500), ("cnv", 1200), ("meth", 900)], 32),   # cfg4 family
     ("CrossModalPred", [("gex", 2000), ("cnv", 1600), ("meth", 1200)], 64),      # section 8(f): encode gex+cnv, decode meth+gex
