@@ -112,7 +112,9 @@ def run_sweep(param_list: List[dict], trial_fn: Callable[[int, dict], Tuple[floa
               costs: Optional[Sequence[float]] = None, device="cpu", state_shapes: Optional[Dict[str, tuple]] = None):
     """Shard ``param_list`` over the ranks, run ``trial_fn(trial_id, params) -> (val_loss, epochs, state_dict)``
     locally, gather the result table, and (if ``state_shapes`` is given) broadcast the winner's weights.
-    Returns (table [n,4], best_trial_id, best_state or None)."""
+    ``state_shapes`` may be a dict (all trials share one architecture) or a callable ``params -> {key: shape}``
+    (HPO: latent size / hidden factor differ per trial, so the winner's layout is derived from its parameters on
+    every rank).  Returns (table [n,4], best_trial_id, best_state or None)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     n = len(param_list)
@@ -134,7 +136,8 @@ def run_sweep(param_list: List[dict], trial_fn: Callable[[int, dict], Tuple[floa
     best_state = None
     if state_shapes is not None and math.isfinite(table[best, 1]):
         owner = next(r for r, lst in enumerate(assign_trials(costs, world)) if best in lst)
-        best_state = broadcast_state(states.get(best), state_shapes, owner, device)
+        shapes = state_shapes(param_list[best]) if callable(state_shapes) else state_shapes
+        best_state = broadcast_state(states.get(best), shapes, owner, device)
     return table, best, best_state
 
 

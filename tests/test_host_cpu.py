@@ -215,7 +215,9 @@ def _worker(rank, world, port, out):
         state = {"w": torch.full((2, 3), float(tid)), "bn.num_batches_tracked": torch.tensor(tid * 3)}
         return val, p["epochs"], state
 
-    table, best, state = trials.run_sweep(params, trial_fn, costs=[1.0] * 7, device="cpu", state_shapes=shapes)
+    # the winner's layout is derived from ITS parameters on every rank (HPO trials differ in architecture)
+    table, best, state = trials.run_sweep(params, trial_fn, costs=[1.0] * 7, device="cpu",
+                                          state_shapes=lambda p: dict(shapes) if "epochs" in p else None)
     out.put((rank, list(dat.keys()), float(dat["zeta"].sum()), table.tolist(), best,
              state["w"].tolist(), int(state["bn.num_batches_tracked"])))
     dist.destroy_process_group()
