@@ -730,3 +730,89 @@ def test_linear_bwd_x_bf16x3_vs_fp64(M, N, K):
     scale = dy.double().abs() @ W.double().abs()
     assert ((dx.double() - ref).abs() / scale).max().item() <= 2e-5
     assert ((dx.double() - ref).norm() / ref.norm()).item() <= 1e-5
+
+
+def _random_config(seed):
+    """A random point of the reference's search space (config.py:7-15) x model class x layer/head layout."""
+    rng = np.random.default_rng(seed)
+    model = ["DirectPred", "supervised_vae", "MultiTripletNetwork", "CrossModalPred"][seed % 4]
+    n_layers = int(rng.integers(1, 4)) if model != "CrossModalPred" else 3
+    names = ["gex", "cnv", "meth"][:n_layers]
+    layers = [(n, int(rng.integers(40, 900))) for n in names]
+    heads = []
+    if model == "MultiTripletNetwork" or rng.random() < 0.6:
+        heads.append(("c", "categorical", int(rng.integers(2, 6))))
+    if rng.random() < 0.7 or not heads:
+        heads.append(("y", "numerical", 1))
+    surv = (None, None)
+    if model != "MultiTripletNetwork" and rng.random() < 0.4:
+        heads.append(("event", "numerical", 1))
+        surv = ("event", "time")
+    io = (None, None)
+    if model == "CrossModalPred":
+        io = (list(rng.permutation(names)[: int(rng.integers(1, 4))]), list(rng.permutation(names)[: int(rng.integers(1, 4))]))
+    return dict(model=model, layers=layers, latent=int(rng.integers(4, 129)), factor=float(rng.uniform(0.2, 0.5)),
+                sup=int(rng.integers(2, 33)), heads=heads, surv=surv, io=io, B=int(rng.choice([8, 17, 32, 64, 128])),
+                weighting=bool(rng.random() < 0.8))
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_random_configurations_one_step_vs_oracle(seed):
+    """Seeded sweep over model class x layer count x widths x head layout x batch size: one optimisation step of the
+    HIP engine against the CPU oracle from identical state, inputs and random draws (everything is in the small-
+    parameter regime here, so all tensors are compared element-wise)."""
+    from flexynesis_amd.arch import ArchSpec
+    from flexynesis_amd.engine import ParamStore, StepPlan
+    from oracle import restate as O
+    c = _random_config(seed)
+    dev = _dev()
+    aspec = ArchSpec(c["model"], c["layers"], c["latent"], c["factor"], c["sup"], c["heads"], c["surv"][0], c["surv"][1],
+                     c["weighting"], c["io"][0], c["io"][1])
+    ospec = _oracle_spec(aspec)
+    B, lr = c["B"], 1e-3
+    rows = 3 * B if c["model"] == "MultiTripletNetwork" else B
+    dat, ann = O.synthetic_cohort(c["layers"], max(rows, 16), seed=seed)
+    ann["event"] = (torch.rand(max(rows, 16), generator=torch.Generator().manual_seed(seed)) < 0.6).float()
+    st0 = O.init_state(ospec, seed=seed + 1)
+    store = ParamStore(aspec, dev)
+    store.load_state(st0)
+    plan = StepPlan(store, B, train=True, fused=True, supplied_draws=True)
+    gen = torch.Generator().manual_seed(seed + 2)
+    y = {k: ann[k][:B].clone() for k in plan.y}
+    if "y" in y and B > 4:
+        y["y"][1] = float("nan")                       # a missing numerical label
+    if "c" in y and B > 4:
+        y["c"] = torch.minimum(y["c"], torch.tensor(float(dict((h[0], h[2]) for h in c["heads"])["c"] - 1)))
+        y["c"][2] = -1.0                               # a missing categorical label
+    draws = {}
+    for name, t in plan.draws.items():
+        draws[name] = torch.randn(t.shape, generator=gen) if (name == "eps" or name.startswith("prior.")) \
+            else (torch.rand(t.shape, generator=gen) < 0.9).float()
+    if c["model"] == "MultiTripletNetwork":
+        parts = [[dat[n][j * B:(j + 1) * B] for n, _ in c["layers"]] for j in range(3)]
+        batch = {"anchor": parts[0], "positive": parts[1], "negative": parts[2], "y": y}
+        plan.set_batch(parts=[[x.to(dev) for x in p] for p in parts], y={k: v.to(dev) for k, v in y.items()})
+    else:
+        xs = [dat[n][:B] for n, _ in c["layers"]]
+        batch = {"x": xs, "y": y}
+        plan.set_batch(x_list=[x.to(dev) for x in xs], y={k: v.to(dev) for k, v in y.items()})
+    plan.set_draws({k: v.to(dev) for k, v in draws.items()})
+    plan.train_step(lr)
+    st1, _, info = O.train_step(ospec, st0, {}, batch, draws, lr)
+    got = plan.losses()
+    for k, v in info["losses"].items():
+        close(got[k], v, LOSS_RTOL, 1e-6, f"{c['model']} seed {seed} loss {k}")
+    exact = sum(float((gv.double() ** 2).sum()) for gv in info["grads"].values()) ** 0.5
+    close(store.ctrl[5], exact, 2e-4, 1e-7, "grad_norm")
+    sd = store.state_dict()
+    gn = float(info["grad_norm"])
+    for k in sd:
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == int(st1[k]), k
+        elif O.is_buffer(k):
+            close(sd[k], st1[k], 1e-4, 1e-6, k)
+        elif k in store.big_keys:
+            bad = (sd[k].cpu().double() - st1[k].double()).abs() > 2e-5 + 1e-3 * st1[k].double().abs()
+            assert float(bad.double().mean()) <= 1e-3, k
+        else:
+            close(sd[k], st1[k], 1e-4, noise_atol(info["grads"].get(k), gn, lr, 2e-6), f"{c['model']} seed {seed} {k}")
