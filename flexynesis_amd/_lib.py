@@ -8,6 +8,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch FIRST: PyTorch-ROCm ships its own libamdhip64.  libfxhip.so must bind to that already-loaded runtime --
+# loaded before torch it would pull in /opt/rocm's copy, and the process would hold two HIP runtimes (launches then
+# fail with "no ROCm-capable device is detected" and torch's device pointers mean nothing to the second runtime).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # FXHIP_LIB: A/B-test another build of the SAME ABI (e.g. a previous libfxhip.so); never a fallback
 LIB_PATH = os.environ.get("FXHIP_LIB") or os.path.join(_HERE, "csrc", "libfxhip.so")
