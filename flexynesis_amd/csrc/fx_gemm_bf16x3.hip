@@ -371,6 +371,130 @@ __global__ __launch_bounds__(128 * WN) void fx_gemm_bf16x3_kernel(XGemmArgs g) {
   }
 }
 
+// ---- wide forward with several M tiles per workgroup ------------------------------------------------------
+// M > 128 (the triplet network stacks anchor / positive / negative: M = 3B) used to launch one workgroup per 128-row
+// M tile, each streaming the same W tile from HBM (3x the traffic: 650 us instead of ~250 per modality at cfg4;
+// co-scheduling the tiles on one XCD did not produce L2 hits).  Here one workgroup owns MT M-tiles of one N tile:
+// W is loaded and split once per K-step and multiplied into MT accumulator sets.  LDS holds one stage
+// ([MT x (X hi, X lo)] + [W hi, W lo] = 64 KB at MT = 3); X is prefetched one K-step ahead in registers and W, the
+// HBM stream, two (its latency is ~2 us; X comes from L2).  Loads and stashes are unconditional; K-steps past the
+// slice are requested out of range (zeros).
+template <int MT>
+__global__ __launch_bounds__(512) void fx_fwd_bf16x3_mt_kernel(XGemmArgs g) {
+  constexpr int TN = 128, ARR = TM * TK;                        // one 128 x 32 bf16 array
+  __shared__ __attribute__((aligned(16))) __bf16 smem[(2 * MT + 2) * ARR];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid & 1, wc = wid >> 1;
+  const int groups_m = (g.M + MT * TM - 1) / (MT * TM);
+  int lin = blockIdx.x;
+  const int z = lin % g.splitk;
+  lin /= g.splitk;
+  const int gm = lin % groups_m, tn = lin / groups_m;
+  const int m0 = gm * MT * TM, n0 = tn * TN;
+  const int k_begin = z * g.kchunk;
+  const int k_end = min(g.K, k_begin + g.kchunk);
+  const int nk = (k_end > k_begin) ? (k_end - k_begin) / TK : 0;
+  const __amdgpu_buffer_rsrc_t rAh = fx_rsrc(g.Ahi, (long)g.K * g.a_rp * 2), rAl = fx_rsrc(g.Alo, (long)g.K * g.a_rp * 2);
+  const __amdgpu_buffer_rsrc_t rB = fx_rsrc(g.Bf, (long)g.N * g.ldb * 4);
+  const int a_row = tid >> 2, a_c = tid & 3;
+  const unsigned a_off = (unsigned)(((long)(m0 + a_row) * TK + 8 * a_c) * 2);
+  const unsigned a_tile = TM * TK * 2u;                         // bytes between M tiles of one K-step (K-blocked X)
+  const unsigned a_step = (unsigned)g.a_rp * (TK * 2u), a_kb = (unsigned)(k_begin / TK) * a_step;
+  const int bn = tid >> 3, k4 = tid & 7;
+  const unsigned b_off0 = (unsigned)(((long)(n0 + bn) * g.ldb + 4 * k4) * 4);
+  const unsigned b_off1 = (unsigned)(((long)(n0 + bn + 64) * g.ldb + 4 * k4) * 4);
+  const unsigned b_kb = (unsigned)k_begin * 4u, b_step = TK * 4u;
+  const int a_lds = swz(a_row, a_c);
+  const int b_lds0 = swz(bn, k4 >> 1) + ((k4 & 1) << 2), b_lds1 = swz(bn + 64, k4 >> 1) + ((k4 & 1) << 2);
+  __bf16* const Bh = smem + 2 * MT * ARR;
+  __bf16* const Bl = Bh + ARR;
+
+  u32x4 pah[MT], pal[MT], s0_b0, s0_b1, s1_b0, s1_b1;
+#define MT_LOAD_A(kt)                                                            \
+  {                                                                              \
+    const unsigned past = ((kt) < nk) ? 0u : 0xFFFFFFF0u;                        \
+    const unsigned ka = a_kb + (unsigned)(kt) * a_step;                          \
+    _Pragma("unroll") for (int m = 0; m < MT; ++m) {                             \
+      pah[m] = bld128(rAh, (a_off + m * a_tile + ka) | past);                    \
+      pal[m] = bld128(rAl, (a_off + m * a_tile + ka) | past);                    \
+    }                                                                            \
+  }
+#define MT_LOAD_B(P, kt)                                                         \
+  {                                                                              \
+    const unsigned past = ((kt) < nk) ? 0u : 0xFFFFFFF0u;                        \
+    const unsigned kb = b_kb + (unsigned)(kt) * b_step;                          \
+    P##_b0 = bld128(rB, (b_off0 + kb) | past);                                   \
+    P##_b1 = bld128(rB, (b_off1 + kb) | past);                                   \
+  }
+#define MT_STASH(P)                                                              \
+  {                                                                              \
+    _Pragma("unroll") for (int m = 0; m < MT; ++m) {                             \
+      *reinterpret_cast<u32x4*>(smem + (2 * m) * ARR + a_lds) = pah[m];          \
+      *reinterpret_cast<u32x4*>(smem + (2 * m + 1) * ARR + a_lds) = pal[m];      \
+    }                                                                            \
+    split_store4(P##_b0, Bh + b_lds0, Bl + b_lds0);                              \
+    split_store4(P##_b1, Bh + b_lds1, Bl + b_lds1);                              \
+  }
+  f32x16 acc[MT][2];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc[m][0][i] = 0.f; acc[m][1][i] = 0.f; }
+  const int arow = wr * 64 + (lane & 31), brow = wc * 32 + (lane & 31), kh = lane >> 5;
+#define MT_COMPUTE()                                                                              \
+  {                                                                                               \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                            \
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Bh + swz(brow, 2 * ks + kh));            \
+      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Bl + swz(brow, 2 * ks + kh));            \
+      _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                            \
+        const __bf16* Ah = smem + (2 * m) * ARR;                                                  \
+        const __bf16* Al = Ah + ARR;                                                              \
+        const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(Ah + swz(arow, 2 * ks + kh));         \
+        const bf16x8 al0 = *reinterpret_cast<const bf16x8*>(Al + swz(arow, 2 * ks + kh));         \
+        const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(Ah + swz(arow + 32, 2 * ks + kh));    \
+        const bf16x8 al1 = *reinterpret_cast<const bf16x8*>(Al + swz(arow + 32, 2 * ks + kh));    \
+        acc[m][0] = MFMA_BF16(al0, bh, acc[m][0]); acc[m][1] = MFMA_BF16(al1, bh, acc[m][1]);     \
+        acc[m][0] = MFMA_BF16(ah0, bl, acc[m][0]); acc[m][1] = MFMA_BF16(ah1, bl, acc[m][1]);     \
+        acc[m][0] = MFMA_BF16(ah0, bh, acc[m][0]); acc[m][1] = MFMA_BF16(ah1, bh, acc[m][1]);     \
+      }                                                                                           \
+    }                                                                                             \
+  }
+  MT_LOAD_B(s0, 0);
+  MT_LOAD_B(s1, 1);
+  MT_LOAD_A(0);
+  for (int kt = 0; kt < nk; kt += 2) {
+    __syncthreads();
+    MT_STASH(s0);
+    __syncthreads();
+    MT_LOAD_A(kt + 1);
+    MT_LOAD_B(s0, kt + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    MT_COMPUTE();
+    __syncthreads();
+    MT_STASH(s1);
+    __syncthreads();
+    MT_LOAD_A(kt + 2);
+    MT_LOAD_B(s1, kt + 3);
+    __builtin_amdgcn_sched_barrier(0);
+    MT_COMPUTE();                       // an odd trailing K-step was requested out of range: zeros
+  }
+  const int n = n0 + wc * 32 + (lane & 31);
+  const unsigned oob = (n < g.N) ? 0u : 0xFFFFFFF0u;
+  const __amdgpu_buffer_rsrc_t rC = fx_rsrc(g.C + (long)z * g.slab_stride, (long)g.M * g.ldc * 4);
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      const int mbase = m0 + m * TM + wr * 64 + blk * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int mm = mbase + (r & 3) + 8 * (r >> 2);
+        const unsigned off = (unsigned)(((long)mm * g.ldc + n) * 4) | oob;       // rows >= M fall outside the slab
+        bst32f(acc[m][blk][r], rC, off);
+      }
+    }
+}
+
 // ---- operand splitting ----------------------------------------------------------------------------------
 // hi/lo K-BLOCKED [Cp/32][Rp][32] from x [R, C]: element (r, c) at ((c/32)*Rp + r)*32 + c%32; columns C..Cp-1 are
 // written as zeros (Cp = C rounded up to 32); rows R..Rp-1 are never written (the caller allocates them as zeros)
@@ -425,9 +549,22 @@ static int fwd_wn() { return env_int("FX_FWD_WN", 4) == 2 ? 2 : 4; }
 static int adam_wn() { return env_int("FX_ADAM_WN", 4) == 2 ? 2 : 4; }
 
 // split-K so that the grid fills the chip about once: 256 CUs x (3 workgroups of 256 threads | 2 of 512)
+// M > 128 takes fx_fwd_bf16x3_mt_kernel: MT M-tiles per workgroup, one workgroup (64 KB LDS, ~190 VGPRs) per CU
+static int fwd_mt(int M) { return M > 2 * TM ? 3 : (M > TM ? 2 : 1); }
+
 static int pick_splitk_x(int M, int N, int K, int wn) {
   const int forced = env_int("FX_SPLITK", 0);
   if (forced > 0) return forced;
+  if (wn == 4 && M > TM && env_int("FX_FWD_MT", 1)) {
+    const int mt = fwd_mt(M);
+    const long tiles = (long)((M + mt * TM - 1) / (mt * TM)) * ((N + 127) / 128);
+    if (tiles >= 128 || K <= 8 * TK) return 1;
+    int s = (int)(256 / tiles);
+    const int maxs = (K + 8 * TK - 1) / (8 * TK);
+    if (s > maxs) s = maxs;
+    if (s > 64) s = 64;
+    return s < 1 ? 1 : s;
+  }
   const int tn = 32 * wn;
   const long tiles = (long)((M + TM - 1) / TM) * ((N + tn - 1) / tn);
   const long slots = wn == 2 ? 768 : 512;
@@ -528,7 +665,13 @@ static int fwd_bf16x3_impl(float* Y, const void* xhi, const void* xlo, const flo
   const long nblk = (long)((M + TM - 1) / TM) * ((N + tn - 1) / tn) * s;
   FX_REQUIRE(nblk < (1L << 31), "fx_linear_fwd_bf16x3: grid too large");
   const int nt = env_int("FX_NT_FWD", 0);
-  if (kn) {
+  if (!kn && wn == 4 && M > TM && env_int("FX_FWD_MT", 1)) {
+    const int mt = fwd_mt(M);
+    const long nb = (long)((M + mt * TM - 1) / (mt * TM)) * ((N + 127) / 128) * s;
+    FX_REQUIRE(nb < (1L << 31), "fx_linear_fwd_bf16x3: grid too large");
+    if (mt == 3) hipLaunchKernelGGL((fx_fwd_bf16x3_mt_kernel<3>), dim3((unsigned)nb), dim3(512), 0, stream, g);
+    else hipLaunchKernelGGL((fx_fwd_bf16x3_mt_kernel<2>), dim3((unsigned)nb), dim3(512), 0, stream, g);
+  } else if (kn) {
     hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<true, XEPI_STORE, 0, 4, true>), dim3((unsigned)nblk), dim3(512), 0, stream, g);
   } else if (wn == 4) {
     if (nt) hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<true, XEPI_STORE, 2, 4>), dim3((unsigned)nblk), dim3(512), 0, stream, g);
