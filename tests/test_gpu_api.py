@@ -355,3 +355,41 @@ def test_fit_keeps_partial_batch_and_fine_tune_runs():
     assert set(results[0]) == {"learning_rate", "average_val_loss", "freeze", "epochs"}
     assert final is not m and set(final.state_dict()) == set(m.state_dict())
     assert set(final.predict(ds)) == {"y", "c"}
+
+
+def test_pipelined_graph_replay_is_bit_reproducible():
+    """Race detector for the branch-parallel, double-buffered hipGraphs: two runs from the same state, tables and
+    seeds give bit-identical parameters, moments and losses (scripts/soak_determinism.py does this at cfg2-4 scale)."""
+    from flexynesis_amd.arch import ArchSpec
+    from flexynesis_amd.data import synthetic_cohort
+    from flexynesis_amd.engine import ParamStore, PipelinedStep
+    dev = torch.device("cuda:0")
+    layers = [("gex", 2600), ("cnv", 2100), ("meth", 1500)]
+    spec = ArchSpec("supervised_vae", layers, 32, 0.5, 16, [("c", "categorical", 4), ("event", "numerical", 1)], "event", "time", True)
+    cohort = synthetic_cohort(layers, 500, dev, seed=1)
+    torch.manual_seed(0)
+    init = ParamStore(spec, dev, materialize_big_grads=False).state_dict()
+
+    def run():
+        store = ParamStore(spec, dev, materialize_big_grads=False)
+        store.load_state(init)
+        pipe = PipelinedStep(store, 64, cohort=cohort, n_batches=5, seed=3)
+        g = torch.Generator(device=dev)
+        g.manual_seed(7)
+        pipe.idx.copy_(torch.randint(0, 500, (5 * 64,), generator=g, device=dev))
+        pipe.prime()
+        pipe.step(1e-3)
+        pipe.capture(1e-3)
+        curve = []
+        for _ in range(40):
+            if pipe.epoch_end_next():
+                pipe.idx.copy_(torch.randint(0, 500, (5 * 64,), generator=g, device=dev))
+            pipe.replay()
+            curve.append(pipe.last.loss_vec.clone())
+        return torch.stack(curve).cpu(), store.state_dict()
+
+    c1, s1 = run()
+    c2, s2 = run()
+    assert torch.isfinite(c1).all() and torch.equal(c1, c2)
+    for k in s1:
+        assert torch.equal(s1[k], s2[k]), k
