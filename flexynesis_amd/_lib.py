@@ -40,6 +40,8 @@ PROTOTYPES = {
     "fx_gram_hadamard_blocks": (I, [L]),
     "fx_gram_hadamard": (I, [P, P, I, P, I, L, P]),
     "fx_gather_split": (I, [P, P, P, P, P, P, P, I, I, L, L, L, L, P, L, P]),
+    "fx_block_bwd_blocks": (I, [I]),
+    "fx_block_bwd": (I, [P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, P, P, P, L, P, P, I, I, L, L, I, I, F, P]),
     "fx_heads_fwd": (I, [P, I, P, L, I, I, I, F, P, P]),
     "fx_heads_bwd": (I, [P, I, P, L, P, L, I, I, I, F, P]),
     "fx_split_bf16": (I, [P, P, P, I, I, L, L, P]),
@@ -73,7 +75,7 @@ PROTOTYPES = {
 }
 
 # functions whose int return value is a size/count, not an error code
-_QUERIES = {"fx_version", "fx_gemm_splitk", "fx_linear_fwd_bf16x3_splitk", "fx_gram_hadamard_blocks", "fx_gemm_workspace_bytes", "fx_linear_fwd_bf16x3_workspace_bytes", "fx_mmd_workspace_floats", "fx_recon_blocks", "fx_sumsq_blocks",
+_QUERIES = {"fx_version", "fx_block_bwd_blocks", "fx_gemm_splitk", "fx_linear_fwd_bf16x3_splitk", "fx_gram_hadamard_blocks", "fx_gemm_workspace_bytes", "fx_linear_fwd_bf16x3_workspace_bytes", "fx_mmd_workspace_floats", "fx_recon_blocks", "fx_sumsq_blocks",
             "fx_last_error_string"}
 
 

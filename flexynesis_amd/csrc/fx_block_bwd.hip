@@ -1,0 +1,311 @@
+// fx_block_bwd.hip -- the whole backward of an encoder's "wide Linear -> BatchNorm block -> small Linear(s)" tail in
+// ONE launch.
+//
+// Reference autograd ops replaced (per modality): mm (dX of the small Linears following the block), the BatchNorm /
+// ReLU / Dropout (or LeakyReLU) backward, mm + sum (weight and bias gradients of the small Linears), and -- for the
+// engine's fused optimiser -- the pieces the wide layer's dW+clip+Adam kernel needs: the transposed split-bf16 dY
+// operand and this layer's contribution to the global gradient norm.  These were 7 dependent launches of 5-17 us per
+// modality on the critical path between the loss and the clip coefficient (MLP encoder, modules.py:145-149:
+// layer_out <- Dropout <- ReLU <- BatchNorm <- layer_1; VAE encoder, modules.py:25-41,47-56: FC_mean, FC_var <-
+// BatchNorm <- LeakyReLU <- hidden Linear).
+//
+// One workgroup owns 32 columns of the block (all B <= 128 rows): everything is column-local except the norm, whose
+// contribution ||dY_blk^T X||_F^2 = <dY_blk dY_blk^T, X X^T> is one double per workgroup (summed by
+// fx_clip_finalize in a fixed order).  Thread (cx = column, ry = row group) keeps its 8 rows of x, the block output
+// and the gradient in registers; the small operands (dE [B, L], 32-column tiles) go through LDS.  512 threads: the
+// phases are LDS-latency bound, and with 157 workgroups on 256 CUs the only latency hiding is inside the workgroup
+// (256 threads: 42 us, phase ablation in scripts/bench_block_bwd.py).
+#include "fx_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define BB_COLS 32
+#define BB_RG 16
+#define BB_RPT 8
+#define BB_T 512
+#define BB_MAXL 64
+#define BB_ACT_NONE 0
+#define BB_ACT_LEAKY 1
+#define BB_ACT_RELU 2
+#define BB_LEAKY 0.2f
+
+struct BlockBwdArgs {
+  // up to two small Linears fed by the block output: dE_k [B, L_k] (upstream gradient), W_k [L_k, C]
+  const float* dE[2]; long ldE[2]; const float* W[2]; float* gW[2]; float* gb[2]; int L[2]; int n_up;
+  const float* x;          // [B, C] saved wide-Linear output (block input)
+  const float* out;        // [B, C] saved block output (input of the small Linears; ReLU/dropout gate)
+  const float* gamma; const float* save_mean; const float* save_invstd;
+  float* dgamma; float* dbeta; float* dbias;
+  float* dy;               // optional [B, C] fp32 gradient at the wide Linear's output
+  __bf16* dyT_hi; __bf16* dyT_lo; long ldt;     // optional transposed split [C, ldt] (ldt >= round32(B), zero padded)
+  const float* gram_x;     // optional [B, B] = X X^T: then slots[blockIdx] = this block's share of ||dW_wide||_F^2
+  double* slots;
+  int B, C; long ldx, ldo;
+  int pre_act, post_act; float drop_p;
+};
+
+__device__ __forceinline__ float bb_colsum(float v, float (*red)[BB_COLS], int cx, int ry) {
+  __syncthreads();
+  red[ry][cx] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < BB_RG; ++i) s += red[i][cx];
+  return s;
+}
+
+// One upstream Linear (dE [B, L], W [L, C]): da[16] += dE . W for this thread's rows/column, gW = dE^T . out, gb = colsum(dE).
+// Plain pointer arguments: indexing the kernel-argument arrays with a runtime k put the whole struct in scratch.
+__device__ __forceinline__ void bb_upstream(const float* __restrict__ dE, long ldE, const float* __restrict__ W,
+                                            float* __restrict__ gW, float* __restrict__ gb, int L, int B, int C, int c0, int cc,
+                                            int r0, float* dEs, float (*T)[132], float (*Ws)[BB_COLS], float da[BB_RPT]) {
+  const int t = threadIdx.x;
+  // the upstream width L (latent size: any integer) is processed in chunks of 64 rows of W / columns of dE
+  for (int lc0 = 0; lc0 < L; lc0 += BB_MAXL) {
+    const int Lc = min(BB_MAXL, L - lc0);
+    // W chunk [64][32 columns] -> LDS (a register array indexed by l would need the l loop fully unrolled: 1024 FMAs
+    // with 256 live LDS vectors -> 3.4 KB of scratch per thread in the first version)
+    float wv[4];
+    {
+      const int wl = t >> 5;                       // 16 rows per pass, 4 passes
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wv[j] = W[(long)(lc0 + min(wl + 16 * j, Lc - 1)) * C + cc];
+    }
+    __syncthreads();                               // previous users of dEs / first use of T
+    {   // stage dE_k[:, lc0 : lc0+64] row-major [128][64], zero padded: thread = (row t>>4 + 32 j, 4 columns)
+      const int lq = 4 * (t & 15), rb = t >> 4;
+      float v[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = min(rb + 32 * j, B - 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[j][q] = dE[(long)r * ldE + lc0 + min(lq + q, Lc - 1)];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = rb + 32 * j;
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = (r < B && lq + q < Lc) ? v[j][q] : 0.f;
+        *reinterpret_cast<f32x4*>(&dEs[r * BB_MAXL + lq]) = o;
+      }
+    }
+    {
+      const int wl = t >> 5, cxx = t & 31;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Ws[wl + 16 * j][cxx] = (wl + 16 * j < Lc) ? wv[j] : 0.f;
+    }
+    __syncthreads();
+    // da[i] += sum_l dE[r0+i][l] * W[l][c]
+    {
+      const int cxx = t & 31;
+#pragma unroll 4
+      for (int l4 = 0; l4 < BB_MAXL; l4 += 4) {
+        const float w0 = Ws[l4][cxx], w1 = Ws[l4 + 1][cxx], w2 = Ws[l4 + 2][cxx], w3 = Ws[l4 + 3][cxx];
+#pragma unroll
+        for (int i = 0; i < BB_RPT; ++i) {
+          const f32x4 d = *reinterpret_cast<const f32x4*>(&dEs[(r0 + i) * BB_MAXL + l4]);
+          da[i] = fmaf(d[0], w0, da[i]);
+          da[i] = fmaf(d[1], w1, da[i]);
+          da[i] = fmaf(d[2], w2, da[i]);
+          da[i] = fmaf(d[3], w3, da[i]);
+        }
+      }
+    }
+    // gW_k[lc0 + l][c0 + c'] = sum_r dE[r][l] * out[r][c']: thread (l = t & 63, columns cg*4 .. cg*4+3)
+    {
+      const int l = t & 63, cg = t >> 6;
+      float g[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] = 0.f;
+#pragma unroll 4
+      for (int r = 0; r < 128; r += 4) {
+        const float d0 = dEs[r * BB_MAXL + l], d1 = dEs[(r + 1) * BB_MAXL + l], d2 = dEs[(r + 2) * BB_MAXL + l],
+                    d3 = dEs[(r + 3) * BB_MAXL + l];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(&T[cg * 4 + j][r]);
+          g[j] = fmaf(d0, av[0], g[j]);
+          g[j] = fmaf(d1, av[1], g[j]);
+          g[j] = fmaf(d2, av[2], g[j]);
+          g[j] = fmaf(d3, av[3], g[j]);
+        }
+      }
+      if (l < Lc) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (c0 + cg * 4 + j < C) gW[(long)(lc0 + l) * C + c0 + cg * 4 + j] = g[j];
+      }
+      if (gb && blockIdx.x == 0 && t < Lc) {   // bias gradient = column sums of dE_k
+        float sg = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < 128; ++r) sg += dEs[r * BB_MAXL + t];
+        gb[lc0 + t] = sg;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(BB_T) void fx_block_bwd_kernel(BlockBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float dEs[128 * BB_MAXL];      // [r][L] upstream gradient (rows >= B zero)
+  __shared__ __attribute__((aligned(16))) float T[BB_COLS][132];         // [c][r]: block output, later dy
+  __shared__ float Ws[BB_MAXL][BB_COLS];                                  // one 64-row chunk of an upstream weight
+  __shared__ float red[BB_RG][BB_COLS];
+  __shared__ double dred[BB_T / 64];
+  const int t = threadIdx.x, cx = t & 31, ry = t >> 5;
+  const int c0 = blockIdx.x * BB_COLS, c = c0 + cx, B = a.B;
+  const int cc = min(c, a.C - 1);                    // clamped column: loads are unconditional, stores predicated
+  const bool cok = c < a.C;
+  const int r0 = ry * BB_RPT;
+  // ---- this thread's 16 rows of x and of the block output
+  float xv[BB_RPT], ov[BB_RPT];
+#pragma unroll
+  for (int i = 0; i < BB_RPT; ++i) {
+    const int r = min(r0 + i, B - 1);
+    xv[i] = a.x[(long)r * a.ldx + cc];
+    ov[i] = a.out[(long)r * a.ldo + cc];
+  }
+  const float mean = a.save_mean[cc], invstd = a.save_invstd[cc], gm = a.gamma[cc];
+#pragma unroll
+  for (int i = 0; i < BB_RPT; ++i) {
+    const bool rok = r0 + i < B;
+    ov[i] = (rok && cok) ? ov[i] : 0.f;
+    T[cx][r0 + i] = ov[i];
+  }
+  // ---- da = sum_k dE_k . W_k (this thread: 16 rows x its column), and the small Linears' weight/bias gradients
+  float da[BB_RPT];
+#pragma unroll
+  for (int i = 0; i < BB_RPT; ++i) da[i] = 0.f;
+  bb_upstream(a.dE[0], a.ldE[0], a.W[0], a.gW[0], a.gb[0], a.L[0], B, a.C, c0, cc, r0, dEs, T, Ws, da);
+  if (a.n_up > 1) bb_upstream(a.dE[1], a.ldE[1], a.W[1], a.gW[1], a.gb[1], a.L[1], B, a.C, c0, cc, r0, dEs, T, Ws, da);
+  // ---- gate (ReLU + dropout in one test on the saved output) and BatchNorm backward (fx_bn_bwd_kernel's expressions)
+  const float gate_scale = 1.0f / (1.0f - a.drop_p);
+  float s1 = 0.f, s2 = 0.f;
+  float xh[BB_RPT];
+#pragma unroll
+  for (int i = 0; i < BB_RPT; ++i) {
+    const bool rok = r0 + i < B;
+    float d = da[i];
+    if (a.post_act == BB_ACT_RELU) d = (ov[i] > 0.f) ? d * gate_scale : 0.f;
+    d = (rok && cok) ? d : 0.f;
+    const float xr = xv[i];
+    const float xa = (a.pre_act == BB_ACT_LEAKY) ? (xr > 0.f ? xr : xr * BB_LEAKY) : xr;
+    xh[i] = rok ? (xa - mean) * invstd : 0.f;
+    da[i] = d;
+    s1 += d;
+    s2 += d * xh[i];
+  }
+  const float sum_dy = bb_colsum(s1, red, cx, ry);
+  const float sum_dy_xh = bb_colsum(s2, red, cx, ry);
+  const float invB = 1.0f / (float)B;
+  float sb = 0.f;
+#pragma unroll
+  for (int i = 0; i < BB_RPT; ++i) {
+    const bool rok = r0 + i < B;
+    float d = gm * invstd * (da[i] - invB * sum_dy - xh[i] * invB * sum_dy_xh);
+    if (a.pre_act == BB_ACT_LEAKY) d = xv[i] > 0.f ? d : d * BB_LEAKY;
+    d = (rok && cok) ? d : 0.f;
+    da[i] = d;
+    sb += d;
+  }
+  const float sum_dx = bb_colsum(sb, red, cx, ry);     // (its barriers also order the last reads of T above)
+  if (cok && ry == 0) {
+    a.dgamma[c] = sum_dy_xh;
+    a.dbeta[c] = sum_dy;
+    if (a.dbias) a.dbias[c] = sum_dx;
+  }
+  if (a.dy && cok) {
+#pragma unroll
+    for (int i = 0; i < BB_RPT; ++i)
+      if (r0 + i < B) a.dy[(long)(r0 + i) * a.ldx + c] = da[i];
+  }
+  // ---- dy tile (transposed) for the operand split and the norm
+#pragma unroll
+  for (int i = 0; i < BB_RPT; ++i) T[cx][r0 + i] = da[i];
+  __syncthreads();
+  if (a.dyT_hi) {      // thread: column t >> 4, rows (t & 15) * 8 .. +8  -> one 16-byte store per array
+    const int col = t >> 4, rb = (t & 15) * 8;
+    if (c0 + col < a.C && rb < a.ldt) {
+      bf16x8 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = T[col][rb + j];
+        hi[j] = (__bf16)v;
+        lo[j] = (__bf16)(v - (float)hi[j]);
+      }
+      *reinterpret_cast<bf16x8*>(a.dyT_hi + (long)(c0 + col) * a.ldt + rb) = hi;
+      *reinterpret_cast<bf16x8*>(a.dyT_lo + (long)(c0 + col) * a.ldt + rb) = lo;
+    }
+  }
+  if (a.gram_x) {      // <dY_blk dY_blk^T, X X^T>: thread owns the 4 x 8 block (i0.., j0..) of the B x B product
+    const int i0 = (t >> 4) * 4, j0 = (t & 15) * 8;
+    float p[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) p[i][j] = 0.f;
+#pragma unroll 4
+    for (int col = 0; col < BB_COLS; ++col) {
+      const f32x4 vi = *reinterpret_cast<const f32x4*>(&T[col][i0]);
+      const f32x4 vj0 = *reinterpret_cast<const f32x4*>(&T[col][j0]), vj1 = *reinterpret_cast<const f32x4*>(&T[col][j0 + 4]);
+      const float vj[8] = {vj0[0], vj0[1], vj0[2], vj0[3], vj1[0], vj1[1], vj1[2], vj1[3]};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p[i][j] = fmaf(vi[i], vj[j], p[i][j]);
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i0 + i < B) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j0 + j < B) acc += (double)p[i][j] * (double)a.gram_x[(long)(i0 + i) * B + j0 + j];
+      }
+    }
+    acc = fx_wave_sum_d(acc);
+    if ((t & 63) == 0) dred[t >> 6] = acc;
+    __syncthreads();
+    if (t == 0) {
+      double tot = 0.0;
+#pragma unroll
+      for (int i = 0; i < BB_T / 64; ++i) tot += dred[i];
+      a.slots[blockIdx.x] = tot;
+    }
+  }
+}
+
+extern "C" {
+
+int fx_block_bwd_blocks(int C) { return (C + BB_COLS - 1) / BB_COLS; }
+
+// see include/fxhip.h
+int fx_block_bwd(const float* const* dE, const long* ldE, const float* const* W, float* const* gW, float* const* gb,
+                 const int* L, int n_up, const float* x, const float* out, const float* gamma, const float* save_mean,
+                 const float* save_invstd, float* dgamma, float* dbeta, float* dbias, float* dy, void* dyT_hi, void* dyT_lo,
+                 long ldt, const float* gram_x, double* slots, int B, int C, long ldx, long ldo, int pre_act, int post_act,
+                 float drop_p, hipStream_t stream) {
+  FX_REQUIRE(dE && ldE && W && gW && gb && L && n_up >= 1 && n_up <= 2, "fx_block_bwd: 1 or 2 upstream Linears");
+  FX_REQUIRE(x && out && gamma && save_mean && save_invstd && dgamma && dbeta, "fx_block_bwd: null pointer");
+  FX_REQUIRE(B > 1 && B <= 128 && C > 0, "fx_block_bwd: B=%d must be in 2..128", B);
+  FX_REQUIRE(!dyT_hi || (dyT_lo && ldt % 8 == 0 && ldt >= (B + 31) / 32 * 32 && ldt <= 128),
+             "fx_block_bwd: dyT needs hi and lo, ld %% 8 == 0, round32(B) <= ld <= 128 (got %ld)", ldt);
+  FX_REQUIRE(!gram_x || slots, "fx_block_bwd: gram_x needs the norm slots");
+  BlockBwdArgs a{};
+  for (int k = 0; k < n_up; ++k) {
+    FX_REQUIRE(dE[k] && W[k] && gW[k] && L[k] > 0 && ldE[k] >= L[k], "fx_block_bwd: upstream %d: bad L=%d / ld=%ld", k, L[k],
+               ldE[k]);
+    a.dE[k] = dE[k]; a.ldE[k] = ldE[k]; a.W[k] = W[k]; a.gW[k] = gW[k]; a.gb[k] = gb[k]; a.L[k] = L[k];
+  }
+  a.n_up = n_up;
+  a.x = x; a.out = out; a.gamma = gamma; a.save_mean = save_mean; a.save_invstd = save_invstd;
+  a.dgamma = dgamma; a.dbeta = dbeta; a.dbias = dbias; a.dy = dy;
+  a.dyT_hi = (__bf16*)dyT_hi; a.dyT_lo = (__bf16*)dyT_lo; a.ldt = ldt;
+  a.gram_x = gram_x; a.slots = slots;
+  a.B = B; a.C = C; a.ldx = ldx; a.ldo = ldo; a.pre_act = pre_act; a.post_act = post_act; a.drop_p = drop_p;
+  hipLaunchKernelGGL(fx_block_bwd_kernel, dim3(fx_block_bwd_blocks(C)), dim3(BB_T), 0, stream, a);
+  return fx_check_launch("fx_block_bwd");
+}
+
+}  // extern "C"

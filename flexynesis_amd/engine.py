@@ -223,6 +223,8 @@ class StepPlan:
         self._branch = 0
         self.branches = bool(branches) and os.environ.get("FX_BRANCHES", "1") != "0"   # per-modality chains as parallel hipGraph branches
         self.bn_slabs = False                   # fold the wide layer's split-K reduce into BatchNorm (measured: no gain)
+        # whole encoder-tail backward in one launch (fx_block_bwd); FX_BLOCK_BWD=0 is an A/B switch for benchmarks
+        self.block_bwd = os.environ.get("FX_BLOCK_BWD", "1") != "0"
         # all supervisor heads in one launch each way (fx_heads_fwd/bwd); FX_FUSE_HEADS=0 is an A/B switch for benchmarks
         self.fuse_heads = bool(fuse_heads) and os.environ.get("FX_FUSE_HEADS", "1") != "0"
         self._gram_x: Dict[int, tuple] = {}
@@ -313,6 +315,12 @@ class StepPlan:
         st, H = self.store, self.store.shapes[prefix + ".layer_1.weight"][0]
         y1, a1 = self.buf[prefix + "/y1"], self.buf[prefix + "/a1"]
         sm, si = self.buf[prefix + "/save_mean"], self.buf[prefix + "/save_invstd"]
+        if dx is None and self._block_ok(rows, passes) and not self._is_frozen(prefix + ".layer_out.weight"):
+            bias_key = prefix + ".layer_out.bias"
+            self._tail_bwd(rec, [(dout, prefix + ".layer_out.weight", bias_key if bias_key in st.shapes else None)], x, y1, a1,
+                           (prefix + ".batchnorm", prefix), prefix + ".layer_1.bias", prefix + ".layer_1.weight",
+                           ACT_NONE, ACT_RELU, DROPOUT_P)
+            return
         da1 = self._new(prefix + "/da1", rows, H)           # also holds dy1 (BN backward runs in place)
         self._weight_grad(rec, prefix + ".layer_out.weight", dout, a1)
         if prefix + ".layer_out.bias" in st.shapes:
@@ -369,8 +377,7 @@ class StepPlan:
                 sp = ops.new_split_kb(x.shape[0], x.shape[1], self.dev)
                 self._split_cache[("fwd", x.data_ptr())] = sp
                 ops.split_bf16(rec, sp[0], sp[1], x)
-            if self.fused and self.train and self.clip and not self._is_frozen(wkey):
-                self._gram_x_for(rec, x)
+            self._want_gram(rec, x, wkey, x.shape[0], self.passes if x.shape[0] == self.R else 1)
             # Stagger the HBM-bound wide kernels of the parallel modality branches: two of them side by side
             # take as long as back to back, but back to back lets modality i's narrow post-chain (reduce, BN,
             # layer_out) run underneath modality i+1's wide kernel instead of after both.
@@ -438,6 +445,62 @@ class StepPlan:
             self._jobs[key] = (dy, x, dyt, xt)
         else:
             ops.linear_bwd_w(rec, self.store.g(key), dy, x, self.ws)
+
+    def _block_ok(self, rows, passes) -> bool:
+        """fx_block_bwd covers one BatchNorm pass of at most 128 rows (everything but the triplet network's stacked passes)."""
+        return self.block_bwd and self.train and passes == 1 and rows <= 128
+
+    def _gram_full(self, rec, x):
+        """X X^T [R, R] (reduced): the batch-only factor of the Gram norm that fx_block_bwd consumes."""
+        gx = self._gram_x.get(("full", x.data_ptr()))
+        if gx is None:
+            R = x.shape[0]
+            gx = self._new(f"gram_x_full/{x.data_ptr()}", R, R)
+            ops.gemm(rec, ops.GEMM_NT, gx, x, x, None, self.ws)
+            self._gram_x[("full", x.data_ptr())] = gx
+        return gx
+
+    def _want_gram(self, rec, x, wkey, rows, passes):
+        """Emit the batch-only Gram factor for wide weight ``wkey`` in the form its backward will consume."""
+        if not (self.fused and self.train and self.clip) or self._is_frozen(wkey) or wkey not in self.store.big:
+            return
+        if self._block_ok(rows, passes):
+            self._gram_full(rec, x)
+        else:
+            self._gram_x_for(rec, x)
+
+    def _tail_bwd(self, rec, ups, x_in, y, out, bn_prefix, bias_key, wkey, pre_act, post_act, drop_p):
+        """Encoder tail backward through fx_block_bwd, then hand the wide layer ``wkey`` to the optimiser.
+        ups = [(dE, weight key, bias key | None)]; y / out = saved wide-Linear output / block output."""
+        st = self.store
+        B, H = y.shape
+        big = self.fused and wkey in st.big and not self._is_frozen(wkey)
+        want_t = big and self.precision == "bf16x3"
+        dyT = ops.new_split(H, B, self.dev) if want_t else None
+        dy = None if want_t else self._new(f"dy/{wkey}", B, H)
+        gx = slots = None
+        if big and self.clip:
+            gx = self._gram_full(rec, x_in)
+            nb = ops.block_bwd_blocks(H)
+            slots = self.slots[self._slot_o:self._slot_o + nb]
+            self._slot_o += nb
+        sm, si = self.buf[bn_prefix[1] + "/save_mean"], self.buf[bn_prefix[1] + "/save_invstd"]
+        bp = bn_prefix[0]
+        ops.block_bwd(rec, [(dE, st.p(wk), st.g(wk), st.g(bk) if bk else None) for (dE, wk, bk) in ups], y, out,
+                      st.p(bp + ".weight"), sm[0], si[0], st.g(bp + ".weight"), st.g(bp + ".bias"), st.g(bias_key),
+                      pre_act, post_act, drop_p, dy=dy, dyT=dyT, gram_x=gx, slots=slots)
+        if big:
+            xt = None
+            if want_t:
+                self.buf[f"dyT/{wkey}"], self.buf[f"dyT_lo/{wkey}"] = dyT
+                xt = self._split_cache.get(("T", x_in.data_ptr()))
+                if xt is None:
+                    xt = ops.new_split(x_in.shape[1], x_in.shape[0], self.dev)
+                    self._split_cache[("T", x_in.data_ptr())] = xt
+                    ops.split_bf16_t(rec, xt[0], xt[1], x_in)
+            self._jobs[wkey] = (dy, x_in, dyT, xt)
+        elif not self._is_frozen(wkey):
+            ops.linear_bwd_w(rec, st.g(wkey), dy, x_in, self.ws)
 
     def _gram_x_for(self, rec, x):
         """X X^T split-K slabs (depends on the batch only): emitted once per operand, in whatever branch asks
@@ -552,8 +615,12 @@ class StepPlan:
                                      n_rows=self.R)
                 else:
                     ops.gather_rows(rg, self.X[i], self.cohort.dat[name], self.idx, cur, self.R)
-                if self.fused and self.clip and wk in self.store.big and not self._is_frozen(wk):
-                    self._gram_x_for(rg, self.X[i])      # batch-only half of the Gram norm: part of batch assembly
+                if wk is not None:
+                    self._branch = i if self.branches else 0
+                    while len(self._ws) <= self._branch:
+                        self._ws.append(Workspace(self.dev))
+                    self._want_gram(rg, self.X[i], wk, self.R, self.passes)   # batch-only half of the Gram norm: part of batch assembly
+                    self._branch = 0
             gpar.branch(0)
             for k, t in self.y.items():      # labels of the anchors = first B indices of each batch row block
                 ops.gather_rows(rg, t, self.cohort.ann[k], self.idx, cur, self.R)
@@ -714,6 +781,11 @@ class StepPlan:
         for i in range(n):
             p = f"encoders.{i}"
             dm, dv = dmcat[:, i * L:(i + 1) * L], dvcat[:, i * L:(i + 1) * L]
+            if self._block_ok(B, 1):
+                self._tail_bwd(rb, [(dm, p + ".FC_mean.weight", p + ".FC_mean.bias"), (dv, p + ".FC_var.weight", p + ".FC_var.bias")],
+                               self.X[enc[i]], self.buf[p + "/y"], hs[i], (p + ".hidden_layers.2", p), p + ".hidden_layers.0.bias",
+                               p + ".hidden_layers.0.weight", ACT_LEAKY, ACT_NONE, 0.0)
+                continue
             dh = self._new(p + "/dh", B, st.shapes[p + ".hidden_layers.0.weight"][0])
             self._weight_grad(rb, p + ".FC_mean.weight", dm, hs[i])
             ops.colsum(rb, st.g(p + ".FC_mean.bias"), dm)
@@ -763,7 +835,10 @@ class StepPlan:
         st = self.store
         n = ops.sumsq_blocks(st.n_small)
         for k in st.big_keys:
-            n += ops.gram_hadamard_blocks(self.R * self.R) if self.fused else ops.sumsq_blocks(st.big[k]["W"].numel())
+            if self.fused:       # Gram-hadamard blocks, or one slot per 32 columns when fx_block_bwd produces the norm share
+                n += max(ops.gram_hadamard_blocks(self.R * self.R), ops.block_bwd_blocks(st.big[k]["W"].shape[0]))
+            else:
+                n += ops.sumsq_blocks(st.big[k]["W"].numel())
         self.slots = torch.zeros(n, dtype=torch.float64, device=self.dev)
 
     # ---- execution ----------------------------------------------------------------------------------

@@ -412,6 +412,35 @@ def gather_split(rec, x, hi, lo, hiT, loT, src, idx, ctrl_cursor=None, cursor_st
              int(cursor_stride))
 
 
+def block_bwd_blocks(C: int) -> int:
+    return int(lib.fx_block_bwd_blocks(int(C)))
+
+
+def block_bwd(rec, ups, x, out, gamma, save_mean, save_invstd, dgamma, dbeta, dbias, pre_act, post_act, drop_p,
+              dy=None, dyT=None, gram_x=None, slots=None):
+    """Backward of "wide Linear -> BatchNorm block -> small Linears" in one launch (include/fxhip.h: fx_block_bwd).
+    ``ups`` = [(dE [B, L], W [L, C], gW [L, C], gb [L] | None), ...] (1 or 2 entries)."""
+    _chk2d(x, "block_bwd.x")
+    _chk2d(out, "block_bwd.out")
+    B, Cc = x.shape
+    n = len(ups)
+    PA, LA, IA = C.c_void_p * n, C.c_long * n, C.c_int * n
+    for (dE, W, gW, gb) in ups:
+        _chk2d(dE, "block_bwd.dE")
+        _chk2d(W, "block_bwd.W")
+        if dE.shape[0] != B or W.shape != (dE.shape[1], Cc) or gW.shape != W.shape or not W.is_contiguous() or not gW.is_contiguous():
+            raise FxError("block_bwd: upstream shapes must be dE [B, L], W / gW [L, C] contiguous")
+    arrs = (PA(*[u[0].data_ptr() for u in ups]), LA(*[_ld(u[0]) for u in ups]), PA(*[u[1].data_ptr() for u in ups]),
+            PA(*[u[2].data_ptr() for u in ups]), PA(*[_ptr(u[3]) for u in ups]), IA(*[u[0].shape[1] for u in ups]))
+    if hasattr(rec, "keep"):
+        rec.keep(arrs)
+    rec.emit("fx_block_bwd", *[C.addressof(a_) for a_ in arrs], n, x.data_ptr(), out.data_ptr(), gamma.data_ptr(),
+             save_mean.data_ptr(), save_invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dbias), _ptr(dy),
+             _ptr(dyT[0]) if dyT else None, _ptr(dyT[1]) if dyT else None, _ld(dyT[0]) if dyT else 0, _ptr(gram_x),
+             _ptr(slots), B, Cc, _ld(x), _ld(out), int(pre_act), int(post_act), float(drop_p))
+    return arrs
+
+
 HEADS_MAX = dict(B=128, L=128, hidden=32, n_out=32, heads=8)     # limits of fx_heads_fwd / fx_heads_bwd
 
 

@@ -140,6 +140,22 @@ int fx_heads_fwd(const fx_head_desc* heads, int n_heads, const float* x, long ld
 int fx_heads_bwd(const fx_head_desc* heads, int n_heads, const float* x, long ldx, float* dx, long lddx, int dx_accumulate,
                  int B, int L, float drop_p, fx_stream_t stream);
 
+/* ---- the whole backward of an encoder tail "wide Linear -> BatchNorm block -> 1 or 2 small Linears" in one launch
+ *      (MLP encoder, modules.py:145-149; VAE encoder, modules.py:25-41,47-56): autograd's mm for the small Linears'
+ *      data gradient, the BatchNorm(+ReLU+Dropout | LeakyReLU) backward, mm + sum for the small Linears' weight / bias
+ *      gradients, plus what the wide layer's fused optimiser kernel needs: dY as a transposed split-bf16 operand
+ *      (fx_split_bf16_t layout) and this layer's share of the squared gradient norm <dY dY^T, gram_x> with
+ *      gram_x = X X^T [B, B] (one double per workgroup into slots[0 .. fx_block_bwd_blocks(C))).
+ *      dE / ldE / W / gW / gb / L are HOST arrays of n_up (1 or 2) entries: upstream gradient [B, L_k], weight
+ *      [L_k, C], its gradient [L_k, C], bias gradient [L_k] or NULL.  Optional outputs may be NULL (dy, dyT_*, gram_x).
+ *      B <= 128. */
+int fx_block_bwd_blocks(int C);
+int fx_block_bwd(const float* const* dE, const long* ldE, const float* const* W, float* const* gW, float* const* gb,
+                 const int* L, int n_up, const float* x, const float* out, const float* gamma, const float* save_mean,
+                 const float* save_invstd, float* dgamma, float* dbeta, float* dbias, float* dy, void* dyT_hi, void* dyT_lo,
+                 long ldt, const float* gram_x, double* slots, int B, int C, long ldx, long ldo, int pre_act, int post_act,
+                 float drop_p, fx_stream_t stream);
+
 /* ---- BatchNorm1d (+LeakyReLU before | +ReLU+Dropout after), train & eval (modules.py:25-34,145-148) */
 int fx_bn_act_fwd(float* out, const float* x, const float* gamma, const float* beta, float* running_mean,
                   float* running_var, float* save_mean, float* save_invstd, const float* mask, float* mask_out, int B,

@@ -858,3 +858,56 @@ def test_free_running_training_curve_tracks_oracle(model):
     assert np.all(np.abs(got - ref) <= 2e-2 * np.abs(ref) + 1e-3), (np.abs(got - ref) / np.abs(ref)).max()
     assert abs(got[0] - ref[0]) <= 1e-4 * abs(ref[0])
     assert ref[-5:].mean() < 0.8 * ref[:5].mean() and got[-5:].mean() < 0.8 * got[:5].mean()
+
+
+@pytest.mark.parametrize("B,C,Ls,pre,post", [(128, 5000, (64,), 0, 2), (100, 700, (64, 64), 1, 0), (37, 95, (17,), 0, 2),
+                                              (128, 1250, (100, 33), 1, 0)])
+def test_block_bwd_vs_autograd_fp64(B, C, Ls, pre, post):
+    """fx_block_bwd (whole encoder-tail backward in one launch) against torch autograd in fp64: data gradient through
+    the small Linears, BatchNorm(+ReLU+dropout | LeakyReLU) backward, the small Linears' weight/bias gradients, the
+    transposed split-bf16 dY and the Gram share of the wide layer's gradient norm."""
+    from flexynesis_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(B + C)
+    x = torch.randn(B, C, generator=g, dtype=torch.float64)
+    gamma = torch.rand(C, generator=g, dtype=torch.float64) + 0.5
+    beta = torch.randn(C, generator=g, dtype=torch.float64) * 0.1
+    mask = (torch.rand(B, C, generator=g) < 0.9).double()
+    Ws = [torch.randn(L, C, generator=g, dtype=torch.float64) / C ** 0.5 for L in Ls]
+    dEs = [torch.randn(B, L, generator=g, dtype=torch.float64) for L in Ls]
+    X = torch.randn(B, 300, generator=g, dtype=torch.float64)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    Wr = [w.clone().requires_grad_(True) for w in Ws]
+    h = torch.where(xr > 0, xr, 0.2 * xr) if pre == 1 else xr
+    mean, var = h.mean(0), h.var(0, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    yb = (h - mean) * invstd * gr + br
+    out = torch.relu(yb) * (mask / 0.9) if post == 2 else yb
+    sum(((out @ w.t()) * d).sum() for w, d in zip(Wr, dEs)).backward()
+    f32 = lambda t: t.float().to(dev).contiguous()
+    xd, od = f32(x), f32(out.detach())
+    ups = [(f32(d), f32(w), torch.full(w.shape, float("nan"), device=dev), torch.full((w.shape[0],), float("nan"), device=dev))
+           for w, d in zip(Ws, dEs)]
+    dg, db, dbias = (torch.full((C,), float("nan"), device=dev) for _ in range(3))
+    dy = torch.full((B, C), float("nan"), device=dev)
+    dyT = ops.new_split(C, B, dev)
+    for t in dyT:
+        t.fill_(5.0)
+    gx = f32(X @ X.t())
+    nb = ops.block_bwd_blocks(C)
+    slots = torch.full((nb,), float("nan"), dtype=torch.float64, device=dev)
+    ops.block_bwd(ops.IMMEDIATE, ups, xd, od, f32(gamma), f32(mean.detach()), f32(invstd.detach()), dg, db, dbias, pre, post,
+                  0.1 if post == 2 else 0.0, dy=dy, dyT=dyT, gram_x=gx, slots=slots)
+    close(dy, xr.grad, 2e-4, 2e-5 * float(xr.grad.abs().max()), "dy")
+    close(dg, gr.grad, 2e-4, 2e-4 * float(gr.grad.abs().max()), "dgamma")
+    close(db, br.grad, 2e-4, 2e-4 * float(br.grad.abs().max()), "dbeta")
+    close(dbias, xr.grad.sum(0), 1e-3, 2e-4 * float(xr.grad.abs().max()) * B ** 0.5, "dbias")
+    for (d, w, gW, gb), wr in zip(ups, Wr):
+        close(gW, wr.grad, 2e-4, 2e-5 * float(wr.grad.abs().max()), "gW")
+        close(gb, d.double().sum(0), 2e-4, 1e-5, "gb")
+    back = dyT[0].float() + dyT[1].float()                    # [C, pad32(B)] = dy^T, zero padded
+    close(back[:, :B].t(), dy, 1e-4, 2.0 ** -15 * float(dy.abs().max()), "dyT")
+    assert float(back[:, B:].abs().sum()) == 0.0
+    ref_norm2 = float(((xr.grad.t() @ X) ** 2).sum())
+    assert abs(float(slots.sum()) - ref_norm2) <= 2e-5 * ref_norm2, (float(slots.sum()), ref_norm2)
