@@ -891,7 +891,7 @@ class StepPlan:
         pass ``warmup=False`` when an eager step has already been run (fit() does: its first step is eager)."""
         torch.cuda.synchronize()
         if warmup:
-            s = torch.cuda.Stream()
+            s = ops.capture_stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
                 self._step_for_capture(lr, gather)
@@ -899,7 +899,7 @@ class StepPlan:
             torch.cuda.synchronize()
             self.bump_nbt()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, stream=ops.capture_stream()):
             self._step_for_capture(lr, gather)
         self.graph = g
         return g
@@ -951,7 +951,6 @@ class PipelinedStep:
         self.k = 0                       # plan holding the batch of the next step
         self.done = 0                    # steps issued since prime()
         self.graphs = [None, None]
-        self._pool: List[torch.cuda.Stream] = []
 
     def prime(self):
         """Assemble table row 0 into plan 0 and point the cursor one row ahead of the step counter."""
@@ -971,7 +970,7 @@ class PipelinedStep:
         ops.step_begin(ops.IMMEDIATE, self.store.ctrl, lr, self.n_batches)
         cur.t_fwd.run()
         main = torch.cuda.current_stream()
-        used = nxt.t_gather.fork_from(main, self._pool)   # fork: batch assembly of step t+1 ...
+        used = nxt.t_gather.fork_from(main)               # fork: batch assembly of step t+1 ...
         cur.t_bwd.run()                                   # ... overlaps the head / backward chain of step t
         for st in used:
             main.wait_stream(st)                          # join before the HBM-saturating dW+Adam launches
@@ -990,7 +989,7 @@ class PipelinedStep:
         torch.cuda.synchronize()
         for k in (0, 1):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, stream=ops.capture_stream()):
                 self._issue(k, lr)
             self.graphs[k] = g
 

@@ -44,6 +44,39 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+# ---- process-wide side-stream pool ---------------------------------------------------------------------------
+# torch hands out torch.cuda.Stream() objects round-robin from 32 pre-created HIP streams per device.  Creating fresh
+# Stream objects per tape / plan wraps that pool after a few model fits, and a "new" side stream then ALIASES another
+# live one -- including the graph-capture stream itself, which crashed hipGraph replay (4th fit() in one process).
+# All tapes therefore share one small set of streams that are checked to be pairwise distinct: group 0 = branches of a
+# tape segment, group 1 = the detached prefetch fork of PipelinedStep, group 2 = graph capture.
+_POOLS: dict = {}
+_GROUP = 8
+
+
+def side_streams(n: int, group: int = 0) -> List["torch.cuda.Stream"]:
+    dev = torch.cuda.current_device()
+    pool = _POOLS.setdefault(dev, [])
+    need = group * _GROUP + n
+    if n > _GROUP:
+        raise FxError(f"at most {_GROUP} parallel branches per tape segment (got {n})")
+    tries = 0
+    while len(pool) < need:
+        st = torch.cuda.Stream()
+        tries += 1
+        taken = {p.cuda_stream for p in pool} | {torch.cuda.current_stream().cuda_stream, torch.cuda.default_stream().cuda_stream}
+        if st.cuda_stream in taken:
+            if tries > 64:
+                raise FxError("could not obtain enough distinct HIP streams from torch's stream pool")
+            continue
+        pool.append(st)
+    return pool[group * _GROUP: group * _GROUP + n]
+
+
+def capture_stream() -> "torch.cuda.Stream":
+    return side_streams(1, group=2)[0]
+
+
 class ImmediateRecorder:
     """Launch each op immediately on the current stream."""
 
@@ -85,7 +118,6 @@ class TapeRecorder:
         self.segments: List[List[List[tuple]]] = [[[]]]
         self._cur = 0
         self.keepalive: List[object] = []
-        self._side: List[torch.cuda.Stream] = []
 
     @property
     def calls(self):
@@ -138,32 +170,29 @@ class TapeRecorder:
                 self._issue(live[0], hook)
                 continue
             main = torch.cuda.current_stream()
-            while len(self._side) < len(live) - 1:
-                self._side.append(torch.cuda.Stream())
-            for br, st in zip(live[1:], self._side):
+            side = side_streams(len(live) - 1, group=0)
+            for br, st in zip(live[1:], side):
                 st.wait_stream(main)          # fork point: recorded BEFORE any branch work is queued on main
             self._issue(live[0], hook)
-            for br, st in zip(live[1:], self._side):
+            for br, st in zip(live[1:], side):
                 with torch.cuda.stream(st):
                     self._issue(br, hook)
-            for st in self._side[:len(live) - 1]:
+            for st in side:
                 main.wait_stream(st)          # join
 
     def run(self):
         self._run(None)
 
-    def fork_from(self, main, pool: List["torch.cuda.Stream"]):
-        """Issue the whole tape off the critical path: every branch goes to its own stream of ``pool``, each
-        forked DIRECTLY from ``main``; returns the streams the caller must join (``main.wait_stream``).
+    def fork_from(self, main, pool=None):
+        """Issue the whole tape off the critical path: every branch goes to its own stream (group 1 of the shared
+        pool), each forked DIRECTLY from ``main``; returns the streams the caller must join (``main.wait_stream``).
         (A fork made from an already-forked stream -- i.e. ``run()`` under ``torch.cuda.stream(side)`` --
         crashes hipGraph capture in ROCm 7.2's hipStreamEndCapture, so nested forks are never generated.)"""
         live = [[br for br in seg if br] for seg in self.segments]
         live = [seg for seg in live if seg]
         if len(live) != 1:
             raise FxError("fork_from: only tapes with a single (parallel) segment can run as a detached fork")
-        while len(pool) < len(live[0]):
-            pool.append(torch.cuda.Stream())
-        used = pool[:len(live[0])]
+        used = side_streams(len(live[0]), group=1)
         for st in used:
             st.wait_stream(main)
         for br, st in zip(live[0], used):

@@ -393,3 +393,27 @@ def test_pipelined_graph_replay_is_bit_reproducible():
     assert torch.isfinite(c1).all() and torch.equal(c1, c2)
     for k in s1:
         assert torch.equal(s1[k], s2[k]), k
+
+
+@pytest.mark.parametrize("name,targets,frozen", [("MultiTripletNetwork", ["c", "y"], ("encoders.",)), ("MultiTripletNetwork", ["c", "y"], ("MLPs.",)),
+                                                 ("supervised_vae", ["c"], ("encoders.",)), ("supervised_vae", ["c"], ("MLPs.",))])
+def test_frozen_groups_fit_every_model_family(name, targets, frozen):
+    """FineTuner freeze configurations (reference main.py:530-539) on the triplet and VAE schedules: frozen groups stay
+    bit-identical, the rest trains, BatchNorm buffers of frozen blocks still move."""
+    import flexynesis_amd.models as M
+    from flexynesis_amd.fit import fit
+    ds = _synthetic_ds(n=260)
+    torch.manual_seed(3)
+    cfg = {"latent_dim": 16, "hidden_dim_factor": 0.25, "lr": 3e-3, "supervisor_hidden_dim": 8, "epochs": 2, "batch_size": 32}
+    m = getattr(M, name)(cfg, ds, targets, device_type="cuda")
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    res = fit(m, ds, list(range(200)), list(range(200, 260)), batch_size=32, epochs=2, lr=3e-3, seed=5, device="cuda",
+              clip=False, frozen=frozen, drop_last=False, fresh_optimizer=True)
+    assert np.isfinite(res.val_loss) and res.steps == 2 * 7
+    after = m.state_dict()
+    moved = [k for k in before if not torch.equal(before[k].to(after[k].device), after[k])]
+    for k in before:
+        if k.startswith(frozen) and not k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            assert k not in moved, k
+    assert any(k.startswith(frozen) and k.endswith("running_mean") for k in moved)
+    assert any(not k.startswith(frozen) and k.endswith(".weight") for k in moved)
