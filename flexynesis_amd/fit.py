@@ -304,13 +304,16 @@ def split_indices(n: int, val_size: float, seed: int):
 
 def run_trial(model_class, params: dict, dataset, target_variables, batch_variables=None, surv_event_var=None,
               surv_time_var=None, use_loss_weighting=True, val_size: float = 0.2, early_stop_patience: int = 10,
-              seed: int = 0, device=None, use_graph: bool = True):
+              seed: int = 0, device=None, use_graph: bool = True, **model_kwargs):
     """One HPO trial = reference ``objective(params)`` (main.py:228-333): split -> new model -> fit ->
     validate -> (val_loss, epochs, model).  A failed / non-finite trial reports +inf instead of raising so a
     sharded sweep never hangs on a bad configuration."""
     torch.manual_seed(int(seed))
-    model = model_class(params, dataset, target_variables, batch_variables, surv_event_var, surv_time_var,
-                        use_loss_weighting, device_type=str(device) if device is not None else None)
+    # keyword arguments, like the reference's model_args dict (main.py:230-261): CrossModalPred's positional order
+    # differs (input_layers / output_layers come before use_loss_weighting) and it takes them through **model_kwargs
+    model = model_class(config=params, dataset=dataset, target_variables=target_variables, batch_variables=batch_variables,
+                        surv_event_var=surv_event_var, surv_time_var=surv_time_var, use_loss_weighting=use_loss_weighting,
+                        device_type=str(device) if device is not None else None, **model_kwargs)
     n = len(dataset)
     if model.spec.model == "MultiTripletNetwork":
         lab = np.asarray(dataset.ann[model.main_var])

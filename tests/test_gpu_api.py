@@ -417,3 +417,14 @@ def test_frozen_groups_fit_every_model_family(name, targets, frozen):
             assert k not in moved, k
     assert any(k.startswith(frozen) and k.endswith("running_mean") for k in moved)
     assert any(not k.startswith(frozen) and k.endswith(".weight") for k in moved)
+
+
+def test_run_trial_crossmodal_takes_layer_lists():
+    import flexynesis_amd.models as M
+    from flexynesis_amd.fit import run_trial
+    ds = _synthetic_ds(n=200)
+    params = {"latent_dim": 16, "hidden_dim_factor": 0.3, "lr": 3e-3, "supervisor_hidden_dim": 8, "epochs": 3, "batch_size": 32}
+    val, epochs, model, info = run_trial(M.CrossModalPred, params, ds, ["y"], early_stop_patience=0, seed=2, device="cuda",
+                                         input_layers=["cnv"], output_layers=["gex"])
+    assert "error" not in info and np.isfinite(val) and epochs == 3
+    assert model.input_layers == ["cnv"] and model.output_layers == ["gex"] and len(model.encoders) == 1
