@@ -81,10 +81,17 @@ class ParamStore:
         self.nbt: Dict[str, int] = {k: 0 for k in self.nbt_keys}
         # wide weights
         self.big: Dict[str, Dict[str, Optional[torch.Tensor]]] = {}
+        # Rows are padded to a multiple of 32 floats: with an arbitrary feature count the rows of W / m / v start at
+        # arbitrary offsets inside a 128-byte line, every 512-byte row segment of the dW+Adam kernel then straddles a
+        # fifth line (reads) and partial lines (writes) -- the decoders' [20000, 5000] weights took 510-630 us per launch
+        # instead of ~430.  "W"/"M"/"V"/"G" are the [out, in] VIEWS (state_dict layout), "_W".. the padded buffers.
         for k in self.big_keys:
-            shp = self.shapes[k]
-            self.big[k] = {"W": torch.zeros(shp, **f), "M": torch.zeros(shp, **f), "V": torch.zeros(shp, **f),
-                           "G": torch.zeros(shp, **f) if materialize_big_grads else None}
+            self.big[k] = {}
+            for name in ("W", "M", "V"):
+                self._big_alloc(k, name)
+            self.big[k]["G"] = None
+            if materialize_big_grads:
+                self._big_alloc(k, "G")
         self.ctrl = torch.zeros(ops.CTRL_FLOATS, **f)
         self.ctrl[ops.CTRL_CLIP_COEF] = 1.0
         self.reset_parameters()
@@ -110,10 +117,16 @@ class ParamStore:
         o, n = self.boff[key]
         return self.Bf[o:o + n].view(self.shapes[key])
 
+    def _big_alloc(self, key, name):
+        out, fin = self.shapes[key]
+        buf = torch.zeros(out, (fin + 31) // 32 * 32, dtype=torch.float32, device=self.device)
+        self.big[key]["_" + name] = buf
+        self.big[key][name] = buf[:, :fin]
+
     def ensure_big_grads(self):
         for k, d in self.big.items():
             if d["G"] is None:
-                d["G"] = torch.zeros_like(d["W"])
+                self._big_alloc(k, "G")
 
     # -- init / (de)serialisation ------------------------------------------------------------------
     @torch.no_grad()
@@ -801,9 +814,9 @@ class StepPlan:
         o = self._slot_o
         if not self.fused:
             for k in st.big_keys:
-                g = st.big[k]["G"]
-                ops.sumsq(ro, self.slots[o:], g.view(-1))
-                o += ops.sumsq_blocks(g.numel())
+                gbuf = st.big[k]["_G"]
+                ops.sumsq(ro, self.slots[o:], gbuf.view(-1))      # padded buffer: the padding is zero
+                o += ops.sumsq_blocks(gbuf.numel())
         ops.sumsq(ro, self.slots[o:], st.G)
         o += ops.sumsq_blocks(st.n_small)
         assert o <= self.slots.numel(), (o, self.slots.numel())
@@ -827,7 +840,7 @@ class StepPlan:
                 dy, x, _, _ = self._jobs[k]
                 ops.linear_dw_adam(ro, d["W"], d["M"], d["V"], dy, x, st.ctrl)
             else:
-                ops.adam_flat(ro, d["W"].view(-1), d["G"].view(-1), d["M"].view(-1), d["V"].view(-1), st.ctrl)
+                ops.adam_flat(ro, d["_W"].view(-1), d["_G"].view(-1), d["_M"].view(-1), d["_V"].view(-1), st.ctrl)   # padding stays 0
 
     def _alloc_slots(self):
         """fp64 partial sums of the squared grad norm: Gram blocks per wide weight (fused) or Sum g^2 blocks of the
@@ -838,7 +851,7 @@ class StepPlan:
             if self.fused:       # Gram-hadamard blocks, or one slot per 32 columns when fx_block_bwd produces the norm share
                 n += max(ops.gram_hadamard_blocks(self.R * self.R), ops.block_bwd_blocks(st.big[k]["W"].shape[0]))
             else:
-                n += ops.sumsq_blocks(st.big[k]["W"].numel())
+                n += ops.sumsq_blocks(st.big[k]["_W"].numel())
         self.slots = torch.zeros(n, dtype=torch.float64, device=self.dev)
 
     # ---- execution ----------------------------------------------------------------------------------
