@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=0, help="CPU baseline steps (0 = auto, about 10-30 s)")
     ap.add_argument("--lr", type=float, default=1e-3)
+    ap.add_argument("--features", type=int, default=0, help="override the per-layer feature count (shape experiments; "
+                    "the headline metric is quoted on the default)")
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "f32"],
                     help="wide-layer contraction: split-bf16 MFMA with fp32 accumulate (default) or exact fp32 MFMA")
     return ap.parse_args()
@@ -99,7 +101,9 @@ def main():
     from flexynesis_amd.data import synthetic_cohort
     from flexynesis_amd.engine import ParamStore, PipelinedStep
 
-    cfg = CONFIGS[a.config]
+    cfg = dict(CONFIGS[a.config])
+    if a.features:
+        cfg["layers"] = [(n, a.features) for n, _ in cfg["layers"]]
     B = a.batch
     spec = ArchSpec(cfg["model"], cfg["layers"], 64, 0.25, 16, cfg["variables"], cfg["surv"][0], cfg["surv"][1], True)
     cohort = synthetic_cohort(cfg["layers"], cfg["n_samples"], dev, seed=1234 + rank)
