@@ -718,12 +718,17 @@ class StepPlan:
         rf, rb = self.t_fwd, self.t_bwd
         mcat, vcat = self._new("mcat", B, n * L), self._new("vcat", B, n * L)
         hs = []
-        for i in range(n):
-            p = f"encoders.{i}"
-            h = self._hidden_fwd(rf, p, self.X[enc[i]], B)
-            hs.append(h)
-            ops.linear_fwd(rf, mcat[:, i * L:(i + 1) * L], h, st.p(p + ".FC_mean.weight"), st.p(p + ".FC_mean.bias"), self.ws)
-            ops.linear_fwd(rf, vcat[:, i * L:(i + 1) * L], h, st.p(p + ".FC_var.weight"), st.p(p + ".FC_var.bias"), self.ws)
+        vae_par = self.branches and os.environ.get("FX_VAE_BRANCHES", "1") != "0"
+        with rf.parallel(n if vae_par else 1) as par:       # one graph branch per encoder (wide kernels staggered)
+            for i in range(n):
+                if vae_par:
+                    self._enter_branch(par, i)
+                p = f"encoders.{i}"
+                h = self._hidden_fwd(rf, p, self.X[enc[i]], B)
+                hs.append(h)
+                ops.linear_fwd(rf, mcat[:, i * L:(i + 1) * L], h, st.p(p + ".FC_mean.weight"), st.p(p + ".FC_mean.bias"), self.ws)
+                ops.linear_fwd(rf, vcat[:, i * L:(i + 1) * L], h, st.p(p + ".FC_var.weight"), st.p(p + ".FC_var.bias"), self.ws)
+        self._branch = 0
         mean, logv, z = self._new("mean", B, L), self._new("log_var", B, L), self._new("z", B, L)
         ops.linear_fwd(rf, mean, mcat, st.p("FC_mean.weight"), st.p("FC_mean.bias"), self.ws)
         ops.linear_fwd(rf, logv, vcat, st.p("FC_log_var.weight"), st.p("FC_log_var.bias"), self.ws)
@@ -740,14 +745,18 @@ class StepPlan:
         rec_part = self._new("recon_part", 1024)
         # dz must start from zero each step: the first head's data-grad GEMM overwrites it (accumulate=False),
         # so heads go FIRST in the backward tape and the MMD rows kernel (+=) is emitted after them.
-        for i in range(nd):
-            p = f"decoders.{i}"
-            F = spec.layers[dec[i]][1]
-            h = self._hidden_fwd(rf, p, z, B)
-            hd.append(h)
-            lg = self._new(p + "/logits", B, F)
-            logits.append(lg)
-            self._lin_fwd(rf, lg, h, p + ".FC_output.weight", p + ".FC_output.bias")
+        with rf.parallel(nd if vae_par else 1) as par:      # one graph branch per decoder
+            for i in range(nd):
+                if vae_par:
+                    self._enter_branch(par, i)
+                p = f"decoders.{i}"
+                F = spec.layers[dec[i]][1]
+                h = self._hidden_fwd(rf, p, z, B)
+                hd.append(h)
+                lg = self._new(p + "/logits", B, F)
+                logits.append(lg)
+                self._lin_fwd(rf, lg, h, p + ".FC_output.weight", p + ".FC_output.bias")
+        self._branch = 0
         self.xhat = [self._new(f"xhat.{i}", B, spec.layers[dec[i]][1]) for i in range(nd)] if not self.train else None
         priors = []
         for i in range(nd):
@@ -791,7 +800,13 @@ class StepPlan:
             return          # FineTuner "encoders": True -- the encoders need no gradient
         ops.linear_bwd_x(rb, dmcat, dz, st.p("FC_mean.weight"), self.ws)
         ops.linear_bwd_x(rb, dvcat, dlv, st.p("FC_log_var.weight"), self.ws)
+        enc_par = vae_par and self._block_ok(B, 1)
+        if enc_par:
+            _par_ctx = rb.parallel(n)
+            par = _par_ctx.__enter__()
         for i in range(n):
+            if enc_par:
+                self._enter_branch(par, i)
             p = f"encoders.{i}"
             dm, dv = dmcat[:, i * L:(i + 1) * L], dvcat[:, i * L:(i + 1) * L]
             if self._block_ok(B, 1):
@@ -807,6 +822,9 @@ class StepPlan:
             ops.linear_bwd_x(rb, dh, dm, st.p(p + ".FC_mean.weight"), self.ws)
             ops.linear_bwd_x(rb, dh, dv, st.p(p + ".FC_var.weight"), self.ws, accumulate=True)
             self._hidden_bwd(rb, p, self.X[enc[i]], dh)
+        if enc_par:
+            _par_ctx.__exit__(None, None, None)
+            self._branch = 0
 
     def _build_optimizer(self):
         """clip_grad_norm_(1.0) + Adam over every parameter (main.py:216-217, direct_pred.py:143)."""
