@@ -72,10 +72,16 @@ PROTOTYPES = {
     "fx_hadamard_sum": (I, [P, P, P, L, P]),
     "fx_clip_finalize": (I, [P, P, I, F, P]),
     "fx_adam_flat": (I, [P, P, P, P, L, P, P, P]),
+    "fx_col_moments_chunks": (I, [I, I]),
+    "fx_col_moments_workspace_bytes": (L, [I, I]),
+    "fx_col_moments": (I, [P, I, L, I, I, P, P, I, P, P, P, P, P]),
+    "fx_col_median": (I, [P, I, L, I, P, I, P, P]),
+    "fx_row_moments": (I, [P, I, L, I, P, I, P, P, P]),
+    "fx_ingest_transform": (I, [P, I, L, P, I, P, I, P, I, P, P, P, L, P]),
 }
 
 # functions whose int return value is a size/count, not an error code
-_QUERIES = {"fx_version", "fx_block_bwd_blocks", "fx_gemm_splitk", "fx_linear_fwd_bf16x3_splitk", "fx_gram_hadamard_blocks", "fx_gemm_workspace_bytes", "fx_linear_fwd_bf16x3_workspace_bytes", "fx_mmd_workspace_floats", "fx_recon_blocks", "fx_sumsq_blocks",
+_QUERIES = {"fx_version", "fx_col_moments_chunks", "fx_col_moments_workspace_bytes", "fx_block_bwd_blocks", "fx_gemm_splitk", "fx_linear_fwd_bf16x3_splitk", "fx_gram_hadamard_blocks", "fx_gemm_workspace_bytes", "fx_linear_fwd_bf16x3_workspace_bytes", "fx_mmd_workspace_floats", "fx_recon_blocks", "fx_sumsq_blocks",
             "fx_last_error_string"}
 
 

@@ -645,3 +645,76 @@ def mul(rec, y, a, b):
 
 def fill_normal(rec, y, seed, offset, ctrl=None):
     rec.emit("fx_fill_normal", y.data_ptr(), y.numel(), int(seed), int(offset), _ptr(ctrl))
+
+
+# ---- device-side ingest (csrc/fx_ingest.hip; reference data.py:360-452,519-545) -----------------------------------
+IN_F32, IN_F64 = 0, 1
+
+
+def _in_dtype(x: torch.Tensor, name: str) -> int:
+    if not x.is_cuda or x.dim() != 2 or x.stride(1) != 1 or x.dtype not in (torch.float32, torch.float64):
+        raise FxError(f"{name}: expected a row-major fp32/fp64 [n_samples, n_features] matrix on the GPU, got "
+                      f"{x.dtype} {tuple(x.shape)} on {x.device}")
+    return IN_F32 if x.dtype == torch.float32 else IN_F64
+
+
+def _i32(t: Optional[torch.Tensor], name: str):
+    if t is not None and not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
+        raise FxError(f"{name}: index lists are contiguous int32 tensors on the GPU")
+    return _ptr(t)
+
+
+def _f64(t: Optional[torch.Tensor], name: str):
+    if t is not None and not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
+        raise FxError(f"{name}: expected a contiguous fp64 tensor on the GPU")
+    return _ptr(t)
+
+
+def col_moments(rec, x, rows=None, med=None, log1p=False):
+    """Per-column (count int32, mean fp64, m2 fp64) over ``rows`` (None = all), NaN skipped, after imputation with
+    ``med`` and the optional log1p."""
+    dt = _in_dtype(x, "col_moments")
+    n_rows = int(rows.numel()) if rows is not None else x.shape[0]
+    F = x.shape[1]
+    dev = x.device
+    count = torch.empty(F, dtype=torch.int32, device=dev)
+    mean = torch.empty(F, dtype=torch.float64, device=dev)
+    m2 = torch.empty(F, dtype=torch.float64, device=dev)
+    ws = torch.empty(int(lib.fx_col_moments_workspace_bytes(n_rows, F)) // 8 + 1, dtype=torch.float64, device=dev)
+    rec.emit("fx_col_moments", x.data_ptr(), dt, x.stride(0), n_rows, F, _i32(rows, "col_moments"),
+             _f64(med, "col_moments"), int(bool(log1p)), count.data_ptr(), mean.data_ptr(), m2.data_ptr(), ws.data_ptr())
+    return count, mean, m2
+
+
+def col_median(rec, x, cols, med_out):
+    """med_out[c] = median of the non-NaN entries of column c for every c in ``cols`` (int32)."""
+    dt = _in_dtype(x, "col_median")
+    if med_out.numel() != x.shape[1]:
+        raise FxError("col_median: med_out is an n_features-long fp64 vector")
+    rec.emit("fx_col_median", x.data_ptr(), dt, x.stride(0), x.shape[0], _i32(cols, "col_median"), int(cols.numel()),
+             _f64(med_out, "col_median"))
+
+
+def row_moments(rec, x, cols, med=None):
+    """Per-sample ddof=1 variance (fp64) over the listed columns after imputation."""
+    dt = _in_dtype(x, "row_moments")
+    var = torch.empty(x.shape[0], dtype=torch.float64, device=x.device)
+    rec.emit("fx_row_moments", x.data_ptr(), dt, x.stride(0), x.shape[0], _i32(cols, "row_moments"), int(cols.numel()),
+             _f64(med, "row_moments"), var.data_ptr())
+    return var
+
+
+def ingest_transform(rec, x, out, rows=None, cols=None, med=None, log1p=False, mean=None, scale=None):
+    """out[i, j] = fp32((value(x[rows[i], cols[j]]) - mean[j]) / scale[j]) (see include/fxhip.h)."""
+    dt = _in_dtype(x, "ingest_transform")
+    _chk2d(out, "ingest_transform.out")
+    n_rows = int(rows.numel()) if rows is not None else x.shape[0]
+    n_cols = int(cols.numel()) if cols is not None else x.shape[1]
+    if tuple(out.shape) != (n_rows, n_cols):
+        raise FxError(f"ingest_transform: out is {tuple(out.shape)}, expected {(n_rows, n_cols)}")
+    for v in (mean, scale):
+        if v is not None and v.numel() != n_cols:
+            raise FxError("ingest_transform: mean / scale have one entry per output column")
+    rec.emit("fx_ingest_transform", x.data_ptr(), dt, x.stride(0), _i32(rows, "ingest_transform"), n_rows,
+             _i32(cols, "ingest_transform"), n_cols, _f64(med, "ingest_transform"), int(bool(log1p)),
+             _f64(mean, "ingest_transform"), _f64(scale, "ingest_transform"), out.data_ptr(), _ld(out))

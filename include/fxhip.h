@@ -206,6 +206,37 @@ int fx_adam_flat(float* p, const float* g, float* m, float* v, long n, const flo
                  const float* trainable /* optional 0/1 per element: 0 = requires_grad False, skipped (main.py:530-539,562-566) */,
                  fx_stream_t stream);
 
+/* ---- device-side ingest of a raw omics matrix.  x is the matrix as the reference's HDF5
+ *      importer reads it: contiguous [n_samples, n_features], samples as rows (h5_dataloader.py:88-116,
+ *      csv_to_h5.py:13-21); dtype FX_IN_F32 (HDF5 path) or FX_IN_F64 (what pd.read_csv yields).  The four stages are
+ *      the per-matrix arithmetic of DataImporter.cleanup_data / transform_data / normalize_data (data.py:360-452,
+ *      519-545); the F-length decisions in between (variance quantile, NaN fraction, harmonize) stay on the host.
+ *      "value" below = the entry after NaN -> med[column] (when med != NULL) and log1p (when log1p != 0).
+ *      fx_col_moments: per column over the listed rows (rows == NULL: all n_rows), skipping NaN: count, mean and the
+ *        sum of squared deviations m2 in fp64 (df.var(axis=1) = m2/(count-1), data.py:373; StandardScaler.fit =
+ *        m2/count, data.py:527).  ws: fx_col_moments_workspace_bytes(n_rows, F) bytes, 8-byte aligned.
+ *      fx_col_median: med_out[c] (an F-length vector indexed by column) = median of the non-NaN entries of each listed
+ *        column c over all N rows (data.py:413-415); an even count averages the two middle values, fp32 input rounds
+ *        the result to fp32 (the frame's dtype); an all-NaN column gives NaN.  Unlisted entries are left untouched.
+ *      fx_row_moments: per sample, the ddof=1 variance over the listed columns after imputation (df.std(axis=0)**2,
+ *        data.py:426).
+ *      fx_ingest_transform: out[i, j] = fp32((value(x[rows[i], cols[j]]) - mean[j]) / scale[j]); mean/scale NULL = no
+ *        scaling; rows / cols NULL = identity.  fp32 input rounds to fp32 after the subtraction as sklearn's in-place
+ *        float32 transform does; fp64 input rounds once at the end (data.py:533-540,549). */
+#define FX_IN_F32 0
+#define FX_IN_F64 1
+int fx_col_moments_chunks(int n_rows, int F);
+long fx_col_moments_workspace_bytes(int n_rows, int F);
+int fx_col_moments(const void* x, int dtype, long ldx, int n_rows, int F, const int* rows, const double* med, int log1p,
+                   int* count, double* mean, double* m2, void* ws, fx_stream_t stream);
+int fx_col_median(const void* x, int dtype, long ldx, int N, const int* cols, int n_cols, double* med_out,
+                  fx_stream_t stream);
+int fx_row_moments(const void* x, int dtype, long ldx, int N, const int* cols, int n_cols, const double* med,
+                   double* var_out, fx_stream_t stream);
+int fx_ingest_transform(const void* x, int dtype, long ldx, const int* rows, int n_rows, const int* cols, int n_cols,
+                        const double* med, int log1p, const double* mean, const double* scale, float* out, long ldo,
+                        fx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
