@@ -14,7 +14,6 @@
 #include "fx_common.h"
 
 #define ING_T 256        // threads per workgroup = columns per workgroup
-#define ING_PIVOT_ROWS 8 // rows scanned for the shift pivot
 
 namespace {
 
@@ -27,84 +26,117 @@ struct InMode<double> { static constexpr bool f32 = false; };
 
 // The value the reference's pipeline holds after NaN imputation and the optional log1p.  In fp32 mode the
 // DataFrame is float32 throughout (imputed median and np.log1p results are float32), in fp64 mode float64.
-template <typename T>
-__device__ __forceinline__ double ingest_value(T raw, const double* __restrict__ med, int c, int log1p_flag) {
+template <typename T, bool LOG>
+__device__ __forceinline__ double ingest_value(T raw, double medv) {
+  // medv = the column's imputation value, NaN when there is none (a NaN entry then stays NaN): branch-free select
   if (InMode<T>::f32) {
     float v = (float)raw;
-    if (med != nullptr && v != v) v = (float)med[c];
-    if (log1p_flag) v = (float)log1p((double)v);
+    v = (v != v) ? (float)medv : v;
+    if (LOG) v = (float)log1p((double)v);
     return (double)v;
   } else {
     double v = (double)raw;
-    if (med != nullptr && v != v) v = med[c];
-    if (log1p_flag) v = log1p(v);
+    v = (v != v) ? medv : v;
+    if (LOG) v = log1p(v);
     return v;
   }
 }
+__device__ __forceinline__ double ingest_med(const double* __restrict__ med, int c) {
+  return med ? med[c] : __builtin_nan("");
+}
 
 // ---- per-column moments ----------------------------------------------------------------------------------------
-// Shifted one-pass sums: d = value - K with K the column's first non-NaN value among the first rows, so that
-// q - s*s/n does not cancel (K is within a few standard deviations of the mean).  NaNs are skipped (pandas skipna,
-// sklearn nansum).  Each (column block, row chunk) workgroup writes its partial n/s/q; the merge adds the chunks
-// in index order.
-template <typename T>
-__global__ __launch_bounds__(ING_T) void fx_col_moments_kernel(const T* __restrict__ x, long ldx, int n_rows, int F,
-                                                               const int* __restrict__ rows,
-                                                               const double* __restrict__ med, int log1p_flag,
-                                                               int rows_per_chunk, int* __restrict__ pn,
-                                                               double* __restrict__ ps, double* __restrict__ pq,
-                                                               double* __restrict__ pivot) {
+// Shifted one-pass sums: d = value - K with K the column's first non-NaN value among the first rows (a tiny
+// pre-pass), so that q - s*s/n does not cancel (K is within a few standard deviations of the mean).  NaNs are
+// skipped (pandas skipna, sklearn nansum).  Each (column block, row chunk) workgroup writes its partial n/s/q; the
+// merge adds the chunks in index order, so the result is bit-reproducible.
+// Two adjacent columns per thread are read with one 8/16-byte load when F, ldx and the base address allow it.
+#define ING_PIVOT_ROWS 8
+template <typename T, bool LOG>
+__global__ __launch_bounds__(ING_T) void fx_col_pivot_kernel(const T* __restrict__ x, long ldx, int n_rows, int F,
+                                                             const int* __restrict__ rows,
+                                                             const double* __restrict__ med,
+                                                             double* __restrict__ pivot) {
   const int c = blockIdx.x * ING_T + threadIdx.x;
   if (c >= F) return;
+  const double mv = ingest_med(med, c);
+  const int np = n_rows < ING_PIVOT_ROWS ? n_rows : ING_PIVOT_ROWS;
   double K = 0.0;
-  {
-    const int np = n_rows < ING_PIVOT_ROWS ? n_rows : ING_PIVOT_ROWS;
-    bool have = false;
-    for (int i = 0; i < np; ++i) {
-      const long r = rows ? rows[i] : i;
-      const double v = ingest_value<T>(x[r * ldx + c], med, c, log1p_flag);
-      if (!have && v == v) { K = v; have = true; }
-    }
+  bool have = false;
+  for (int i = 0; i < np; ++i) {
+    const long r = rows ? rows[i] : i;
+    const double v = ingest_value<T, LOG>(x[r * ldx + c], mv);
+    if (!have && v == v) { K = v; have = true; }
+  }
+  pivot[c] = K;
+}
+
+template <typename T, int VEC>
+struct InVec { T v[VEC]; };
+
+template <typename T, int VEC, bool LOG>
+__global__ __launch_bounds__(ING_T) void fx_col_moments_kernel(const T* __restrict__ x, long ldx, int n_rows, int F,
+                                                               const int* __restrict__ rows,
+                                                               const double* __restrict__ med,
+                                                               int rows_per_chunk, const double* __restrict__ pivot,
+                                                               int* __restrict__ pn, double* __restrict__ ps,
+                                                               double* __restrict__ pq) {
+  typedef InVec<T, VEC> __attribute__((aligned(sizeof(T) * VEC))) VT;
+  const int c = (blockIdx.x * ING_T + threadIdx.x) * VEC;
+  if (c >= F) return;
+  double K[VEC], mv[VEC], s[VEC], q[VEC];
+  int n[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    mv[e] = ingest_med(med, c + e);
+    K[e] = pivot[c + e];
+    s[e] = 0.0; q[e] = 0.0; n[e] = 0;
   }
   const int r0 = blockIdx.y * rows_per_chunk;
   int r1 = r0 + rows_per_chunk;
   if (r1 > n_rows) r1 = n_rows;
-  int n = 0;
-  double s = 0.0, q = 0.0;
+  constexpr int UN = 8;
   int i = r0;
-  for (; i + 8 <= r1; i += 8) {
-    T raw[8];
+  for (; i + UN <= r1; i += UN) {
+    VT raw[UN];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < UN; ++u) {
       const long r = rows ? rows[i + u] : (i + u);
-      raw[u] = x[r * ldx + c];
+      raw[u] = *(const VT*)(x + r * ldx + c);
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const double v = ingest_value<T>(raw[u], med, c, log1p_flag);
-      if (v == v) {
-        const double d = v - K;
-        n += 1;
-        s += d;
-        q += d * d;
+    for (int u = 0; u < UN; ++u) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const double v = ingest_value<T, LOG>(raw[u].v[e], mv[e]);
+        const bool ok = (v == v);
+        const double d = ok ? v - K[e] : 0.0;
+        n[e] += ok ? 1 : 0;
+        s[e] += d;
+        q[e] += d * d;
       }
     }
   }
   for (; i < r1; ++i) {
     const long r = rows ? rows[i] : i;
-    const double v = ingest_value<T>(x[r * ldx + c], med, c, log1p_flag);
-    if (v == v) {
-      const double d = v - K;
-      n += 1;
-      s += d;
-      q += d * d;
+    const VT raw = *(const VT*)(x + r * ldx + c);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const double v = ingest_value<T, LOG>(raw.v[e], mv[e]);
+      const bool ok = (v == v);
+      const double d = ok ? v - K[e] : 0.0;
+      n[e] += ok ? 1 : 0;
+      s[e] += d;
+      q[e] += d * d;
     }
   }
   const long o = (long)blockIdx.y * F + c;
-  pn[o] = n;
-  ps[o] = s;
-  pq[o] = q;
-  if (blockIdx.y == 0) pivot[c] = K;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    pn[o + e] = n[e];
+    ps[o + e] = s[e];
+    pq[o + e] = q[e];
+  }
 }
 
 __global__ __launch_bounds__(ING_T) void fx_col_moments_merge_kernel(const int* __restrict__ pn,
@@ -117,6 +149,7 @@ __global__ __launch_bounds__(ING_T) void fx_col_moments_merge_kernel(const int* 
   if (c >= F) return;
   int n = 0;
   double s = 0.0, q = 0.0;
+#pragma unroll 8
   for (int k = 0; k < chunks; ++k) {
     const long o = (long)k * F + c;
     n += pn[o];
@@ -243,38 +276,71 @@ __global__ __launch_bounds__(ING_T) void fx_col_median_kernel(const T* __restric
 }
 
 // ---- per-row variance over the kept, imputed columns (ddof = 1) ---------------------------------------------------
+// One 1024-thread workgroup per 8 samples: a thread owns a kept column per step and reads it for the 8 rows, so the
+// column index and its imputation value are fetched once per 8 elements and 8 loads are in flight per thread; the
+// 24 partial sums are reduced with wavefront shuffles and one LDS exchange, in a fixed order.
+#define ING_RT 1024
+#define ING_RR 8
 template <typename T>
-__global__ __launch_bounds__(ING_T) void fx_row_moments_kernel(const T* __restrict__ x, long ldx,
-                                                               const int* __restrict__ cols, int n_cols,
-                                                               const double* __restrict__ med,
-                                                               double* __restrict__ var_out) {
-  __shared__ double red[16];
-  const long r = blockIdx.x;
-  const T* xr = x + r * ldx;
+__global__ __launch_bounds__(ING_RT) void fx_row_moments_kernel(const T* __restrict__ x, long ldx, int N,
+                                                                const int* __restrict__ cols, int n_cols,
+                                                                const double* __restrict__ med,
+                                                                double* __restrict__ var_out) {
+  __shared__ double red[ING_RT / 64][3 * ING_RR];
+  const int r0 = blockIdx.x * ING_RR;
   const int c0 = cols[0];
-  const double K0 = ingest_value<T>(xr[c0], med, c0, 0);
-  const double K = (K0 == K0) ? K0 : 0.0;
-  int n = 0;
-  double s = 0.0, q = 0.0;
-  for (int j = threadIdx.x; j < n_cols; j += ING_T) {
+  const double m0 = ingest_med(med, c0);
+  const T* xr[ING_RR];
+  double K[ING_RR], s[ING_RR], q[ING_RR], n[ING_RR];
+#pragma unroll
+  for (int u = 0; u < ING_RR; ++u) {
+    int r = r0 + u;
+    if (r >= N) r = N - 1;
+    xr[u] = x + (long)r * ldx;
+    const double k0 = ingest_value<T, false>(xr[u][c0], m0);
+    K[u] = (k0 == k0) ? k0 : 0.0;
+    s[u] = 0.0; q[u] = 0.0; n[u] = 0.0;
+  }
+  for (int j = threadIdx.x; j < n_cols; j += ING_RT) {
     const int c = cols[j];
-    const double v = ingest_value<T>(xr[c], med, c, 0);
-    if (v == v) {
-      const double d = v - K;
-      n += 1;
-      s += d;
-      q += d * d;
+    const double mv = ingest_med(med, c);
+    T raw[ING_RR];
+#pragma unroll
+    for (int u = 0; u < ING_RR; ++u) raw[u] = xr[u][c];
+#pragma unroll
+    for (int u = 0; u < ING_RR; ++u) {
+      const double v = ingest_value<T, false>(raw[u], mv);
+      const bool ok = (v == v);
+      const double d = ok ? v - K[u] : 0.0;
+      n[u] += ok ? 1.0 : 0.0;
+      s[u] += d;
+      q[u] += d * d;
     }
   }
-  const double nt = fx_block_sum_d((double)n, red);
-  const double st = fx_block_sum_d(s, red);
-  const double qt = fx_block_sum_d(q, red);
-  if (threadIdx.x == 0) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int u = 0; u < ING_RR; ++u) {
+    const double a = fx_wave_sum_d(n[u]), b = fx_wave_sum_d(s[u]), c = fx_wave_sum_d(q[u]);
+    if (lane == 0) {
+      red[wid][3 * u] = a;
+      red[wid][3 * u + 1] = b;
+      red[wid][3 * u + 2] = c;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < ING_RR && r0 + (int)threadIdx.x < N) {
+    const int u = threadIdx.x;
+    double nt = 0.0, st = 0.0, qt = 0.0;
+    for (int w = 0; w < ING_RT / 64; ++w) {
+      nt += red[w][3 * u];
+      st += red[w][3 * u + 1];
+      qt += red[w][3 * u + 2];
+    }
     if (nt < 2.0) {
-      var_out[r] = __builtin_nan("");
+      var_out[r0 + u] = __builtin_nan("");
     } else {
       const double m2 = qt - st * (st / nt);
-      var_out[r] = (m2 > 0.0 ? m2 : 0.0) / (nt - 1.0);
+      var_out[r0 + u] = (m2 > 0.0 ? m2 : 0.0) / (nt - 1.0);
     }
   }
 }
@@ -283,11 +349,11 @@ __global__ __launch_bounds__(ING_T) void fx_row_moments_kernel(const T* __restri
 // fp64 input: the reference scales the float64 frame and casts the result once (data.py:533-540, 549).  fp32 input:
 // sklearn's in-place `X -= mean_; X /= scale_` on a float32 array computes each op in fp64 and rounds to fp32.
 #define ING_ROWS 16
-template <typename T>
+template <typename T, bool LOG>
 __global__ __launch_bounds__(ING_T) void fx_ingest_transform_kernel(const T* __restrict__ x, long ldx,
                                                                     const int* __restrict__ rows, int n_rows,
                                                                     const int* __restrict__ cols, int n_cols,
-                                                                    const double* __restrict__ med, int log1p_flag,
+                                                                    const double* __restrict__ med,
                                                                     const double* __restrict__ mean,
                                                                     const double* __restrict__ scale,
                                                                     float* __restrict__ out, long ldo) {
@@ -296,6 +362,7 @@ __global__ __launch_bounds__(ING_T) void fx_ingest_transform_kernel(const T* __r
   const int c = cols ? cols[j] : j;
   const double mu = mean ? mean[j] : 0.0;
   const double sc = scale ? scale[j] : 1.0;
+  const double mv = ingest_med(med, c);
   const int i0 = blockIdx.y * ING_ROWS;
   T raw[ING_ROWS];
 #pragma unroll
@@ -309,7 +376,7 @@ __global__ __launch_bounds__(ING_T) void fx_ingest_transform_kernel(const T* __r
   for (int u = 0; u < ING_ROWS; ++u) {
     const int i = i0 + u;
     if (i < n_rows) {
-      const double v = ingest_value<T>(raw[u], med, c, log1p_flag);
+      const double v = ingest_value<T, LOG>(raw[u], mv);
       float o;
       if (mean == nullptr && scale == nullptr) {
         o = (float)v;
@@ -325,8 +392,8 @@ __global__ __launch_bounds__(ING_T) void fx_ingest_transform_kernel(const T* __r
 }
 
 inline int col_chunks(int n_rows, int F) {
-  const int cb = (F + ING_T - 1) / ING_T;
-  int want = (2048 + cb - 1) / cb;
+  const int cb = (F + 2 * ING_T - 1) / (2 * ING_T);  // column blocks of the 2-wide path
+  int want = (512 + cb - 1) / cb;                    // ~512 workgroups: 2 per CU, each streaming >= 16 rows
   const int maxc = (n_rows + 15) / 16;
   if (want > maxc) want = maxc;
   if (want > 256) want = 256;
@@ -357,16 +424,33 @@ int fx_col_moments(const void* x, int dtype, long ldx, int n_rows, int F, const 
   double* pq = ps + (long)ch * F;
   double* pivot = pq + (long)ch * F;
   int* pn = (int*)(pivot + F);
-  const dim3 grid((F + ING_T - 1) / ING_T, ch);
-  if (dtype == 0)
-    hipLaunchKernelGGL(fx_col_moments_kernel<float>, grid, dim3(ING_T), 0, stream, (const float*)x, ldx, n_rows, F, rows,
-                       med, log1p_flag, rpc, pn, ps, pq, pivot);
-  else
-    hipLaunchKernelGGL(fx_col_moments_kernel<double>, grid, dim3(ING_T), 0, stream, (const double*)x, ldx, n_rows, F,
-                       rows, med, log1p_flag, rpc, pn, ps, pq, pivot);
+  {
+    const dim3 g1((F + ING_T - 1) / ING_T);
+#define FX_PV_LAUNCH(T, LG) \
+  hipLaunchKernelGGL((fx_col_pivot_kernel<T, LG>), g1, dim3(ING_T), 0, stream, (const T*)x, ldx, n_rows, F, rows, med, pivot)
+    if (dtype == 0) { if (log1p_flag) FX_PV_LAUNCH(float, true); else FX_PV_LAUNCH(float, false); }
+    else { if (log1p_flag) FX_PV_LAUNCH(double, true); else FX_PV_LAUNCH(double, false); }
+#undef FX_PV_LAUNCH
+  }
+  // two adjacent columns per thread (8/16-byte loads) when alignment allows; measured 33-40 us for 2048 x 20000
+  // fp32 across 1/2/4 columns per thread, fewer and fatter workgroups being what matters
+  const bool can2 = (F % 2 == 0) && (ldx % 2 == 0) && ((((uintptr_t)x) & 15) == 0);
+  const int per = can2 ? 2 : 1;
+  const dim3 grid((F + ING_T * per - 1) / (ING_T * per), ch);
+#define FX_CM_LAUNCH2(T, V, LG)                                                                                          \
+  hipLaunchKernelGGL((fx_col_moments_kernel<T, V, LG>), grid, dim3(ING_T), 0, stream, (const T*)x, ldx, n_rows, F, rows, \
+                     med, rpc, pivot, pn, ps, pq)
+#define FX_CM_LAUNCH(T, V) do { if (log1p_flag) FX_CM_LAUNCH2(T, V, true); else FX_CM_LAUNCH2(T, V, false); } while (0)
+  if (dtype == 0) {
+    if (per == 2) FX_CM_LAUNCH(float, 2); else FX_CM_LAUNCH(float, 1);
+  } else {
+    if (per == 2) FX_CM_LAUNCH(double, 2); else FX_CM_LAUNCH(double, 1);
+  }
+#undef FX_CM_LAUNCH2
+#undef FX_CM_LAUNCH
   int rc = fx_check_launch("fx_col_moments");
   if (rc) return rc;
-  hipLaunchKernelGGL(fx_col_moments_merge_kernel, dim3(grid.x), dim3(ING_T), 0, stream, pn, ps, pq, pivot, ch, F, count,
+  hipLaunchKernelGGL(fx_col_moments_merge_kernel, dim3((F + ING_T - 1) / ING_T), dim3(ING_T), 0, stream, pn, ps, pq, pivot, ch, F, count,
                      mean, m2);
   return fx_check_launch("fx_col_moments(merge)");
 }
@@ -390,11 +474,12 @@ int fx_row_moments(const void* x, int dtype, long ldx, int N, const int* cols, i
   FX_REQUIRE(x && cols && var_out, "fx_row_moments: null pointer");
   FX_REQUIRE(N > 0 && n_cols > 0 && ldx > 0, "fx_row_moments: bad shape");
   FX_REQUIRE(dtype == 0 || dtype == 1, "fx_row_moments: dtype must be 0 (f32) or 1 (f64)");
+  const dim3 grid((N + ING_RR - 1) / ING_RR);
   if (dtype == 0)
-    hipLaunchKernelGGL(fx_row_moments_kernel<float>, dim3(N), dim3(ING_T), 0, stream, (const float*)x, ldx, cols, n_cols,
+    hipLaunchKernelGGL(fx_row_moments_kernel<float>, grid, dim3(ING_RT), 0, stream, (const float*)x, ldx, N, cols, n_cols,
                        med, var_out);
   else
-    hipLaunchKernelGGL(fx_row_moments_kernel<double>, dim3(N), dim3(ING_T), 0, stream, (const double*)x, ldx, cols,
+    hipLaunchKernelGGL(fx_row_moments_kernel<double>, grid, dim3(ING_RT), 0, stream, (const double*)x, ldx, N, cols,
                        n_cols, med, var_out);
   return fx_check_launch("fx_row_moments");
 }
@@ -407,12 +492,12 @@ int fx_ingest_transform(const void* x, int dtype, long ldx, const int* rows, int
   FX_REQUIRE(dtype == 0 || dtype == 1, "fx_ingest_transform: dtype must be 0 (f32) or 1 (f64)");
   FX_REQUIRE((mean == nullptr) == (scale == nullptr), "fx_ingest_transform: mean and scale go together");
   const dim3 grid((n_cols + ING_T - 1) / ING_T, (n_rows + ING_ROWS - 1) / ING_ROWS);
-  if (dtype == 0)
-    hipLaunchKernelGGL(fx_ingest_transform_kernel<float>, grid, dim3(ING_T), 0, stream, (const float*)x, ldx, rows,
-                       n_rows, cols, n_cols, med, log1p_flag, mean, scale, out, ldo);
-  else
-    hipLaunchKernelGGL(fx_ingest_transform_kernel<double>, grid, dim3(ING_T), 0, stream, (const double*)x, ldx, rows,
-                       n_rows, cols, n_cols, med, log1p_flag, mean, scale, out, ldo);
+#define FX_TR_LAUNCH(T, LG)                                                                                       \
+  hipLaunchKernelGGL((fx_ingest_transform_kernel<T, LG>), grid, dim3(ING_T), 0, stream, (const T*)x, ldx, rows, n_rows, \
+                     cols, n_cols, med, mean, scale, out, ldo)
+  if (dtype == 0) { if (log1p_flag) FX_TR_LAUNCH(float, true); else FX_TR_LAUNCH(float, false); }
+  else { if (log1p_flag) FX_TR_LAUNCH(double, true); else FX_TR_LAUNCH(double, false); }
+#undef FX_TR_LAUNCH
   return fx_check_launch("fx_ingest_transform");
 }
 
