@@ -78,10 +78,18 @@ PROTOTYPES = {
     "fx_col_median": (I, [P, I, L, I, P, I, P, P]),
     "fx_row_moments": (I, [P, I, L, I, P, I, P, P, P]),
     "fx_ingest_transform": (I, [P, I, L, P, I, P, I, P, I, P, P, P, L, P]),
+    "fx_gnn_row_blocks": (I, [L]),
+    "fx_spmm_rows": (I, [P, P, P, P, P, I, I, I, P]),
+    "fx_rowlin2": (I, [P, P, P, I, P, P, I, P, L, I, I, I, P]),
+    "fx_rowlin_wgrad_workspace_bytes": (L, [L, I, I]),
+    "fx_rowlin_wgrad": (I, [P, P, P, P, L, I, I, I, P, P]),
+    "fx_bn_rows_workspace_bytes": (L, [L, I]),
+    "fx_bn_rows_fwd": (I, [P, P, P, P, P, P, P, P, P, L, I, I, I, F, U64, U64, P, P, P]),
+    "fx_bn_rows_bwd": (I, [P, P, P, P, P, P, P, P, P, L, I, I, F, U64, U64, P, P, P]),
 }
 
 # functions whose int return value is a size/count, not an error code
-_QUERIES = {"fx_version", "fx_col_moments_chunks", "fx_col_moments_workspace_bytes", "fx_block_bwd_blocks", "fx_gemm_splitk", "fx_linear_fwd_bf16x3_splitk", "fx_gram_hadamard_blocks", "fx_gemm_workspace_bytes", "fx_linear_fwd_bf16x3_workspace_bytes", "fx_mmd_workspace_floats", "fx_recon_blocks", "fx_sumsq_blocks",
+_QUERIES = {"fx_version", "fx_gnn_row_blocks", "fx_rowlin_wgrad_workspace_bytes", "fx_bn_rows_workspace_bytes", "fx_col_moments_chunks", "fx_col_moments_workspace_bytes", "fx_block_bwd_blocks", "fx_gemm_splitk", "fx_linear_fwd_bf16x3_splitk", "fx_gram_hadamard_blocks", "fx_gemm_workspace_bytes", "fx_linear_fwd_bf16x3_workspace_bytes", "fx_mmd_workspace_floats", "fx_recon_blocks", "fx_sumsq_blocks",
             "fx_last_error_string"}
 
 

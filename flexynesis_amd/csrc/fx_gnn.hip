@@ -1,0 +1,518 @@
+// Graph-convolution encoder kernels (reference flexGCN, modules.py:153-262; GNN model, models/gnn_early.py:103-158).
+//
+// Activations are [B, nodes, C] fp32, node-major inside a sample and contiguous, i.e. exactly the memory the
+// reference's `x.view(-1, C)` (BatchNorm over batch*nodes rows) and `x.view(B, -1)` (flatten before fc) see; C is the
+// node embedding width (4..32 in the reference's search space, config.py:45) or the node feature count (1..3).
+// One graph is shared by every sample (gnn_early.py:93-96), so message passing is an SpMM with a tiny dense side:
+//   fx_spmm_rows      out[b, i, :] = sum_{e in row i} w[e] * x[b, idx[e], :]        (CSR by target: forward;
+//                                                                                    CSR by source: backward)
+//   fx_rowlin2        out[r, :] = a[r, :] Wa^T (+ b[r, :] Wb^T) (+ bias)            (the convs' Linear layers; `trans`
+//                                                                                    applies W instead of W^T: dX)
+//   fx_rowlin_wgrad   dW = dY^T X, db = colsum(dY) over all rows                     (deterministic two-stage sum)
+//   fx_bn_rows_*      BatchNorm1d over R = B*nodes rows + activation + Dropout, forward and backward
+// Lane layout of every kernel: lane = row_sub * CP + channel with CP = the power of two >= C, so a wavefront reads
+// 64/CP consecutive rows as one contiguous span and per-channel sums are shuffle reductions over the row_sub bits.
+// The gathered operand of one sample ([nodes, C], <= 1.3 MB) is L2-resident: workgroups of one sample are placed on
+// one XCD (blockIdx -> sample mapping below), so HBM traffic stays at one read of x and one write of out while the
+// E*B*C gathered values come out of that XCD's L2.
+#include "fx_common.h"
+
+#define GN_T 256
+enum { GACT_RELU = 0, GACT_SIGMOID = 1, GACT_LEAKY = 2, GACT_TANH = 3, GACT_GELU = 4 };  // flexGCN act_options
+#define GN_LEAKY 0.01f  // nn.LeakyReLU() default slope (modules.py:213)
+
+namespace {
+
+__device__ __forceinline__ int cp_of(int C) {  // smallest power of two >= C (C <= 32)
+  int p = 1;
+  while (p < C) p <<= 1;
+  return p;
+}
+inline int h_cp_of(int C) {
+  int p = 1;
+  while (p < C) p <<= 1;
+  return p;
+}
+
+// sum over the row_sub bits of the lane id (lanes that differ only above log2(CP))
+__device__ __forceinline__ float sum_over_rowsub(float v, int CP) {
+  for (int off = 32; off >= CP; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// ---- SpMM with a narrow dense side -------------------------------------------------------------------------------
+// One wavefront walks a tile of `npw` nodes of one sample; for a node, 64/CP edges are in flight at once.
+__global__ __launch_bounds__(GN_T) void fx_spmm_rows_kernel(float* __restrict__ out, const float* __restrict__ x,
+                                                            const int* __restrict__ rowptr, const int* __restrict__ idx,
+                                                            const float* __restrict__ w, int B, int nodes, int C,
+                                                            int tiles, int npw) {
+  // XCD-aware placement: consecutive block ids go round-robin over the 8 XCDs, so ids congruent mod 8 share an L2;
+  // give each XCD whole samples.
+  const int id = blockIdx.x;
+  const int j = id >> 3, xcd = id & 7;
+  const int b = xcd + 8 * (j / tiles);
+  const int tile = j % tiles;
+  if (b >= B) return;
+  const int CP = cp_of(C), EG = 64 / CP;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & (CP - 1), eg = lane / CP;
+  const bool cok = c < C;
+  const float* xb = x + (long)b * nodes * C;
+  float* ob = out + (long)b * nodes * C;
+  const int n0 = (tile * (GN_T / 64) + wave) * npw;
+  for (int i = n0; i < n0 + npw && i < nodes; ++i) {
+    const int e0 = rowptr[i], e1 = rowptr[i + 1];
+    float acc = 0.f;
+    for (int e = e0 + eg; e < e1; e += EG) {
+      const int s = idx[e];
+      const float we = w[e];
+      if (cok) acc += we * xb[(long)s * C + c];
+    }
+    acc = sum_over_rowsub(acc, CP);
+    if (eg == 0 && cok) ob[(long)i * C + c] = acc;
+  }
+}
+
+// ---- two-input row-wise Linear ----------------------------------------------------------------------------------
+// Thread per row; the zero padded weights sit in LDS and are read as broadcasts.  CI / CO = channel counts rounded up
+// to 4, 8, 16 or 32, so the loops unroll and the accumulators stay in registers.
+#define GN_CMAX 32
+#define GN_WLD (GN_CMAX + 4)
+template <int CI, int CO>
+__global__ __launch_bounds__(GN_T) void fx_rowlin2_kernel(float* __restrict__ out, const float* __restrict__ a,
+                                                          const float* __restrict__ Wa, const float* __restrict__ bsrc,
+                                                          const float* __restrict__ Wb, const float* __restrict__ bias,
+                                                          long R, int Ca, int Cb, int Cout, int trans, int accumulate) {
+  __shared__ __attribute__((aligned(16))) float sWa[CO][GN_WLD], sWb[CO][GN_WLD];
+  __shared__ float sbias[CO];
+  for (int t = threadIdx.x; t < CO * CI; t += GN_T) {
+    const int o = t / CI, c = t % CI;
+    // trans == 0: W is [Cout, Cin] (nn.Linear layout), out = in W^T; trans == 1: W is [Cin, Cout], out = in W
+    float va = 0.f, vb = 0.f;
+    if (o < Cout && c < Ca) va = trans ? Wa[(long)c * Cout + o] : Wa[(long)o * Ca + c];
+    if (bsrc && o < Cout && c < Cb) vb = trans ? Wb[(long)c * Cout + o] : Wb[(long)o * Cb + c];
+    sWa[o][c] = va;
+    sWb[o][c] = vb;
+  }
+  if (threadIdx.x < CO) sbias[threadIdx.x] = (bias && threadIdx.x < Cout) ? bias[threadIdx.x] : 0.f;
+  __syncthreads();
+  const long r = (long)blockIdx.x * GN_T + threadIdx.x;
+  if (r >= R) return;
+  // padded channels re-read the last valid one (no conditional loads); their weights are zero
+  float av[CI], bv[CI];
+#pragma unroll
+  for (int c = 0; c < CI; ++c) av[c] = a[r * Ca + (c < Ca ? c : Ca - 1)];
+  if (bsrc) {
+#pragma unroll
+    for (int c = 0; c < CI; ++c) bv[c] = bsrc[r * Cb + (c < Cb ? c : Cb - 1)];
+  } else {
+#pragma unroll
+    for (int c = 0; c < CI; ++c) bv[c] = 0.f;
+  }
+  float acc[CO];
+#pragma unroll
+  for (int o = 0; o < CO; ++o) {
+    float s = sbias[o];
+#pragma unroll
+    for (int c = 0; c < CI; ++c) s += av[c] * sWa[o][c];
+    if (bsrc) {
+#pragma unroll
+      for (int c = 0; c < CI; ++c) s += bv[c] * sWb[o][c];
+    }
+    acc[o] = s;
+  }
+#pragma unroll
+  for (int o = 0; o < CO; ++o) {
+    if (o < Cout) {
+      float v = acc[o];
+      if (accumulate) v += out[r * Cout + o];
+      out[r * Cout + o] = v;
+    }
+  }
+}
+
+// ---- weight gradient of a row-wise Linear: dW[o][c] = sum_r dy[r][o] x[r][c], db[o] = sum_r dy[r][o] ---------------
+// Stage 1: each workgroup reduces its row chunk (tiles of 64 rows staged in LDS) into partial[blockIdx][Cout*(Cin+1)];
+// stage 2 adds the partials in block order.
+#define GN_WG_ROWS 64
+__global__ __launch_bounds__(GN_T) void fx_rowlin_wgrad_kernel(float* __restrict__ partial, const float* __restrict__ dy,
+                                                               const float* __restrict__ x, long R, int Cin, int Cout,
+                                                               long rows_per_block) {
+  __shared__ float sdy[GN_WG_ROWS][GN_CMAX + 1], sx[GN_WG_ROWS][GN_CMAX + 2];
+  const int npairs = Cout * (Cin + 1);  // column Cin of x is the constant 1 -> bias gradient
+  float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // ceil(32*33/256) = 5 pairs per thread
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  long r1 = r0 + rows_per_block;
+  if (r1 > R) r1 = R;
+  for (long rt = r0; rt < r1; rt += GN_WG_ROWS) {
+    const int nr = (int)((r1 - rt) < GN_WG_ROWS ? (r1 - rt) : GN_WG_ROWS);
+    __syncthreads();
+    for (int t = threadIdx.x; t < GN_WG_ROWS * Cout; t += GN_T) {
+      const int rr = t / Cout, o = t % Cout;
+      sdy[rr][o] = rr < nr ? dy[(rt + rr) * Cout + o] : 0.f;
+    }
+    for (int t = threadIdx.x; t < GN_WG_ROWS * (Cin + 1); t += GN_T) {
+      const int rr = t / (Cin + 1), c = t % (Cin + 1);
+      sx[rr][c] = rr < nr ? (c < Cin ? x[(rt + rr) * Cin + c] : 1.f) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int p = threadIdx.x + k * GN_T;
+      if (p < npairs) {
+        const int o = p / (Cin + 1), c = p % (Cin + 1);
+        float s = acc[k];
+        for (int rr = 0; rr < GN_WG_ROWS; ++rr) s += sdy[rr][o] * sx[rr][c];
+        acc[k] = s;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int p = threadIdx.x + k * GN_T;
+    if (p < npairs) partial[(long)blockIdx.x * npairs + p] = acc[k];
+  }
+}
+
+__global__ __launch_bounds__(GN_T) void fx_rowlin_wgrad_merge_kernel(float* __restrict__ dW, float* __restrict__ db,
+                                                                     const float* __restrict__ partial, int blocks,
+                                                                     int Cin, int Cout, int accumulate) {
+  const int npairs = Cout * (Cin + 1);
+  const int p = blockIdx.x * GN_T + threadIdx.x;
+  if (p >= npairs) return;
+  float s = 0.f;
+  for (int k = 0; k < blocks; ++k) s += partial[(long)k * npairs + p];
+  const int o = p / (Cin + 1), c = p % (Cin + 1);
+  if (c < Cin) {
+    if (dW) dW[o * Cin + c] = accumulate ? dW[o * Cin + c] + s : s;
+  } else if (db) {
+    db[o] = accumulate ? db[o] + s : s;
+  }
+}
+
+// ---- BatchNorm over R rows of C <= 32 channels -----------------------------------------------------------------------
+__device__ __forceinline__ float gact(float z, int act) {
+  switch (act) {
+    case GACT_RELU: return fmaxf(z, 0.f);
+    case GACT_SIGMOID: return 1.f / (1.f + expf(-z));
+    case GACT_LEAKY: return z >= 0.f ? z : z * GN_LEAKY;
+    case GACT_TANH: return tanhf(z);
+    default: return 0.5f * z * (1.f + erff(z * 0.70710678118654752440f));
+  }
+}
+__device__ __forceinline__ float gact_grad(float z, int act) {
+  switch (act) {
+    case GACT_RELU: return z > 0.f ? 1.f : 0.f;
+    case GACT_SIGMOID: { const float s = 1.f / (1.f + expf(-z)); return s * (1.f - s); }
+    case GACT_LEAKY: return z >= 0.f ? 1.f : GN_LEAKY;   // torch: grad 1 for z > 0, slope otherwise; z == 0 has measure 0
+    case GACT_TANH: { const float t = tanhf(z); return 1.f - t * t; }
+    default: return 0.5f * (1.f + erff(z * 0.70710678118654752440f)) + z * 0.39894228040143267794f * expf(-0.5f * z * z);
+  }
+}
+
+// Two per-channel sums over the rows of a chunk, as doubles: partial[blockIdx][2][C].
+//   mode 0 (forward statistics): s0 = sum (x - shift), s1 = sum (x - shift)^2   with shift = x[0, c]
+//   mode 1 (backward):           g = dA * mask/keep * act'(z);  s0 = sum g, s1 = sum g * xhat;  g is written over dA
+struct BnRows {
+  const float* x;        // [R, C] conv output (BatchNorm input)
+  float* da;             // mode 1: [R, C] upstream gradient in, g out
+  const float* gamma; const float* beta; const float* save_mean; const float* save_invstd;
+  const float* mask;     // optional explicit dropout mask [R, C]
+  const float* ctrl;
+  double* partial;
+  long R; int C; int act; int mode; float drop_p;
+  unsigned long long seed, offset;
+  long rows_per_block;
+};
+
+__device__ __forceinline__ unsigned long long gn_step_offset(const float* ctrl, unsigned long long offset) {
+  return ctrl ? offset + (((unsigned long long)ctrl[FXC_STEP]) << 44) : offset;
+}
+__device__ __forceinline__ float gn_mask(const BnRows& a, unsigned long long rng_off, long e) {
+  if (a.drop_p <= 0.f) return 1.f;
+  const float keep_scale = 1.0f / (1.0f - a.drop_p);
+  const float mk = a.mask ? a.mask[e] : (fx_rand_uniform(a.seed, rng_off, (unsigned long long)e) <= (1.0f - a.drop_p) ? 1.f : 0.f);
+  return mk * keep_scale;
+}
+
+__global__ __launch_bounds__(GN_T) void fx_bn_rows_reduce_kernel(BnRows a) {
+  __shared__ double red[GN_T / 64][2][GN_CMAX];
+  const int C = a.C, CP = cp_of(C), RS = 64 / CP;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & (CP - 1), rs = lane / CP;
+  const bool cok = c < C;
+  const long r0 = (long)blockIdx.x * a.rows_per_block;
+  long r1 = r0 + a.rows_per_block;
+  if (r1 > a.R) r1 = a.R;
+  double s0 = 0.0, s1 = 0.0;
+  if (cok) {
+    if (a.mode == 0) {
+      const float shift = a.x[c];
+      for (long r = r0 + wave * RS + rs; r < r1; r += (GN_T / 64) * RS) {
+        const float d = a.x[r * C + c] - shift;
+        s0 += (double)d;
+        s1 += (double)d * (double)d;
+      }
+    } else {
+      const float mu = a.save_mean[c], is = a.save_invstd[c], gm = a.gamma[c], bt = a.beta[c];
+      const unsigned long long rng_off = gn_step_offset(a.ctrl, a.offset);
+      for (long r = r0 + wave * RS + rs; r < r1; r += (GN_T / 64) * RS) {
+        const long e = r * C + c;
+        const float xhat = (a.x[e] - mu) * is;
+        const float z = xhat * gm + bt;
+        const float g = a.da[e] * gn_mask(a, rng_off, e) * gact_grad(z, a.act);
+        a.da[e] = g;
+        s0 += (double)g;
+        s1 += (double)g * (double)xhat;
+      }
+    }
+  }
+  for (int off = 32; off >= CP; off >>= 1) {
+    s0 += __shfl_xor(s0, off, 64);
+    s1 += __shfl_xor(s1, off, 64);
+  }
+  if (rs == 0 && cok) {
+    red[wave][0][c] = s0;
+    red[wave][1][c] = s1;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * C) {
+    const int k = threadIdx.x / C, cc = threadIdx.x % C;
+    double t = 0.0;
+    for (int wv = 0; wv < GN_T / 64; ++wv) t += red[wv][k][cc];
+    a.partial[((long)blockIdx.x * 2 + k) * C + cc] = t;
+  }
+}
+
+// forward finalize: batch statistics, running statistics (momentum 0.1, unbiased running_var)
+__global__ void fx_bn_rows_stats_finalize_kernel(const double* __restrict__ partial, int blocks, const float* __restrict__ x,
+                                                 long R, int C, float* __restrict__ save_mean,
+                                                 float* __restrict__ save_invstd, float* __restrict__ running_mean,
+                                                 float* __restrict__ running_var) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int k = 0; k < blocks; ++k) {
+    s0 += partial[((long)k * 2) * C + c];
+    s1 += partial[((long)k * 2 + 1) * C + c];
+  }
+  const double n = (double)R;
+  const double dm = s0 / n;
+  const double mean = (double)x[c] + dm;
+  double var_b = s1 / n - dm * dm;
+  if (var_b < 0.0) var_b = 0.0;
+  save_mean[c] = (float)mean;
+  save_invstd[c] = (float)(1.0 / sqrt(var_b + (double)FX_BN_EPS));
+  const double var_u = R > 1 ? var_b * (n / (n - 1.0)) : var_b;
+  running_mean[c] = (1.0f - FX_BN_MOMENTUM) * running_mean[c] + FX_BN_MOMENTUM * (float)mean;
+  running_var[c] = (1.0f - FX_BN_MOMENTUM) * running_var[c] + FX_BN_MOMENTUM * (float)var_u;
+}
+
+// backward finalize: dgamma = sum g*xhat, dbeta = sum g
+__global__ void fx_bn_rows_bwd_finalize_kernel(const double* __restrict__ partial, int blocks, int C,
+                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                               float* __restrict__ sums /* [2][C]: sum g, sum g*xhat as floats */) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int k = 0; k < blocks; ++k) {
+    s0 += partial[((long)k * 2) * C + c];
+    s1 += partial[((long)k * 2 + 1) * C + c];
+  }
+  if (dbeta) dbeta[c] = (float)s0;
+  if (dgamma) dgamma[c] = (float)s1;
+  sums[c] = (float)s0;
+  sums[C + c] = (float)s1;
+}
+
+// forward apply: out = dropout(act(gamma * xhat + beta));  train == 0 uses the running statistics.  Same row chunks
+// and lane layout as the reduction (no per-element modulo).
+__global__ __launch_bounds__(GN_T) void fx_bn_rows_apply_kernel(float* __restrict__ out, BnRows a,
+                                                                const float* __restrict__ running_mean,
+                                                                const float* __restrict__ running_var, int train) {
+  const int C = a.C, CP = cp_of(C), RS = 64 / CP;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & (CP - 1), rs = lane / CP;
+  if (c >= C) return;
+  const long r0 = (long)blockIdx.x * a.rows_per_block;
+  long r1 = r0 + a.rows_per_block;
+  if (r1 > a.R) r1 = a.R;
+  const float mu = train ? a.save_mean[c] : running_mean[c];
+  const float is = train ? a.save_invstd[c] : 1.0f / sqrtf(running_var[c] + FX_BN_EPS);
+  const float gm = a.gamma[c], bt = a.beta[c];
+  const unsigned long long rng_off = gn_step_offset(a.ctrl, a.offset);
+  for (long r = r0 + wave * RS + rs; r < r1; r += (GN_T / 64) * RS) {
+    const long e = r * C + c;
+    float y = gact((a.x[e] - mu) * is * gm + bt, a.act);
+    if (train) y = y * gn_mask(a, rng_off, e);
+    out[e] = y;
+  }
+}
+
+// backward apply (in place on g): dx = gamma * invstd * (g - sum_g / R - xhat * sum_gxhat / R)
+__global__ __launch_bounds__(GN_T) void fx_bn_rows_bwd_apply_kernel(float* __restrict__ g, const float* __restrict__ x,
+                                                                    const float* __restrict__ gamma,
+                                                                    const float* __restrict__ save_mean,
+                                                                    const float* __restrict__ save_invstd,
+                                                                    const float* __restrict__ sums, long R, int C,
+                                                                    long rows_per_block) {
+  const int CP = cp_of(C), RS = 64 / CP;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & (CP - 1), rs = lane / CP;
+  if (c >= C) return;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  long r1 = r0 + rows_per_block;
+  if (r1 > R) r1 = R;
+  const float inv_r = 1.0f / (float)R;
+  const float is = save_invstd[c], mu = save_mean[c];
+  const float k0 = gamma[c] * is, m0 = sums[c] * inv_r, m1 = sums[C + c] * inv_r;
+  for (long r = r0 + wave * RS + rs; r < r1; r += (GN_T / 64) * RS) {
+    const long e = r * C + c;
+    const float xhat = (x[e] - mu) * is;
+    g[e] = k0 * (g[e] - m0 - xhat * m1);
+  }
+}
+
+inline int row_blocks(long R, long* rows_per_block) {
+  long b = (R + 255) / 256;
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  long rpb = (R + b - 1) / b;
+  rpb = ((rpb + 63) / 64) * 64;  // whole 64-row tiles
+  *rows_per_block = rpb;
+  return (int)((R + rpb - 1) / rpb);
+}
+
+}  // namespace
+
+extern "C" {
+
+int fx_gnn_row_blocks(long R) {
+  long rpb;
+  return row_blocks(R, &rpb);
+}
+
+int fx_spmm_rows(float* out, const float* x, const int* rowptr, const int* idx, const float* w, int B, int nodes, int C,
+                 hipStream_t stream) {
+  FX_REQUIRE(out && x && rowptr && idx && w, "fx_spmm_rows: null pointer");
+  FX_REQUIRE(B > 0 && nodes > 0 && C > 0 && C <= GN_CMAX, "fx_spmm_rows: need 1 <= C <= 32 (B=%d nodes=%d C=%d)", B, nodes, C);
+  FX_REQUIRE(out != x, "fx_spmm_rows: not in place");
+  const int waves = GN_T / 64;
+  int npw = 8;  // nodes per wavefront
+  const int tiles = (nodes + waves * npw - 1) / (waves * npw);
+  const int bgroups = (B + 7) / 8;
+  hipLaunchKernelGGL(fx_spmm_rows_kernel, dim3(8 * bgroups * tiles), dim3(GN_T), 0, stream, out, x, rowptr, idx, w, B, nodes,
+                     C, tiles, npw);
+  return fx_check_launch("fx_spmm_rows");
+}
+
+int fx_rowlin2(float* out, const float* a, const float* Wa, int Ca, const float* b, const float* Wb, int Cb,
+               const float* bias, long R, int Cout, int trans, int accumulate, hipStream_t stream) {
+  FX_REQUIRE(out && a && Wa, "fx_rowlin2: null pointer");
+  FX_REQUIRE((b == nullptr) == (Wb == nullptr), "fx_rowlin2: second input and its weight go together");
+  FX_REQUIRE(R > 0 && Ca > 0 && Ca <= GN_CMAX && Cout > 0 && Cout <= GN_CMAX && (!b || (Cb > 0 && Cb <= GN_CMAX)),
+             "fx_rowlin2: channel counts must be in 1..32");
+  const int cin = (b && Cb > Ca) ? Cb : Ca;
+  const int ci = cin <= 4 ? 4 : (cin <= 8 ? 8 : (cin <= 16 ? 16 : 32));
+  const int co = Cout <= 4 ? 4 : (Cout <= 8 ? 8 : (Cout <= 16 ? 16 : 32));
+  const dim3 grid((unsigned)((R + GN_T - 1) / GN_T));
+#define FX_RL(CI, CO)                                                                                             \
+  hipLaunchKernelGGL((fx_rowlin2_kernel<CI, CO>), grid, dim3(GN_T), 0, stream, out, a, Wa, b, Wb, bias, R, Ca, Cb, Cout, \
+                     trans, accumulate)
+#define FX_RL_CO(CI)                                                                     \
+  do {                                                                                   \
+    if (co == 4) FX_RL(CI, 4); else if (co == 8) FX_RL(CI, 8); else if (co == 16) FX_RL(CI, 16); else FX_RL(CI, 32); \
+  } while (0)
+  if (ci == 4) FX_RL_CO(4); else if (ci == 8) FX_RL_CO(8); else if (ci == 16) FX_RL_CO(16); else FX_RL_CO(32);
+#undef FX_RL_CO
+#undef FX_RL
+  return fx_check_launch("fx_rowlin2");
+}
+
+long fx_rowlin_wgrad_workspace_bytes(long R, int Cin, int Cout) {
+  long rpb;
+  const int blocks = row_blocks(R, &rpb);
+  return (long)blocks * Cout * (Cin + 1) * sizeof(float) + 64;
+}
+
+int fx_rowlin_wgrad(float* dW, float* db, const float* dy, const float* x, long R, int Cin, int Cout, int accumulate,
+                    void* ws, hipStream_t stream) {
+  FX_REQUIRE(dy && x && ws && (dW || db), "fx_rowlin_wgrad: null pointer");
+  FX_REQUIRE(R > 0 && Cin > 0 && Cin <= GN_CMAX && Cout > 0 && Cout <= GN_CMAX, "fx_rowlin_wgrad: channel counts must be in 1..32");
+  long rpb;
+  const int blocks = row_blocks(R, &rpb);
+  float* partial = (float*)ws;
+  hipLaunchKernelGGL(fx_rowlin_wgrad_kernel, dim3(blocks), dim3(GN_T), 0, stream, partial, dy, x, R, Cin, Cout, rpb);
+  int rc = fx_check_launch("fx_rowlin_wgrad");
+  if (rc) return rc;
+  const int npairs = Cout * (Cin + 1);
+  hipLaunchKernelGGL(fx_rowlin_wgrad_merge_kernel, dim3((npairs + GN_T - 1) / GN_T), dim3(GN_T), 0, stream, dW, db, partial,
+                     blocks, Cin, Cout, accumulate);
+  return fx_check_launch("fx_rowlin_wgrad(merge)");
+}
+
+long fx_bn_rows_workspace_bytes(long R, int C) {
+  long rpb;
+  const int blocks = row_blocks(R, &rpb);
+  return (long)blocks * 2 * C * sizeof(double) + 2 * C * sizeof(float) + 64;
+}
+
+// BatchNorm1d over the R rows of x [R, C] -> activation -> Dropout(drop_p), flexGCN.forward (modules.py:253-256).
+int fx_bn_rows_fwd(float* out, const float* x, const float* gamma, const float* beta, float* running_mean,
+                   float* running_var, float* save_mean, float* save_invstd, const float* mask, long R, int C, int act,
+                   int train, float drop_p, unsigned long long seed, unsigned long long offset, const float* ctrl, void* ws,
+                   hipStream_t stream) {
+  FX_REQUIRE(out && x && gamma && beta && running_mean && running_var, "fx_bn_rows_fwd: null pointer");
+  FX_REQUIRE(R > 0 && C > 0 && C <= GN_CMAX, "fx_bn_rows_fwd: need 1 <= C <= 32");
+  FX_REQUIRE(act >= 0 && act <= GACT_GELU, "fx_bn_rows_fwd: unknown activation %d", act);
+  FX_REQUIRE(!train || (save_mean && save_invstd && ws), "fx_bn_rows_fwd: training needs save_mean/save_invstd/workspace");
+  BnRows a{};
+  a.x = x; a.gamma = gamma; a.beta = beta; a.save_mean = save_mean; a.save_invstd = save_invstd; a.mask = mask; a.ctrl = ctrl;
+  a.R = R; a.C = C; a.act = act; a.mode = 0; a.drop_p = train ? drop_p : 0.f; a.seed = seed; a.offset = offset;
+  if (train) {
+    long rpb;
+    const int blocks = row_blocks(R, &rpb);
+    a.partial = (double*)ws;
+    a.rows_per_block = rpb;
+    hipLaunchKernelGGL(fx_bn_rows_reduce_kernel, dim3(blocks), dim3(GN_T), 0, stream, a);
+    int rc = fx_check_launch("fx_bn_rows_fwd(stats)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(fx_bn_rows_stats_finalize_kernel, dim3(1), dim3(64), 0, stream, a.partial, blocks, x, R, C, save_mean,
+                       save_invstd, running_mean, running_var);
+    rc = fx_check_launch("fx_bn_rows_fwd(finalize)");
+    if (rc) return rc;
+  }
+  long rpb_a;
+  const int blocks_a = row_blocks(R, &rpb_a);
+  a.rows_per_block = rpb_a;
+  hipLaunchKernelGGL(fx_bn_rows_apply_kernel, dim3(blocks_a), dim3(GN_T), 0, stream, out, a, running_mean, running_var, train);
+  return fx_check_launch("fx_bn_rows_fwd(apply)");
+}
+
+// Backward of the same block, in place: da [R, C] holds dL/d(out) on entry and dL/dx on return.
+int fx_bn_rows_bwd(float* da, float* dgamma, float* dbeta, const float* x, const float* gamma, const float* beta,
+                   const float* save_mean, const float* save_invstd, const float* mask, long R, int C, int act, float drop_p,
+                   unsigned long long seed, unsigned long long offset, const float* ctrl, void* ws, hipStream_t stream) {
+  FX_REQUIRE(da && x && gamma && beta && save_mean && save_invstd && ws, "fx_bn_rows_bwd: null pointer");
+  FX_REQUIRE(R > 0 && C > 0 && C <= GN_CMAX, "fx_bn_rows_bwd: need 1 <= C <= 32");
+  FX_REQUIRE(act >= 0 && act <= GACT_GELU, "fx_bn_rows_bwd: unknown activation %d", act);
+  BnRows a{};
+  a.x = x; a.da = da; a.gamma = gamma; a.beta = beta; a.save_mean = save_mean; a.save_invstd = save_invstd; a.mask = mask;
+  a.ctrl = ctrl; a.R = R; a.C = C; a.act = act; a.mode = 1; a.drop_p = drop_p; a.seed = seed; a.offset = offset;
+  long rpb;
+  const int blocks = row_blocks(R, &rpb);
+  a.partial = (double*)ws;
+  a.rows_per_block = rpb;
+  float* sums = (float*)((char*)ws + (long)blocks * 2 * C * sizeof(double));
+  hipLaunchKernelGGL(fx_bn_rows_reduce_kernel, dim3(blocks), dim3(GN_T), 0, stream, a);
+  int rc = fx_check_launch("fx_bn_rows_bwd(reduce)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(fx_bn_rows_bwd_finalize_kernel, dim3(1), dim3(64), 0, stream, a.partial, blocks, C, dgamma, dbeta, sums);
+  rc = fx_check_launch("fx_bn_rows_bwd(finalize)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(fx_bn_rows_bwd_apply_kernel, dim3(blocks), dim3(GN_T), 0, stream, da, x, gamma, save_mean, save_invstd,
+                     sums, R, C, rpb);
+  return fx_check_launch("fx_bn_rows_bwd(apply)");
+}
+
+}  // extern "C"

@@ -718,3 +718,74 @@ def ingest_transform(rec, x, out, rows=None, cols=None, med=None, log1p=False, m
     rec.emit("fx_ingest_transform", x.data_ptr(), dt, x.stride(0), _i32(rows, "ingest_transform"), n_rows,
              _i32(cols, "ingest_transform"), n_cols, _f64(med, "ingest_transform"), int(bool(log1p)),
              _f64(mean, "ingest_transform"), _f64(scale, "ingest_transform"), out.data_ptr(), _ld(out))
+
+
+# ---- graph-convolution encoder (csrc/fx_gnn.hip; reference modules.py:153-262) -------------------------------------
+GACT = {"relu": 0, "sigmoid": 1, "leakyrelu": 2, "tanh": 3, "gelu": 4}      # flexGCN act_options (modules.py:210-216)
+
+
+def _chk_act3(t: torch.Tensor, name: str):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 3):
+        raise FxError(f"{name}: expected a contiguous fp32 [B, nodes, C] tensor on the GPU, got {t.dtype} {tuple(t.shape)}")
+
+
+def spmm_rows(rec, out, x, rowptr, idx, w):
+    """out[b, i, :] = sum_e w[e] * x[b, idx[e], :] over the CSR row i (message passing over one shared graph)."""
+    _chk_act3(x, "spmm_rows.x")
+    _chk_act3(out, "spmm_rows.out")
+    B, nodes, Cc = x.shape
+    if out.shape != x.shape or rowptr.numel() != nodes + 1:
+        raise FxError("spmm_rows: shape mismatch")
+    rec.emit("fx_spmm_rows", out.data_ptr(), x.data_ptr(), _i32(rowptr, "spmm_rows"), _i32(idx, "spmm_rows"),
+             w.data_ptr(), B, nodes, Cc)
+
+
+def rowlin2(rec, out, a, Wa, b=None, Wb=None, bias=None, trans=False, accumulate=False):
+    """out[r, :] (+)= a[r, :] Wa^T (+ b[r, :] Wb^T) (+ bias) over the rows of the flattened [R, C] views."""
+    R = a.numel() // a.shape[-1]
+    Ca, Cout = a.shape[-1], out.shape[-1]
+    Cb = b.shape[-1] if b is not None else 0
+    want = (Ca, Cout) if trans else (Cout, Ca)
+    if tuple(Wa.shape) != want or out.numel() != R * Cout:
+        raise FxError(f"rowlin2: weight {tuple(Wa.shape)} / out {tuple(out.shape)} do not fit a {tuple(a.shape)} input")
+    rec.emit("fx_rowlin2", out.data_ptr(), a.data_ptr(), Wa.data_ptr(), Ca, _ptr(b), _ptr(Wb), Cb, _ptr(bias), R, Cout,
+             int(bool(trans)), int(bool(accumulate)))
+
+
+def gnn_scratch(R: int, C: int, device) -> torch.Tensor:
+    """Scratch big enough for fx_rowlin_wgrad (Cin, Cout <= C) and fx_bn_rows_* over R rows of C channels; give each
+    call chain that may overlap another its own."""
+    n = max(int(lib.fx_rowlin_wgrad_workspace_bytes(R, 32, 32)), int(lib.fx_bn_rows_workspace_bytes(R, 32)))
+    return torch.empty(n // 8 + 2, dtype=torch.float64, device=device)
+
+
+def rowlin_wgrad(rec, dW, db, dy, x, ws: torch.Tensor, accumulate=False):
+    """dW [Cout, Cin] (+)= dy^T x and db [Cout] (+)= colsum(dy) over all rows, in a fixed summation order."""
+    Cin, Cout = x.shape[-1], dy.shape[-1]
+    R = x.numel() // Cin
+    if ws.numel() * ws.element_size() < int(lib.fx_rowlin_wgrad_workspace_bytes(R, Cin, Cout)):
+        raise FxError("rowlin_wgrad: scratch too small")
+    rec.emit("fx_rowlin_wgrad", _ptr(dW), _ptr(db), dy.data_ptr(), x.data_ptr(), R, Cin, Cout, int(bool(accumulate)),
+             ws.data_ptr())
+
+
+def bn_rows_fwd(rec, out, x, gamma, beta, rmean, rvar, save_mean, save_invstd, act, train, drop_p, ws: torch.Tensor,
+                mask=None, seed=0, offset=0, ctrl=None):
+    C_ = x.shape[-1]
+    R = x.numel() // C_
+    if ws.numel() * ws.element_size() < int(lib.fx_bn_rows_workspace_bytes(R, C_)):
+        raise FxError("bn_rows_fwd: scratch too small")
+    rec.emit("fx_bn_rows_fwd", out.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(),
+             rvar.data_ptr(), _ptr(save_mean), _ptr(save_invstd), _ptr(mask), R, C_, int(act), int(bool(train)),
+             float(drop_p), int(seed), int(offset), _ptr(ctrl), ws.data_ptr())
+
+
+def bn_rows_bwd(rec, da, dgamma, dbeta, x, gamma, beta, save_mean, save_invstd, act, drop_p, ws: torch.Tensor, mask=None,
+                seed=0, offset=0, ctrl=None):
+    C_ = x.shape[-1]
+    R = x.numel() // C_
+    if ws.numel() * ws.element_size() < int(lib.fx_bn_rows_workspace_bytes(R, C_)):
+        raise FxError("bn_rows_bwd: scratch too small")
+    rec.emit("fx_bn_rows_bwd", da.data_ptr(), _ptr(dgamma), _ptr(dbeta), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+             save_mean.data_ptr(), save_invstd.data_ptr(), _ptr(mask), R, C_, int(act), float(drop_p), int(seed),
+             int(offset), _ptr(ctrl), ws.data_ptr())

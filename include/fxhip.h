@@ -237,6 +237,37 @@ int fx_ingest_transform(const void* x, int dtype, long ldx, const int* rows, int
                         const double* med, int log1p, const double* mean, const double* scale, float* out, long ldo,
                         fx_stream_t stream);
 
+/* ---- graph-convolution encoder (flexGCN, modules.py:153-262; GNN, models/gnn_early.py:103-158).  Activations are
+ *      [B, nodes, C] fp32 contiguous (node-major in a sample: what x.view(-1, C) and x.view(B, -1) see), 1 <= C <= 32.
+ *      The convolutions are torch_geometric's GraphConv / SAGEConv / GCNConv (un-vendored): each is
+ *        out = (A x) Wa^T [+ x Wr^T] + bias   with A the weighted adjacency the host builds once per graph
+ *      (GC: weight 1; SAGE: 1/in-degree; GCN: self loops + D^-1/2 A D^-1/2), stored as CSR by target node for the
+ *      forward and CSR by source node for the backward (u = A^T dOut; dWa = u^T x; dWr = dOut^T x; dx = u Wa + dOut Wr).
+ *      fx_spmm_rows:    out[b, i, :] = sum_{e in [rowptr[i], rowptr[i+1])} w[e] * x[b, idx[e], :]   (not in place)
+ *      fx_rowlin2:      out[r, :] (+)= a[r, :] Wa^T (+ b[r, :] Wb^T) (+ bias); trans != 0 applies W instead of W^T
+ *                       (Wa then is [Ca, Cout]).  nn.Linear semantics per row, R = B * nodes rows.
+ *      fx_rowlin_wgrad: dW[Cout, Cin] (+)= dy^T x, db[Cout] (+)= column sums of dy, summed in a fixed order.
+ *      fx_bn_rows_fwd:  BatchNorm1d over the R rows (biased batch variance; running stats with momentum 0.1 and the
+ *                       unbiased variance) -> act (0 relu, 1 sigmoid, 2 leakyrelu(0.01), 3 tanh, 4 gelu(erf)) ->
+ *                       Dropout(drop_p) with an explicit mask [R, C] or Philox(seed, offset + step from ctrl).
+ *      fx_bn_rows_bwd:  in place: da holds dL/d(out) on entry, dL/dx on return; dgamma / dbeta are written. */
+int fx_gnn_row_blocks(long R);
+int fx_spmm_rows(float* out, const float* x, const int* rowptr, const int* idx, const float* w, int B, int nodes, int C,
+                 fx_stream_t stream);
+int fx_rowlin2(float* out, const float* a, const float* Wa, int Ca, const float* b, const float* Wb, int Cb,
+               const float* bias, long R, int Cout, int trans, int accumulate, fx_stream_t stream);
+long fx_rowlin_wgrad_workspace_bytes(long R, int Cin, int Cout);
+int fx_rowlin_wgrad(float* dW, float* db, const float* dy, const float* x, long R, int Cin, int Cout, int accumulate,
+                    void* ws, fx_stream_t stream);
+long fx_bn_rows_workspace_bytes(long R, int C);
+int fx_bn_rows_fwd(float* out, const float* x, const float* gamma, const float* beta, float* running_mean,
+                   float* running_var, float* save_mean, float* save_invstd, const float* mask, long R, int C, int act,
+                   int train, float drop_p, unsigned long long seed, unsigned long long offset, const float* ctrl, void* ws,
+                   fx_stream_t stream);
+int fx_bn_rows_bwd(float* da, float* dgamma, float* dbeta, const float* x, const float* gamma, const float* beta,
+                   const float* save_mean, const float* save_invstd, const float* mask, long R, int C, int act, float drop_p,
+                   unsigned long long seed, unsigned long long offset, const float* ctrl, void* ws, fx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

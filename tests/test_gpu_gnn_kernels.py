@@ -1,0 +1,132 @@
+"""Graph-convolution encoder kernels (csrc/fx_gnn.hip through the C ABI) against torch fp64 autograd of the same
+arithmetic: message passing over a shared graph, the row-wise Linear layers and their weight gradients, BatchNorm over
+batch*nodes rows with every flexGCN activation and Dropout(0.2), forward and backward."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def csr_by(key, other, w, n):
+    order = torch.argsort(key, stable=True)
+    rowptr = torch.zeros(n + 1, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(torch.bincount(key, minlength=n), 0)
+    return rowptr.int().cuda(), other[order].int().cuda(), w[order].float().cuda()
+
+
+@pytest.mark.parametrize("B,nodes,C,E", [(5, 40, 3, 200), (9, 257, 16, 3000), (16, 100, 7, 900), (3, 64, 32, 5000), (8, 33, 1, 90)])
+def test_spmm_rows(B, nodes, C, E):
+    from flexynesis_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + C)
+    src = torch.randint(0, nodes, (E,), generator=g)
+    dst = torch.randint(0, nodes, (E,), generator=g)
+    dst[: E // 4] = 7                                             # a hub
+    w = torch.rand(E, generator=g, dtype=torch.float64)
+    x = torch.randn(B, nodes, C, generator=g)
+    rowptr, idx, wv = csr_by(dst, src, w, nodes)
+    out = torch.full((B, nodes, C), float("nan"), device="cuda")
+    ops.spmm_rows(ops.ImmediateRecorder(), out, x.cuda(), rowptr, idx, wv)
+    ref = torch.zeros(B, nodes, C, dtype=torch.float64).index_add(1, dst, x.double()[:, src, :] * w.float().double()[None, :, None])
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("R,Ca,Cb,Cout", [(1000, 3, 3, 16), (777, 16, 16, 16), (513, 32, 32, 32), (300, 7, 0, 5), (64, 1, 1, 4),
+                                          (2000, 20, 20, 9)])
+def test_rowlin2_and_wgrad(R, Ca, Cb, Cout):
+    from flexynesis_amd import ops
+    rec = ops.ImmediateRecorder()
+    g = torch.Generator().manual_seed(R + Ca)
+    a = torch.randn(R, Ca, generator=g)
+    Wa = torch.randn(Cout, Ca, generator=g)
+    bias = torch.randn(Cout, generator=g)
+    b = torch.randn(R, Cb, generator=g) if Cb else None
+    Wb = torch.randn(Cout, Cb, generator=g) if Cb else None
+    ref = a.double() @ Wa.double().t() + bias.double() + (b.double() @ Wb.double().t() if Cb else 0)
+    out = torch.empty(R, Cout, device="cuda")
+    ops.rowlin2(rec, out, a.cuda(), Wa.cuda(), b.cuda() if Cb else None, Wb.cuda() if Cb else None, bias.cuda())
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=1e-5, atol=1e-4)
+    # transposed application (the data gradient): dx = dy Wa, accumulated on top of a first term
+    dy = torch.randn(R, Cout, generator=g)
+    dx = torch.ones(R, Ca, device="cuda")
+    ops.rowlin2(rec, dx, dy.cuda(), Wa.cuda(), trans=True, accumulate=True)
+    torch.testing.assert_close(dx.cpu().double(), 1.0 + dy.double() @ Wa.double(), rtol=1e-5, atol=1e-4)
+    # weight / bias gradient
+    ws = ops.gnn_scratch(R, 32, "cuda")
+    dW = torch.empty(Cout, Ca, device="cuda")
+    db = torch.empty(Cout, device="cuda")
+    ops.rowlin_wgrad(rec, dW, db, dy.cuda(), a.cuda(), ws)
+    torch.testing.assert_close(dW.cpu().double(), dy.double().t() @ a.double(), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(db.cpu().double(), dy.double().sum(0), rtol=1e-4, atol=1e-3)
+    dW2 = dW.clone()
+    ops.rowlin_wgrad(rec, dW2, None, dy.cuda(), a.cuda(), ws, accumulate=True)
+    torch.testing.assert_close(dW2, 2 * dW, rtol=1e-6, atol=1e-6)
+
+
+def ref_act(z, act):
+    return {"relu": torch.relu, "sigmoid": torch.sigmoid, "leakyrelu": lambda t: torch.nn.functional.leaky_relu(t, 0.01),
+            "tanh": torch.tanh, "gelu": torch.nn.functional.gelu}[act](z)
+
+
+@pytest.mark.parametrize("act", ["relu", "sigmoid", "leakyrelu", "tanh", "gelu"])
+@pytest.mark.parametrize("R,C", [(4000, 16), (1234, 7), (70000, 32), (65, 4)])
+def test_bn_rows_fwd_bwd(act, R, C):
+    from flexynesis_amd import ops
+    rec = ops.ImmediateRecorder()
+    g = torch.Generator().manual_seed(R + C)
+    x = (torch.randn(R, C, generator=g) * 2 + 3)
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.3
+    mask = (torch.rand(R, C, generator=g) < 0.8).float()
+    dout = torch.randn(R, C, generator=g)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    xd = x.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    mean = xd.mean(0)
+    var = ((xd - mean) ** 2).mean(0)
+    z = (xd - mean) / torch.sqrt(var + 1e-5) * gd + bd
+    ref = ref_act(z, act) * (mask.double() / 0.8)
+    ref.backward(dout.double())
+    ws = ops.gnn_scratch(R, 32, "cuda")
+    out = torch.empty(R, C, device="cuda")
+    sm, si = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    rmc, rvc = rm.cuda(), rv.cuda()
+    ops.bn_rows_fwd(rec, out, x.cuda(), gamma.cuda(), beta.cuda(), rmc, rvc, sm, si, ops.GACT[act], True, 0.2, ws, mask=mask.cuda())
+    torch.testing.assert_close(out.cpu().double(), ref.detach(), rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(rmc.cpu().double(), 0.1 * mean.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rvc.cpu().double(), 0.9 + 0.1 * var.detach() * R / (R - 1), rtol=1e-5, atol=1e-6)
+    da = dout.cuda().clone()
+    dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    ops.bn_rows_bwd(rec, da, dg, db, x.cuda(), gamma.cuda(), beta.cuda(), sm, si, ops.GACT[act], 0.2, ws, mask=mask.cuda())
+    scale = float(xd.grad.abs().max())
+    torch.testing.assert_close(da.cpu().double(), xd.grad, rtol=1e-4, atol=1e-5 * max(scale, 1.0))
+    torch.testing.assert_close(dg.cpu().double(), gd.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(db.cpu().double(), bd.grad, rtol=1e-4, atol=1e-3)
+    # eval mode: running statistics, no dropout
+    oute = torch.empty(R, C, device="cuda")
+    ops.bn_rows_fwd(rec, oute, x.cuda(), gamma.cuda(), beta.cuda(), rmc, rvc, None, None, ops.GACT[act], False, 0.2, ws)
+    refe = ref_act((x.double() - rmc.cpu().double()) / torch.sqrt(rvc.cpu().double() + 1e-5) * gamma.double() + beta.double(), act)
+    torch.testing.assert_close(oute.cpu().double(), refe, rtol=2e-5, atol=2e-5)
+
+
+def test_bn_rows_philox_mask_is_consistent_between_forward_and_backward():
+    from flexynesis_amd import ops
+    rec = ops.ImmediateRecorder()
+    R, C = 5000, 12
+    x = torch.randn(R, C, device="cuda")
+    gamma, beta = torch.ones(C, device="cuda"), torch.full((C,), 3.0, device="cuda")     # z > 0 almost surely
+    ws = ops.gnn_scratch(R, 32, "cuda")
+    out = torch.empty(R, C, device="cuda")
+    sm, si = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    ops.bn_rows_fwd(rec, out, x, gamma, beta, torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), sm, si, 0, True, 0.2, ws,
+                    seed=11, offset=1 << 32)
+    kept = (out != 0)
+    assert 0.78 < float(kept.float().mean()) < 0.82
+    da = torch.ones(R, C, device="cuda")
+    g_only = torch.ones(R, C, device="cuda")
+    # the backward's first pass writes g = dA * mask/keep * act'(z): zero exactly where the forward dropped
+    ops.bn_rows_bwd(rec, da, torch.empty(C, device="cuda"), torch.empty(C, device="cuda"), x, gamma, beta, sm, si, 0, 0.2, ws,
+                    seed=11, offset=1 << 32)
+    db = torch.empty(C, device="cuda")
+    ops.bn_rows_bwd(rec, g_only, torch.empty(C, device="cuda"), db, x, gamma, beta, sm, si, 0, 0.2, ws, seed=11, offset=1 << 32)
+    torch.testing.assert_close(db, kept.float().sum(0) / 0.8, rtol=1e-5, atol=1e-3)
