@@ -9,7 +9,8 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
-MODEL_KINDS = ("DirectPred", "supervised_vae", "MultiTripletNetwork", "CrossModalPred")
+MODEL_KINDS = ("DirectPred", "supervised_vae", "MultiTripletNetwork", "CrossModalPred", "GNN")
+GNN_CONVS = ("GC", "SAGE", "GCN")        # --gnn_conv_type choices (reference __main__.py:536); GAT is not offered by the CLI
 
 
 @dataclass
@@ -26,6 +27,10 @@ class ArchSpec:
     # CrossModalPred (crossmodal_pred.py:62-65): layers that are encoded / reconstructed; None = every layer
     input_layers: Optional[List[str]] = None
     output_layers: Optional[List[str]] = None
+    # GNN (models/gnn_early.py:103-118): one flexGCN encoder over a graph shared by all samples.  ``layers`` then holds the
+    # single pseudo-layer ("nodes", n_nodes * n_node_features) = the flattened [n_nodes, n_node_features] sample.
+    # keys: nodes, node_features, embedding_dim, num_convs, conv (GC|SAGE|GCN), act, edge_index (int64 ndarray [2, E])
+    gnn: Optional[dict] = None
 
     # -- derived sizes ---------------------------------------------------------------------------
     @property
@@ -63,7 +68,7 @@ class ArchSpec:
     @property
     def extra_loss(self) -> Optional[str]:
         return {"DirectPred": None, "supervised_vae": "mmd_loss", "MultiTripletNetwork": "triplet_loss",
-                "CrossModalPred": "mmd_loss"}[self.model]
+                "CrossModalPred": "mmd_loss", "GNN": None}[self.model]
 
     def loss_names(self) -> List[str]:
         """Insertion order of the reference's ``losses`` dict in training_step
@@ -113,6 +118,21 @@ class ArchSpec:
             if n > 1:
                 out["fusion_block.weight"] = (L, n * L)
                 out["fusion_block.bias"] = (L,)
+        elif self.model == "GNN":
+            # flexGCN (modules.py:197-249) with torch_geometric's parameter names per conv type
+            g = self.gnn
+            C, cin = int(g["embedding_dim"]), int(g["node_features"])
+            for k in range(int(g["num_convs"])):
+                wa, ba, wr = gnn_conv_keys(f"encoders.0.convs.{k}", g["conv"])
+                out[wa] = (C, cin)
+                out[ba] = (C,)
+                if wr:
+                    out[wr] = (C, cin)
+                cin = C
+            for k in range(int(g["num_convs"])):
+                bn(f"encoders.0.bns.{k}", C)
+            out["encoders.0.fc.weight"] = (L, C * int(g["nodes"]))
+            out["encoders.0.fc.bias"] = (L,)
         else:
             n = len(self.enc_idx)
             for j, i in enumerate(self.enc_idx):
@@ -138,18 +158,33 @@ class ArchSpec:
         return out
 
 
+def gnn_conv_keys(prefix: str, conv: str):
+    """(weight applied to the aggregate, bias, weight applied to the node itself or None) of one conv layer:
+    GraphConv lin_rel(+bias) / lin_root, SAGEConv lin_l(+bias) / lin_r, GCNConv lin + bias (torch_geometric names)."""
+    if conv == "GC":
+        return prefix + ".lin_rel.weight", prefix + ".lin_rel.bias", prefix + ".lin_root.weight"
+    if conv == "SAGE":
+        return prefix + ".lin_l.weight", prefix + ".lin_l.bias", prefix + ".lin_r.weight"
+    if conv == "GCN":
+        return prefix + ".lin.weight", prefix + ".bias", None
+    raise ValueError(f"Unknown convolution type {conv!r}. Choose one of: {list(GNN_CONVS)}")
+
+
 def is_buffer_key(key: str) -> bool:
     return key.endswith(("running_mean", "running_var", "num_batches_tracked"))
 
 
 def spec_from_dataset(model: str, config: dict, dataset, target_variables, batch_variables=None,
                       surv_event_var=None, surv_time_var=None, use_loss_weighting=True, input_layers=None,
-                      output_layers=None) -> ArchSpec:
+                      output_layers=None, gnn_conv_type=None) -> ArchSpec:
     """Same derivations as the reference constructors.  ``dataset`` is only read for ``.dat.keys()``,
     ``.features[layer]``, ``.ann[var]`` and ``.variable_types`` (also satisfied by the SimpleNamespace of
     reference inference.py:116-122)."""
     if model not in MODEL_KINDS:
         raise ValueError(f"unknown model class {model!r}")
+    if model == "GNN":
+        return _gnn_spec(config, dataset, target_variables, batch_variables, surv_event_var, surv_time_var,
+                         use_loss_weighting, gnn_conv_type)
     targets = list(target_variables)
     if surv_event_var is not None and surv_time_var is not None:
         targets = targets + [surv_event_var]          # direct_pred.py:48-49
@@ -175,3 +210,45 @@ def spec_from_dataset(model: str, config: dict, dataset, target_variables, batch
                     bool(use_loss_weighting),
                     list(input_layers) if (model == "CrossModalPred" and input_layers) else None,
                     list(output_layers) if (model == "CrossModalPred" and output_layers) else None)
+
+
+def _var_specs(dataset, variables):
+    out = []
+    for v in variables:
+        if dataset.variable_types[v] == "numerical":
+            out.append((v, "numerical", 1))
+        else:
+            ann = dataset.ann[v]
+            arr = ann.detach().cpu().numpy() if hasattr(ann, "detach") else np.asarray(ann)
+            out.append((v, "categorical", int(len(np.unique(arr)))))
+    return out
+
+
+def _gnn_spec(config, dataset, target_variables, batch_variables, surv_event_var, surv_time_var, use_loss_weighting,
+              gnn_conv_type) -> ArchSpec:
+    """GNN.__init__ (reference models/gnn_early.py:58-130): ``dataset`` is a MultiOmicDatasetNW -- node feature
+    tensor [n_samples, n_nodes, n_node_features] and one edge_index for all samples."""
+    conv = gnn_conv_type if gnn_conv_type is not None else "GC"       # flexGCN's default conv (modules.py:205)
+    gnn_conv_keys("x", conv)                                           # validates the choice
+    act = str(config.get("activation", "relu"))
+    if act not in ("relu", "sigmoid", "leakyrelu", "tanh", "gelu"):
+        raise ValueError(f"Invalid activation function string {act!r}")
+    targets = list(target_variables)
+    if surv_event_var is not None and surv_time_var is not None:
+        targets = targets + [surv_event_var]
+    variables = targets + list(batch_variables) if batch_variables else targets
+    src = getattr(dataset, "multiomic_dataset", dataset)
+    x0 = dataset[0][0]
+    nodes, nf = int(x0.shape[0]), int(x0.shape[1])
+    ei = dataset.edge_index
+    ei = ei.detach().cpu().numpy() if hasattr(ei, "detach") else np.asarray(ei)
+    if ei.ndim != 2 or ei.shape[0] != 2:
+        raise ValueError(f"edge_index must be [2, n_edges], got {ei.shape}")
+    if ei.size and (ei.min() < 0 or ei.max() >= nodes):
+        raise ValueError("edge_index refers to nodes outside the node feature tensor")
+    gnn = {"nodes": nodes, "node_features": nf, "embedding_dim": int(config["node_embedding_dim"]),
+           "num_convs": int(config["num_convs"]), "conv": conv, "act": act, "edge_index": ei.astype(np.int64)}
+    if not (1 <= gnn["embedding_dim"] <= 32 and 1 <= nf <= 32):
+        raise ValueError("the graph kernels cover node widths 1..32 (reference search space: 4..32, config.py:45)")
+    return ArchSpec("GNN", [("nodes", nodes * nf)], int(config["latent_dim"]), 0.0, int(config["supervisor_hidden_dim"]),
+                    _var_specs(src, variables), surv_event_var, surv_time_var, bool(use_loss_weighting), gnn=gnn)

@@ -150,3 +150,80 @@ def synthetic_cohort(layers, n: int, device, seed: int = 1234, n_classes: int = 
         "event": (torch.rand(n, generator=g, device=dev) < 0.5).float(),
     }
     return DeviceCohort(dat, ann, dev)
+
+
+class MultiOmicDatasetNW(Dataset):
+    """Network view of a MultiOmicDataset for the GNN model (reference data.py:1153-1266): nodes = the features that
+    occur both in some omics layer and in the interaction table, one feature per layer on every node (sorted layer
+    names), features a layer lacks filled with the per-sample median over the nodes, one ``edge_index`` for all
+    samples.  ``interaction_df`` has columns protein1 / protein2 (the reference's STRING table); an ``edge_index``
+    [2, E] over ``node_names`` can be given instead.
+    ``dat`` / ``features`` expose the node tensor as the single pseudo-layer "nodes" ([n_samples, nodes * layers]) so the
+    engine's cohort and fit loop see an ordinary dataset."""
+
+    def __init__(self, multiomic_dataset, interaction_df=None, modality_order=None, *, edge_index=None, node_names=None):
+        self.multiomic_dataset = multiomic_dataset
+        self.interaction_df = interaction_df
+        md = multiomic_dataset
+        self.modality_order = modality_order if modality_order else sorted(md.dat.keys())
+        feats = {k: [str(f) for f in md.features[k]] for k in md.dat.keys()}
+        all_feats = set().union(*(set(v) for v in feats.values()))
+        if interaction_df is not None:
+            p1, p2 = [str(a) for a in interaction_df["protein1"]], [str(a) for a in interaction_df["protein2"]]
+            self.common_features = sorted(all_feats & (set(p1) | set(p2)))
+            self.gene_to_index = {g: i for i, g in enumerate(self.common_features)}
+            keep = [(self.gene_to_index[a], self.gene_to_index[b]) for a, b in zip(p1, p2)
+                    if a in self.gene_to_index and b in self.gene_to_index]
+            self.edge_index = torch.tensor(keep, dtype=torch.long).t().reshape(2, -1)
+        else:
+            if edge_index is None or node_names is None:
+                raise ValueError("give interaction_df, or edge_index together with node_names")
+            self.common_features = [str(n) for n in node_names]
+            self.gene_to_index = {g: i for i, g in enumerate(self.common_features)}
+            self.edge_index = torch.as_tensor(edge_index, dtype=torch.long).reshape(2, -1)
+        self.samples = md.samples
+        self.variable_types = md.variable_types
+        self.label_mappings = md.label_mappings
+        self.ann = md.ann
+        self.labels = dict(md.ann)
+        self.node_features_tensor = self.precompute_node_features()
+
+    def precompute_node_features(self):
+        md = self.multiomic_dataset
+        first = next(iter(md.dat.values()))
+        n, nodes, dev = len(self.samples), len(self.common_features), first.device
+        order = sorted(md.dat.keys())                                   # reference data.py:1219
+        out = torch.full((n, nodes, len(order)), float("nan"), dtype=torch.float32, device=dev)
+        for i, layer in enumerate(order):
+            pos = {str(f): j for j, f in enumerate(md.features[layer])}
+            have = [(self.gene_to_index[gname], pos[gname]) for gname in self.common_features if gname in pos]
+            if have:
+                node_pos = torch.tensor([a for a, _ in have], dtype=torch.long, device=dev)
+                col = torch.tensor([b for _, b in have], dtype=torch.long, device=dev)
+                out[:, node_pos, i] = md.dat[layer][:, col].to(torch.float32)
+        med = torch.nanmedian(out, dim=1, keepdim=True).values           # per sample and layer, over the nodes
+        nan = torch.isnan(out)
+        out[nan] = med.expand_as(out)[nan]
+        return out
+
+    @property
+    def dat(self):
+        return {"nodes": self.node_features_tensor.reshape(len(self.samples), -1)}
+
+    @property
+    def features(self):
+        k = self.node_features_tensor.shape[2]
+        return {"nodes": [f"{g}:{j}" for g in self.common_features for j in range(k)]}
+
+    def subset(self, indices):
+        sub = self.multiomic_dataset.subset(indices)
+        return MultiOmicDatasetNW(sub, self.interaction_df, self.modality_order,
+                                  edge_index=None if self.interaction_df is not None else self.edge_index,
+                                  node_names=None if self.interaction_df is not None else self.common_features)
+
+    def __getitem__(self, idx):
+        y = {k: v[idx] for k, v in self.labels.items()}
+        return self.node_features_tensor[idx], y, self.samples[idx]
+
+    def __len__(self):
+        return len(self.samples)

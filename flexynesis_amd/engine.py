@@ -35,6 +35,7 @@ from .arch import ArchSpec, is_buffer_key
 from .ops import ACT_LEAKY, ACT_NONE, ACT_RELU, TapeRecorder, Workspace
 
 DROPOUT_P = 0.1          # nn.Dropout(p=0.1), reference modules.py:132
+GNN_DROPOUT_P = 0.2      # flexGCN(dropout_rate=0.2), reference modules.py:204
 MMD_PRIOR = 200          # torch.randn(200, latent_dim), reference supervised_vae.py:545
 CLIP_MAX_NORM = 1.0      # gradient_clip_val=1.0, reference main.py:216
 TRIPLET_MARGIN = 1.0
@@ -141,8 +142,10 @@ class ParamStore:
             t, shp = self.p(k), self.shapes[k]
             if k.startswith("log_vars."):
                 t.zero_()
-            elif ".batchnorm." in k or ".hidden_layers.2." in k:
+            elif ".batchnorm." in k or ".hidden_layers.2." in k or ".bns." in k:
                 t.fill_(1.0) if k.endswith("weight") else t.zero_()
+            elif ".convs." in k and k.endswith(".bias"):
+                t.zero_()                                    # torch_geometric initialises conv biases to zero
             elif k.endswith(".weight"):
                 fan_out, fan_in = shp
                 xavier = (k.startswith(("encoders.", "decoders.")) and
@@ -619,6 +622,8 @@ class StepPlan:
             for i, (name, F) in enumerate(spec.layers):
                 gpar.branch(i if self.branches else 0)
                 wk = first_w.format(enc_pos[i]) if i in enc_pos else None      # layers that are only reconstructed have no encoder
+                if spec.model == "GNN":
+                    wk = None                                                    # node features feed a graph conv, not a wide Linear
                 if self.precision == "bf16x3" and wk in self.store.big:
                     # one pass: gather + fp32 copy + the bf16 splits the wide-layer kernels consume
                     sp, spt = ops.new_split_kb(self.R, F, self.dev), ops.new_split(F, self.R, self.dev)
@@ -642,6 +647,8 @@ class StepPlan:
             self._alloc_slots()
         if spec.is_vae:
             self._build_svae()
+        elif spec.model == "GNN":
+            self._build_gnn()
         else:
             self._build_mlp_family()
         if self.train:
@@ -694,6 +701,77 @@ class StepPlan:
                 self._enter_branch(par, i)
                 self._mlp_bwd(rb, f"encoders.{i}", self.X[i], decat[:, i * L:(i + 1) * L], R, self.passes)
         self._branch = 0
+
+    def _build_gnn(self):
+        """GNN (models/gnn_early.py:142-198): flexGCN encoder (modules.py:251-262: per layer conv -> BatchNorm1d over the
+        batch*nodes rows -> act -> Dropout(0.2); flatten; fc) -> supervisor heads, losses as DirectPred.
+        A conv layer is out = (A h) Wa^T + [h Wr^T] + b with A the graph's weighted adjacency (graph.py); its backward
+        is u = A^T dOut, dWa = u^T h, dWr = dOut^T h, db = colsum(dOut), dh = u Wa + dOut Wr."""
+        from . import graph as G
+        from .arch import gnn_conv_keys
+        spec, st, B, L = self.spec, self.store, self.B, self.spec.latent_dim
+        g = spec.gnn
+        nodes, C, K = int(g["nodes"]), int(g["embedding_dim"]), int(g["num_convs"])
+        rf, rb = self.t_fwd, self.t_bwd
+        gop = G.build(g["edge_index"], nodes, g["conv"], self.dev)
+        self.buf["graph"] = gop
+        act = ops.GACT[g["act"]]
+        scratch = ops.gnn_scratch(B * nodes, 32, self.dev)
+        self.buf["gnn/scratch"] = scratch
+        drop = GNN_DROPOUT_P if self.train else 0.0
+        h = self.X[0].view(B, nodes, int(g["node_features"]))
+        layers = []
+        for k in range(K):
+            p, bnp = f"encoders.0.convs.{k}", f"encoders.0.bns.{k}"
+            wa, ba, wr = gnn_conv_keys(p, g["conv"])
+            cin = h.shape[2]
+            agg = self._new(p + "/agg", B, nodes, cin)
+            ops.spmm_rows(rf, agg, h, gop.t_rowptr, gop.t_idx, gop.t_w)
+            y = self._new(p + "/y", B, nodes, C)
+            ops.rowlin2(rf, y, agg, st.p(wa), h if wr else None, st.p(wr) if wr else None, st.p(ba))
+            a = self._new(p + "/a", B, nodes, C)
+            sm, si = self._new(bnp + "/save_mean", C), self._new(bnp + "/save_invstd", C)
+            mask = self._draw(f"encoders.0.drop.{k}", B, nodes, C) if (self.supplied and self.train) else None
+            seed, off = self._rng()
+            ops.bn_rows_fwd(rf, a, y, st.p(bnp + ".weight"), st.p(bnp + ".bias"), st.b(bnp + ".running_mean"),
+                            st.b(bnp + ".running_var"), sm if self.train else None, si if self.train else None, act,
+                            self.train, drop, scratch, mask=mask, seed=seed, offset=off, ctrl=st.ctrl)
+            layers.append((h, y, sm, si, mask, seed, off, wa, ba, wr, bnp))
+            h = a
+        hflat = h.view(B, nodes * C)
+        emb = self._new("emb", B, L)
+        self._lin_fwd(rf, emb, hflat, "encoders.0.fc.weight", "encoders.0.fc.bias")
+        self.embeddings = emb
+        self._head_losses(rf, emb)
+        self._total(rf)
+        if not self.train:
+            return
+        # ---- backward
+        demb = self._new("demb", B, L)
+        self._head_bwd(rb, emb, demb)
+        if self._is_frozen("encoders.0.fc.weight"):
+            return              # FineTuner "encoders": True
+        self._weight_grad(rb, "encoders.0.fc.weight", demb, hflat)
+        ops.colsum(rb, st.g("encoders.0.fc.bias"), demb)
+        dh = self._new("gnn/dh", B, nodes * C)
+        self._lin_bwd_x(rb, dh, demb, "encoders.0.fc.weight")
+        da = dh.view(B, nodes, C)
+        for k in reversed(range(K)):
+            h_in, y, sm, si, mask, seed, off, wa, ba, wr, bnp = layers[k]
+            ops.bn_rows_bwd(rb, da, st.g(bnp + ".weight"), st.g(bnp + ".bias"), y, st.p(bnp + ".weight"), st.p(bnp + ".bias"),
+                            sm, si, act, drop, scratch, mask=mask, seed=seed, offset=off, ctrl=st.ctrl)      # da <- dL/dy
+            u = self._new(f"encoders.0.convs.{k}/u", B, nodes, C)
+            ops.spmm_rows(rb, u, da, gop.s_rowptr, gop.s_idx, gop.s_w)
+            if wr:
+                ops.rowlin_wgrad(rb, st.g(wa), None, u, h_in, scratch)
+                ops.rowlin_wgrad(rb, st.g(wr), st.g(ba), da, h_in, scratch)
+            else:
+                ops.rowlin_wgrad(rb, st.g(wa), None, u, h_in, scratch)
+                ops.rowlin_wgrad(rb, None, st.g(ba), da, h_in, scratch)
+            if k > 0:
+                dx = self._new(f"encoders.0.convs.{k}/dx", B, nodes, h_in.shape[2])
+                ops.rowlin2(rb, dx, u, st.p(wa), da if wr else None, st.p(wr) if wr else None, None, trans=True)
+                da = dx
 
     def _enter_branch(self, par, i):
         """Route subsequent emits to graph branch i (with its own split-K scratch)."""

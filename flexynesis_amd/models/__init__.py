@@ -4,5 +4,6 @@ from .direct_pred import DirectPred
 from .supervised_vae import supervised_vae
 from .triplet_encoder import MultiTripletNetwork
 from .crossmodal_pred import CrossModalPred
+from .gnn import GNN
 
-__all__ = ["DirectPred", "supervised_vae", "MultiTripletNetwork", "CrossModalPred"]
+__all__ = ["DirectPred", "supervised_vae", "MultiTripletNetwork", "CrossModalPred", "GNN"]
