@@ -41,7 +41,10 @@ __device__ __forceinline__ float sum_over_rowsub(float v, int CP) {
 }
 
 // ---- SpMM with a narrow dense side -------------------------------------------------------------------------------
-// One wavefront walks a tile of `npw` nodes of one sample; for a node, 64/CP edges are in flight at once.
+// One wavefront walks a tile of `npw` nodes of one sample.  A lane owns VEC consecutive channels (one 16-byte load
+// when C % 4 == 0) of one edge slot; 64 / CP edge slots work on a node at once (CP = power of two >= C / VEC), two
+// edges per slot are in flight, and the slots are combined with shuffles.
+template <int VEC>
 __global__ __launch_bounds__(GN_T) void fx_spmm_rows_kernel(float* __restrict__ out, const float* __restrict__ x,
                                                             const int* __restrict__ rowptr, const int* __restrict__ idx,
                                                             const float* __restrict__ w, int B, int nodes, int C,
@@ -53,23 +56,50 @@ __global__ __launch_bounds__(GN_T) void fx_spmm_rows_kernel(float* __restrict__ 
   const int b = xcd + 8 * (j / tiles);
   const int tile = j % tiles;
   if (b >= B) return;
-  const int CP = cp_of(C), EG = 64 / CP;
+  const int CQ = C / VEC, CP = cp_of(CQ), EG = 64 / CP;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = lane & (CP - 1), eg = lane / CP;
-  const bool cok = c < C;
-  const float* xb = x + (long)b * nodes * C;
-  float* ob = out + (long)b * nodes * C;
+  const int cq = lane & (CP - 1), eg = lane / CP;
+  const bool cok = cq < CQ;
+  const int coff = (cok ? cq : 0) * VEC;
+  const float* xb = x + (long)b * nodes * C + coff;
+  float* ob = out + (long)b * nodes * C + coff;
+  typedef float __attribute__((ext_vector_type(VEC))) vf;
   const int n0 = (tile * (GN_T / 64) + wave) * npw;
   for (int i = n0; i < n0 + npw && i < nodes; ++i) {
     const int e0 = rowptr[i], e1 = rowptr[i + 1];
-    float acc = 0.f;
-    for (int e = e0 + eg; e < e1; e += EG) {
-      const int s = idx[e];
-      const float we = w[e];
-      if (cok) acc += we * xb[(long)s * C + c];
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+    for (int e = e0 + eg; e < e1; e += 2 * EG) {
+      const int e2 = e + EG;
+      const bool two = e2 < e1;
+      const int sa = idx[e], sb = idx[two ? e2 : e];
+      const float wa = w[e], wb = two ? w[e2] : 0.f;
+      float va[VEC], vb[VEC];
+      if (VEC == 4) {
+        const float4 ta = *(const float4*)(xb + (long)sa * C), tb = *(const float4*)(xb + (long)sb * C);
+        va[0] = ta.x; va[1 % VEC] = ta.y; va[2 % VEC] = ta.z; va[3 % VEC] = ta.w;
+        vb[0] = tb.x; vb[1 % VEC] = tb.y; vb[2 % VEC] = tb.z; vb[3 % VEC] = tb.w;
+      } else {
+        va[0] = xb[(long)sa * C];
+        vb[0] = xb[(long)sb * C];
+      }
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] += wa * va[v] + wb * vb[v];
     }
-    acc = sum_over_rowsub(acc, CP);
-    if (eg == 0 && cok) ob[(long)i * C + c] = acc;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      float t = cok ? acc[v] : 0.f;
+      for (int off = 32; off >= CP; off >>= 1) t += __shfl_xor(t, off, 64);
+      acc[v] = t;
+    }
+    if (eg == 0 && cok) {
+      if (VEC == 4) {
+        *(float4*)(ob + (long)i * C) = make_float4(acc[0], acc[1 % VEC], acc[2 % VEC], acc[3 % VEC]);
+      } else {
+        ob[(long)i * C] = acc[0];
+      }
+    }
   }
 }
 
@@ -174,19 +204,30 @@ __global__ __launch_bounds__(GN_T) void fx_rowlin_wgrad_kernel(float* __restrict
   }
 }
 
+// 256 threads = 32 pairs x 8 slices of the block range; the 8 slice sums are added in slice order.
 __global__ __launch_bounds__(GN_T) void fx_rowlin_wgrad_merge_kernel(float* __restrict__ dW, float* __restrict__ db,
                                                                      const float* __restrict__ partial, int blocks,
                                                                      int Cin, int Cout, int accumulate) {
+  __shared__ float part[8][32];
   const int npairs = Cout * (Cin + 1);
-  const int p = blockIdx.x * GN_T + threadIdx.x;
-  if (p >= npairs) return;
+  const int pl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int p = blockIdx.x * 32 + pl;
   float s = 0.f;
-  for (int k = 0; k < blocks; ++k) s += partial[(long)k * npairs + p];
+  if (p < npairs) {
+#pragma unroll 4
+    for (int k = sl; k < blocks; k += 8) s += partial[(long)k * npairs + p];
+  }
+  part[sl][pl] = s;
+  __syncthreads();
+  if (sl != 0 || p >= npairs) return;
+  float t = 0.f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) t += part[q][pl];
   const int o = p / (Cin + 1), c = p % (Cin + 1);
   if (c < Cin) {
-    if (dW) dW[o * Cin + c] = accumulate ? dW[o * Cin + c] + s : s;
+    if (dW) dW[o * Cin + c] = accumulate ? dW[o * Cin + c] + t : t;
   } else if (db) {
-    db[o] = accumulate ? db[o] + s : s;
+    db[o] = accumulate ? db[o] + t : t;
   }
 }
 
@@ -284,18 +325,43 @@ __global__ __launch_bounds__(GN_T) void fx_bn_rows_reduce_kernel(BnRows a) {
   }
 }
 
+// Sum the per-block partials [blocks][2][C]: 256 threads = 32 channels x 8 slices of the block range, slice sums
+// added in slice order (fixed summation order -> bit-reproducible).
+__device__ __forceinline__ void bn_rows_sum_partials(const double* __restrict__ partial, int blocks, int C, double& s0,
+                                                     double& s1) {
+  __shared__ double part[2][8][32];
+  const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  double a0 = 0.0, a1 = 0.0;
+  if (c < C) {
+#pragma unroll 4
+    for (int k = sl; k < blocks; k += 8) {
+      a0 += partial[((long)k * 2) * C + c];
+      a1 += partial[((long)k * 2 + 1) * C + c];
+    }
+  }
+  part[0][sl][c] = a0;
+  part[1][sl][c] = a1;
+  __syncthreads();
+  s0 = 0.0;
+  s1 = 0.0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    s0 += part[0][q][c];
+    s1 += part[1][q][c];
+  }
+}
+
 // forward finalize: batch statistics, running statistics (momentum 0.1, unbiased running_var)
-__global__ void fx_bn_rows_stats_finalize_kernel(const double* __restrict__ partial, int blocks, const float* __restrict__ x,
-                                                 long R, int C, float* __restrict__ save_mean,
-                                                 float* __restrict__ save_invstd, float* __restrict__ running_mean,
-                                                 float* __restrict__ running_var) {
+__global__ __launch_bounds__(GN_T) void fx_bn_rows_stats_finalize_kernel(const double* __restrict__ partial, int blocks,
+                                                                         const float* __restrict__ x, long R, int C,
+                                                                         float* __restrict__ save_mean,
+                                                                         float* __restrict__ save_invstd,
+                                                                         float* __restrict__ running_mean,
+                                                                         float* __restrict__ running_var) {
+  double s0, s1;
+  bn_rows_sum_partials(partial, blocks, C, s0, s1);
   const int c = threadIdx.x;
   if (c >= C) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int k = 0; k < blocks; ++k) {
-    s0 += partial[((long)k * 2) * C + c];
-    s1 += partial[((long)k * 2 + 1) * C + c];
-  }
   const double n = (double)R;
   const double dm = s0 / n;
   const double mean = (double)x[c] + dm;
@@ -309,16 +375,13 @@ __global__ void fx_bn_rows_stats_finalize_kernel(const double* __restrict__ part
 }
 
 // backward finalize: dgamma = sum g*xhat, dbeta = sum g
-__global__ void fx_bn_rows_bwd_finalize_kernel(const double* __restrict__ partial, int blocks, int C,
-                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                               float* __restrict__ sums /* [2][C]: sum g, sum g*xhat as floats */) {
+__global__ __launch_bounds__(GN_T) void fx_bn_rows_bwd_finalize_kernel(const double* __restrict__ partial, int blocks, int C,
+                                                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                       float* __restrict__ sums /* [2][C] as floats */) {
+  double s0, s1;
+  bn_rows_sum_partials(partial, blocks, C, s0, s1);
   const int c = threadIdx.x;
   if (c >= C) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int k = 0; k < blocks; ++k) {
-    s0 += partial[((long)k * 2) * C + c];
-    s1 += partial[((long)k * 2 + 1) * C + c];
-  }
   if (dbeta) dbeta[c] = (float)s0;
   if (dgamma) dgamma[c] = (float)s1;
   sums[c] = (float)s0;
@@ -375,7 +438,7 @@ __global__ __launch_bounds__(GN_T) void fx_bn_rows_bwd_apply_kernel(float* __res
 
 inline int row_blocks(long R, long* rows_per_block) {
   long b = (R + 255) / 256;
-  if (b > 1024) b = 1024;
+  if (b > 512) b = 512;        // 2 workgroups per CU; the partial sums are merged by one small workgroup
   if (b < 1) b = 1;
   long rpb = (R + b - 1) / b;
   rpb = ((rpb + 63) / 64) * 64;  // whole 64-row tiles
@@ -401,8 +464,13 @@ int fx_spmm_rows(float* out, const float* x, const int* rowptr, const int* idx, 
   int npw = 8;  // nodes per wavefront
   const int tiles = (nodes + waves * npw - 1) / (waves * npw);
   const int bgroups = (B + 7) / 8;
-  hipLaunchKernelGGL(fx_spmm_rows_kernel, dim3(8 * bgroups * tiles), dim3(GN_T), 0, stream, out, x, rowptr, idx, w, B, nodes,
-                     C, tiles, npw);
+  const bool v4 = (C % 4 == 0) && ((((uintptr_t)x) & 15) == 0) && ((((uintptr_t)out) & 15) == 0);
+  if (v4)
+    hipLaunchKernelGGL(fx_spmm_rows_kernel<4>, dim3(8 * bgroups * tiles), dim3(GN_T), 0, stream, out, x, rowptr, idx, w, B,
+                       nodes, C, tiles, npw);
+  else
+    hipLaunchKernelGGL(fx_spmm_rows_kernel<1>, dim3(8 * bgroups * tiles), dim3(GN_T), 0, stream, out, x, rowptr, idx, w, B,
+                       nodes, C, tiles, npw);
   return fx_check_launch("fx_spmm_rows");
 }
 
@@ -446,8 +514,8 @@ int fx_rowlin_wgrad(float* dW, float* db, const float* dy, const float* x, long 
   int rc = fx_check_launch("fx_rowlin_wgrad");
   if (rc) return rc;
   const int npairs = Cout * (Cin + 1);
-  hipLaunchKernelGGL(fx_rowlin_wgrad_merge_kernel, dim3((npairs + GN_T - 1) / GN_T), dim3(GN_T), 0, stream, dW, db, partial,
-                     blocks, Cin, Cout, accumulate);
+  hipLaunchKernelGGL(fx_rowlin_wgrad_merge_kernel, dim3((npairs + 31) / 32), dim3(GN_T), 0, stream, dW, db, partial, blocks,
+                     Cin, Cout, accumulate);
   return fx_check_launch("fx_rowlin_wgrad(merge)");
 }
 
@@ -477,7 +545,7 @@ int fx_bn_rows_fwd(float* out, const float* x, const float* gamma, const float* 
     hipLaunchKernelGGL(fx_bn_rows_reduce_kernel, dim3(blocks), dim3(GN_T), 0, stream, a);
     int rc = fx_check_launch("fx_bn_rows_fwd(stats)");
     if (rc) return rc;
-    hipLaunchKernelGGL(fx_bn_rows_stats_finalize_kernel, dim3(1), dim3(64), 0, stream, a.partial, blocks, x, R, C, save_mean,
+    hipLaunchKernelGGL(fx_bn_rows_stats_finalize_kernel, dim3(1), dim3(GN_T), 0, stream, a.partial, blocks, x, R, C, save_mean,
                        save_invstd, running_mean, running_var);
     rc = fx_check_launch("fx_bn_rows_fwd(finalize)");
     if (rc) return rc;
@@ -507,7 +575,7 @@ int fx_bn_rows_bwd(float* da, float* dgamma, float* dbeta, const float* x, const
   hipLaunchKernelGGL(fx_bn_rows_reduce_kernel, dim3(blocks), dim3(GN_T), 0, stream, a);
   int rc = fx_check_launch("fx_bn_rows_bwd(reduce)");
   if (rc) return rc;
-  hipLaunchKernelGGL(fx_bn_rows_bwd_finalize_kernel, dim3(1), dim3(64), 0, stream, a.partial, blocks, C, dgamma, dbeta, sums);
+  hipLaunchKernelGGL(fx_bn_rows_bwd_finalize_kernel, dim3(1), dim3(GN_T), 0, stream, a.partial, blocks, C, dgamma, dbeta, sums);
   rc = fx_check_launch("fx_bn_rows_bwd(finalize)");
   if (rc) return rc;
   hipLaunchKernelGGL(fx_bn_rows_bwd_apply_kernel, dim3(blocks), dim3(GN_T), 0, stream, da, x, gamma, save_mean, save_invstd,
