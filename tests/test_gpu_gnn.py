@@ -216,3 +216,81 @@ def test_gnn_model_class_protocol_and_fit(conv):
     m2 = copy.deepcopy(model)
     m2.load_state_dict(model.state_dict())
     assert np.allclose(m2.predict(nw)["y"], pred["y"], atol=1e-6)
+
+
+@pytest.mark.parametrize("frozen", [("encoders.",), ("MLPs.",)])
+def test_gnn_finetune_step_frozen_groups_vs_oracle(frozen):
+    """FineTuner configuration (reference main.py:530-539,562-566): requires_grad=False groups, no clipping."""
+    from flexynesis_amd.engine import ParamStore, StepPlan
+    from oracle import restate as O
+    dev = torch.device("cuda:0")
+    variables = [("y", "numerical", 1), ("c", "categorical", 3)]
+    aspec, ospec = make_specs("GC", "relu", 150, 2, 8, 2, variables)
+    st = O.init_state(ospec, seed=6)
+    B = 24
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 300, generator=gen)
+    y = {"y": torch.randn(B, generator=gen), "c": torch.randint(0, 3, (B,), generator=gen).float()}
+    store = ParamStore(aspec, dev, big_threshold=1 << 10)
+    store.load_state(st)
+    plan = StepPlan(store, B, train=True, fused=True, supplied_draws=True, clip=False, frozen=frozen)
+    draws = {n: (torch.rand(t.shape, generator=gen) < (0.8 if ".drop." in n else 0.9)).float() for n, t in plan.draws.items()}
+    plan.set_batch(x_list=[x.to(dev)], y={k: v.to(dev) for k, v in y.items()})
+    plan.set_draws({k: v.to(dev) for k, v in draws.items()})
+    plan.train_step(1e-3)
+    st2, _, info = O.train_step(ospec, st, {}, {"x": [x], "y": y}, draws, 1e-3, clip=False, frozen=frozen)
+    got = plan.losses()
+    for k, v in info["losses"].items():
+        close(got[k], v, 2e-5, 1e-6, f"loss {k}")
+    sd = store.state_dict()
+    for k in st:
+        if k.endswith("num_batches_tracked"):
+            continue
+        if k.startswith(frozen) and "running" not in k:
+            assert torch.equal(sd[k], st[k]), f"frozen parameter {k} moved"
+        elif k in store.big_keys:
+            a, b_ = sd[k].double(), st2[k].double()
+            assert float((a - b_).norm() / (b_ - st[k].double()).norm()) <= 2e-2, k
+        else:
+            atol = noise_atol(info["grads"].get(k), info["grad_norm"], 1e-3, 3e-6)
+            close(sd[k], st2[k], 2e-4, atol, k)
+
+
+def test_gnn_run_trial_and_fine_tune():
+    from flexynesis_amd.models import GNN
+    from flexynesis_amd.fit import run_trial, fine_tune
+    ds, nw = _nw_dataset(n=80)
+    params = {"latent_dim": 16, "node_embedding_dim": 6, "num_convs": 2, "lr": 1e-3, "supervisor_hidden_dim": 8, "epochs": 2,
+              "batch_size": 16, "activation": "relu"}
+    val, epochs, model, info = run_trial(GNN, params, nw, ["y", "c"], seed=1, device="cuda:0", gnn_conv_type="SAGE")
+    assert np.isfinite(val) and epochs == 2 and model.spec.gnn["conv"] == "SAGE", info
+    final, best, results = fine_tune(model, nw, n_splits=2, batch_size=16, max_epoch=2, learning_rates=[1e-3],
+                                     freeze_configs=[{"encoders": True, "supervisors": False}, {"encoders": False, "supervisors": False}])
+    assert len(results) == 2 and np.isfinite(best["average_val_loss"])
+    assert np.isfinite(final.predict(nw)["y"]).all()
+
+
+def test_gnn_and_ingest_bad_arguments_raise():
+    from flexynesis_amd import ops
+    from flexynesis_amd.ops import FxError
+    rec = ops.ImmediateRecorder()
+    x = torch.zeros(2, 10, 40, device="cuda")                      # C = 40 > 32
+    rp = torch.zeros(11, dtype=torch.int32, device="cuda")
+    e = torch.zeros(1, dtype=torch.int32, device="cuda")
+    w = torch.zeros(1, device="cuda")
+    with pytest.raises(FxError):
+        ops.spmm_rows(rec, torch.zeros_like(x), x, rp, e, w)
+    x8 = torch.zeros(2, 10, 8, device="cuda")
+    with pytest.raises(FxError):
+        ops.spmm_rows(rec, x8, x8, rp, e, w)                        # in place
+    with pytest.raises(FxError):
+        ops.rowlin2(rec, torch.zeros(20, 8, device="cuda"), x8, torch.zeros(4, 4, device="cuda"))
+    with pytest.raises(FxError):
+        ops.bn_rows_fwd(rec, x8.clone(), x8, w, w, w, w, None, None, 9, False, 0.0, ops.gnn_scratch(20, 32, "cuda"))   # unknown act
+    with pytest.raises(FxError):
+        ops.col_moments(rec, torch.zeros(4, 4, dtype=torch.float16, device="cuda"))
+    with pytest.raises(FxError):
+        ops.ingest_transform(rec, torch.zeros(4, 4, device="cuda"), torch.zeros(3, 4, device="cuda"))
+    from flexynesis_amd.arch import gnn_conv_keys
+    with pytest.raises(ValueError):
+        gnn_conv_keys("x", "GAT")
