@@ -208,3 +208,22 @@ def test_full_size_properties_and_fit_on_ingested_cohort():
                         "epochs": 2}, ds, ["y"], device_type="cuda")
     r = fit(model, ds, np.arange(0, 1792), np.arange(1792, N), batch_size=128, epochs=2, lr=1e-3, patience=5, seed=0)
     assert np.isfinite(r.val_loss) and r.steps == 2 * (1792 // 128)
+
+
+def test_strided_device_views_are_ingested_in_place():
+    """A column window of a wider resident matrix (leading dimension > n_features, base address not 16-byte aligned)
+    goes through the scalar-load path without a copy and gives the same result as the compact matrix."""
+    rng = np.random.default_rng(31)
+    N, F = 120, 333
+    big = rng.normal(size=(N, F + 10)) * 2 + 1
+    big[rng.integers(0, N, 60), rng.integers(0, F + 10, 60)] = np.nan
+    for dt in (torch.float32, torch.float64):
+        wide = torch.from_numpy(big).to(dt).cuda()
+        view = wide[:, 3:3 + F]
+        assert view.stride(0) == F + 10 and view.data_ptr() % 16 != 0
+        a = _imp().import_matrices({"x": view})
+        b = _imp().import_matrices({"x": view.contiguous()})
+        assert np.array_equal(a.features["x"], b.features["x"]) and np.array_equal(a.train_rows, b.train_rows)
+        assert torch.equal(a.train["x"], b.train["x"])
+        out = R.import_matrices({"x": big[:, 3:3 + F].astype(np.float32 if dt == torch.float32 else np.float64)})
+        close_fp32(a.train["x"], out["train"]["x"], what=str(dt), min_exact=0.999)
