@@ -80,6 +80,10 @@ __global__ __launch_bounds__(GN_T) void fx_spmm_rows_kernel(float* __restrict__ 
         const float4 ta = *(const float4*)(xb + (long)sa * C), tb = *(const float4*)(xb + (long)sb * C);
         va[0] = ta.x; va[1 % VEC] = ta.y; va[2 % VEC] = ta.z; va[3 % VEC] = ta.w;
         vb[0] = tb.x; vb[1 % VEC] = tb.y; vb[2 % VEC] = tb.z; vb[3 % VEC] = tb.w;
+      } else if (VEC == 2) {
+        const float2 ta = *(const float2*)(xb + (long)sa * C), tb = *(const float2*)(xb + (long)sb * C);
+        va[0] = ta.x; va[1 % VEC] = ta.y;
+        vb[0] = tb.x; vb[1 % VEC] = tb.y;
       } else {
         va[0] = xb[(long)sa * C];
         vb[0] = xb[(long)sb * C];
@@ -96,6 +100,8 @@ __global__ __launch_bounds__(GN_T) void fx_spmm_rows_kernel(float* __restrict__ 
     if (eg == 0 && cok) {
       if (VEC == 4) {
         *(float4*)(ob + (long)i * C) = make_float4(acc[0], acc[1 % VEC], acc[2 % VEC], acc[3 % VEC]);
+      } else if (VEC == 2) {
+        *(float2*)(ob + (long)i * C) = make_float2(acc[0], acc[1 % VEC]);
       } else {
         ob[(long)i * C] = acc[0];
       }
@@ -162,45 +168,109 @@ __global__ __launch_bounds__(GN_T) void fx_rowlin2_kernel(float* __restrict__ ou
 }
 
 // ---- weight gradient of a row-wise Linear: dW[o][c] = sum_r dy[r][o] x[r][c], db[o] = sum_r dy[r][o] ---------------
-// Stage 1: each workgroup reduces its row chunk (tiles of 64 rows staged in LDS) into partial[blockIdx][Cout*(Cin+1)];
-// stage 2 adds the partials in block order.
+// Stage 1: each workgroup reduces its row chunk into partial[blockIdx][Cout*(Cin+1)] (column Cin = the bias gradient);
+// stage 2 adds the partials in a fixed order.  Tiles of 64 rows are staged in LDS.  A thread owns a 2 (out) x 4 (in)
+// block of dW for one of RG row groups (RG = 256 / number of blocks, a power of two): per row it reads dy twice
+// (broadcast) and x once (16 bytes) for 8 FMAs.  The row groups are summed in group order at the end.
 #define GN_WG_ROWS 64
+#define GN_XLD (GN_CMAX + 4)
+// global [nr, C] (contiguous) -> LDS rows of stride ld, channels >= C and rows >= nr zeroed
+__device__ __forceinline__ void stage_tile(float* __restrict__ dst, int ld, const float* __restrict__ src, int C, int nr,
+                                           int tid) {
+  const int total = GN_WG_ROWS * C, valid = nr * C;
+  if ((C & 3) == 0 && ((((uintptr_t)src) & 15) == 0)) {
+    float4 v[2];
+    int e[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {          // 64 * 32 / 4 = 512 float4 at most: two per thread
+      e[q] = 4 * (tid + q * GN_T);
+      const int ec = e[q] < valid ? e[q] : 0;
+      v[q] = *reinterpret_cast<const float4*>(src + ec);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (e[q] < total) {
+        const bool ok = e[q] < valid;
+        const int rr = e[q] / C, c = e[q] - rr * C;
+        float* d = dst + rr * ld + c;
+        d[0] = ok ? v[q].x : 0.f; d[1] = ok ? v[q].y : 0.f; d[2] = ok ? v[q].z : 0.f; d[3] = ok ? v[q].w : 0.f;
+      }
+    }
+  } else {
+    for (int e0 = tid; e0 < total; e0 += GN_T) {
+      const int rr = e0 / C, c = e0 - rr * C;
+      const float v = src[e0 < valid ? e0 : 0];
+      dst[rr * ld + c] = e0 < valid ? v : 0.f;
+    }
+  }
+}
+
 __global__ __launch_bounds__(GN_T) void fx_rowlin_wgrad_kernel(float* __restrict__ partial, const float* __restrict__ dy,
                                                                const float* __restrict__ x, long R, int Cin, int Cout,
                                                                long rows_per_block) {
-  __shared__ float sdy[GN_WG_ROWS][GN_CMAX + 1], sx[GN_WG_ROWS][GN_CMAX + 2];
-  const int npairs = Cout * (Cin + 1);  // column Cin of x is the constant 1 -> bias gradient
-  float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // ceil(32*33/256) = 5 pairs per thread
+  __shared__ __attribute__((aligned(16))) float sx[GN_WG_ROWS][GN_XLD];
+  __shared__ float sdy[GN_WG_ROWS][GN_CMAX + 2];
+  __shared__ float comb[GN_T][10];                 // per thread: 8 dW entries + 2 bias entries
+  const int tid = threadIdx.x;
+  const int ob = (Cout + 1) >> 1, cb = (Cin + 3) >> 2, nb = ob * cb;    // <= 16 * 8 = 128 blocks
+  int RG = 2;
+  while (RG * 2 * nb <= GN_T && RG < GN_WG_ROWS) RG <<= 1;
+  const int rg = tid / nb, blk = tid - rg * nb;
+  const bool active = rg < RG;
+  const int o0 = 2 * (blk / cb), c4 = blk % cb, c0 = 4 * c4;
+  float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  float accb[2] = {0.f, 0.f};
   const long r0 = (long)blockIdx.x * rows_per_block;
   long r1 = r0 + rows_per_block;
   if (r1 > R) r1 = R;
   for (long rt = r0; rt < r1; rt += GN_WG_ROWS) {
     const int nr = (int)((r1 - rt) < GN_WG_ROWS ? (r1 - rt) : GN_WG_ROWS);
     __syncthreads();
-    for (int t = threadIdx.x; t < GN_WG_ROWS * Cout; t += GN_T) {
-      const int rr = t / Cout, o = t % Cout;
-      sdy[rr][o] = rr < nr ? dy[(rt + rr) * Cout + o] : 0.f;
-    }
-    for (int t = threadIdx.x; t < GN_WG_ROWS * (Cin + 1); t += GN_T) {
-      const int rr = t / (Cin + 1), c = t % (Cin + 1);
-      sx[rr][c] = rr < nr ? (c < Cin ? x[(rt + rr) * Cin + c] : 1.f) : 0.f;
-    }
+    // a tile is one contiguous block of nr * C floats in each array: copy it with unconditional (clamped) 16-byte
+    // loads issued together, then scatter into the padded LDS rows; rows past nr are stored as zeros
+    stage_tile(&sdy[0][0], GN_CMAX + 2, dy + rt * Cout, Cout, nr, tid);
+    stage_tile(&sx[0][0], GN_XLD, x + rt * Cin, Cin, nr, tid);
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      const int p = threadIdx.x + k * GN_T;
-      if (p < npairs) {
-        const int o = p / (Cin + 1), c = p % (Cin + 1);
-        float s = acc[k];
-        for (int rr = 0; rr < GN_WG_ROWS; ++rr) s += sdy[rr][o] * sx[rr][c];
-        acc[k] = s;
+    if (active) {
+      for (int rr = rg; rr < GN_WG_ROWS; rr += RG) {
+        const float d0 = sdy[rr][o0], d1 = sdy[rr][o0 + 1];
+        const float4 xv = *reinterpret_cast<const float4*>(&sx[rr][c0]);
+        acc[0][0] += d0 * xv.x; acc[0][1] += d0 * xv.y; acc[0][2] += d0 * xv.z; acc[0][3] += d0 * xv.w;
+        acc[1][0] += d1 * xv.x; acc[1][1] += d1 * xv.y; acc[1][2] += d1 * xv.z; acc[1][3] += d1 * xv.w;
+        accb[0] += d0;
+        accb[1] += d1;
       }
     }
   }
+  __syncthreads();
+  if (active) {
 #pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    const int p = threadIdx.x + k * GN_T;
-    if (p < npairs) partial[(long)blockIdx.x * npairs + p] = acc[k];
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) comb[tid][i * 4 + j] = acc[i][j];
+      comb[tid][8 + i] = accb[i];
+    }
+  }
+  __syncthreads();
+  if (tid < nb) {      // row group 0's threads add the groups in order and write this block's partial
+    const int ld = Cin + 1;
+    float* pp = partial + (long)blockIdx.x * Cout * ld;
+    float t8[10];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) t8[q] = 0.f;
+    for (int g2 = 0; g2 < RG; ++g2) {
+#pragma unroll
+      for (int q = 0; q < 10; ++q) t8[q] += comb[g2 * nb + tid][q];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (o0 + i < Cout) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (c0 + j < Cin) pp[(o0 + i) * ld + c0 + j] = t8[i * 4 + j];
+        if (c4 == 0) pp[(o0 + i) * ld + Cin] = t8[8 + i];
+      }
+    }
   }
 }
 
@@ -465,8 +535,12 @@ int fx_spmm_rows(float* out, const float* x, const int* rowptr, const int* idx, 
   const int tiles = (nodes + waves * npw - 1) / (waves * npw);
   const int bgroups = (B + 7) / 8;
   const bool v4 = (C % 4 == 0) && ((((uintptr_t)x) & 15) == 0) && ((((uintptr_t)out) & 15) == 0);
+  const bool v2 = (C % 2 == 0) && ((((uintptr_t)x) & 7) == 0) && ((((uintptr_t)out) & 7) == 0);
   if (v4)
     hipLaunchKernelGGL(fx_spmm_rows_kernel<4>, dim3(8 * bgroups * tiles), dim3(GN_T), 0, stream, out, x, rowptr, idx, w, B,
+                       nodes, C, tiles, npw);
+  else if (v2)
+    hipLaunchKernelGGL(fx_spmm_rows_kernel<2>, dim3(8 * bgroups * tiles), dim3(GN_T), 0, stream, out, x, rowptr, idx, w, B,
                        nodes, C, tiles, npw);
   else
     hipLaunchKernelGGL(fx_spmm_rows_kernel<1>, dim3(8 * bgroups * tiles), dim3(GN_T), 0, stream, out, x, rowptr, idx, w, B,

@@ -46,7 +46,8 @@ def _align4(n: int) -> int:
 
 
 class ParamStore:
-    def __init__(self, spec: ArchSpec, device, big_threshold: int = 1 << 20, materialize_big_grads: bool = True):
+    def __init__(self, spec: ArchSpec, device, big_threshold: int = 1 << 20, materialize_big_grads: bool = True,
+                 big_min_dim: Optional[int] = None):
         self.spec = spec
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -55,8 +56,14 @@ class ParamStore:
         self.param_keys = [k for k in self.shapes if not is_buffer_key(k)]
         self.buffer_keys = [k for k in self.shapes if is_buffer_key(k) and not k.endswith("num_batches_tracked")]
         self.nbt_keys = [k for k in self.shapes if k.endswith("num_batches_tracked")]
+        # "wide" weights take the split-bf16 MFMA kernels with the fused dW+clip+Adam epilogue and the Gram-identity norm.
+        # That pays when BOTH dimensions are large: for a short-fat weight such as the GNN's fc [latent <= 128,
+        # nodes * C] the Gram factors cost more than materialising dW (measured at [64, 128000]: 1.36 vs 1.18 ms/step),
+        # so such weights stay in the small-parameter arena.  An explicit big_threshold (tests) disables the rule.
+        if big_min_dim is None:
+            big_min_dim = 256 if big_threshold == (1 << 20) else 1
         self.big_keys = [k for k in self.param_keys if len(self.shapes[k]) == 2
-                         and int(np.prod(self.shapes[k])) >= big_threshold]
+                         and int(np.prod(self.shapes[k])) >= big_threshold and min(self.shapes[k]) >= big_min_dim]
         self.small_keys = [k for k in self.param_keys if k not in self.big_keys]
         # small arena
         self.off: Dict[str, Tuple[int, int]] = {}
@@ -410,6 +417,17 @@ class StepPlan:
             if stagger:
                 self._last_wide_ev = torch.cuda.Event()
                 rec.record_event(self._last_wide_ev)
+        elif (self.precision == "bf16x3" and x.shape[1] >= 8192 and x.shape[1] % 8 == 0 and st.p(wkey).data_ptr() % 16 == 0
+              and x.is_contiguous()):
+            # long contraction through a short-fat arena weight (the GNN's fc [latent, nodes * C]): the split-bf16 MFMA
+            # forward streams it at ~2x the rate of the exact-fp32 GEMM's 1 x 1 output tiling (100 -> ~50 us at
+            # [64, 128000], B = 32); gradients and Adam stay on the arena path
+            sp = self._split_cache.get(("fwd", x.data_ptr()))
+            if sp is None:
+                sp = ops.new_split_kb(x.shape[0], x.shape[1], self.dev)
+                self._split_cache[("fwd", x.data_ptr())] = sp
+                ops.split_bf16(rec, sp[0], sp[1], x)
+            ops.linear_fwd_bf16x3(rec, y, sp[0], sp[1], st.p(wkey), st.p(bkey), self.ws)
         else:
             ops.linear_fwd(rec, y, x, st.p(wkey), st.p(bkey), self.ws)
         return None

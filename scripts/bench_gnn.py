@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--conv", default="GC")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--cpu", action="store_true")
+    ap.add_argument("--big-threshold", type=int, default=1 << 20, help="weights with at least this many elements take the wide-layer path")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(0)
@@ -43,7 +44,7 @@ def main():
     X = torch.randn(N, a.nodes * a.feat, generator=g, device=dev)
     ann = {"y": X[:, :16].sum(1) / 4, "c": torch.randint(0, 4, (N,), generator=g, device=dev).float()}
     cohort = DeviceCohort({"nodes": X}, ann, dev)
-    store = ParamStore(spec, dev)
+    store = ParamStore(spec, dev, big_threshold=a.big_threshold)
     nb = N // a.batch
     pipe = PipelinedStep(store, a.batch, cohort=cohort, n_batches=nb, seed=1, epoch_acc=True)
     def reshuffle():
