@@ -774,22 +774,36 @@ class StepPlan:
         dh = self._new("gnn/dh", B, nodes * C)
         self._lin_bwd_x(rb, dh, demb, "encoders.0.fc.weight")
         da = dh.view(B, nodes, C)
-        for k in reversed(range(K)):
-            h_in, y, sm, si, mask, seed, off, wa, ba, wr, bnp = layers[k]
-            ops.bn_rows_bwd(rb, da, st.g(bnp + ".weight"), st.g(bnp + ".bias"), y, st.p(bnp + ".weight"), st.p(bnp + ".bias"),
-                            sm, si, act, drop, scratch, mask=mask, seed=seed, offset=off, ctrl=st.ctrl)      # da <- dL/dy
-            u = self._new(f"encoders.0.convs.{k}/u", B, nodes, C)
-            ops.spmm_rows(rb, u, da, gop.s_rowptr, gop.s_idx, gop.s_w)
-            if wr:
-                ops.rowlin_wgrad(rb, st.g(wa), None, u, h_in, scratch)
-                ops.rowlin_wgrad(rb, st.g(wr), st.g(ba), da, h_in, scratch)
-            else:
-                ops.rowlin_wgrad(rb, st.g(wa), None, u, h_in, scratch)
-                ops.rowlin_wgrad(rb, None, st.g(ba), da, h_in, scratch)
-            if k > 0:
-                dx = self._new(f"encoders.0.convs.{k}/dx", B, nodes, h_in.shape[2])
-                ops.rowlin2(rb, dx, u, st.p(wa), da if wr else None, st.p(wr) if wr else None, None, trans=True)
-                da = dx
+        # Two graph branches: the chain that carries dL/dh down the layers, and the weight-gradient reductions, which only
+        # consume (u_k, dL/dy_k, h_k) and are off the critical path (FX_GNN_BRANCHES=0: one chain, A/B switch)
+        two = self.branches and os.environ.get("FX_GNN_BRANCHES", "1") != "0"
+        scratch_w = ops.gnn_scratch(B * nodes, 32, self.dev) if two else scratch
+        self.buf["gnn/scratch_w"] = scratch_w
+        jobs = []
+        with rb.parallel(2 if two else 1) as par:
+            par.branch(0)
+            for k in reversed(range(K)):
+                h_in, y, sm, si, mask, seed, off, wa, ba, wr, bnp = layers[k]
+                ops.bn_rows_bwd(rb, da, st.g(bnp + ".weight"), st.g(bnp + ".bias"), y, st.p(bnp + ".weight"),
+                                st.p(bnp + ".bias"), sm, si, act, drop, scratch, mask=mask, seed=seed, offset=off,
+                                ctrl=st.ctrl)                                                     # da <- dL/dy
+                u = self._new(f"encoders.0.convs.{k}/u", B, nodes, C)
+                ops.spmm_rows(rb, u, da, gop.s_rowptr, gop.s_idx, gop.s_w)
+                ev = torch.cuda.Event() if two else None
+                if two:
+                    rb.record_event(ev)
+                jobs.append((ev, u, da, h_in, wa, ba, wr))
+                if k > 0:
+                    dx = self._new(f"encoders.0.convs.{k}/dx", B, nodes, h_in.shape[2])
+                    ops.rowlin2(rb, dx, u, st.p(wa), da if wr else None, st.p(wr) if wr else None, None, trans=True)
+                    da = dx
+            par.branch(1 if two else 0)
+            for ev, u, dy, h_in, wa, ba, wr in jobs:
+                if two:
+                    rb.wait_event(ev)
+                ops.rowlin_wgrad(rb, st.g(wa), None, u, h_in, scratch_w)
+                ops.rowlin_wgrad(rb, st.g(wr) if wr else None, st.g(ba), dy, h_in, scratch_w)
+        self.buf["gnn/events"] = [j[0] for j in jobs]
 
     def _enter_branch(self, par, i):
         """Route subsequent emits to graph branch i (with its own split-K scratch)."""
