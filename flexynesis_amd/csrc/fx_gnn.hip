@@ -359,7 +359,20 @@ __global__ __launch_bounds__(GN_T) void fx_bn_rows_reduce_kernel(BnRows a) {
   if (cok) {
     if (a.mode == 0) {
       const float shift = a.x[c];
-      for (long r = r0 + wave * RS + rs; r < r1; r += (GN_T / 64) * RS) {
+      const long S = (GN_T / 64) * RS;
+      long r = r0 + wave * RS + rs;
+      for (; r + 3 * S < r1; r += 4 * S) {          // four independent rows in flight per lane
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = a.x[(r + u * S) * C + c];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float d = v[u] - shift;
+          s0 += (double)d;
+          s1 += (double)d * (double)d;
+        }
+      }
+      for (; r < r1; r += S) {
         const float d = a.x[r * C + c] - shift;
         s0 += (double)d;
         s1 += (double)d * (double)d;
@@ -367,11 +380,29 @@ __global__ __launch_bounds__(GN_T) void fx_bn_rows_reduce_kernel(BnRows a) {
     } else {
       const float mu = a.save_mean[c], is = a.save_invstd[c], gm = a.gamma[c], bt = a.beta[c];
       const unsigned long long rng_off = gn_step_offset(a.ctrl, a.offset);
-      for (long r = r0 + wave * RS + rs; r < r1; r += (GN_T / 64) * RS) {
+      const long S = (GN_T / 64) * RS;
+      long r = r0 + wave * RS + rs;
+      for (; r + 3 * S < r1; r += 4 * S) {
+        float xv[4], dv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          xv[u] = a.x[(r + u * S) * C + c];
+          dv[u] = a.da[(r + u * S) * C + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const long e = (r + u * S) * C + c;
+          const float xhat = (xv[u] - mu) * is;
+          const float g = dv[u] * gn_mask(a, rng_off, e) * gact_grad(xhat * gm + bt, a.act);
+          a.da[e] = g;
+          s0 += (double)g;
+          s1 += (double)g * (double)xhat;
+        }
+      }
+      for (; r < r1; r += S) {
         const long e = r * C + c;
         const float xhat = (a.x[e] - mu) * is;
-        const float z = xhat * gm + bt;
-        const float g = a.da[e] * gn_mask(a, rng_off, e) * gact_grad(z, a.act);
+        const float g = a.da[e] * gn_mask(a, rng_off, e) * gact_grad(xhat * gm + bt, a.act);
         a.da[e] = g;
         s0 += (double)g;
         s1 += (double)g * (double)xhat;
@@ -474,7 +505,21 @@ __global__ __launch_bounds__(GN_T) void fx_bn_rows_apply_kernel(float* __restric
   const float is = train ? a.save_invstd[c] : 1.0f / sqrtf(running_var[c] + FX_BN_EPS);
   const float gm = a.gamma[c], bt = a.beta[c];
   const unsigned long long rng_off = gn_step_offset(a.ctrl, a.offset);
-  for (long r = r0 + wave * RS + rs; r < r1; r += (GN_T / 64) * RS) {
+  const long S = (GN_T / 64) * RS;
+  long r = r0 + wave * RS + rs;
+  for (; r + 3 * S < r1; r += 4 * S) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = a.x[(r + u * S) * C + c];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long e = (r + u * S) * C + c;
+      float y = gact((v[u] - mu) * is * gm + bt, a.act);
+      if (train) y = y * gn_mask(a, rng_off, e);
+      out[e] = y;
+    }
+  }
+  for (; r < r1; r += S) {
     const long e = r * C + c;
     float y = gact((a.x[e] - mu) * is * gm + bt, a.act);
     if (train) y = y * gn_mask(a, rng_off, e);
@@ -499,10 +544,223 @@ __global__ __launch_bounds__(GN_T) void fx_bn_rows_bwd_apply_kernel(float* __res
   const float inv_r = 1.0f / (float)R;
   const float is = save_invstd[c], mu = save_mean[c];
   const float k0 = gamma[c] * is, m0 = sums[c] * inv_r, m1 = sums[C + c] * inv_r;
-  for (long r = r0 + wave * RS + rs; r < r1; r += (GN_T / 64) * RS) {
+  const long S = (GN_T / 64) * RS;
+  long r = r0 + wave * RS + rs;
+  for (; r + 3 * S < r1; r += 4 * S) {
+    float xv[4], gv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      xv[u] = x[(r + u * S) * C + c];
+      gv[u] = g[(r + u * S) * C + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) g[(r + u * S) * C + c] = k0 * (gv[u] - m0 - (xv[u] - mu) * is * m1);
+  }
+  for (; r < r1; r += S) {
     const long e = r * C + c;
     const float xhat = (x[e] - mu) * is;
     g[e] = k0 * (g[e] - m0 - xhat * m1);
+  }
+}
+
+// ---- four channels per lane (C % 4 == 0): 16-byte accesses, and one Philox block serves the lane's four elements
+// (element e takes output e & 3 of block e >> 2 in both layouts, so the masks are identical to the scalar kernels').
+__device__ __forceinline__ float4 gn_mask4(const BnRows& a, unsigned long long rng_off, long e0) {
+  if (a.drop_p <= 0.f) return make_float4(1.f, 1.f, 1.f, 1.f);
+  const float ks = 1.0f / (1.0f - a.drop_p), keep = 1.0f - a.drop_p;
+  if (a.mask) {
+    const float4 m = *reinterpret_cast<const float4*>(a.mask + e0);
+    return make_float4(m.x * ks, m.y * ks, m.z * ks, m.w * ks);
+  }
+  uint32_t r[4];
+  fx_philox4(a.seed, rng_off + ((unsigned long long)e0 >> 2), r);
+  return make_float4(fx_u01(r[0]) <= keep ? ks : 0.f, fx_u01(r[1]) <= keep ? ks : 0.f, fx_u01(r[2]) <= keep ? ks : 0.f,
+                     fx_u01(r[3]) <= keep ? ks : 0.f);
+}
+
+__global__ __launch_bounds__(GN_T) void fx_bn_rows_reduce4_kernel(BnRows a) {
+  __shared__ double red[GN_T / 64][2][GN_CMAX];
+  const int C = a.C, CQ = C >> 2, CP = cp_of(CQ), RS = 64 / CP;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cq = lane & (CP - 1), rs = lane / CP, c0 = 4 * cq;
+  const bool cok = cq < CQ;
+  const long r0 = (long)blockIdx.x * a.rows_per_block;
+  long r1 = r0 + a.rows_per_block;
+  if (r1 > a.R) r1 = a.R;
+  double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
+  if (cok) {
+    const long S = (GN_T / 64) * RS;
+    long r = r0 + wave * RS + rs;
+    if (a.mode == 0) {
+      const float4 sh = *reinterpret_cast<const float4*>(a.x + c0);
+      const float shv[4] = {sh.x, sh.y, sh.z, sh.w};
+      for (; r + S < r1; r += 2 * S) {
+        const float4 va = *reinterpret_cast<const float4*>(a.x + r * C + c0);
+        const float4 vb = *reinterpret_cast<const float4*>(a.x + (r + S) * C + c0);
+        const float xa[4] = {va.x, va.y, va.z, va.w}, xb[4] = {vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float da_ = xa[j] - shv[j], db_ = xb[j] - shv[j];
+          s0[j] += (double)da_ + (double)db_;
+          s1[j] += (double)da_ * (double)da_ + (double)db_ * (double)db_;
+        }
+      }
+      for (; r < r1; r += S) {
+        const float4 va = *reinterpret_cast<const float4*>(a.x + r * C + c0);
+        const float xa[4] = {va.x, va.y, va.z, va.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float d = xa[j] - shv[j];
+          s0[j] += (double)d;
+          s1[j] += (double)d * (double)d;
+        }
+      }
+    } else {
+      const float4 mu4 = *reinterpret_cast<const float4*>(a.save_mean + c0), is4 = *reinterpret_cast<const float4*>(a.save_invstd + c0);
+      const float4 gm4 = *reinterpret_cast<const float4*>(a.gamma + c0), bt4 = *reinterpret_cast<const float4*>(a.beta + c0);
+      const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, is[4] = {is4.x, is4.y, is4.z, is4.w};
+      const float gm[4] = {gm4.x, gm4.y, gm4.z, gm4.w}, bt[4] = {bt4.x, bt4.y, bt4.z, bt4.w};
+      const unsigned long long rng_off = gn_step_offset(a.ctrl, a.offset);
+      for (; r < r1; r += S) {
+        const long e0 = r * C + c0;
+        const float4 xv4 = *reinterpret_cast<const float4*>(a.x + e0);
+        const float4 dv4 = *reinterpret_cast<const float4*>(a.da + e0);
+        const float4 mk4 = gn_mask4(a, rng_off, e0);
+        const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w}, dv[4] = {dv4.x, dv4.y, dv4.z, dv4.w};
+        const float mk[4] = {mk4.x, mk4.y, mk4.z, mk4.w};
+        float g[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xhat = (xv[j] - mu[j]) * is[j];
+          g[j] = dv[j] * mk[j] * gact_grad(xhat * gm[j] + bt[j], a.act);
+          s0[j] += (double)g[j];
+          s1[j] += (double)g[j] * (double)xhat;
+        }
+        *reinterpret_cast<float4*>(a.da + e0) = make_float4(g[0], g[1], g[2], g[3]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    for (int off = 32; off >= CP; off >>= 1) {
+      s0[j] += __shfl_xor(s0[j], off, 64);
+      s1[j] += __shfl_xor(s1[j], off, 64);
+    }
+  }
+  if (rs == 0 && cok) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      red[wave][0][c0 + j] = s0[j];
+      red[wave][1][c0 + j] = s1[j];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * C) {
+    const int k = threadIdx.x / C, cc = threadIdx.x % C;
+    double t = 0.0;
+    for (int wv = 0; wv < GN_T / 64; ++wv) t += red[wv][k][cc];
+    a.partial[((long)blockIdx.x * 2 + k) * C + cc] = t;
+  }
+}
+
+__global__ __launch_bounds__(GN_T) void fx_bn_rows_apply4_kernel(float* __restrict__ out, BnRows a,
+                                                                 const float* __restrict__ running_mean,
+                                                                 const float* __restrict__ running_var, int train) {
+  const int C = a.C, CQ = C >> 2, CP = cp_of(CQ), RS = 64 / CP;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cq = lane & (CP - 1), rs = lane / CP, c0 = 4 * cq;
+  if (cq >= CQ) return;
+  const long r0 = (long)blockIdx.x * a.rows_per_block;
+  long r1 = r0 + a.rows_per_block;
+  if (r1 > a.R) r1 = a.R;
+  float mu[4], is[4], gm[4], bt[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    mu[j] = train ? a.save_mean[c0 + j] : running_mean[c0 + j];
+    is[j] = train ? a.save_invstd[c0 + j] : 1.0f / sqrtf(running_var[c0 + j] + FX_BN_EPS);
+    gm[j] = a.gamma[c0 + j];
+    bt[j] = a.beta[c0 + j];
+  }
+  const unsigned long long rng_off = gn_step_offset(a.ctrl, a.offset);
+  const long S = (GN_T / 64) * RS;
+  long r = r0 + wave * RS + rs;
+  for (; r + S < r1; r += 2 * S) {
+    const long ea = r * C + c0, eb = (r + S) * C + c0;
+    const float4 va = *reinterpret_cast<const float4*>(a.x + ea), vb = *reinterpret_cast<const float4*>(a.x + eb);
+    float4 ma = make_float4(1.f, 1.f, 1.f, 1.f), mb = ma;
+    if (train) { ma = gn_mask4(a, rng_off, ea); mb = gn_mask4(a, rng_off, eb); }
+    const float xa[4] = {va.x, va.y, va.z, va.w}, xb[4] = {vb.x, vb.y, vb.z, vb.w};
+    const float ka[4] = {ma.x, ma.y, ma.z, ma.w}, kb[4] = {mb.x, mb.y, mb.z, mb.w};
+    float ya[4], yb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ya[j] = gact((xa[j] - mu[j]) * is[j] * gm[j] + bt[j], a.act) * ka[j];
+      yb[j] = gact((xb[j] - mu[j]) * is[j] * gm[j] + bt[j], a.act) * kb[j];
+    }
+    *reinterpret_cast<float4*>(out + ea) = make_float4(ya[0], ya[1], ya[2], ya[3]);
+    *reinterpret_cast<float4*>(out + eb) = make_float4(yb[0], yb[1], yb[2], yb[3]);
+  }
+  for (; r < r1; r += S) {
+    const long ea = r * C + c0;
+    const float4 va = *reinterpret_cast<const float4*>(a.x + ea);
+    float4 ma = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (train) ma = gn_mask4(a, rng_off, ea);
+    const float xa[4] = {va.x, va.y, va.z, va.w}, ka[4] = {ma.x, ma.y, ma.z, ma.w};
+    float ya[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ya[j] = gact((xa[j] - mu[j]) * is[j] * gm[j] + bt[j], a.act) * ka[j];
+    *reinterpret_cast<float4*>(out + ea) = make_float4(ya[0], ya[1], ya[2], ya[3]);
+  }
+}
+
+__global__ __launch_bounds__(GN_T) void fx_bn_rows_bwd_apply4_kernel(float* __restrict__ g, const float* __restrict__ x,
+                                                                     const float* __restrict__ gamma,
+                                                                     const float* __restrict__ save_mean,
+                                                                     const float* __restrict__ save_invstd,
+                                                                     const float* __restrict__ sums, long R, int C,
+                                                                     long rows_per_block) {
+  const int CQ = C >> 2, CP = cp_of(CQ), RS = 64 / CP;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cq = lane & (CP - 1), rs = lane / CP, c0 = 4 * cq;
+  if (cq >= CQ) return;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  long r1 = r0 + rows_per_block;
+  if (r1 > R) r1 = R;
+  const float inv_r = 1.0f / (float)R;
+  float mu[4], is[4], k0[4], m0[4], m1[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    is[j] = save_invstd[c0 + j];
+    mu[j] = save_mean[c0 + j];
+    k0[j] = gamma[c0 + j] * is[j];
+    m0[j] = sums[c0 + j] * inv_r;
+    m1[j] = sums[C + c0 + j] * inv_r;
+  }
+  const long S = (GN_T / 64) * RS;
+  long r = r0 + wave * RS + rs;
+  for (; r + S < r1; r += 2 * S) {
+    const long ea = r * C + c0, eb = (r + S) * C + c0;
+    const float4 xa4 = *reinterpret_cast<const float4*>(x + ea), xb4 = *reinterpret_cast<const float4*>(x + eb);
+    const float4 ga4 = *reinterpret_cast<const float4*>(g + ea), gb4 = *reinterpret_cast<const float4*>(g + eb);
+    const float xa[4] = {xa4.x, xa4.y, xa4.z, xa4.w}, xb[4] = {xb4.x, xb4.y, xb4.z, xb4.w};
+    const float ga[4] = {ga4.x, ga4.y, ga4.z, ga4.w}, gb[4] = {gb4.x, gb4.y, gb4.z, gb4.w};
+    float oa[4], ob[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      oa[j] = k0[j] * (ga[j] - m0[j] - (xa[j] - mu[j]) * is[j] * m1[j]);
+      ob[j] = k0[j] * (gb[j] - m0[j] - (xb[j] - mu[j]) * is[j] * m1[j]);
+    }
+    *reinterpret_cast<float4*>(g + ea) = make_float4(oa[0], oa[1], oa[2], oa[3]);
+    *reinterpret_cast<float4*>(g + eb) = make_float4(ob[0], ob[1], ob[2], ob[3]);
+  }
+  for (; r < r1; r += S) {
+    const long ea = r * C + c0;
+    const float4 xa4 = *reinterpret_cast<const float4*>(x + ea), ga4 = *reinterpret_cast<const float4*>(g + ea);
+    const float xa[4] = {xa4.x, xa4.y, xa4.z, xa4.w}, ga[4] = {ga4.x, ga4.y, ga4.z, ga4.w};
+    float oa[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) oa[j] = k0[j] * (ga[j] - m0[j] - (xa[j] - mu[j]) * is[j] * m1[j]);
+    *reinterpret_cast<float4*>(g + ea) = make_float4(oa[0], oa[1], oa[2], oa[3]);
   }
 }
 
@@ -514,6 +772,12 @@ inline int row_blocks(long R, long* rows_per_block) {
   rpb = ((rpb + 63) / 64) * 64;  // whole 64-row tiles
   *rows_per_block = rpb;
   return (int)((R + rpb - 1) / rpb);
+}
+
+inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }   // NULL counts as aligned
+inline int row_blocks_n(long R) {
+  long rpb;
+  return row_blocks(R, &rpb);
 }
 
 }  // namespace
@@ -608,6 +872,8 @@ int fx_bn_rows_fwd(float* out, const float* x, const float* gamma, const float* 
   FX_REQUIRE(R > 0 && C > 0 && C <= GN_CMAX, "fx_bn_rows_fwd: need 1 <= C <= 32");
   FX_REQUIRE(act >= 0 && act <= GACT_GELU, "fx_bn_rows_fwd: unknown activation %d", act);
   FX_REQUIRE(!train || (save_mean && save_invstd && ws), "fx_bn_rows_fwd: training needs save_mean/save_invstd/workspace");
+  const bool v4 = (C % 4 == 0) && al16(out) && al16(x) && al16(gamma) && al16(beta) && al16(save_mean) && al16(save_invstd) &&
+                  al16(mask);
   BnRows a{};
   a.x = x; a.gamma = gamma; a.beta = beta; a.save_mean = save_mean; a.save_invstd = save_invstd; a.mask = mask; a.ctrl = ctrl;
   a.R = R; a.C = C; a.act = act; a.mode = 0; a.drop_p = train ? drop_p : 0.f; a.seed = seed; a.offset = offset;
@@ -616,7 +882,8 @@ int fx_bn_rows_fwd(float* out, const float* x, const float* gamma, const float* 
     const int blocks = row_blocks(R, &rpb);
     a.partial = (double*)ws;
     a.rows_per_block = rpb;
-    hipLaunchKernelGGL(fx_bn_rows_reduce_kernel, dim3(blocks), dim3(GN_T), 0, stream, a);
+    if (v4) hipLaunchKernelGGL(fx_bn_rows_reduce4_kernel, dim3(blocks), dim3(GN_T), 0, stream, a);
+    else hipLaunchKernelGGL(fx_bn_rows_reduce_kernel, dim3(blocks), dim3(GN_T), 0, stream, a);
     int rc = fx_check_launch("fx_bn_rows_fwd(stats)");
     if (rc) return rc;
     hipLaunchKernelGGL(fx_bn_rows_stats_finalize_kernel, dim3(1), dim3(GN_T), 0, stream, a.partial, blocks, x, R, C, save_mean,
@@ -627,7 +894,8 @@ int fx_bn_rows_fwd(float* out, const float* x, const float* gamma, const float* 
   long rpb_a;
   const int blocks_a = row_blocks(R, &rpb_a);
   a.rows_per_block = rpb_a;
-  hipLaunchKernelGGL(fx_bn_rows_apply_kernel, dim3(blocks_a), dim3(GN_T), 0, stream, out, a, running_mean, running_var, train);
+  if (v4) hipLaunchKernelGGL(fx_bn_rows_apply4_kernel, dim3(blocks_a), dim3(GN_T), 0, stream, out, a, running_mean, running_var, train);
+  else hipLaunchKernelGGL(fx_bn_rows_apply_kernel, dim3(blocks_a), dim3(GN_T), 0, stream, out, a, running_mean, running_var, train);
   return fx_check_launch("fx_bn_rows_fwd(apply)");
 }
 
@@ -638,6 +906,8 @@ int fx_bn_rows_bwd(float* da, float* dgamma, float* dbeta, const float* x, const
   FX_REQUIRE(da && x && gamma && beta && save_mean && save_invstd && ws, "fx_bn_rows_bwd: null pointer");
   FX_REQUIRE(R > 0 && C > 0 && C <= GN_CMAX, "fx_bn_rows_bwd: need 1 <= C <= 32");
   FX_REQUIRE(act >= 0 && act <= GACT_GELU, "fx_bn_rows_bwd: unknown activation %d", act);
+  const bool v4 = (C % 4 == 0) && al16(da) && al16(x) && al16(gamma) && al16(beta) && al16(save_mean) && al16(save_invstd) &&
+                  al16(mask) && al16((const char*)ws + (long)row_blocks_n(R) * 2 * C * sizeof(double));
   BnRows a{};
   a.x = x; a.da = da; a.gamma = gamma; a.beta = beta; a.save_mean = save_mean; a.save_invstd = save_invstd; a.mask = mask;
   a.ctrl = ctrl; a.R = R; a.C = C; a.act = act; a.mode = 1; a.drop_p = drop_p; a.seed = seed; a.offset = offset;
@@ -646,14 +916,19 @@ int fx_bn_rows_bwd(float* da, float* dgamma, float* dbeta, const float* x, const
   a.partial = (double*)ws;
   a.rows_per_block = rpb;
   float* sums = (float*)((char*)ws + (long)blocks * 2 * C * sizeof(double));
-  hipLaunchKernelGGL(fx_bn_rows_reduce_kernel, dim3(blocks), dim3(GN_T), 0, stream, a);
+  if (v4) hipLaunchKernelGGL(fx_bn_rows_reduce4_kernel, dim3(blocks), dim3(GN_T), 0, stream, a);
+  else hipLaunchKernelGGL(fx_bn_rows_reduce_kernel, dim3(blocks), dim3(GN_T), 0, stream, a);
   int rc = fx_check_launch("fx_bn_rows_bwd(reduce)");
   if (rc) return rc;
   hipLaunchKernelGGL(fx_bn_rows_bwd_finalize_kernel, dim3(1), dim3(GN_T), 0, stream, a.partial, blocks, C, dgamma, dbeta, sums);
   rc = fx_check_launch("fx_bn_rows_bwd(finalize)");
   if (rc) return rc;
-  hipLaunchKernelGGL(fx_bn_rows_bwd_apply_kernel, dim3(blocks), dim3(GN_T), 0, stream, da, x, gamma, save_mean, save_invstd,
-                     sums, R, C, rpb);
+  if (v4)
+    hipLaunchKernelGGL(fx_bn_rows_bwd_apply4_kernel, dim3(blocks), dim3(GN_T), 0, stream, da, x, gamma, save_mean, save_invstd,
+                       sums, R, C, rpb);
+  else
+    hipLaunchKernelGGL(fx_bn_rows_bwd_apply_kernel, dim3(blocks), dim3(GN_T), 0, stream, da, x, gamma, save_mean, save_invstd,
+                       sums, R, C, rpb);
   return fx_check_launch("fx_bn_rows_bwd(apply)");
 }
 

@@ -130,3 +130,28 @@ def test_bn_rows_philox_mask_is_consistent_between_forward_and_backward():
     db = torch.empty(C, device="cuda")
     ops.bn_rows_bwd(rec, g_only, torch.empty(C, device="cuda"), db, x, gamma, beta, sm, si, 0, 0.2, ws, seed=11, offset=1 << 32)
     torch.testing.assert_close(db, kept.float().sum(0) / 0.8, rtol=1e-5, atol=1e-3)
+
+
+def test_bn_rows_vector_and_scalar_layouts_agree_bitwise():
+    """C % 4 == 0 takes the four-channels-per-lane kernels; an input that is not 16-byte aligned takes the scalar ones.
+    Same statistics order is not guaranteed, but the Philox dropout mask must be the same element for element."""
+    from flexynesis_amd import ops
+    rec = ops.ImmediateRecorder()
+    R, C = 3000, 16
+    g = torch.Generator(device="cuda").manual_seed(0)
+    xa = torch.randn(R, C, generator=g, device="cuda")     # aligned
+    store = torch.empty(R * C + 4, device="cuda")
+    xs = store[1: R * C + 1].view(R, C)                    # 4 bytes off
+    xs.copy_(xa)
+    gamma, beta = torch.ones(C, device="cuda"), torch.full((C,), 8.0, device="cuda")      # z > 0: out == 0 <=> dropped
+    ws = ops.gnn_scratch(R, 32, "cuda")
+    outs = []
+    for x in (xa, xs):
+        out = torch.empty(R, C, device="cuda")
+        sm, si = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        ops.bn_rows_fwd(rec, out, x, gamma, beta, torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), sm, si, 0, True,
+                        0.2, ws, seed=5, offset=3 << 32)
+        outs.append(out)
+    assert xs.data_ptr() % 16 != 0 and xa.data_ptr() % 16 == 0
+    assert torch.equal(outs[0] == 0, outs[1] == 0)                       # same elements dropped
+    torch.testing.assert_close(outs[0], outs[1], rtol=1e-6, atol=1e-6)
