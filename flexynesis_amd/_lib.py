@@ -79,7 +79,7 @@ PROTOTYPES = {
     "fx_row_moments": (I, [P, I, L, I, P, I, P, P, P]),
     "fx_ingest_transform": (I, [P, I, L, P, I, P, I, P, I, P, P, P, L, P]),
     "fx_gnn_row_blocks": (I, [L]),
-    "fx_spmm_rows": (I, [P, P, P, P, P, I, I, I, P]),
+    "fx_spmm_rows": (I, [P, P, P, P, P, I, I, I, L, P]),
     "fx_rowlin2": (I, [P, P, P, I, P, P, I, P, L, I, I, I, P]),
     "fx_rowlin_wgrad_workspace_bytes": (L, [L, I, I]),
     "fx_rowlin_wgrad": (I, [P, P, P, P, L, I, I, I, P, P]),

@@ -41,14 +41,16 @@ __device__ __forceinline__ float sum_over_rowsub(float v, int CP) {
 }
 
 // ---- SpMM with a narrow dense side -------------------------------------------------------------------------------
-// One wavefront walks a tile of `npw` nodes of one sample.  A lane owns VEC consecutive channels (one 16-byte load
-// when C % 4 == 0) of one edge slot; 64 / CP edge slots work on a node at once (CP = power of two >= C / VEC), two
-// edges per slot are in flight, and the slots are combined with shuffles.
+// One wavefront walks a tile of `npw` nodes of one sample, NG nodes at a time.  A lane owns VEC consecutive channels
+// (one 8/16-byte load when C % 2/4 == 0) of one edge slot; the 64 / CP edge slots (CP = power of two >= C / VEC) are
+// split evenly over the NG nodes, two edges per slot are in flight, and a node's slots are combined with shuffles.
+// Several nodes per wavefront matter because most nodes have few edges: with the whole wavefront on one node the
+// kernel was a chain of per-node latencies (row pointers -> indices -> gather -> reduce -> store).
 template <int VEC>
 __global__ __launch_bounds__(GN_T) void fx_spmm_rows_kernel(float* __restrict__ out, const float* __restrict__ x,
                                                             const int* __restrict__ rowptr, const int* __restrict__ idx,
                                                             const float* __restrict__ w, int B, int nodes, int C,
-                                                            int tiles, int npw) {
+                                                            int tiles, int npw, int NG) {
   // XCD-aware placement: consecutive block ids go round-robin over the 8 XCDs, so ids congruent mod 8 share an L2;
   // give each XCD whole samples.
   const int id = blockIdx.x;
@@ -56,22 +58,25 @@ __global__ __launch_bounds__(GN_T) void fx_spmm_rows_kernel(float* __restrict__ 
   const int b = xcd + 8 * (j / tiles);
   const int tile = j % tiles;
   if (b >= B) return;
-  const int CQ = C / VEC, CP = cp_of(CQ), EG = 64 / CP;
+  const int CQ = C / VEC, CP = cp_of(CQ), EG = 64 / CP, SPN = EG / NG;    // SPN edge slots per node
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int cq = lane & (CP - 1), eg = lane / CP;
+  const int cq = lane & (CP - 1), slot = lane / CP;
+  const int ng = slot / SPN, es = slot - ng * SPN;
   const bool cok = cq < CQ;
   const int coff = (cok ? cq : 0) * VEC;
   const float* xb = x + (long)b * nodes * C + coff;
   float* ob = out + (long)b * nodes * C + coff;
-  typedef float __attribute__((ext_vector_type(VEC))) vf;
   const int n0 = (tile * (GN_T / 64) + wave) * npw;
-  for (int i = n0; i < n0 + npw && i < nodes; ++i) {
-    const int e0 = rowptr[i], e1 = rowptr[i + 1];
+  for (int it = 0; it < npw; it += NG) {
+    const int i = n0 + it + ng;
+    const bool iok = i < nodes;
+    const int ic = iok ? i : nodes - 1;
+    const int e0 = rowptr[ic], e1 = iok ? rowptr[ic + 1] : e0;
     float acc[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
-    for (int e = e0 + eg; e < e1; e += 2 * EG) {
-      const int e2 = e + EG;
+    for (int e = e0 + es; e < e1; e += 2 * SPN) {
+      const int e2 = e + SPN;
       const bool two = e2 < e1;
       const int sa = idx[e], sb = idx[two ? e2 : e];
       const float wa = w[e], wb = two ? w[e2] : 0.f;
@@ -94,10 +99,10 @@ __global__ __launch_bounds__(GN_T) void fx_spmm_rows_kernel(float* __restrict__ 
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       float t = cok ? acc[v] : 0.f;
-      for (int off = 32; off >= CP; off >>= 1) t += __shfl_xor(t, off, 64);
+      for (int off = (CP * SPN) >> 1; off >= CP; off >>= 1) t += __shfl_xor(t, off, 64);
       acc[v] = t;
     }
-    if (eg == 0 && cok) {
+    if (es == 0 && cok && iok) {
       if (VEC == 4) {
         *(float4*)(ob + (long)i * C) = make_float4(acc[0], acc[1 % VEC], acc[2 % VEC], acc[3 % VEC]);
       } else if (VEC == 2) {
@@ -790,7 +795,7 @@ int fx_gnn_row_blocks(long R) {
 }
 
 int fx_spmm_rows(float* out, const float* x, const int* rowptr, const int* idx, const float* w, int B, int nodes, int C,
-                 hipStream_t stream) {
+                 long n_edges, hipStream_t stream) {
   FX_REQUIRE(out && x && rowptr && idx && w, "fx_spmm_rows: null pointer");
   FX_REQUIRE(B > 0 && nodes > 0 && C > 0 && C <= GN_CMAX, "fx_spmm_rows: need 1 <= C <= 32 (B=%d nodes=%d C=%d)", B, nodes, C);
   FX_REQUIRE(out != x, "fx_spmm_rows: not in place");
@@ -800,15 +805,27 @@ int fx_spmm_rows(float* out, const float* x, const int* rowptr, const int* idx, 
   const int bgroups = (B + 7) / 8;
   const bool v4 = (C % 4 == 0) && ((((uintptr_t)x) & 15) == 0) && ((((uintptr_t)out) & 15) == 0);
   const bool v2 = (C % 2 == 0) && ((((uintptr_t)x) & 7) == 0) && ((((uintptr_t)out) & 7) == 0);
-  if (v4)
-    hipLaunchKernelGGL(fx_spmm_rows_kernel<4>, dim3(8 * bgroups * tiles), dim3(GN_T), 0, stream, out, x, rowptr, idx, w, B,
-                       nodes, C, tiles, npw);
-  else if (v2)
-    hipLaunchKernelGGL(fx_spmm_rows_kernel<2>, dim3(8 * bgroups * tiles), dim3(GN_T), 0, stream, out, x, rowptr, idx, w, B,
-                       nodes, C, tiles, npw);
+  const int vec = v4 ? 4 : (v2 ? 2 : 1);
+  const int eg = 64 / h_cp_of(C / vec);
+  // Nodes in flight per wavefront: about 6 edges per edge slot and node keeps both the hubs' tail short and the
+  // per-node latency chain amortised (measured at 8000 nodes: 50 edges/node -> 2 nodes of 8 slots, 10 -> 4 of 4).
+  int ng = 2;
+  if (n_edges > 0) {
+    const double per_node = (double)n_edges / nodes;
+    int spn = 1;
+    while (spn * 2 <= eg && spn * 6 < per_node) spn *= 2;
+    ng = eg / spn;
+  }
+  if (ng > eg) ng = eg;
+  if (ng > npw) ng = npw;
+  if (ng < 1) ng = 1;
+  const dim3 grid(8 * bgroups * tiles);
+  if (vec == 4)
+    hipLaunchKernelGGL(fx_spmm_rows_kernel<4>, grid, dim3(GN_T), 0, stream, out, x, rowptr, idx, w, B, nodes, C, tiles, npw, ng);
+  else if (vec == 2)
+    hipLaunchKernelGGL(fx_spmm_rows_kernel<2>, grid, dim3(GN_T), 0, stream, out, x, rowptr, idx, w, B, nodes, C, tiles, npw, ng);
   else
-    hipLaunchKernelGGL(fx_spmm_rows_kernel<1>, dim3(8 * bgroups * tiles), dim3(GN_T), 0, stream, out, x, rowptr, idx, w, B,
-                       nodes, C, tiles, npw);
+    hipLaunchKernelGGL(fx_spmm_rows_kernel<1>, grid, dim3(GN_T), 0, stream, out, x, rowptr, idx, w, B, nodes, C, tiles, npw, ng);
   return fx_check_launch("fx_spmm_rows");
 }
 

@@ -737,7 +737,7 @@ def spmm_rows(rec, out, x, rowptr, idx, w):
     if out.shape != x.shape or rowptr.numel() != nodes + 1:
         raise FxError("spmm_rows: shape mismatch")
     rec.emit("fx_spmm_rows", out.data_ptr(), x.data_ptr(), _i32(rowptr, "spmm_rows"), _i32(idx, "spmm_rows"),
-             w.data_ptr(), B, nodes, Cc)
+             w.data_ptr(), B, nodes, Cc, int(idx.numel()))
 
 
 def rowlin2(rec, out, a, Wa, b=None, Wb=None, bias=None, trans=False, accumulate=False):

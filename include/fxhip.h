@@ -253,7 +253,7 @@ int fx_ingest_transform(const void* x, int dtype, long ldx, const int* rows, int
  *      fx_bn_rows_bwd:  in place: da holds dL/d(out) on entry, dL/dx on return; dgamma / dbeta are written. */
 int fx_gnn_row_blocks(long R);
 int fx_spmm_rows(float* out, const float* x, const int* rowptr, const int* idx, const float* w, int B, int nodes, int C,
-                 fx_stream_t stream);
+                 long n_edges /* = rowptr[nodes], a scheduling hint; 0 if unknown */, fx_stream_t stream);
 int fx_rowlin2(float* out, const float* a, const float* Wa, int Ca, const float* b, const float* Wb, int Cb,
                const float* bias, long R, int Cout, int trans, int accumulate, fx_stream_t stream);
 long fx_rowlin_wgrad_workspace_bytes(long R, int Cin, int Cout);
