@@ -141,9 +141,23 @@ __global__ __launch_bounds__(GN_T) void fx_rowlin2_kernel(float* __restrict__ ou
   if (r >= R) return;
   // padded channels re-read the last valid one (no conditional loads); their weights are zero
   float av[CI], bv[CI];
+  if ((Ca & 3) == 0 && ((((uintptr_t)a) & 15) == 0)) {
 #pragma unroll
-  for (int c = 0; c < CI; ++c) av[c] = a[r * Ca + (c < Ca ? c : Ca - 1)];
-  if (bsrc) {
+    for (int c = 0; c < CI; c += 4) {
+      const float4 t = *reinterpret_cast<const float4*>(a + r * Ca + (c < Ca ? c : Ca - 4));
+      av[c] = t.x; av[c + 1] = t.y; av[c + 2] = t.z; av[c + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < CI; ++c) av[c] = a[r * Ca + (c < Ca ? c : Ca - 1)];
+  }
+  if (bsrc && (Cb & 3) == 0 && ((((uintptr_t)bsrc) & 15) == 0)) {
+#pragma unroll
+    for (int c = 0; c < CI; c += 4) {
+      const float4 t = *reinterpret_cast<const float4*>(bsrc + r * Cb + (c < Cb ? c : Cb - 4));
+      bv[c] = t.x; bv[c + 1] = t.y; bv[c + 2] = t.z; bv[c + 3] = t.w;
+    }
+  } else if (bsrc) {
 #pragma unroll
     for (int c = 0; c < CI; ++c) bv[c] = bsrc[r * Cb + (c < Cb ? c : Cb - 1)];
   } else {
@@ -162,12 +176,27 @@ __global__ __launch_bounds__(GN_T) void fx_rowlin2_kernel(float* __restrict__ ou
     }
     acc[o] = s;
   }
+  if ((Cout & 3) == 0 && ((((uintptr_t)out) & 15) == 0)) {     // 16-byte stores: a row is written as Cout / 4 full segments
 #pragma unroll
-  for (int o = 0; o < CO; ++o) {
-    if (o < Cout) {
-      float v = acc[o];
-      if (accumulate) v += out[r * Cout + o];
-      out[r * Cout + o] = v;
+    for (int o = 0; o < CO; o += 4) {
+      if (o < Cout) {
+        float4* dst = reinterpret_cast<float4*>(out + r * Cout + o);
+        float4 v = make_float4(acc[o], acc[o + 1], acc[o + 2], acc[o + 3]);
+        if (accumulate) {
+          const float4 p = *dst;
+          v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        *dst = v;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int o = 0; o < CO; ++o) {
+      if (o < Cout) {
+        float v = acc[o];
+        if (accumulate) v += out[r * Cout + o];
+        out[r * Cout + o] = v;
+      }
     }
   }
 }
