@@ -327,10 +327,7 @@ int fx_gemm_f32(int layout, float* C, const float* A, const float* B, const floa
   g.accumulate = 0;
   int rc = gemm_dispatch(a_kc, b_kc, g, EPI_STORE, stream);
   if (rc) return rc;
-  const long total = (long)M * N;
-  const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
-  hipLaunchKernelGGL(fx_reduce_slabs_kernel, dim3(blocks), dim3(256), 0, stream, C, (const float*)workspace, bias, M, N,
-                     ldc, s, g.slab_stride, accumulate);
+  fx_launch_reduce_slabs(C, (const float*)workspace, bias, M, N, ldc, s, g.slab_stride, accumulate, stream);
   return fx_check_launch("fx_reduce_slabs");
 }
 

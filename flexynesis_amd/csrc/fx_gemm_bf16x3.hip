@@ -695,10 +695,7 @@ static int fwd_bf16x3_impl(float* Y, const void* xhi, const void* xlo, const flo
   }
   int rc = fx_check_launch("fx_linear_fwd_bf16x3");
   if (rc || !reduce) return rc;
-  const long total = (long)M * N;
-  const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
-  hipLaunchKernelGGL(fx_reduce_slabs_kernel, dim3(blocks), dim3(256), 0, stream, Y, (const float*)workspace, bias, M, N, ldy,
-                     s, g.slab_stride, 0);
+  fx_launch_reduce_slabs(Y, (const float*)workspace, bias, M, N, ldy, s, g.slab_stride, 0, stream);
   return fx_check_launch("fx_reduce_slabs");
 }
 
