@@ -183,10 +183,28 @@ def main():
                             traffic = d["hbm_bytes_per_launch_corrected"]
             except Exception:
                 traffic = None
+            # Boxes of the pool differ by +-10 % in what their HBM delivers: record this box's plain device-to-device
+            # copy rate (1 GiB read + 1 GiB write, HIP events) next to the kernel's figure.  `frac` stays relative to
+            # the 8 TB/s vendor peak.
+            copy_gbs = None
+            try:
+                src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+                dst = torch.empty_like(src)
+                dst.copy_(src)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    dst.copy_(src)
+                e1.record()
+                torch.cuda.synchronize()
+                copy_gbs = round(5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+                del src, dst
+            except Exception:
+                copy_gbs = None
             roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(ms),
-                    "algorithmic_bytes_per_launch": bytes_per_launch}
+                    "algorithmic_bytes_per_launch": bytes_per_launch, "device_copy_GBps_this_box": copy_gbs}
     P = store.n_params()
     sumF = sum(F for _, F in cfg["layers"])
     k_reads = 3 if cfg["model"] == "MultiTripletNetwork" else 1
