@@ -32,6 +32,11 @@ class ArchSpec:
     # keys: nodes, node_features, embedding_dim, num_convs, conv (GC|SAGE|GCN), act, edge_index (int64 ndarray [2, E])
     gnn: Optional[dict] = None
 
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d.pop("_graph_ops", None)        # device-side CSR cache of the engine (engine._build_gnn): never copied / pickled
+        return d
+
     # -- derived sizes ---------------------------------------------------------------------------
     @property
     def is_vae(self) -> bool:

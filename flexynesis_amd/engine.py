@@ -731,7 +731,11 @@ class StepPlan:
         g = spec.gnn
         nodes, C, K = int(g["nodes"]), int(g["embedding_dim"]), int(g["num_convs"])
         rf, rb = self.t_fwd, self.t_bwd
-        gop = G.build(g["edge_index"], nodes, g["conv"], self.dev)
+        # the graph operator is a property of the model, not of the plan: build the two CSR matrices once per (spec, device)
+        cache = spec.__dict__.setdefault("_graph_ops", {})
+        gop = cache.get(str(self.dev))
+        if gop is None:
+            gop = cache[str(self.dev)] = G.build(g["edge_index"], nodes, g["conv"], self.dev)
         self.buf["graph"] = gop
         act = ops.GACT[g["act"]]
         scratch = ops.gnn_scratch(B * nodes, 32, self.dev)
