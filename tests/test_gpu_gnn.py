@@ -294,3 +294,43 @@ def test_gnn_and_ingest_bad_arguments_raise():
     from flexynesis_amd.arch import gnn_conv_keys
     with pytest.raises(ValueError):
         gnn_conv_keys("x", "GAT")
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_gnn_random_configurations_one_step_vs_oracle(seed):
+    """Randomised shapes: any width 1..32 (vector and scalar kernel layouts), 1-3 node features, 1-4 conv layers, odd node
+    counts, sparse to dense graphs with isolated nodes, batch 2..70, all conv types and activations."""
+    from flexynesis_amd.arch import ArchSpec
+    from flexynesis_amd.engine import ParamStore, StepPlan
+    from oracle import restate as O
+    rng = np.random.default_rng(1000 + seed)
+    conv = ["GC", "SAGE", "GCN"][seed % 3]
+    act = ["relu", "sigmoid", "leakyrelu", "tanh", "gelu"][int(rng.integers(0, 5))]
+    nodes = int(rng.integers(20, 400))
+    nf, C, K = int(rng.integers(1, 4)), int(rng.integers(1, 33)), int(rng.integers(1, 5))
+    B, L = int(rng.integers(2, 71)), int(rng.integers(4, 40))
+    E = int(nodes * rng.uniform(0.5, 12))
+    ei = torch.from_numpy(rng.integers(0, max(nodes - 5, 2), size=(2, E)))            # the last nodes stay isolated
+    variables = [("y", "numerical", 1), ("c", "categorical", int(rng.integers(2, 6)))]
+    gn = dict(nodes=nodes, node_features=nf, embedding_dim=C, num_convs=K, conv=conv, act=act)
+    ospec = O.Spec("GNN", [("nodes", nodes * nf)], L, 0.0, 8, variables, gnn=dict(gn, edge_index=ei))
+    aspec = ArchSpec("GNN", [("nodes", nodes * nf)], L, 0.0, 8, variables, gnn=dict(gn, edge_index=ei.numpy()))
+    st = O.init_state(ospec, seed=seed)
+    dev = torch.device("cuda:0")
+    store = ParamStore(aspec, dev, big_threshold=(1 << 12) if seed % 2 else (1 << 30))
+    store.load_state(st)
+    plan = StepPlan(store, B, train=True, fused=True, supplied_draws=True)
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, nodes * nf, generator=gen)
+    y = {"y": torch.randn(B, generator=gen), "c": torch.randint(0, variables[1][2], (B,), generator=gen).float()}
+    draws = {n: (torch.rand(t.shape, generator=gen) < (0.8 if ".drop." in n else 0.9)).float() for n, t in plan.draws.items()}
+    plan.set_batch(x_list=[x.to(dev)], y={k: v.to(dev) for k, v in y.items()})
+    plan.set_draws({k: v.to(dev) for k, v in draws.items()})
+    plan.train_step(1e-3)
+    st2, _, info = O.train_step(ospec, st, {}, {"x": [x], "y": y}, draws, 1e-3)
+    got = plan.losses()
+    tag = f"seed {seed}: {conv}/{act} nodes {nodes} nf {nf} C {C} K {K} B {B} E {E}"
+    for k, v in info["losses"].items():
+        close(got[k], v, 5e-5, 1e-6, f"{tag} loss {k}")                         # gate 1e-4
+    exact = sum(float((gv.double() ** 2).sum()) for gv in info["grads"].values()) ** 0.5
+    close(store.ctrl[5], exact, 2e-4, 1e-7, f"{tag} grad_norm")
