@@ -724,7 +724,7 @@ class StepPlan:
         """GNN (models/gnn_early.py:142-198): flexGCN encoder (modules.py:251-262: per layer conv -> BatchNorm1d over the
         batch*nodes rows -> act -> Dropout(0.2); flatten; fc) -> supervisor heads, losses as DirectPred.
         A conv layer is out = (A h) Wa^T + [h Wr^T] + b with A the graph's weighted adjacency (graph.py); its backward
-        is u = A^T dOut, dWa = u^T h, dWr = dOut^T h, db = colsum(dOut), dh = u Wa + dOut Wr."""
+        is dWa = dOut^T (A h) (the forward's aggregate), dWr = dOut^T h, db = colsum(dOut), dh = A^T (dOut Wa) + dOut Wr."""
         from . import graph as G
         from .arch import gnn_conv_keys
         spec, st, B, L = self.spec, self.store, self.B, self.spec.latent_dim
@@ -758,7 +758,7 @@ class StepPlan:
             ops.bn_rows_fwd(rf, a, y, st.p(bnp + ".weight"), st.p(bnp + ".bias"), st.b(bnp + ".running_mean"),
                             st.b(bnp + ".running_var"), sm if self.train else None, si if self.train else None, act,
                             self.train, drop, scratch, mask=mask, seed=seed, offset=off, ctrl=st.ctrl)
-            layers.append((h, y, sm, si, mask, seed, off, wa, ba, wr, bnp))
+            layers.append((h, y, sm, si, mask, seed, off, wa, ba, wr, bnp, agg))
             h = a
         hflat = h.view(B, nodes * C)
         emb = self._new("emb", B, L)
@@ -787,25 +787,31 @@ class StepPlan:
         with rb.parallel(2 if two else 1) as par:
             par.branch(0)
             for k in reversed(range(K)):
-                h_in, y, sm, si, mask, seed, off, wa, ba, wr, bnp = layers[k]
+                h_in, y, sm, si, mask, seed, off, wa, ba, wr, bnp, agg = layers[k]
                 ops.bn_rows_bwd(rb, da, st.g(bnp + ".weight"), st.g(bnp + ".bias"), y, st.p(bnp + ".weight"),
                                 st.p(bnp + ".bias"), sm, si, act, drop, scratch, mask=mask, seed=seed, offset=off,
                                 ctrl=st.ctrl)                                                     # da <- dL/dy
-                u = self._new(f"encoders.0.convs.{k}/u", B, nodes, C)
-                ops.spmm_rows(rb, u, da, gop.s_rowptr, gop.s_idx, gop.s_w)
                 ev = torch.cuda.Event() if two else None
                 if two:
                     rb.record_event(ev)
-                jobs.append((ev, u, da, h_in, wa, ba, wr))
+                jobs.append((ev, da, agg, h_in, wa, ba, wr))
                 if k > 0:
-                    dx = self._new(f"encoders.0.convs.{k}/dx", B, nodes, h_in.shape[2])
-                    ops.rowlin2(rb, dx, u, st.p(wa), da if wr else None, st.p(wr) if wr else None, None, trans=True)
+                    # dL/dh_in = A^T (dY Wa) + dY Wr: the transposed message passing runs at the layer's INPUT width, and
+                    # dWa = dY^T (A h_in) reuses the forward's aggregate -- no SpMM for the weight gradient, none at all
+                    # in the first layer
+                    cin = h_in.shape[2]
+                    t = self._new(f"encoders.0.convs.{k}/t", B, nodes, cin)
+                    ops.rowlin2(rb, t, da, st.p(wa), trans=True)
+                    dx = self._new(f"encoders.0.convs.{k}/dx", B, nodes, cin)
+                    ops.spmm_rows(rb, dx, t, gop.s_rowptr, gop.s_idx, gop.s_w)
+                    if wr:
+                        ops.rowlin2(rb, dx, da, st.p(wr), trans=True, accumulate=True)
                     da = dx
             par.branch(1 if two else 0)
-            for ev, u, dy, h_in, wa, ba, wr in jobs:
+            for ev, dy, agg, h_in, wa, ba, wr in jobs:
                 if two:
                     rb.wait_event(ev)
-                ops.rowlin_wgrad(rb, st.g(wa), None, u, h_in, scratch_w)
+                ops.rowlin_wgrad(rb, st.g(wa), None, dy, agg, scratch_w)
                 ops.rowlin_wgrad(rb, st.g(wr) if wr else None, st.g(ba), dy, h_in, scratch_w)
         self.buf["gnn/events"] = [j[0] for j in jobs]
 

@@ -242,7 +242,8 @@ int fx_ingest_transform(const void* x, int dtype, long ldx, const int* rows, int
  *      The convolutions are torch_geometric's GraphConv / SAGEConv / GCNConv (un-vendored): each is
  *        out = (A x) Wa^T [+ x Wr^T] + bias   with A the weighted adjacency the host builds once per graph
  *      (GC: weight 1; SAGE: 1/in-degree; GCN: self loops + D^-1/2 A D^-1/2), stored as CSR by target node for the
- *      forward and CSR by source node for the backward (u = A^T dOut; dWa = u^T x; dWr = dOut^T x; dx = u Wa + dOut Wr).
+ *      forward and CSR by source node for the backward (dWa = dOut^T (A x), the forward's aggregate; dWr = dOut^T x;
+ *      dx = A^T (dOut Wa) + dOut Wr, i.e. the transposed message passing runs at the layer's input width).
  *      fx_spmm_rows:    out[b, i, :] = sum_{e in [rowptr[i], rowptr[i+1])} w[e] * x[b, idx[e], :]   (not in place)
  *      fx_rowlin2:      out[r, :] (+)= a[r, :] Wa^T (+ b[r, :] Wb^T) (+ bias); trans != 0 applies W instead of W^T
  *                       (Wa then is [Ca, Cout]).  nn.Linear semantics per row, R = B * nodes rows.
