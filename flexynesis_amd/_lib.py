@@ -43,7 +43,7 @@ PROTOTYPES = {
     "fx_block_bwd_blocks": (I, [I]),
     "fx_block_bwd": (I, [P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, P, P, P, L, P, P, I, I, L, L, I, I, F, P]),
     "fx_heads_fwd": (I, [P, I, P, L, I, I, I, F, P, P]),
-    "fx_heads_bwd": (I, [P, I, P, L, P, L, I, I, I, F, P]),
+    "fx_heads_bwd": (I, [P, I, P, L, P, L, I, I, I, F, P, P]),
     "fx_split_bf16": (I, [P, P, P, I, I, L, L, P]),
     "fx_split_bf16_t": (I, [P, P, P, I, I, L, L, P]),
     "fx_linear_fwd_bf16x3_workspace_bytes": (L, [I, I, I]),

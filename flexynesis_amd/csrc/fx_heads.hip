@@ -36,6 +36,8 @@ struct HeadsArgs {
   int B, L, train;
   float drop_p;
   const float* ctrl;
+  float* dx_part;      // optional scratch [n_heads][B][L] + one unsigned counter behind it: per-head dx workgroups
+  unsigned* dx_count;
 };
 
 __device__ __forceinline__ unsigned long long heads_step_offset(const float* ctrl, unsigned long long offset) {
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(256) void fx_heads_bwd_kernel(HeadsArgs a) {
   const int t = threadIdx.x, r = t & 127, hf = t >> 7, col = t & 31, rg = t >> 5;
   const int B = a.B, Ld = a.L;
   const float gate_scale = 1.0f / (1.0f - a.drop_p);
-  const bool dx_role = (int)blockIdx.x == a.n_heads;
+  const bool dx_role = (int)blockIdx.x >= a.n_heads;
   if (!dx_role) {
     // ================= parameter gradients of head blockIdx.x =================
     const FxHeadDesc& h = a.h[blockIdx.x];
@@ -433,18 +435,23 @@ __global__ __launch_bounds__(256) void fx_heads_bwd_kernel(HeadsArgs a) {
     }
     return;
   }
-  // ================= embedding gradient, accumulated over the heads in registers =================
+  // ================= embedding gradient =================
+  // One workgroup accumulates over all heads in registers (dx_part == NULL), or -- with scratch -- one workgroup per
+  // head writes that head's contribution and the last one to finish adds the contributions in head order
+  // (deterministic), so several heads cost one head's latency chain instead of their sum.
   if (!a.dx) return;
+  const bool split = a.dx_part != nullptr && a.n_heads > 1;
+  const int h_lo = split ? (int)blockIdx.x - a.n_heads : 0, h_hi = split ? h_lo + 1 : a.n_heads;
   const int Lh = (Ld + 1) >> 1, l0 = hf * Lh;
   float* W1s = &L.R2[0][0];             // HB*33 floats >= HS*HL
   float accx[HL / 2];
 #pragma unroll
   for (int j = 0; j < HL / 2; ++j) accx[j] = 0.f;
-  if (a.dx_accumulate) {
+  if (a.dx_accumulate && !split) {
 #pragma unroll
     for (int j = 0; j < HL / 2; ++j) accx[j] = a.dx[(long)min(r, B - 1) * a.lddx + min(l0 + j, Ld - 1)];   // only in-range lanes are stored
   }
-  for (int hi = 0; hi < a.n_heads; ++hi) {
+  for (int hi = h_lo; hi < h_hi; ++hi) {
     const FxHeadDesc& h = a.h[hi];
     const int S = h.S;
     float vy[16], vw1[HS * HL / 256];
@@ -472,11 +479,39 @@ __global__ __launch_bounds__(256) void fx_heads_bwd_kernel(HeadsArgs a) {
       for (int j = 0; j < HL / 2; ++j) accx[j] = fmaf(d, w[j], accx[j]);
     }
   }
+  if (!split) {
+    if (r < B) {
+#pragma unroll
+      for (int j = 0; j < HL / 2; ++j)
+        if (j < Lh && l0 + j < Ld) a.dx[(long)r * a.lddx + l0 + j] = accx[j];
+    }
+    return;
+  }
+  // per-head contribution -> scratch; the last workgroup to arrive sums them in head order
   if (r < B) {
+    float* mine = a.dx_part + ((long)h_lo * B + r) * Ld;
 #pragma unroll
     for (int j = 0; j < HL / 2; ++j)
-      if (j < Lh && l0 + j < Ld) a.dx[(long)r * a.lddx + l0 + j] = accx[j];
+      if (j < Lh && l0 + j < Ld) mine[l0 + j] = accx[j];
   }
+  __threadfence();
+  __syncthreads();
+  __shared__ int s_last;
+  if (t == 0) s_last = (atomicAdd(a.dx_count, 1u) == (unsigned)(a.n_heads - 1));
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  if (r < B) {
+#pragma unroll
+    for (int j = 0; j < HL / 2; ++j) {
+      if (j < Lh && l0 + j < Ld) {
+        float sacc = a.dx_accumulate ? a.dx[(long)r * a.lddx + l0 + j] : 0.f;
+        for (int hi = 0; hi < a.n_heads; ++hi) sacc += __builtin_nontemporal_load(a.dx_part + ((long)hi * B + r) * Ld + l0 + j);
+        a.dx[(long)r * a.lddx + l0 + j] = sacc;
+      }
+    }
+  }
+  if (t == 0) *a.dx_count = 0u;          // ready for the next launch / graph replay
 }
 
 extern "C" {
@@ -511,7 +546,7 @@ int fx_heads_fwd(const void* heads_, int n_heads, const float* x, long ldx, int 
 }
 
 int fx_heads_bwd(const void* heads_, int n_heads, const float* x, long ldx, float* dx, long lddx, int dx_accumulate, int B,
-                 int L, float drop_p, hipStream_t stream) {
+                 int L, float drop_p, void* dx_scratch, hipStream_t stream) {
   const FxHeadDesc* heads = (const FxHeadDesc*)heads_;
   if (int rc = heads_check(heads, n_heads, x, B, L, "fx_heads_bwd")) return rc;
   HeadsArgs a{};
@@ -523,7 +558,13 @@ int fx_heads_bwd(const void* heads_, int n_heads, const float* x, long ldx, floa
   }
   a.n_heads = n_heads; a.x = x; a.ldx = ldx; a.dx = dx; a.lddx = lddx; a.dx_accumulate = dx_accumulate;
   a.B = B; a.L = L; a.train = 1; a.drop_p = drop_p;
-  hipLaunchKernelGGL(fx_heads_bwd_kernel, dim3(n_heads + 1), dim3(256), 0, stream, a);
+  const bool split = dx_scratch != nullptr && dx != nullptr && n_heads > 1;
+  if (split) {
+    FX_REQUIRE((((uintptr_t)dx_scratch) & 3) == 0, "fx_heads_bwd: scratch must be 4-byte aligned");
+    a.dx_part = (float*)dx_scratch;
+    a.dx_count = (unsigned*)((float*)dx_scratch + (long)n_heads * B * L);    // zero on first use (caller zero-fills once)
+  }
+  hipLaunchKernelGGL(fx_heads_bwd_kernel, dim3(split ? 2 * n_heads : n_heads + 1), dim3(256), 0, stream, a);
   return fx_check_launch("fx_heads_bwd");
 }
 

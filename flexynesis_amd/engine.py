@@ -611,7 +611,13 @@ class StepPlan:
                                  ("gbeta", st.g(pre + ".batchnorm.bias")), ("gW2", st.g(pre + ".layer_out.weight")),
                                  ("gb2", st.g(bias_key) if bias_key in st.shapes else None)):
                     setattr(d, field, t.data_ptr() if t is not None else None)
-            ops.heads_bwd(rec_b, self._head_descs, emb, demb, self.B, emb.shape[1], DROPOUT_P, dx_accumulate=first_accumulate)
+            scratch = None
+            if len(self._head_descs) > 1 and demb is not None and os.environ.get("FX_HEADS_SPLIT_DX", "1") != "0":
+                scratch = self.buf.get("heads/dx_scratch")
+                if scratch is None:
+                    scratch = self.buf["heads/dx_scratch"] = ops.heads_bwd_scratch(len(self._head_descs), self.B, emb.shape[1], self.dev)
+            ops.heads_bwd(rec_b, self._head_descs, emb, demb, self.B, emb.shape[1], DROPOUT_P, dx_accumulate=first_accumulate,
+                          scratch=scratch)
             return
         acc = first_accumulate
         for (v, kind, C) in self.spec.variables:

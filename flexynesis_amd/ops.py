@@ -497,12 +497,19 @@ def heads_fwd(rec, descs, x, B, L, train, drop_p, ctrl=None):
     return arr
 
 
-def heads_bwd(rec, descs, x, dx, B, L, drop_p, dx_accumulate=False):
+def heads_bwd_scratch(n_heads: int, B: int, L: int, device) -> torch.Tensor:
+    """Zero-filled scratch for fx_heads_bwd's per-head dx workgroups (shares + arrival counter)."""
+    return torch.zeros(n_heads * B * L + 4, dtype=torch.float32, device=device)
+
+
+def heads_bwd(rec, descs, x, dx, B, L, drop_p, dx_accumulate=False, scratch=None):
     """All supervisor heads backward + the summed embedding gradient in one launch."""
     _chk2d(x, "heads_bwd.x")
     arr = _head_array(rec, descs)
+    if scratch is not None and scratch.numel() < len(descs) * int(B) * int(L) + 1:
+        raise FxError("heads_bwd: scratch too small")
     rec.emit("fx_heads_bwd", C.addressof(arr), len(descs), x.data_ptr(), _ld(x), _ptr(dx), _ld(dx) if dx is not None else 0,
-             int(bool(dx_accumulate)), int(B), int(L), float(drop_p))
+             int(bool(dx_accumulate)), int(B), int(L), float(drop_p), _ptr(scratch))
     return arr
 
 

@@ -137,8 +137,11 @@ typedef struct fx_head_desc {
 } fx_head_desc;
 int fx_heads_fwd(const fx_head_desc* heads, int n_heads, const float* x, long ldx, int B, int L, int train, float drop_p,
                  const float* ctrl, fx_stream_t stream);
+/* dx_scratch (optional): n_heads * B * L floats + one 32-bit counter, ZERO-FILLED ONCE by the caller and then owned by
+ * these launches.  With it every head's share of dx is computed by its own workgroup and the last one to finish adds
+ * the shares in head order (deterministic); without it one workgroup walks the heads one after the other. */
 int fx_heads_bwd(const fx_head_desc* heads, int n_heads, const float* x, long ldx, float* dx, long lddx, int dx_accumulate,
-                 int B, int L, float drop_p, fx_stream_t stream);
+                 int B, int L, float drop_p, void* dx_scratch, fx_stream_t stream);
 
 /* ---- the whole backward of an encoder tail "wide Linear -> BatchNorm block -> 1 or 2 small Linears" in one launch
  *      (MLP encoder, modules.py:145-149; VAE encoder, modules.py:25-41,47-56): autograd's mm for the small Linears'
