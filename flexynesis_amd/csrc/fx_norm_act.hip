@@ -186,8 +186,15 @@ __global__ __launch_bounds__(256) void fx_colsum_kernel(float* __restrict__ out,
   const int cx = threadIdx.x & (COLS - 1), ry = threadIdx.x / COLS;
   const int c = blockIdx.x * COLS + cx;
   float s = 0.f;
-  if (c < C)
-    for (int r = ry; r < B; r += RGRP) s += x[(long)r * ldx + c];
+  if (c < C) {
+    int r = ry;
+    for (; r + 3 * RGRP < B; r += 4 * RGRP) {      // four rows in flight per thread (same summation order)
+      const float v0 = x[(long)r * ldx + c], v1 = x[(long)(r + RGRP) * ldx + c];
+      const float v2 = x[(long)(r + 2 * RGRP) * ldx + c], v3 = x[(long)(r + 3 * RGRP) * ldx + c];
+      s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; r < B; r += RGRP) s += x[(long)r * ldx + c];
+  }
   s = col_reduce(s, red, cx, ry);
   if (c < C && ry == 0) out[c] = s;
 }
