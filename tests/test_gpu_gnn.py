@@ -334,3 +334,21 @@ def test_gnn_random_configurations_one_step_vs_oracle(seed):
         close(got[k], v, 5e-5, 1e-6, f"{tag} loss {k}")                         # gate 1e-4
     exact = sum(float((gv.double() ** 2).sum()) for gv in info["grads"].values()) ** 0.5
     close(store.ctrl[5], exact, 2e-4, 1e-7, f"{tag} grad_norm")
+
+
+def test_nw_dataset_from_device_resident_layers_trains():
+    """Layers that live in HBM (what DeviceImporter / to_dataset produce) give a device-resident node tensor equal to the
+    host-built one, and the GNN trains on it without a host round trip."""
+    from flexynesis_amd.data import MultiOmicDataset, MultiOmicDatasetNW
+    from flexynesis_amd.models import GNN
+    from flexynesis_amd.fit import fit
+    ds, nw = _nw_dataset(n=64, genes=60)
+    ds_dev = MultiOmicDataset({k: v.cuda() for k, v in ds.dat.items()}, ds.ann, ds.variable_types, ds.features, ds.samples, {})
+    nw_dev = MultiOmicDatasetNW(ds_dev, nw.interaction_df)
+    assert nw_dev.node_features_tensor.is_cuda
+    assert torch.equal(nw_dev.node_features_tensor.cpu(), nw.node_features_tensor) and torch.equal(nw_dev.edge_index, nw.edge_index)
+    cfg = {"latent_dim": 8, "node_embedding_dim": 4, "num_convs": 1, "lr": 1e-3, "supervisor_hidden_dim": 4, "epochs": 2,
+           "batch_size": 16, "activation": "relu"}
+    model = GNN(cfg, nw_dev, ["y"], device_type="cuda", gnn_conv_type="GCN")
+    r = fit(model, nw_dev, np.arange(0, 48), np.arange(48, 64), batch_size=16, epochs=2, lr=1e-3, patience=5, seed=0)
+    assert np.isfinite(r.val_loss) and r.steps == 6
