@@ -388,14 +388,15 @@ __global__ __launch_bounds__(128 * WN) void fx_gemm_bf16x3_kernel(XGemmArgs g) {
 // M > 128 (the triplet network stacks anchor / positive / negative: M = 3B) used to launch one workgroup per 128-row
 // M tile, each streaming the same W tile from HBM (3x the traffic: 650 us instead of ~250 per modality at cfg4;
 // co-scheduling the tiles on one XCD did not produce L2 hits).  Here one workgroup owns MT M-tiles of one N tile:
-// W is loaded and split once per K-step and multiplied into MT accumulator sets.  LDS holds one stage
-// ([MT x (X hi, X lo)] + [W hi, W lo] = 64 KB at MT = 3); X is prefetched one K-step ahead in registers and W, the
+// W is loaded and split once per K-step and multiplied into MT accumulator sets.  LDS holds two stages of
+// [MT x (X hi, X lo)] + [W hi, W lo] (2 x 64 KB at MT = 3); X is prefetched one K-step ahead in registers and W, the
 // HBM stream, two (its latency is ~2 us; X comes from L2).  Loads and stashes are unconditional; K-steps past the
 // slice are requested out of range (zeros).
 template <int MT>
 __global__ __launch_bounds__(512) void fx_fwd_bf16x3_mt_kernel(XGemmArgs g) {
   constexpr int TN = 128, ARR = TM * TK;                        // one 128 x 32 bf16 array
-  __shared__ __attribute__((aligned(16))) __bf16 smem[(2 * MT + 2) * ARR];
+  constexpr int STAGE = (2 * MT + 2) * ARR;                     // MT x (X hi, X lo) + (W hi, W lo)
+  __shared__ __attribute__((aligned(16))) __bf16 smem[2 * STAGE];   // two stages: 96 KB (MT = 2) / 128 KB (MT = 3)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid & 1, wc = wid >> 1;
   const int groups_m = (g.M + MT * TM - 1) / (MT * TM);
@@ -419,9 +420,6 @@ __global__ __launch_bounds__(512) void fx_fwd_bf16x3_mt_kernel(XGemmArgs g) {
   const unsigned b_kb = (unsigned)k_begin * 4u, b_step = TK * 4u;
   const int a_lds = swz(a_row, a_c);
   const int b_lds0 = swz(bn, k4 >> 1) + ((k4 & 1) << 2), b_lds1 = swz(bn + 64, k4 >> 1) + ((k4 & 1) << 2);
-  __bf16* const Bh = smem + 2 * MT * ARR;
-  __bf16* const Bl = Bh + ARR;
-
   u32x4 pah[MT], pal[MT], s0_b0, s0_b1, s1_b0, s1_b1;
 #define MT_LOAD_A(kt)                                                            \
   {                                                                              \
@@ -439,14 +437,15 @@ __global__ __launch_bounds__(512) void fx_fwd_bf16x3_mt_kernel(XGemmArgs g) {
     P##_b0 = bld128(rB, (b_off0 + kb) | past);                                   \
     P##_b1 = bld128(rB, (b_off1 + kb) | past);                                   \
   }
-#define MT_STASH(P)                                                              \
+#define MT_STASH(P, buf)                                                         \
   {                                                                              \
+    __bf16* base = smem + (buf) * STAGE;                                         \
     _Pragma("unroll") for (int m = 0; m < MT; ++m) {                             \
-      *reinterpret_cast<u32x4*>(smem + (2 * m) * ARR + a_lds) = pah[m];          \
-      *reinterpret_cast<u32x4*>(smem + (2 * m + 1) * ARR + a_lds) = pal[m];      \
+      *reinterpret_cast<u32x4*>(base + (2 * m) * ARR + a_lds) = pah[m];          \
+      *reinterpret_cast<u32x4*>(base + (2 * m + 1) * ARR + a_lds) = pal[m];      \
     }                                                                            \
-    split_store4(P##_b0, Bh + b_lds0, Bl + b_lds0);                              \
-    split_store4(P##_b1, Bh + b_lds1, Bl + b_lds1);                              \
+    split_store4(P##_b0, base + 2 * MT * ARR + b_lds0, base + (2 * MT + 1) * ARR + b_lds0); \
+    split_store4(P##_b1, base + 2 * MT * ARR + b_lds1, base + (2 * MT + 1) * ARR + b_lds1); \
   }
   f32x16 acc[MT][2];
 #pragma unroll
@@ -454,13 +453,16 @@ __global__ __launch_bounds__(512) void fx_fwd_bf16x3_mt_kernel(XGemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc[m][0][i] = 0.f; acc[m][1][i] = 0.f; }
   const int arow = wr * 64 + (lane & 31), brow = wc * 32 + (lane & 31), kh = lane >> 5;
-#define MT_COMPUTE()                                                                              \
+#define MT_COMPUTE(buf)                                                                           \
   {                                                                                               \
+    const __bf16* sb = smem + (buf) * STAGE;                                                      \
+    const __bf16* Bh = sb + 2 * MT * ARR;                                                         \
+    const __bf16* Bl = Bh + ARR;                                                                  \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                            \
       const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Bh + swz(brow, 2 * ks + kh));            \
       const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Bl + swz(brow, 2 * ks + kh));            \
       _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                            \
-        const __bf16* Ah = smem + (2 * m) * ARR;                                                  \
+        const __bf16* Ah = sb + (2 * m) * ARR;                                                    \
         const __bf16* Al = Ah + ARR;                                                              \
         const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(Ah + swz(arow, 2 * ks + kh));         \
         const bf16x8 al0 = *reinterpret_cast<const bf16x8*>(Al + swz(arow, 2 * ks + kh));         \
@@ -472,24 +474,31 @@ __global__ __launch_bounds__(512) void fx_fwd_bf16x3_mt_kernel(XGemmArgs g) {
       }                                                                                           \
     }                                                                                             \
   }
+  // Two LDS stages, one barrier per K-step: while stage j is multiplied, the next K-step's operands (already in
+  // registers) are stashed into the other stage.  (The first version had a single stage and two barriers per step --
+  // stash and MFMA never overlapped: 580 us per modality at cfg4.)
   MT_LOAD_B(s0, 0);
   MT_LOAD_B(s1, 1);
   MT_LOAD_A(0);
+  MT_STASH(s0, 0);
+  __syncthreads();
+  MT_LOAD_A(1);
+  MT_LOAD_B(s0, 2);
+  __builtin_amdgcn_sched_barrier(0);
   for (int kt = 0; kt < nk; kt += 2) {
-    __syncthreads();
-    MT_STASH(s0);
-    __syncthreads();
-    MT_LOAD_A(kt + 1);
-    MT_LOAD_B(s0, kt + 2);
-    __builtin_amdgcn_sched_barrier(0);
-    MT_COMPUTE();
-    __syncthreads();
-    MT_STASH(s1);
+    MT_COMPUTE(0);                      // K-step kt
+    MT_STASH(s1, 1);                    // K-step kt + 1 (zeros past the slice)
     __syncthreads();
     MT_LOAD_A(kt + 2);
     MT_LOAD_B(s1, kt + 3);
     __builtin_amdgcn_sched_barrier(0);
-    MT_COMPUTE();                       // an odd trailing K-step was requested out of range: zeros
+    if (kt + 1 >= nk) break;
+    MT_COMPUTE(1);                      // K-step kt + 1
+    MT_STASH(s0, 0);                    // K-step kt + 2
+    __syncthreads();
+    MT_LOAD_A(kt + 3);
+    MT_LOAD_B(s0, kt + 4);
+    __builtin_amdgcn_sched_barrier(0);
   }
   const int n = n0 + wc * 32 + (lane & 31);
   const unsigned oob = (n < g.N) ? 0u : 0xFFFFFFF0u;
