@@ -52,6 +52,7 @@ struct XGemmArgs {
   long lda, ldb, ldc;
   int splitk, kchunk;
   int n_fast;         // block index walks N tiles first (set when M > N)
+  int xcd_blk;        // > 0: XCD-partitioned, L2-blocked tile order with groups of xcd_blk tiles (see the kernel)
   long slab_stride;
   float* adam_m;
   float* adam_v;
@@ -123,7 +124,28 @@ __global__ __launch_bounds__(128 * WN) void fx_gemm_bf16x3_kernel(XGemmArgs g) {
   // M-fastest order the decoders' weights (out = 20000 rows > in = 5000) re-streamed their 10 MB dY^T operand 40 times
   // and their dW+Adam launches took 508-632 us instead of ~430.
   int tm, tn;
-  if (g.n_fast) {
+  if (g.xcd_blk > 0) {
+    // XCD-partitioned, L2-blocked order (dW+Adam).  Workgroup ids go round-robin over the 8 XCDs and every XCD has its
+    // own 4 MB L2, so with a plain linear order each operand tile is fetched once per XCD, and when the smaller operand
+    // no longer fits one L2 (the triplet network's 3B-row operands: 11.5 MB) it is re-fetched for every tile of the
+    // other one -- PMC: 9.0 GB of HBM traffic per launch at cfg4 for 5.4 GB of W / m / v.  Here XCD x owns a contiguous
+    // 1/8 of the tiles along the longer dimension; inside it walks groups of xcd_blk tiles of the shorter dimension
+    // (the group's operand rows, <= 1.5 MB, stay L2-resident) against each of its own tiles, which is thereby reused
+    // xcd_blk times.
+    const int tiles_n = (g.N + TN - 1) / TN;
+    const int xcd = lin & 7, j = lin >> 3, G = g.xcd_blk;
+    const int ig = j % G, t2 = j / G;
+    if (tiles_n >= tiles_m) {          // split N over the XCDs, group M
+      const int per = (tiles_n + 7) / 8;
+      tn = xcd * per + t2 % per;
+      tm = (t2 / per) * G + ig;
+    } else {                           // split M over the XCDs, group N
+      const int per = (tiles_m + 7) / 8;
+      tm = xcd * per + t2 % per;
+      tn = (t2 / per) * G + ig;
+    }
+    if (tm >= tiles_m || tn >= tiles_n) return;       // padding of the index space (before any barrier)
+  } else if (g.n_fast) {
     const int tiles_n = (g.N + TN - 1) / TN;
     tn = lin % tiles_n;
     tm = lin / tiles_n;
@@ -729,7 +751,24 @@ int fx_linear_dw_adam_bf16x3(float* W, float* adam_m, float* adam_v, const void*
   g.n_fast = n_out > k_in;
   g.adam_m = adam_m; g.adam_v = adam_v; g.ctrl = ctrl;
   const int wn = adam_wn(), tn = 32 * wn;
-  const long nblk = (long)((n_out + TM - 1) / TM) * ((k_in + tn - 1) / tn);
+  long nblk = (long)((n_out + TM - 1) / TM) * ((k_in + tn - 1) / tn);
+  const int xcd_mode = env_int("FX_ADAM_XCD", 1);      // 0 = linear order, 1 = XCD order when it pays, 2 = always (tests)
+  if (xcd_mode) {
+    const int tiles_m = (n_out + TM - 1) / TM, tiles_n = (k_in + tn - 1) / tn;
+    const int longer = tiles_n >= tiles_m ? tiles_n : tiles_m, shorter = tiles_n >= tiles_m ? tiles_m : tiles_n;
+    // group size: the group's operand rows (tile rows x K x (hi + lo)) should fill about 1.5 MB of the 4 MB L2
+    const long tile_bytes = (long)(tiles_n >= tiles_m ? TM : tn) * batch_padded * 4;
+    // Only when the shorter dimension's whole operand does not fit one L2 anyway (measured: cfg2 / cfg3 shapes, 2.5 MB,
+    // are as fast or faster in the linear order; cfg4's 11.5 MB operand costs 9.0 instead of 5.9 GB of HBM traffic)
+    if (longer >= 16 && (xcd_mode == 2 || (long)shorter * tile_bytes > (3L << 20))) {
+      int G = (int)((3L << 19) / tile_bytes);
+      if (G < 1) G = 1;
+      if (G > shorter) G = shorter;
+      g.xcd_blk = G;
+      const int per = (longer + 7) / 8, groups = (shorter + G - 1) / G;
+      nblk = 8L * per * groups * G;
+    }
+  }
   FX_REQUIRE(nblk < (1L << 31), "fx_linear_dw_adam_bf16x3: grid too large");
   const int nt = env_int("FX_NT_ADAM", 1);
   if (wn == 4) {

@@ -463,6 +463,47 @@ def test_engine_vs_oracle_three_steps(model, layers, B):
             assert float((a - b_).norm() / upd_ref.norm()) <= 2e-2, f"{model} {k} step{step}: update norm mismatch"
 
 
+@pytest.mark.parametrize("n_out,k_in,B", [(1100, 2500, 96), (2600, 700, 64), (130, 2100, 32), (2050, 2050, 128)])
+def test_dw_adam_xcd_tile_order_is_bit_identical(n_out, k_in, B):
+    """The XCD-partitioned, L2-blocked tile order of the fused dW+Adam kernel (used when an operand outgrows one L2) only
+    changes WHICH workgroup computes a tile: forced on (FX_ADAM_XCD=2) it must reproduce the linear order bit for bit,
+    including ragged edges and the padded part of the index space."""
+    import os
+    from flexynesis_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(n_out + k_in)
+    dy = (torch.randn(B, n_out, generator=g) * 1e-2).to(dev)
+    x = torch.randn(B, k_in, generator=g).to(dev)
+    ldw = (k_in + 31) // 32 * 32
+    W0 = torch.randn(n_out, ldw, generator=g).to(dev)
+    m0, v0 = torch.randn(n_out, ldw, generator=g).to(dev) * 1e-3, torch.rand(n_out, ldw, generator=g).to(dev) * 1e-5
+    ctrl = torch.zeros(64, device=dev)
+    ctrl[0] = 3.0
+    ops.step_begin(ops.IMMEDIATE, ctrl, 1e-3)
+    ctrl[4] = 0.8
+    dyt, xt = ops.new_split(n_out, B, dev), ops.new_split(k_in, B, dev)
+    ops.split_bf16_t(ops.IMMEDIATE, dyt[0], dyt[1], dy)
+    ops.split_bf16_t(ops.IMMEDIATE, xt[0], xt[1], x)
+    outs = []
+    old = os.environ.get("FX_ADAM_XCD")
+    try:
+        for mode in ("0", "2"):
+            os.environ["FX_ADAM_XCD"] = mode
+            W, m, v = W0.clone(), m0.clone(), v0.clone()
+            ops.linear_dw_adam_bf16x3(ops.IMMEDIATE, W[:, :k_in], m[:, :k_in], v[:, :k_in], dyt[0], dyt[1], xt[0], xt[1], ctrl)
+            torch.cuda.synchronize()
+            outs.append((W, m, v))
+    finally:
+        if old is None:
+            os.environ.pop("FX_ADAM_XCD", None)
+        else:
+            os.environ["FX_ADAM_XCD"] = old
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert not torch.equal(outs[0][0][:, :k_in], W0[:, :k_in])            # the step did something
+    assert torch.equal(outs[0][0][:, k_in:], W0[:, k_in:])                # the row padding is untouched
+
+
 # ---------------------------------------------------------------------------------------------------
 # split-bf16 (bf16x3) wide-layer kernels
 # ---------------------------------------------------------------------------------------------------
