@@ -6,7 +6,7 @@ def load(path, name):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == name:
-            agg[r["Kernel_Name"].replace("void ", "").split("(")[0]].append(float(r["Counter_Value"]))
+            agg[r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]].append(float(r["Counter_Value"]))
     return agg
 f, w = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
 kern = {}
