@@ -50,13 +50,17 @@ template <int VEC>
 __global__ __launch_bounds__(GN_T) void fx_spmm_rows_kernel(float* __restrict__ out, const float* __restrict__ x,
                                                             const int* __restrict__ rowptr, const int* __restrict__ idx,
                                                             const float* __restrict__ w, int B, int nodes, int C,
-                                                            int tiles, int npw, int NG) {
+                                                            int tiles, int npw, int NG, int S) {
   // XCD-aware placement: consecutive block ids go round-robin over the 8 XCDs, so ids congruent mod 8 share an L2;
   // give each XCD whole samples.
   const int id = blockIdx.x;
   const int j = id >> 3, xcd = id & 7;
-  const int b = xcd + 8 * (j / tiles);
-  const int tile = j % tiles;
+  // inside an XCD the samples are taken S at a time and interleaved tile by tile: a tile's slice of the edge list
+  // (indices + weights, 8 B per edge) is then reused by S samples while their operands (S x nodes x C floats <= ~2 MB)
+  // share the L2, instead of the whole edge list being re-streamed for every sample (PMC: 132 -> ~60 MB per launch)
+  const int chunk = j / (tiles * S), rem = j - chunk * (tiles * S);
+  const int tile = rem / S;
+  const int b = xcd + 8 * (chunk * S + rem % S);
   if (b >= B) return;
   const int CQ = C / VEC, CP = cp_of(CQ), EG = 64 / CP, SPN = EG / NG;    // SPN edge slots per node
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -848,13 +852,21 @@ int fx_spmm_rows(float* out, const float* x, const int* rowptr, const int* idx, 
   if (ng > eg) ng = eg;
   if (ng > npw) ng = npw;
   if (ng < 1) ng = 1;
-  const dim3 grid(8 * bgroups * tiles);
+  // samples of one XCD interleaved per tile, as many as keep their operands within ~2 MB of the 4 MB L2
+  long S = (2L << 20) / ((long)nodes * C * 4);
+  if (S < 1) S = 1;
+  if (S > bgroups) S = bgroups;
+  const int chunks = (bgroups + (int)S - 1) / (int)S;
+  const dim3 grid(8 * chunks * (int)S * tiles);
   if (vec == 4)
-    hipLaunchKernelGGL(fx_spmm_rows_kernel<4>, grid, dim3(GN_T), 0, stream, out, x, rowptr, idx, w, B, nodes, C, tiles, npw, ng);
+    hipLaunchKernelGGL(fx_spmm_rows_kernel<4>, grid, dim3(GN_T), 0, stream, out, x, rowptr, idx, w, B, nodes, C, tiles, npw, ng,
+                       (int)S);
   else if (vec == 2)
-    hipLaunchKernelGGL(fx_spmm_rows_kernel<2>, grid, dim3(GN_T), 0, stream, out, x, rowptr, idx, w, B, nodes, C, tiles, npw, ng);
+    hipLaunchKernelGGL(fx_spmm_rows_kernel<2>, grid, dim3(GN_T), 0, stream, out, x, rowptr, idx, w, B, nodes, C, tiles, npw, ng,
+                       (int)S);
   else
-    hipLaunchKernelGGL(fx_spmm_rows_kernel<1>, grid, dim3(GN_T), 0, stream, out, x, rowptr, idx, w, B, nodes, C, tiles, npw, ng);
+    hipLaunchKernelGGL(fx_spmm_rows_kernel<1>, grid, dim3(GN_T), 0, stream, out, x, rowptr, idx, w, B, nodes, C, tiles, npw, ng,
+                       (int)S);
   return fx_check_launch("fx_spmm_rows");
 }
 
