@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--no-graph", action="store_true", help="launch the recorded tapes eagerly instead of a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sweep-trials-per-gpu", type=int, default=8, help="cfg5 leg after the timed region: this many "
+                    "DirectPred HPO trials per GPU, sharded over the ranks with the real collectives (0 = skip)")
     ap.add_argument("--cpu-steps", type=int, default=0, help="CPU baseline steps (0 = auto, about 10-30 s)")
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--features", type=int, default=0, help="override the per-layer feature count (shape experiments; "
@@ -186,31 +188,51 @@ def main():
             # Boxes of the pool differ by +-10 % in what their HBM delivers: record this box's plain device-to-device
             # copy rate (1 GiB read + 1 GiB write, HIP events) next to the kernel's figure.  `frac` stays relative to
             # the 8 TB/s vendor peak.
-            copy_gbs = None
+            copy_gbs = copy_torch = None
             try:
                 src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
                 dst = torch.empty_like(src)
-                dst.copy_(src)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(5):
-                    dst.copy_(src)
-                e1.record()
-                torch.cuda.synchronize()
-                copy_gbs = round(5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+
+                def rate(fn):
+                    fn()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(5):
+                        fn()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    return round(5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+                copy_gbs = rate(lambda: ops.stream_copy(ops.IMMEDIATE, dst, src))      # libfxhip's own 16 B / lane copy
+                copy_torch = rate(lambda: dst.copy_(src))
                 del src, dst
             except Exception:
-                copy_gbs = None
+                pass
             roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(ms),
-                    "algorithmic_bytes_per_launch": bytes_per_launch, "device_copy_GBps_this_box": copy_gbs}
+                    "algorithmic_bytes_per_launch": bytes_per_launch, "device_copy_GBps_this_box": copy_gbs,
+                    "torch_copy_GBps_this_box": copy_torch}
     P = store.n_params()
+    n_launch = pipe.n_launches()
     sumF = sum(F for _, F in cfg["layers"])
     k_reads = 3 if cfg["model"] == "MultiTripletNetwork" else 1
     bytes_step = 28.0 * P + 4.0 * k_reads * B * sumF
     ms_per_step = 1e3 * elapsed / a.steps
     value = world * a.steps * B / elapsed
+
+    # ---- cfg5 leg (outside the timed region): the sharded HPO sweep with its real collectives -- cohort broadcast from
+    # rank 0, LPT assignment, engine trials, all_gather of the records, winner state_dict broadcast (flexynesis_amd/sweep.py)
+    sweep = None
+    if a.sweep_trials_per_gpu > 0:
+        try:
+            del pipe, store, cohort
+            torch.cuda.empty_cache()
+            from flexynesis_amd.sweep import run_cfg5
+            with _stdout_to_stderr():
+                sweep = run_cfg5(dev, n_trials=a.sweep_trials_per_gpu * world, epochs=3,
+                                 features=cfg["layers"][0][1] if a.features else 20000, samples=2048, seed=0)
+        except Exception as e:     # reported, never fatal for the headline number
+            sweep = {"error": repr(e)}
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -239,10 +261,10 @@ def main():
                                    f"hidden_dim_factor 0.25, lr {a.lr}, clip 1.0 + Adam, "
                                    f"{'hipGraph replay' if use_graph else 'eager tapes'}",
                        "params": P, "global_batch": B * world, "parallelism": f"{world} independent trials (trial sharding)",
-                       "launches_per_step": pipe.n_launches(), "algorithmic_bytes_per_step": bytes_step,
+                       "launches_per_step": n_launch, "algorithmic_bytes_per_step": bytes_step,
                        "step_hbm_frac_of_8TBs": round(bytes_step / (ms_per_step * 1e-3) / 8e12, 4),
                        "loss_finite": finite, "last_losses": {k: round(v, 6) for k, v in losses.items()}},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "sweep": sweep,
         }
         print(json.dumps(out), flush=True)
     if use_pg:

@@ -67,6 +67,8 @@ PROTOTYPES = {
     "fx_mmd_finalize": (I, [P, P, I, I, P, I, F, F, I, P]),
     "fx_total_loss": (I, [P, I, I, P, P, P, P, P]),
     "fx_step_begin": (I, [P, F, I, P]),
+    "fx_fill": (I, [P, L, F, P]),
+    "fx_stream_copy": (I, [P, P, L, P]),
     "fx_sumsq_blocks": (I, [L]),
     "fx_sumsq": (I, [P, P, L, P]),
     "fx_hadamard_sum": (I, [P, P, P, L, P]),

@@ -22,7 +22,7 @@ int fx_check_launch(const char* what);
 // Written by fx_step_begin / fx_clip_finalize, read by every optimiser kernel, so that a whole
 // training step can be replayed from a hipGraph without host-side scalar arguments changing.
 enum FxCtrl {
-  FXC_STEP = 0,      // Adam step count t (stored as float, exact up to 2^24)
+  FXC_STEP = 0,      // Adam step count t, low part: an exact fp32 integer in [0, 2^24); t = FXC_STEP_HI * 2^24 + FXC_STEP
   FXC_LR = 1,        // learning rate
   FXC_BC1 = 2,       // 1 - beta1^t
   FXC_BC2_SQRT = 3,  // sqrt(1 - beta2^t)
@@ -30,8 +30,10 @@ enum FxCtrl {
   FXC_GNORM = 5,     // global grad L2 norm of the step
   FXC_SUMSQ = 6,     // reserved
   FXC_LOSS_TOTAL = 7,
-  FXC_BATCH_CURSOR = 8,  // float index of the current batch in the permutation buffer
-  FXC_CURSOR_BASE = 9,   // step count at which the current fit() started (cursor = (t-1-base) mod n_batches)
+  FXC_BATCH_CURSOR = 8,  // float index of the current batch in the permutation buffer; fx_step_begin advances it by one
+                         // row per step and wraps at n_batches
+  FXC_RESERVED9 = 9,
+  FXC_STEP_HI = 10,      // high part of the step count (number of 2^24 wraps)
   FXC_SIZE = 64
 };
 

@@ -28,14 +28,51 @@ int fx_check_launch(const char* what) {
 // ---- step control ----------------------------------------------------------------------------------
 __global__ void fx_step_begin_kernel(float* ctrl, float lr, int n_batches) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const float t = ctrl[FXC_STEP] + 1.0f;
+  // The step count is kept as two exact fp32 integers, t = FXC_STEP_HI * 2^24 + FXC_STEP, so it keeps counting past
+  // 2^24 steps (a single fp32 counter stops incrementing there).  Readers of FXC_STEP alone (the Philox offset uses its
+  // low 20 bits) see a value that keeps changing every step.
+  float t = ctrl[FXC_STEP] + 1.0f;
+  float hi = ctrl[FXC_STEP_HI];
+  if (t >= 16777216.0f) {
+    t -= 16777216.0f;
+    hi += 1.0f;
+    ctrl[FXC_STEP_HI] = hi;
+  }
   ctrl[FXC_STEP] = t;
+  const double te = (double)hi * 16777216.0 + (double)t;
   ctrl[FXC_LR] = lr;
-  ctrl[FXC_BC1] = (float)(1.0 - pow((double)FX_BETA1, (double)t));
-  ctrl[FXC_BC2_SQRT] = (float)sqrt(1.0 - pow((double)FX_BETA2, (double)t));
+  ctrl[FXC_BC1] = (float)(1.0 - pow((double)FX_BETA1, te));
+  ctrl[FXC_BC2_SQRT] = (float)sqrt(1.0 - pow((double)FX_BETA2, te));
   ctrl[FXC_CLIP_COEF] = 1.0f;
   ctrl[FXC_GNORM] = 0.0f;
-  if (n_batches > 0) ctrl[FXC_BATCH_CURSOR] = (float)(((long)t - 1 - (long)ctrl[FXC_CURSOR_BASE]) % n_batches);
+  // The batch cursor advances by one table row per step and wraps at n_batches (start it at -1 for "row 0 first", at 0
+  // when row 0 has already been assembled by a prefetch): exact for any number of steps.
+  if (n_batches > 0) {
+    int c = (int)ctrl[FXC_BATCH_CURSOR] + 1;
+    if (c >= n_batches || c < 0) c = 0;
+    ctrl[FXC_BATCH_CURSOR] = (float)c;
+  }
+}
+
+// Plain streaming copy, 16 bytes per lane, four loads in flight per thread: the box's practical HBM read+write rate,
+// reported by bench.py next to the dominant kernel's (boxes of the pool differ by +-10 %).
+typedef float fx_f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void fx_stream_copy_kernel(fx_f32x4* __restrict__ dst, const fx_f32x4* __restrict__ src, long n4) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const fx_f32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+    const fx_f32x4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+    __builtin_nontemporal_store(a, dst + i);
+    __builtin_nontemporal_store(b, dst + i + stride);
+    __builtin_nontemporal_store(c, dst + i + 2 * stride);
+    __builtin_nontemporal_store(d, dst + i + 3 * stride);
+  }
+  for (; i < n4; i += stride) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(256) void fx_fill_kernel(float* __restrict__ y, long n, float value) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = value;
 }
 
 // ---- sum of squares into double-precision slots ------------------------------------------------------
@@ -131,6 +168,22 @@ int fx_step_begin(float* ctrl, float lr, int n_batches, hipStream_t stream) {
   FX_REQUIRE(ctrl != nullptr, "fx_step_begin: null ctrl");
   hipLaunchKernelGGL(fx_step_begin_kernel, dim3(1), dim3(64), 0, stream, ctrl, lr, n_batches);
   return fx_check_launch("fx_step_begin");
+}
+
+int fx_stream_copy(float* dst, const float* src, long n, hipStream_t stream) {
+  FX_REQUIRE(dst && src && n > 0 && n % 4 == 0 && aligned16(dst) && aligned16(src), "fx_stream_copy: n %% 4 == 0 and 16-byte aligned buffers");
+  const long n4 = n / 4;
+  long b = (n4 + 256L * 4 - 1) / (256L * 4);
+  if (b > 256L * 16) b = 256L * 16;
+  hipLaunchKernelGGL(fx_stream_copy_kernel, dim3((unsigned)b), dim3(256), 0, stream, (fx_f32x4*)dst, (const fx_f32x4*)src, n4);
+  return fx_check_launch("fx_stream_copy");
+}
+
+int fx_fill(float* y, long n, float value, hipStream_t stream) {
+  FX_REQUIRE(y && n > 0, "fx_fill: bad args");
+  long b = (n + 255) / 256;
+  hipLaunchKernelGGL(fx_fill_kernel, dim3((unsigned)(b > 1024 ? 1024 : b)), dim3(256), 0, stream, y, n, value);
+  return fx_check_launch("fx_fill");
 }
 
 int fx_sumsq_blocks(long n) {

@@ -52,6 +52,8 @@ class ParamStore:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("flexynesis_amd.ParamStore needs a GPU device (no CPU path)")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.shapes = spec.state_shapes()
         self.param_keys = [k for k in self.shapes if not is_buffer_key(k)]
         self.buffer_keys = [k for k in self.shapes if is_buffer_key(k) and not k.endswith("num_batches_tracked")]
@@ -212,7 +214,8 @@ class ParamStore:
 
     @torch.no_grad()
     def load_optimizer(self, t: int, m: Dict[str, torch.Tensor], v: Dict[str, torch.Tensor]):
-        self.ctrl[ops.CTRL_STEP] = float(t)
+        self.ctrl[ops.CTRL_STEP] = float(int(t) % (1 << 24))          # t = hi * 2^24 + lo, both exact in fp32 (fx_common.h)
+        self.ctrl[ops.CTRL_STEP_HI] = float(int(t) >> 24)
         for k, val in m.items():
             self.m(k).copy_(torch.as_tensor(val).to(torch.float32))
         for k, val in v.items():
@@ -225,6 +228,7 @@ class ParamStore:
 class StepPlan:
     """Forward/backward/optimiser tapes for one (model, batch size)."""
 
+    @ops.device_guard
     def __init__(self, store: ParamStore, B: int, train: bool = True, fused: bool = True, clip: bool = True,
                  supplied_draws: bool = False, seed: int = 0, cohort=None, n_batches: int = 0,
                  epoch_acc: bool = False, precision: str = "bf16x3", branches: bool = True, share: "StepPlan" = None,
@@ -870,7 +874,8 @@ class StepPlan:
         row_sums = self._new("mmd_rows", 2 * (MMD_PRIOR + B))
         rec_part = self._new("recon_part", 1024)
         # dz must start from zero each step: the first head's data-grad GEMM overwrites it (accumulate=False),
-        # so heads go FIRST in the backward tape and the MMD rows kernel (+=) is emitted after them.
+        # so heads go FIRST in the backward tape and the MMD rows kernel (+=) is emitted after them; without heads an
+        # explicit zero-fill takes their place.
         with rf.parallel(nd if vae_par else 1) as par:      # one graph branch per decoder
             for i in range(nd):
                 if vae_par:
@@ -895,7 +900,12 @@ class StepPlan:
             priors.append(pr)
         self._head_losses(rf, z)
         if self.train:
-            self._head_bwd(rf, z, dz, first_accumulate=False)      # emitted into the forward tape: see note above
+            if spec.variables:
+                self._head_bwd(rf, z, dz, first_accumulate=False)  # emitted into the forward tape: see note above
+            else:
+                # unsupervised run (reference __main__.py:997 accepts supervised_vae / CrossModalPred without target
+                # variables): no head overwrites dz, and every later contribution accumulates into it
+                ops.fill(rf, dz, 0.0)
         for i in range(nd):       # mmd_loss = mean over the reconstructed layers (supervised_vae.py:309-313)
             F = spec.layers[dec[i]][1]
             dlg = logits[i] if self.train else None                  # dlogits overwrite logits in place
@@ -1022,16 +1032,20 @@ class StepPlan:
         for k in self.store.nbt:
             self.store.nbt[k] += self.passes if k.startswith("encoders.") and self.passes > 1 else 1
 
+    @ops.device_guard
     def forward(self):
         self.t_fwd.run()
 
+    @ops.device_guard
     def backward(self):
         self.t_bwd.run()
 
+    @ops.device_guard
     def optimizer_step(self, lr: float):
         ops.step_begin(ops.IMMEDIATE, self.store.ctrl, lr, 0)
         self.t_opt.run()
 
+    @ops.device_guard
     def train_step(self, lr: float, gather: bool = False):
         """One full optimisation step (eager launch of the recorded tapes)."""
         ops.step_begin(ops.IMMEDIATE, self.store.ctrl, lr, self.n_batches)
@@ -1042,6 +1056,7 @@ class StepPlan:
         self.t_opt.run()
         self.bump_nbt()
 
+    @ops.device_guard
     def capture(self, lr: float, gather: bool = True, warmup: bool = True):
         """Capture the whole step (cursor advance, gather, fwd, bwd, clip, Adam) into one hipGraph.
         ``warmup=True`` first runs one REAL step eagerly on a side stream (loads the code objects);
@@ -1070,6 +1085,7 @@ class StepPlan:
         self.t_bwd.run()
         self.t_opt.run()
 
+    @ops.device_guard
     def replay(self):
         self.graph.replay()
         self.bump_nbt()
@@ -1103,17 +1119,16 @@ class PipelinedStep:
                   epoch_acc=epoch_acc, precision=precision, clip=clip, frozen=frozen)
         a = StepPlan(store, B, **kw)
         self.plans = [a, StepPlan(store, B, share=a, **kw)]
-        self.store, self.n_batches = store, int(n_batches)
+        self.store, self.n_batches, self.dev = store, int(n_batches), store.device
         self.idx, self.epoch_acc = a.idx, a.epoch_acc
         self.k = 0                       # plan holding the batch of the next step
         self.done = 0                    # steps issued since prime()
         self.graphs = [None, None]
 
+    @ops.device_guard
     def prime(self):
         """Assemble table row 0 into plan 0 and point the cursor one row ahead of the step counter."""
-        c = self.store.ctrl
-        c[9] = c[0] - 1.0                # fx_step_begin: cursor = (t - 1 - base) mod n_batches = row of step t+1
-        c[8] = 0.0
+        self.store.ctrl[ops.CTRL_CURSOR] = 0.0      # fx_step_begin advances it first: step t assembles row (t + 1) mod n_batches
         self.plans[0].t_gather.run()
         self.k, self.done = 0, 0
 
@@ -1136,11 +1151,13 @@ class PipelinedStep:
         else:
             cur.t_opt.run_timed(*timed)
 
+    @ops.device_guard
     def step(self, lr: float, timed=None):
         """One optimisation step, eager launch."""
         self._issue(self.k, lr, timed)
         self._advance()
 
+    @ops.device_guard
     def capture(self, lr: float):
         """Capture both parities of the step into hipGraphs (no work is executed)."""
         torch.cuda.synchronize()
@@ -1150,6 +1167,7 @@ class PipelinedStep:
                 self._issue(k, lr)
             self.graphs[k] = g
 
+    @ops.device_guard
     def replay(self):
         self.graphs[self.k].replay()
         self._advance()

@@ -121,6 +121,15 @@ def fit(model, dataset, train_idx: Sequence[int], val_idx: Optional[Sequence[int
     trainer (main.py:530-611) is ``clip=False, drop_last=False, frozen=(...)``: state_dict key prefixes with
     requires_grad=False are neither differentiated nor stepped, and the last partial batch of an epoch is used."""
     store = model._bind(device)
+    # streams, events and graph capture are keyed on torch's current device: make it the model's for the whole fit
+    with torch.cuda.device(store.device):
+        return _fit(model, store, dataset, train_idx, val_idx, batch_size=batch_size, epochs=epochs, lr=lr, patience=patience,
+                    seed=seed, use_graph=use_graph, verbose=verbose, clip=clip, frozen=frozen, drop_last=drop_last,
+                    fresh_optimizer=fresh_optimizer)
+
+
+def _fit(model, store, dataset, train_idx, val_idx, *, batch_size, epochs, lr, patience, seed, use_graph, verbose, clip, frozen,
+         drop_last, fresh_optimizer) -> FitResult:
     dev = store.device
     if fresh_optimizer:
         store.reset_optimizer()             # a new torch.optim.Adam per fit (main.py:562-566)
@@ -192,7 +201,6 @@ def fit(model, dataset, train_idx: Sequence[int], val_idx: Optional[Sequence[int
                 write_table()
             tail_plan.idx.copy_(tails.pop(0))
             tail_plan.train_step(lr, gather=True)
-            store.ctrl[9] += 1.0      # the table cursor is derived from the step counter: the tail step is not a table row
             steps += 1
         epochs_run = epoch + 1
         # epoch means weighted by batch size, like Lightning's on_epoch reduction of the logged losses

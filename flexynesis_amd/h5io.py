@@ -95,6 +95,8 @@ def lib():
         "H5Tget_size": (C.c_size_t, [hid_t]),
         "H5Tget_class": (C.c_int, [hid_t]),
         "H5Tclose": (herr_t, [hid_t]),
+        "H5Tis_variable_str": (C.c_int, [hid_t]),
+        "H5Dvlen_reclaim": (herr_t, [hid_t, hid_t, hid_t, C.c_void_p]),
         "H5Pcreate": (hid_t, [hid_t]),
         "H5Pset_chunk": (herr_t, [hid_t, C.c_int, C.POINTER(hsize_t)]),
         "H5Pget_layout": (C.c_int, [hid_t]),
@@ -199,7 +201,9 @@ class H5File:
             L.H5Dclose(d)
 
     def read_strings(self, name: str) -> List[str]:
-        """A 1-D dataset of fixed-length byte strings -> list of str (reference h5_dataloader.py:101-102)."""
+        """A 1-D string dataset -> list of str (reference h5_dataloader.py:101-102).  The converter writes fixed-length
+        byte strings (csv_to_h5.py:111-112, dtype 'S'); h5py writes ``str`` data as VARIABLE-length strings, which the
+        library hands back as an array of char pointers -- both are handled."""
         L = lib()
         d = _chk(L.H5Dopen2(self.id, name.encode(), H5P_DEFAULT), f"open dataset /{name}")
         try:
@@ -210,6 +214,22 @@ class H5File:
             if L.H5Tget_class(t) != H5T_STRING:
                 L.H5Tclose(t)
                 raise H5Error(f"/{name}: expected a string dataset")
+            if L.H5Tis_variable_str(t) > 0:
+                L.H5Tclose(t)
+                mt = _chk(L.H5Tcopy(_g("H5T_C_S1_g")), "H5Tcopy")
+                try:
+                    _chk(L.H5Tset_size(mt, C.c_size_t(-1).value), "H5Tset_size(H5T_VARIABLE)")
+                    ptrs = (C.c_char_p * max(n, 1))()
+                    sp = _chk(L.H5Dget_space(d), "H5Dget_space")
+                    try:
+                        _chk(L.H5Dread(d, mt, H5S_ALL, H5S_ALL, H5P_DEFAULT, C.cast(ptrs, C.c_void_p)), f"H5Dread /{name}")
+                        out = [(ptrs[i] or b"").decode() for i in range(n)]
+                        L.H5Dvlen_reclaim(mt, sp, H5P_DEFAULT, C.cast(ptrs, C.c_void_p))     # the library allocated the strings
+                    finally:
+                        L.H5Sclose(sp)
+                    return out
+                finally:
+                    L.H5Tclose(mt)
             size = L.H5Tget_size(t)
             buf = C.create_string_buffer(max(n * size, 1))
             rc = L.H5Dread(d, t, H5S_ALL, H5S_ALL, H5P_DEFAULT, C.cast(buf, C.c_void_p))
@@ -241,9 +261,24 @@ class H5File:
         L.H5Sclose(sp)
         _chk(rc, f"H5Dwrite /{name}")
 
-    def write_strings(self, name: str, values: Sequence[str]):
+    def write_strings(self, name: str, values: Sequence[str], variable: bool = False):
+        """Fixed-length byte strings (the converter's dtype 'S', default) or, with ``variable``, the variable-length
+        strings h5py writes for ``str`` data."""
         L = lib()
         enc = [str(v).encode() for v in values]
+        if variable:
+            t = _chk(L.H5Tcopy(_g("H5T_C_S1_g")), "H5Tcopy")
+            _chk(L.H5Tset_size(t, C.c_size_t(-1).value), "H5Tset_size(H5T_VARIABLE)")
+            ptrs = (C.c_char_p * max(len(enc), 1))(*enc)
+            dims = (hsize_t * 1)(len(enc))
+            sp = _chk(L.H5Screate_simple(1, dims, None), "H5Screate_simple")
+            d = _chk(L.H5Dcreate2(self.id, name.encode(), t, sp, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT), f"create /{name}")
+            rc = L.H5Dwrite(d, t, H5S_ALL, H5S_ALL, H5P_DEFAULT, C.cast(ptrs, C.c_void_p))
+            L.H5Dclose(d)
+            L.H5Sclose(sp)
+            L.H5Tclose(t)
+            _chk(rc, f"H5Dwrite /{name}")
+            return
         size = max([len(e) for e in enc] + [1])
         arr = np.array(enc, dtype=f"S{size}")                      # numpy 'S' = fixed-length, NUL padded
         t = _chk(L.H5Tcopy(_g("H5T_C_S1_g")), "H5Tcopy")
@@ -312,6 +347,8 @@ def read_matrix_to_device(path: str, device="cuda:0", block_bytes: int = 64 << 2
         rows_per = max(1, min(n, block_bytes // row_bytes))
         pins = _pinned_pair(rows_per * row_bytes)
         stream = torch.cuda.Stream(device=dev)
+        # dst may be a block the caching allocator just recycled: work queued on the current stream can still touch it
+        stream.wait_stream(torch.cuda.current_stream(dev))
         done = [None, None]
         for k, r0 in enumerate(range(0, n, rows_per)):
             r1 = min(n, r0 + rows_per)

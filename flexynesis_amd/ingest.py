@@ -58,6 +58,9 @@ class DeviceImporter:
         self.device = torch.device(device)
         if self.device.type != "cuda" or not torch.cuda.is_available():
             raise FxError("DeviceImporter needs the GPU (flexynesis_amd has no CPU fallback)")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.dev = self.device              # ops.device_guard: kernels launch on this device's current stream
         self._rec = ops.ImmediateRecorder()
 
     # -- host -> HBM ---------------------------------------------------------------------------------------------
@@ -136,6 +139,7 @@ class DeviceImporter:
         return out
 
     # -- import_data's matrix flow (reference data.py:190-231) -----------------------------------------------------------
+    @ops.device_guard
     def import_matrices(self, train: Dict[str, object], test: Optional[Dict[str, object]] = None, *,
                         selected: Optional[Dict[str, Sequence[int]]] = None,
                         train_feature_ids: Optional[Dict[str, Sequence]] = None,

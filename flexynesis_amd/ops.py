@@ -18,11 +18,30 @@ from ._lib import lib, FxError
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 CTRL_FLOATS = 64
-CTRL_STEP, CTRL_LR, CTRL_CLIP_COEF, CTRL_GNORM, CTRL_CURSOR = 0, 1, 4, 5, 8
+CTRL_STEP, CTRL_LR, CTRL_CLIP_COEF, CTRL_GNORM, CTRL_CURSOR, CTRL_STEP_HI = 0, 1, 4, 5, 8, 10
 
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+def device_guard(fn):
+    """Method decorator: run with ``self.dev`` as the current HIP device.  Launch streams, the side-stream pool,
+    events and graph capture are all keyed on torch's CURRENT device while buffers live on the device the caller
+    asked for; without the guard ``fit(..., device='cuda:1')`` from a process whose current device is 0 would launch
+    GPU-0 streams on GPU-1 pointers."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        dev = getattr(self, "dev", None)
+        if dev is None:                      # constructors: the device is the ParamStore's (first argument)
+            dev = (a[0] if a else k["store"]).device
+        if dev.index is None or torch.cuda.current_device() == dev.index:
+            return fn(self, *a, **k)
+        with torch.cuda.device(dev):
+            return fn(self, *a, **k)
+    return wrapped
 
 
 def _chk2d(t: torch.Tensor, name: str):
@@ -609,6 +628,14 @@ def total_loss(rec, total_out, losses, logvars, dlogvars, weighted, epoch_acc=No
     rec.emit("fx_total_loss", total_out.data_ptr(), n, int(weighted), C.cast(la, C.c_void_p),
              C.cast(lv, C.c_void_p) if lv is not None else None, C.cast(dl, C.c_void_p) if dl is not None else None,
              _ptr(epoch_acc))
+
+
+def fill(rec, y, value=0.0):
+    rec.emit("fx_fill", y.data_ptr(), y.numel(), float(value))
+
+
+def stream_copy(rec, dst, src):
+    rec.emit("fx_stream_copy", dst.data_ptr(), src.data_ptr(), src.numel())
 
 
 def step_begin(rec, ctrl, lr, n_batches=0):

@@ -36,6 +36,73 @@ def _cohort(layers, n, device, seed):
     return dat, ann
 
 
+def run_cfg5(dev, n_trials: int = 64, epochs: int = 3, features: int = 20000, samples: int = 2048, seed: int = 0,
+             keep_winner: bool = True) -> dict:
+    """The cfg5 workload on the CURRENT process group (or a single process): rank 0 builds the synthetic cohort and
+    broadcasts it, trials are assigned longest-first, every rank runs its trials with the engine loop, one all_gather
+    collects the records and the winner's state_dict is broadcast.  Returns the summary dict (identical on every rank)."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    layers = [("gex", features), ("cnv", features)]
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    dat, ann = _cohort(layers, samples, dev, 1234) if rank == 0 else (None, None)
+    torch.cuda.synchronize(dev)
+    t_gen = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    dat, ann = trials.broadcast_cohort(dat, ann, dev)
+    torch.cuda.synchronize(dev)
+    t_bcast = time.perf_counter() - t0
+    feats = {k: [f"{k}_{i}" for i in range(v.shape[1])] for k, v in dat.items()}
+    ds = MultiOmicDataset(dat, ann, {"y": "numerical"}, feats, [f"s{i}" for i in range(samples)], {})
+    plist = trials.draw_search_space(n_trials, seed=seed, epochs=epochs)
+    n_train = samples - int(samples * 0.2)
+    costs = [trials.trial_cost(p, 2 * features, n_train) for p in plist]
+    stats = {"samples": 0, "busy": 0.0}
+
+    def trial_fn(tid, params):
+        t = time.perf_counter()
+        val, ep, model, info = run_trial(DirectPred, params, ds, ["y"], early_stop_patience=0, seed=seed * 100003 + tid,
+                                         device=dev)
+        if "error" in info:
+            raise RuntimeError(info["error"])
+        stats["samples"] += info["steps"] * int(params["batch_size"])
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()} if keep_winner else None
+        del model
+        torch.cuda.synchronize(dev)
+        stats["busy"] += time.perf_counter() - t
+        return val, ep, sd
+
+    def shapes_of(params):
+        return spec_from_dataset("DirectPred", params, ds, ["y"]).state_shapes()
+
+    t1 = time.perf_counter()
+    table, best, state = trials.run_sweep(plist, trial_fn, costs, dev, shapes_of if keep_winner else None)
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t1
+    mine = torch.tensor([float(stats["samples"]), wall, stats["busy"]], dtype=torch.float64, device=dev)
+    if world > 1:
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        allr = torch.stack(parts).cpu().numpy()
+    else:
+        allr = mine.cpu().numpy()[None]
+    ok = table[:, 3] == trials.STATUS_OK
+    busy = allr[:, 2]
+    return {
+        "workload": f"cfg5: {n_trials} DirectPred trials (2 x {features} features, N={samples}, {epochs} epochs), "
+                    f"{world} GPU(s), trial sharding (LPT)",
+        "n_gpus": world, "trials": int(n_trials), "trials_ok": int(ok.sum()), "best_trial": best,
+        "best_val_loss": float(table[best, 1]), "best_params": plist[best],
+        "winner_state_tensors": len(state) if state is not None else 0,
+        "cohort_generate_s": round(t_gen, 4), "cohort_broadcast_s": round(t_bcast, 4),
+        "sweep_wall_s": round(float(allr[:, 1].max()), 3),
+        "aggregate_samples_per_s": round(float(allr[:, 0].sum()) / float(allr[:, 1].max()), 1),
+        "rank_busy_s": [round(float(b), 3) for b in busy],
+        "tail_imbalance": round(1.0 - float(busy.mean()) / max(float(busy.max()), 1e-9), 4),
+    }
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--trials", type=int, default=64)
@@ -52,53 +119,9 @@ def main(argv=None):
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
-    layers = [("gex", a.features), ("cnv", a.features)]
-    t0 = time.perf_counter()
-    dat, ann = _cohort(layers, a.samples, dev, 1234) if rank == 0 else (None, None)
-    dat, ann = trials.broadcast_cohort(dat, ann, dev)
-    torch.cuda.synchronize()
-    t_bcast = time.perf_counter() - t0
-    feats = {k: [f"{k}_{i}" for i in range(v.shape[1])] for k, v in dat.items()}
-    ds = MultiOmicDataset(dat, ann, {"y": "numerical"}, feats, [f"s{i}" for i in range(a.samples)], {})
-    plist = trials.draw_search_space(a.trials, seed=a.seed, epochs=a.epochs)
-    n_train = a.samples - int(a.samples * 0.2)
-    costs = [trials.trial_cost(p, 2 * a.features, n_train) for p in plist]
-
-    def trial_fn(tid, params):
-        val, epochs, model, info = run_trial(DirectPred, params, ds, ["y"], early_stop_patience=0, seed=a.seed * 100003 + tid,
-                                             device=dev)
-        if "error" in info:
-            raise RuntimeError(info["error"])
-        trial_fn.samples += info["steps"] * int(params["batch_size"])
-        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
-        del model
-        return val, epochs, sd
-    trial_fn.samples = 0
-
-    def shapes_of(params):
-        return spec_from_dataset("DirectPred", params, ds, ["y"]).state_shapes()
-
-    t1 = time.perf_counter()
-    table, best, state = trials.run_sweep(plist, trial_fn, costs, dev, shapes_of)
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t1
-    tot = torch.tensor([float(trial_fn.samples), wall], dtype=torch.float64, device=dev)
-    if world > 1:
-        s = tot[:1].clone()
-        dist.all_reduce(s, op=dist.ReduceOp.SUM)
-        w = tot[1:].clone()
-        dist.all_reduce(w, op=dist.ReduceOp.MAX)
-        tot = torch.cat([s, w])
+    out = run_cfg5(dev, a.trials, a.epochs, a.features, a.samples, a.seed)
     if rank == 0:
-        ok = table[:, 3] == trials.STATUS_OK
-        print(json.dumps({
-            "workload": f"cfg5: {a.trials} DirectPred trials (2 x {a.features} features, N={a.samples}, {a.epochs} epochs), "
-                        f"{world} GPU(s), trial sharding",
-            "n_gpus": world, "trials": a.trials, "trials_ok": int(ok.sum()), "best_trial": best,
-            "best_val_loss": float(table[best, 1]), "best_params": plist[best],
-            "winner_state_tensors": len(state) if state is not None else 0,
-            "cohort_broadcast_s": round(t_bcast, 4), "sweep_wall_s": round(float(tot[1]), 3),
-            "aggregate_samples_per_s": round(float(tot[0]) / float(tot[1]), 1)}), flush=True)
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

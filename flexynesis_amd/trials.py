@@ -119,8 +119,10 @@ def run_sweep(param_list: List[dict], trial_fn: Callable[[int, dict], Tuple[floa
     rank = dist.get_rank() if dist.is_initialized() else 0
     n = len(param_list)
     costs = list(costs) if costs is not None else [1.0] * n
-    mine = assign_trials(costs, world)[rank]
-    local, states = [], {}
+    assignment = assign_trials(costs, world)
+    mine = assignment[rank]
+    local = []
+    best_local = (float("inf"), -1, None)          # only the best local trial's weights are kept (0.8 GB each at cfg2)
     for tid in mine:
         try:
             val, epochs, state = trial_fn(tid, param_list[tid])
@@ -129,15 +131,25 @@ def run_sweep(param_list: List[dict], trial_fn: Callable[[int, dict], Tuple[floa
         except Exception:                      # a broken trial reports +inf; the sweep goes on
             val, epochs, state, status = float("inf"), 0, None, STATUS_FAILED
         local.append((tid, float(val), int(epochs), status))
-        if state is not None:
-            states[tid] = state
+        # ties resolve to the lowest trial id, like np.argmin over the gathered table
+        if state is not None and status == STATUS_OK and (best_local[2] is None or (val, tid) < best_local[:2]):
+            best_local = (float(val), tid, state)
+        del state
     table = gather_results(local, n, device)
     best = int(np.argmin(table[:, 1]))
     best_state = None
     if state_shapes is not None and math.isfinite(table[best, 1]):
-        owner = next(r for r, lst in enumerate(assign_trials(costs, world)) if best in lst)
-        shapes = state_shapes(param_list[best]) if callable(state_shapes) else state_shapes
-        best_state = broadcast_state(states.get(best), shapes, owner, device)
+        owner = next(r for r, lst in enumerate(assignment) if best in lst)
+        # Every rank must take the same branch: the owner announces whether it actually holds the winner's weights
+        # (a trial_fn may return None for them), so a missing state degrades to best_state=None everywhere instead of the
+        # owner raising while the others wait in the broadcast.
+        have = torch.tensor([1.0 if (rank == owner and best_local[1] == best and best_local[2] is not None) else 0.0],
+                            dtype=torch.float32, device=device)
+        if dist.is_initialized() and world > 1:
+            dist.all_reduce(have, op=dist.ReduceOp.SUM)
+        if float(have.item()) > 0:
+            shapes = state_shapes(param_list[best]) if callable(state_shapes) else state_shapes
+            best_state = broadcast_state(best_local[2] if rank == owner else None, shapes, owner, device)
     return table, best, best_state
 
 

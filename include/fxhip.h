@@ -201,6 +201,11 @@ int fx_total_loss(float* total_out, int n, int weighted, const float* const* los
 
 /* ---- optimiser: Lightning's clip_grad_norm_(1.0) + torch.optim.Adam(lr) (main.py:212-225, direct_pred.py:143) */
 int fx_step_begin(float* ctrl, float lr, int n_batches, fx_stream_t stream);
+/* y[0..n) = value (zero_grad of an accumulator that no kernel of the step overwrites first) */
+int fx_fill(float* y, long n, float value, fx_stream_t stream);
+/* dst[0..n) = src[0..n): plain 16-byte-per-lane streaming copy (n % 4 == 0, 16-byte aligned).  bench.py times it to
+ * quote the box's own read+write HBM rate next to the dominant kernel's roofline fraction. */
+int fx_stream_copy(float* dst, const float* src, long n, fx_stream_t stream);
 int fx_sumsq_blocks(long n);
 int fx_sumsq(double* slots, const float* x, long n, fx_stream_t stream);
 int fx_hadamard_sum(double* slot, const float* g1, const float* g2, long n, fx_stream_t stream);

@@ -99,7 +99,8 @@ def name_draws(spec: Spec, cap: Capture) -> Dict[str, torch.Tensor]:
 
 
 def reference_batch(spec: Spec, batch):
-    samples = tuple(f"s{i}" for i in range(next(iter(batch["y"].values())).shape[0]))
+    first = batch["anchor"][0] if spec.model == "MultiTripletNetwork" else batch["x"][0]
+    samples = tuple(f"s{i}" for i in range(first.shape[0]))          # (no label dict entry exists in unsupervised runs)
     if spec.model == "MultiTripletNetwork":
         d = lambda xs: {name: x for (name, _), x in zip(spec.layers, xs)}
         return (d(batch["anchor"]), d(batch["positive"]), d(batch["negative"]), batch["y"])

@@ -263,7 +263,7 @@ def test_pipelined_step_equals_plain_step(model_name):
         store = ParamStore(spec, dev)
         store.load_state(init)
         plan = StepPlan(store, B, train=True, fused=True, seed=9, cohort=cohort, n_batches=nb, epoch_acc=True)
-        store.ctrl[9] = store.ctrl[0].clone()
+        store.ctrl[8] = -1.0            # fx_step_begin advances the cursor before the gather: row 0 first
         out = []
         for s in range(steps):
             if s % nb == 0:

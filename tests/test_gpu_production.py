@@ -1,0 +1,456 @@
+"""GPU parity tests of EXACTLY what bench.py times (run with -m gpu):
+
+  * one / two optimisation steps at the full BASELINE shapes -- cfg2 (2 x 20000, B = 128), cfg3 (supervised_vae,
+    2 x 20000) and cfg4 (MultiTripletNetwork 3 x 30000, B = 128 -> 384 stacked rows: the multi-M-tile forward and the
+    XCD-partitioned dW+Adam tile order engage on their own) -- against the CPU oracle with supplied draws;
+  * the dominant kernel (fused dW + clip + Adam) against an fp64 reference at 5000 x 20000 / K = 128 and
+    7500 x 30000 / K = 384;
+  * the production RNG mode (in-kernel Philox: what fit() / bench.py run, supplied_draws=False): keep rates, moments of
+    the normal draws, independence across steps / layers / anchor-positive-negative passes, forward mask == backward gate;
+
+(The pipelined / hipGraph-replayed schedule itself is pinned to the plain step in tests/test_gpu_api.py.)
+Nothing here reads /root/reference."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_parity import _dev, _oracle_spec, close
+
+pytestmark = pytest.mark.gpu
+
+FULL = {
+    # bench.py CONFIGS / SURVEY.md section 8(d)
+    "cfg2": dict(model="DirectPred", layers=[("gex", 20000), ("cnv", 20000)], variables=[("y", "numerical", 1)],
+                 surv=(None, None), steps=2),
+    "cfg3": dict(model="supervised_vae", layers=[("gex", 20000), ("cnv", 20000)],
+                 variables=[("c", "categorical", 4), ("event", "numerical", 1)], surv=("event", "time"), steps=1),
+    "cfg4": dict(model="MultiTripletNetwork", layers=[("gex", 30000), ("cnv", 30000), ("meth", 30000)],
+                 variables=[("c", "categorical", 4)], surv=(None, None), steps=1),
+}
+
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4"])
+def test_fullsize_step_vs_oracle(name):
+    """The shapes bench.py times, with supplied draws: named losses <= 1e-4 relative (the north-star gate), grad norm vs
+    the fp64 norm of the oracle's gradients, >= 99.9 % of every wide weight's elements tight after the step, update
+    norm.  Every step starts from the oracle's state (per-step parity)."""
+    from flexynesis_amd.arch import ArchSpec
+    from flexynesis_amd.engine import ParamStore, StepPlan
+    from oracle import restate as O
+    cfg, dev, B, N = FULL[name], _dev(), 128, 512
+    layers, model = cfg["layers"], cfg["model"]
+    aspec = ArchSpec(model, layers, 64, 0.25, 16, cfg["variables"], cfg["surv"][0], cfg["surv"][1], True)
+    ospec = _oracle_spec(aspec)
+    dat, ann = O.synthetic_cohort(layers, N, seed=1234)
+    st = O.init_state(ospec, seed=5)
+    store = ParamStore(aspec, dev, materialize_big_grads=False)
+    assert len(store.big_keys) >= len(layers), store.big_keys          # the wide weights take the fused dW+Adam path
+    store.load_state(st)
+    plan = StepPlan(store, B, train=True, fused=True, supplied_draws=True)
+    gen = torch.Generator().manual_seed(2024)
+    opt, lr = {}, 1e-3
+    for step in range(cfg["steps"]):
+        if step > 0:
+            store.load_state(st)
+            store.reset_optimizer()
+            store.load_optimizer(opt["t"], opt["m"], opt["v"])
+        idx = torch.randperm(N, generator=gen)
+        y = {k: ann[k][idx[:B]] for k in plan.y}
+        draws = {}
+        for dn, t in plan.draws.items():
+            if dn == "eps" or dn.startswith("prior."):
+                draws[dn] = torch.randn(t.shape, generator=gen)
+            else:
+                draws[dn] = (torch.rand(t.shape, generator=gen) < 0.9).float()
+        if model == "MultiTripletNetwork":
+            parts = [[dat[n][idx[j * B:(j + 1) * B]] for n, _ in layers] for j in range(3)]
+            batch = {"anchor": parts[0], "positive": parts[1], "negative": parts[2], "y": y}
+            plan.set_batch(parts=[[x.to(dev) for x in p] for p in parts], y={k: v.to(dev) for k, v in y.items()})
+        else:
+            xs = [dat[n][idx[:B]] for n, _ in layers]
+            batch = {"x": xs, "y": y}
+            plan.set_batch(x_list=[x.to(dev) for x in xs], y={k: v.to(dev) for k, v in y.items()})
+        plan.set_draws({k: v.to(dev) for k, v in draws.items()})
+        plan.train_step(lr)
+        st_prev = st
+        st, opt, info = O.train_step(ospec, st, opt, batch, draws, lr)
+        got = plan.losses()
+        for k, v in info["losses"].items():
+            close(got[k], v, 1e-4, 1e-6, f"{name} step{step} loss {k}")
+        exact = sum(float((gv.double() ** 2).sum()) for gv in info["grads"].values()) ** 0.5
+        close(store.ctrl[5], exact, 1e-4, 1e-7, f"{name} grad norm vs the fp64 norm of the oracle's gradients")
+        sd = store.state_dict()
+        for k in store.big_keys:
+            a, b_ = sd[k].double(), st[k].double()
+            bad = (a - b_).abs() > 2e-5 + 1e-3 * b_.abs()
+            assert float(bad.double().mean()) <= 1e-3, f"{name} {k} step{step}: {int(bad.sum())} of {bad.numel()} elements differ"
+            upd_ref = b_ - st_prev[k].double()
+            assert float((a - b_).norm() / upd_ref.norm()) <= 2e-2, f"{name} {k} step{step}: update norm mismatch"
+            del a, b_, bad, upd_ref
+        for k in store.small_keys:      # every small parameter too (noise-floor entries: DESIGN.md section 3.1)
+            gk = info["grads"].get(k)
+            atol = 3e-6 if gk is None else torch.where(gk.abs() < 1e-6 * exact, torch.tensor(2.1 * lr), torch.tensor(3e-6))
+            close(sd[k], st[k], 2e-4, atol, f"{name} step{step} state {k}")
+
+
+@pytest.mark.parametrize("n_out,k_in,K", [(5000, 20000, 128), (7500, 30000, 384)])
+def test_dominant_kernel_fullsize_vs_fp64(n_out, k_in, K):
+    """fx_linear_dw_adam_bf16x3 at the cfg2 and cfg4 weight shapes (cfg4: K = 3B = 384 and an 11.5 MB dY^T operand, so
+    the XCD-partitioned tile order engages by itself) against dW, m, v, W computed in fp64."""
+    from flexynesis_amd import ops
+    dev = _dev()
+    g = torch.Generator(device=dev)
+    g.manual_seed(n_out + K)
+    dy = torch.randn(K, n_out, generator=g, device=dev) * 1e-3
+    x = torch.randn(K, k_in, generator=g, device=dev)
+    ldw = ops.pad32(k_in)
+    W = torch.randn(n_out, ldw, generator=g, device=dev) * 0.01
+    m = torch.randn(n_out, ldw, generator=g, device=dev) * 1e-4
+    v = torch.rand(n_out, ldw, generator=g, device=dev) * 1e-7
+    W0, m0, v0 = W[:, :k_in].double(), m[:, :k_in].double(), v[:, :k_in].double()
+    pad0 = W[:, k_in:].clone()
+    ctrl = torch.zeros(64, device=dev)
+    ctrl[0] = 4.0
+    lr, coef = 1e-3, 0.37
+    ops.step_begin(ops.IMMEDIATE, ctrl, lr)           # t = 5
+    ctrl[4] = coef
+    dyt, xt = ops.new_split(n_out, K, dev), ops.new_split(k_in, K, dev)
+    ops.split_bf16_t(ops.IMMEDIATE, dyt[0], dyt[1], dy)
+    ops.split_bf16_t(ops.IMMEDIATE, xt[0], xt[1], x)
+    ops.linear_dw_adam_bf16x3(ops.IMMEDIATE, W[:, :k_in], m[:, :k_in], v[:, :k_in], dyt[0], dyt[1], xt[0], xt[1], ctrl)
+    torch.cuda.synchronize()
+    gr = (dy.double().t() @ x.double()) * coef
+    t = 5
+    m_ref = 0.9 * m0 + 0.1 * gr
+    v_ref = 0.999 * v0 + 0.001 * gr * gr
+    denom = v_ref.sqrt() / math.sqrt(1 - 0.999 ** t) + 1e-8
+    W_ref = W0 - (lr / (1 - 0.9 ** t)) * m_ref / denom
+    gscale = float(gr.abs().max())
+    em = (m[:, :k_in].double() - m_ref).abs().max().item()
+    assert em <= 0.1 * 3e-5 * gscale + 1e-9, (em, gscale)          # split-bf16 products: ~2^-16 relative per term
+    ev = ((v[:, :k_in].double() - v_ref).abs() / (v_ref.abs() + 1e-12)).max().item()
+    assert ev <= 1e-3, ev
+    bad = (W[:, :k_in].double() - W_ref).abs() > 2e-6 + 1e-4 * (W_ref - W0).abs()
+    assert float(bad.double().mean()) <= 1e-4, int(bad.sum())
+    rel = ((W[:, :k_in].double() - W_ref).norm() / (W_ref - W0).norm()).item()
+    assert rel <= 1e-4, rel
+    assert torch.equal(W[:, k_in:], pad0)                          # row padding untouched
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# production RNG mode (Philox in the kernels): what fit() and bench.py actually run
+# ---------------------------------------------------------------------------------------------------------------
+def _bn_out(plan, prefix, rows):
+    """Recompute the BatchNorm output (before ReLU / dropout) of an MLP block from the saved tensors of the plan."""
+    st = plan.store
+    y1 = plan.buf[prefix + "/y1"][rows].double()
+    p = rows.start // plan.B if prefix.startswith("encoders.") else 0
+    sm, si = plan.buf[prefix + "/save_mean"][p].double(), plan.buf[prefix + "/save_invstd"][p].double()
+    return (y1 - sm) * si * st.p(prefix + ".batchnorm.weight").double() + st.p(prefix + ".batchnorm.bias").double()
+
+
+def _mask_of(plan, prefix, rows):
+    """(kept, defined): the dropout decision can be read off wherever the ReLU output is safely positive."""
+    bn = _bn_out(plan, prefix, rows)
+    a1 = plan.buf[prefix + "/a1"][rows]
+    defined = bn > 1e-3
+    kept = a1 != 0
+    # kept elements carry exactly bn / 0.9
+    ok = (a1.double() - bn / 0.9).abs() <= 1e-4 * bn.abs() + 1e-5
+    assert bool(ok[defined & kept].all()), f"{prefix}: kept activations are not scaled by 1 / (1 - p)"
+    return kept, defined
+
+
+def _rate_ok(k, n, p, what):
+    sigma = math.sqrt(p * (1 - p) / n)
+    assert abs(k / n - p) <= 4 * sigma + 1e-9, f"{what}: rate {k / n:.5f}, expected {p} +- {4 * sigma:.5f} (n = {n})"
+
+
+@pytest.mark.parametrize("model", ["DirectPred", "MultiTripletNetwork"])
+def test_philox_dropout_statistics_and_independence(model):
+    from flexynesis_amd.arch import ArchSpec
+    from flexynesis_amd.engine import ParamStore, StepPlan
+    dev = _dev()
+    trip = model == "MultiTripletNetwork"
+    layers = [("gex", 3000), ("cnv", 2000)]
+    variables = [("c", "categorical", 4), ("y", "numerical", 1)]
+    spec = ArchSpec(model, layers, 64, 0.25, 16, variables, None, None, True)
+    B = 96
+    torch.manual_seed(3)
+    store = ParamStore(spec, dev)
+    plan = StepPlan(store, B, train=True, fused=True, supplied_draws=False, seed=1234)
+    assert not plan.draws, "production mode must not expose supplied-draw slots"
+    g = torch.Generator().manual_seed(8)
+    R = plan.R
+    xs = [torch.randn(R, F, generator=g).to(dev) for _, F in layers]
+    y = {"c": torch.randint(0, 4, (B,), generator=g).float().to(dev), "y": torch.randn(B, generator=g).to(dev)}
+    if trip:
+        plan.set_batch(parts=[[x[j * B:(j + 1) * B] for x in xs] for j in range(3)], y=y)
+    else:
+        plan.set_batch(x_list=xs, y=y)
+    masks = {}
+    for step in range(2):
+        plan.train_step(1e-3)
+        torch.cuda.synchronize()
+        for i in range(len(layers)):
+            for p in range(plan.passes):
+                kept, defined = _mask_of(plan, f"encoders.{i}", slice(p * B, (p + 1) * B))
+                n, k = int(defined.sum()), int((kept & defined).sum())
+                _rate_ok(k, n, 0.9, f"encoders.{i} pass {p} step {step}")
+                masks[(step, f"enc{i}", p)] = (kept.clone(), defined.clone())
+        for (v, _, _) in variables:
+            kept, defined = _mask_of(plan, f"MLPs.{v}", slice(0, B))
+            masks[(step, f"head.{v}", 0)] = (kept.clone(), defined.clone())
+        kh = sum(int((masks[(step, f"head.{v}", 0)][0] & masks[(step, f"head.{v}", 0)][1]).sum()) for (v, _, _) in variables)
+        nh = sum(int(masks[(step, f"head.{v}", 0)][1].sum()) for (v, _, _) in variables)
+        _rate_ok(kh, nh, 0.9, f"heads step {step}")
+
+    def agreement(a, b):
+        (ka, da), (kb, db) = masks[a], masks[b]
+        both = da & db
+        return float((ka == kb)[both].double().mean()), int(both.sum())
+
+    # independent Bernoulli(0.9) masks agree with probability 0.9^2 + 0.1^2 = 0.82; identical streams would give 1.0
+    pairs = [((0, "enc0", 0), (1, "enc0", 0)), ((0, "enc1", 0), (1, "enc1", 0))]         # step t vs t + 1
+    if trip:
+        pairs += [((0, "enc0", 0), (0, "enc0", 1)), ((0, "enc0", 1), (0, "enc0", 2)), ((0, "enc1", 0), (0, "enc1", 2))]
+    for a, b in pairs:
+        agr, n = agreement(a, b)
+        assert abs(agr - 0.82) <= 4 * math.sqrt(0.82 * 0.18 / n) + 5e-3, (a, b, agr)
+    # two layers of equal shape must not share a stream either: compare the common [B, min(H)] corner
+    (k0, d0), (k1, d1) = masks[(0, "enc0", 0)], masks[(0, "enc1", 0)]
+    h = min(k0.shape[1], k1.shape[1])
+    both = d0[:, :h] & d1[:, :h]
+    agr = float((k0[:, :h] == k1[:, :h])[both].double().mean())
+    assert abs(agr - 0.82) <= 0.02, agr
+    # a second plan with another seed draws another stream; the same seed reproduces it bit for bit
+    res = []
+    for seed in (1234, 1234, 99):
+        torch.manual_seed(3)
+        st2 = ParamStore(spec, dev)
+        p2 = StepPlan(st2, B, train=True, fused=True, supplied_draws=False, seed=seed)
+        if trip:
+            p2.set_batch(parts=[[x[j * B:(j + 1) * B] for x in xs] for j in range(3)], y=y)
+        else:
+            p2.set_batch(x_list=xs, y=y)
+        p2.train_step(1e-3)
+        torch.cuda.synchronize()
+        res.append(p2.buf["encoders.0/a1"].clone())
+    assert torch.equal(res[0], res[1])
+    assert not torch.equal(res[0] == 0, res[2] == 0)
+
+
+@pytest.mark.parametrize("B,C", [(128, 5000), (100, 333)])
+def test_philox_forward_mask_is_backward_gate(B, C):
+    """MLP block in Philox mode: the mask the forward drew (recorded through mask_out) is exactly the gate the backward
+    applies (it gates from the saved output, no mask tensor): dx / dgamma / dbeta vs fp64 autograd with that mask."""
+    from flexynesis_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(B + C)
+    x = torch.randn(B, C, generator=g).to(dev)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.1).to(dev)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    sm, si = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    out, mask = torch.empty(B, C, device=dev), torch.full((B, C), -1.0, device=dev)
+    ctrl = torch.zeros(64, device=dev)
+    ctrl[0] = 7.0
+    ops.bn_act_fwd(ops.IMMEDIATE, out, x, gamma, beta, rm, rv, sm, si, ops.ACT_NONE, ops.ACT_RELU, True, drop_p=0.1,
+                   mask_out=mask, seed=42, offset=5 << 32, ctrl=ctrl)
+    torch.cuda.synchronize()
+    assert bool(((mask == 0) | (mask == 1)).all())
+    _rate_ok(int(mask.sum()), mask.numel(), 0.9, "recorded Philox mask")
+    dout = torch.randn(B, C, generator=g).to(dev)
+    dx = torch.empty(B, C, device=dev)
+    dgm, dbt, dbias = torch.zeros(C, device=dev), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    ops.bn_act_bwd(ops.IMMEDIATE, dx, dgm, dbt, dbias, dout, x, out, gamma, sm, si, ops.ACT_NONE, ops.ACT_RELU, 0.1)
+    xd = x.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    bn = torch.nn.functional.batch_norm(xd, None, None, gd, bd, True, 0.1, 1e-5)
+    ref = torch.relu(bn) * (mask.double() / 0.9)
+    close(out, ref, 1e-5, 1e-5, "forward with the recorded mask")
+    ref.backward(dout.double())
+    close(dx, xd.grad, 1e-3, 2e-5 * float(xd.grad.abs().max()), "dx")
+    close(dgm, gd.grad, 1e-3, 1e-4 * float(gd.grad.abs().max()), "dgamma")
+    close(dbt, bd.grad, 1e-3, 1e-4 * float(bd.grad.abs().max()), "dbeta")
+    # a different step count / offset gives a different mask, the same one reproduces it
+    m2, m3 = torch.empty_like(mask), torch.empty_like(mask)
+    ops.bn_act_fwd(ops.IMMEDIATE, out, x, gamma, beta, rm, rv, sm, si, ops.ACT_NONE, ops.ACT_RELU, True, drop_p=0.1,
+                   mask_out=m2, seed=42, offset=5 << 32, ctrl=ctrl)
+    ctrl[0] = 8.0
+    ops.bn_act_fwd(ops.IMMEDIATE, out, x, gamma, beta, rm, rv, sm, si, ops.ACT_NONE, ops.ACT_RELU, True, drop_p=0.1,
+                   mask_out=m3, seed=42, offset=5 << 32, ctrl=ctrl)
+    torch.cuda.synchronize()
+    assert torch.equal(m2, mask) and not torch.equal(m3, mask)
+    assert abs(float((m3 == mask).float().mean()) - 0.82) < 0.01
+
+
+def _moments_ok(t, what):
+    x = t.double().reshape(-1)
+    n = x.numel()
+    m1, m2, m4 = float(x.mean()), float((x ** 2).mean()), float((x ** 4).mean())
+    assert abs(m1) <= 4 / math.sqrt(n), (what, "mean", m1)
+    assert abs(m2 - 1) <= 4 * math.sqrt(2 / n), (what, "variance", m2)
+    assert abs(m4 - 3) <= 4 * math.sqrt(96 / n), (what, "4th moment", m4)
+    assert float(x.abs().max()) < 7.0, (what, "range")
+
+
+def test_philox_normal_draws_moments_and_independence():
+    """eps of the reparameterisation and the 200 x L MMD priors (supervised_vae.py:198,545) in production mode."""
+    from flexynesis_amd import ops
+    from flexynesis_amd.arch import ArchSpec
+    from flexynesis_amd.engine import ParamStore, StepPlan
+    dev = _dev()
+    big = torch.empty(1 << 20, device=dev)
+    ops.fill_normal(ops.IMMEDIATE, big, 7, 3 << 32)
+    torch.cuda.synchronize()
+    _moments_ok(big, "fx_fill_normal")
+    c = float(torch.corrcoef(torch.stack([big[:-1], big[1:]]))[0, 1])
+    assert abs(c) < 5e-3, c
+    layers = [("gex", 1500), ("cnv", 1100)]
+    spec = ArchSpec("supervised_vae", layers, 64, 0.25, 16, [("c", "categorical", 4)], None, None, True)
+    B = 128
+    torch.manual_seed(1)
+    store = ParamStore(spec, dev)
+    plan = StepPlan(store, B, train=True, fused=True, supplied_draws=False, seed=5)
+    assert not plan.draws
+    g = torch.Generator().manual_seed(0)
+    plan.set_batch(x_list=[torch.randn(B, F, generator=g).to(dev) for _, F in layers],
+                   y={"c": torch.randint(0, 4, (B,), generator=g).float().to(dev)})
+    eps, pri = [], []
+    for step in range(12):
+        plan.train_step(1e-3)
+        torch.cuda.synchronize()
+        eps.append(plan.buf["eps_used"].clone())
+        pri.append(torch.stack([plan.buf["prior.0"].clone(), plan.buf["prior.1"].clone()]))
+        z = plan.buf["mean"] + plan.buf["log_var"] * plan.buf["eps_used"]     # the reference's z = mean + log_var * eps
+        close(plan.buf["z"], z, 1e-6, 1e-6, "reparameterisation uses the recorded eps")
+    _moments_ok(torch.stack(eps), "eps")
+    _moments_ok(torch.stack(pri), "MMD prior")
+    for a, b in ((eps[0], eps[1]), (pri[0][0], pri[0][1]), (pri[0][0], pri[1][0]), (eps[0][:, :64], pri[0][0][:B])):
+        a, b = a.reshape(-1), b.reshape(-1)
+        n = min(a.numel(), b.numel())
+        assert not torch.equal(a[:n], b[:n])
+        c = float(torch.corrcoef(torch.stack([a[:n], b[:n]]))[0, 1])
+        assert abs(c) <= 4 / math.sqrt(n) + 1e-3, c
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# unsupervised VAE family (no supervisor heads): the latent gradient must be rebuilt from zero every step
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("model", ["supervised_vae", "CrossModalPred"])
+def test_unsupervised_vae_steps_vs_oracle(model):
+    """The reference CLI accepts supervised_vae / CrossModalPred without target variables (__main__.py:997).  With no
+    head nothing overwrites dz at the start of the backward, so a stale dz would leak step t's gradient into step
+    t + 1: three consecutive steps on the same plan, each compared with the oracle from identical state."""
+    from flexynesis_amd.arch import ArchSpec
+    from flexynesis_amd.engine import ParamStore, StepPlan
+    from oracle import restate as O
+    dev = _dev()
+    layers = [("gex", 1800), ("cnv", 1300), ("meth", 900)] if model == "CrossModalPred" else [("gex", 1800), ("cnv", 1300)]
+    io = (["gex", "cnv"], ["meth", "gex"]) if model == "CrossModalPred" else (None, None)
+    aspec = ArchSpec(model, layers, 32, 0.6, 16, [], None, None, True, io[0], io[1])
+    ospec = _oracle_spec(aspec)
+    dat, _ = O.synthetic_cohort(layers, 256, seed=4)
+    st = O.init_state(ospec, seed=2)
+    B = 64
+    store = ParamStore(aspec, dev)
+    store.load_state(st)
+    plan = StepPlan(store, B, train=True, fused=True, supplied_draws=True)
+    assert plan.spec.loss_names() == ["mmd_loss"] and not plan.spec.weighted
+    gen = torch.Generator().manual_seed(6)
+    opt, lr = {}, 1e-3
+    for step in range(3):
+        if step > 0:
+            store.load_state(st)
+            store.reset_optimizer()
+            store.load_optimizer(opt["t"], opt["m"], opt["v"])
+        idx = torch.randperm(256, generator=gen)[:B]
+        xs = [dat[n][idx] for n, _ in layers]
+        draws = {n: torch.randn(t.shape, generator=gen) for n, t in plan.draws.items()}
+        assert set(draws) >= {"eps", "prior.0"}
+        plan.set_batch(x_list=[x.to(dev) for x in xs], y={})
+        plan.set_draws({k: v.to(dev) for k, v in draws.items()})
+        plan.train_step(lr)
+        st, opt, info = O.train_step(ospec, st, opt, {"x": xs, "y": {}}, draws, lr)
+        got = plan.losses()
+        for k, v in info["losses"].items():
+            close(got[k], v, 2e-5, 1e-6, f"{model} step{step} loss {k}")
+        exact = sum(float((gv.double() ** 2).sum()) for gv in info["grads"].values()) ** 0.5
+        close(store.ctrl[5], exact, 1e-4, 1e-7, f"{model} step{step} grad norm")       # a stale dz shows up here first
+        sd = store.state_dict()
+        for k in ("FC_mean.weight", "FC_log_var.weight", "encoders.0.FC_mean.weight"):
+            gk = info["grads"][k]
+            atol = torch.where(gk.abs() < 1e-6 * exact, torch.tensor(2.1 * lr), torch.tensor(3e-6))
+            close(sd[k], st[k], 2e-4, atol, f"{model} step{step} {k}")
+        assert float(sd["log_vars.mmd_loss"]) == 0.0                                    # single loss term: no gradient
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# cfg5 on hardware: the sweep's collectives on the RCCL backend (world size 1 on the single-GPU box)
+# ---------------------------------------------------------------------------------------------------------------
+def test_sweep_collectives_on_rccl_world1():
+    """broadcast_cohort -> run_sweep (real engine trials through run_trial, LPT assignment, all_gather of the records)
+    -> broadcast_state on torch.distributed's "nccl" (= RCCL) backend.  A 1-rank group still creates the communicator
+    and runs every collective call; the 8-GPU shape of the same code is covered by the gloo world-2 test."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from flexynesis_amd import trials
+    from flexynesis_amd.sweep import run_cfg5
+    dev = _dev()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert not dist.is_initialized()
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        t = torch.ones(4, device=dev)
+        dist.all_reduce(t)                                   # the communicator exists and works
+        assert float(t.sum()) == 4.0
+        out = run_cfg5(dev, n_trials=5, epochs=2, features=1500, samples=320, seed=3)
+        assert out["trials_ok"] == 5 and out["n_gpus"] == 1
+        assert np.isfinite(out["best_val_loss"]) and out["winner_state_tensors"] > 10
+        assert out["aggregate_samples_per_s"] > 0 and len(out["rank_busy_s"]) == 1
+        # the pieces, with their results checked: cohort order, result table, winner weights
+        dat = {"zeta": torch.randn(64, 300), "alpha": torch.randn(64, 200)}
+        ann = {"y": torch.randn(64)}
+        d2, a2 = trials.broadcast_cohort(dat, ann, dev)
+        assert list(d2) == ["zeta", "alpha"] and d2["zeta"].is_cuda and torch.equal(d2["alpha"].cpu(), dat["alpha"])
+        table = trials.gather_results([(0, 0.5, 3, trials.STATUS_OK), (2, float("inf"), 0, trials.STATUS_FAILED)], 3, dev)
+        assert table[0, 1] == 0.5 and np.isinf(table[1, 1]) and table[1, 3] == trials.STATUS_FAILED
+        shapes = {"w": (3, 4), "bn.num_batches_tracked": ()}
+        st = trials.broadcast_state({"w": torch.arange(12.).reshape(3, 4), "bn.num_batches_tracked": torch.tensor(7)},
+                                    shapes, 0, dev)
+        assert st["w"].is_cuda and st["w"].cpu().tolist() == torch.arange(12.).reshape(3, 4).tolist()
+        assert int(st["bn.num_batches_tracked"]) == 7
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_with_forced_process_group_reports_sweep_object(tmp_path):
+    """`FX_BENCH_FORCE_PG=1 python bench.py --gpus 1`: the bench creates the RCCL group on one GPU, runs the timed cfg2
+    steps and then the cfg5 leg with its collectives; stdout is exactly one JSON line carrying roofline + sweep."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FX_BENCH_FORCE_PG="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
+                        "--features", "3000", "--no-cpu-baseline", "--sweep-trials-per-gpu", "3"],
+                       capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["loss_finite"]
+    assert out["roofline"]["frac"] > 0 and out["roofline"]["device_copy_GBps_this_box"] > 1000
+    sw = out["sweep"]
+    assert "error" not in sw, sw
+    assert sw["trials"] == 3 and sw["trials_ok"] == 3 and sw["winner_state_tensors"] > 10 and sw["aggregate_samples_per_s"] > 0

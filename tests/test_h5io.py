@@ -43,6 +43,20 @@ def test_roundtrip_and_layout(tmp_path):
 
 
 @needs_hdf5
+def test_variable_length_strings(tmp_path):
+    """h5py stores ``str`` data as variable-length strings (char pointers on read), unlike the converter's 'S' dtype."""
+    p = str(tmp_path / "vlen.h5")
+    samples = ["a", "TCGA-0001-long-name", "", "s3"]
+    feats = [f"gene{i}" * (1 + i % 3) for i in range(7)]
+    with h5io.H5File(p, "w") as f:
+        f.write_matrix(np.zeros((4, 7), dtype=np.float32), "matrix", chunks=(1, 7))
+        f.write_strings("sample_ids", samples, variable=True)
+        f.write_strings("feature_names", feats, variable=True)
+    M, s, ft = h5io.read_modality_h5(p)
+    assert s == samples and ft == feats and M.shape == (4, 7)
+
+
+@needs_hdf5
 def test_file_is_what_the_hdf5_tools_see(tmp_path):
     h5dump = shutil.which("h5dump") or ("/opt/conda/bin/h5dump" if os.path.exists("/opt/conda/bin/h5dump") else None)
     if h5dump is None:

@@ -218,8 +218,12 @@ def _worker(rank, world, port, out):
     # the winner's layout is derived from ITS parameters on every rank (HPO trials differ in architecture)
     table, best, state = trials.run_sweep(params, trial_fn, costs=[1.0] * 7, device="cpu",
                                           state_shapes=lambda p: dict(shapes) if "epochs" in p else None)
+    # a winner whose owner holds no weights must degrade to best_state=None on EVERY rank (never a hang in the broadcast)
+    def stateless(tid, p):
+        return (0.25 if tid == 3 else 5.0 + tid), 1, (None if tid == 3 else {"w": torch.zeros(2, 3), "bn.num_batches_tracked": torch.tensor(0)})
+    _, best2, state2 = trials.run_sweep(params, stateless, costs=[1.0] * 7, device="cpu", state_shapes=shapes)
     out.put((rank, list(dat.keys()), float(dat["zeta"].sum()), table.tolist(), best,
-             state["w"].tolist(), int(state["bn.num_batches_tracked"])))
+             state["w"].tolist(), int(state["bn.num_batches_tracked"]), best2, state2 is None))
     dist.destroy_process_group()
 
 
@@ -243,6 +247,7 @@ def test_trial_sharding_gloo_world2():
     assert np.isinf(table[4, 1]) and table[4, 3] == 1.0 and np.isinf(table[5, 1])
     assert r0[4] == r1[4] == 2 and table[2, 1] == 0.5
     assert r0[5] == r1[5] == [[2.0] * 3] * 2 and r0[6] == r1[6] == 6   # winner's weights reached both ranks
+    assert r0[7] == r1[7] == 3 and r0[8] and r1[8]                      # stateless winner: None everywhere, no hang
 
 
 def test_kfold_indices_are_a_partition_with_sklearn_fold_sizes():

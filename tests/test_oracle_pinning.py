@@ -160,6 +160,10 @@ def test_live_reference_step_matches_oracle():
         O.Spec("MultiTripletNetwork", [("a", 20), ("b", 26)], 4, 0.5, 3, [("c", "categorical", 3)]),
         O.Spec("CrossModalPred", [("a", 30), ("b", 18), ("d", 22)], 6, 0.3, 3, [("c", "categorical", 3)],
                input_layers=["b"], output_layers=["a", "d"]),
+        # unsupervised runs (reference __main__.py:997 accepts these classes without target variables): mmd_loss only
+        O.Spec("supervised_vae", [("a", 30), ("b", 18)], 6, 0.3, 3, []),
+        O.Spec("CrossModalPred", [("a", 30), ("b", 18), ("d", 22)], 6, 0.3, 3, [], input_layers=["a", "b"],
+               output_layers=["d", "a"]),
     ]
     for spec in specs:
         dat, ann, vt = make_cohort(spec, 30, seed=9, missing=False)
