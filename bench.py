@@ -55,6 +55,11 @@ class _stdout_to_stderr:
 
     def __exit__(self, *exc):
         sys.stdout.flush()
+        try:        # RCCL prints through C stdio, which is block-buffered on a pipe: flush it while fd 1 is still stderr
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         os.dup2(self._saved, 1)
         os.close(self._saved)
         return False
@@ -268,7 +273,8 @@ def main():
         }
         print(json.dumps(out), flush=True)
     if use_pg:
-        dist.destroy_process_group()
+        with _stdout_to_stderr():
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

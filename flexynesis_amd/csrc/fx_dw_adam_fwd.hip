@@ -1,0 +1,306 @@
+// Fused  dW + clip + Adam + NEXT-STEP FORWARD  for one wide weight (gfx950 / CDNA4, split-bf16 MFMA).
+//
+// The training step has to stream every wide weight twice: once for the optimiser (read + write W, m, v: 24 B/param)
+// and once more for the following step's forward (4 B/param).  The forward of step t+1 only needs W_{t+1} and the
+// batch of step t+1 -- and the engine assembles that batch one step ahead (PipelinedStep).  So this kernel, right after
+// it has produced a tile of W_{t+1} in registers, multiplies it into the next batch and keeps the partial sums: the
+// next step never re-reads W.  28 -> 24 B/param/step, one kernel launch and one split-K slab round trip less per wide
+// weight.
+//
+//   W [M = n_out, N = k_in] (+ m, v)        fp32, row-major, rows padded (ldw)
+//   dY^T [M, K], X^T [N, K]                  split bf16 (hi, lo), K = padded batch (fx_split_bf16_t / fx_gather_split)
+//   Xn  K-blocked [ceil(N/32)][128][32]      split bf16 of the NEXT batch (fx_gather_split / fx_split_bf16), <= 128 rows
+//   Y slabs [S][Mn][M]                       partial sums of Xn . W_new^T; fx_reduce_slabs adds them (+ bias) in order
+//
+// Work decomposition.  A workgroup (512 threads) owns one 64-row block of W and a RUN of consecutive 128-column tiles;
+// per tile:  (1) dW tile = dY^T . X on the MFMA (3 bf16 products, fp32 accumulate), operands streamed from L2 into LDS
+// by LDS-DMA (buffer_load ... lds: no staging registers, the XOR swizzle is applied on the source address);
+// (2) the tile is transposed through LDS so that every lane owns 4 consecutive columns; (3) W, m, v move as 16-byte
+// non-temporal buffer accesses in 512-byte row segments, Adam in registers; W_new is split to bf16 (hi, lo) into LDS;
+// (4) Y[b, h] += Xn[b, tile] . W_new[h, tile]^T on the MFMA, Xn K-steps by LDS-DMA, the accumulators stay in registers
+// for the whole run; at the end of the run one [Mn x 64] block of one slab is stored.  S = floor(512 / row blocks) runs
+// (run c = column tiles c, c + S, ...) cover the columns, so there is about one workgroup per resident slot (2 per CU)
+// and every workgroup does the same work.
+// All descriptors are rebased per row block, so W may exceed 4 GiB.  Deterministic: fixed run / slab order, no atomics.
+#include "fx_common.h"
+#include "fx_reduce.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define FT_M 64
+#define FT_N 128
+#define FT_K 32
+#define FT_T 512
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+struct DwAdamFwdArgs {
+  float* W; float* m; float* v;
+  const __bf16* Ah; const __bf16* Al;       // dY^T [M, lda]
+  const __bf16* Bh; const __bf16* Bl;       // X^T  [N, ldb]
+  const __bf16* Xh; const __bf16* Xl;       // next batch, K-blocked [kblocks][128][32]
+  float* Y;                                 // slabs [S][Mn][M]
+  const float* ctrl;
+  int M, N, K;
+  long lda, ldb, ldw;
+  int Mn, kblocks;
+  int tiles_m, tiles_n, S;
+  long slab_stride;
+};
+
+__device__ __forceinline__ int ft_swz(int row, int chunk) { return row * FT_K + ((chunk ^ ((row >> 2) & 3)) << 3); }
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ft_rsrc(const void* p, long bytes) {
+  const unsigned n = bytes > 0xFFFFFFF0L ? 0xFFFFFFF0u : (bytes < 0 ? 0u : (unsigned)bytes);
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, n, 0x00020000);
+}
+
+#define FT_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+
+template <int NT>
+__global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g) {
+  // LDS map (bf16 elements unless noted), 64 KB:
+  //   phase 1 (dW K-loop)   stage s at s*12288: A hi [64][32] | A lo | B hi [128][32] | B lo          (2 x 24 KB)
+  //   phase 2/3             ct fp32 [64][128] at 0 (32 KB) ; Wn hi [4][64][32] at 16384, Wn lo at 24576 (32 KB)
+  //   phase 4 (forward)     X stage j at j*8192: hi [128][32] | lo                                     (2 x 16 KB)
+  __shared__ __attribute__((aligned(16))) __bf16 smem[32768];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave id, scalar
+  const int tm = blockIdx.x % g.tiles_m, c = blockIdx.x / g.tiles_m;
+  const int m0 = tm * FT_M;
+  const int rows_valid = min(FT_M, g.M - m0);
+  const int nk = g.K / FT_K;
+
+  // ---- descriptors, rebased to this row block (in-block offsets stay far below 4 GiB whatever the weight's size)
+  const long wbytes = ((long)(rows_valid - 1) * g.ldw + g.N) * 4;
+  const __amdgpu_buffer_rsrc_t rP = ft_rsrc(g.W + (long)m0 * g.ldw, wbytes), rM = ft_rsrc(g.m + (long)m0 * g.ldw, wbytes),
+                               rV = ft_rsrc(g.v + (long)m0 * g.ldw, wbytes);
+  const long abytes = (long)rows_valid * g.lda * 2;
+  const __amdgpu_buffer_rsrc_t rAh = ft_rsrc(g.Ah + (long)m0 * g.lda, abytes), rAl = ft_rsrc(g.Al + (long)m0 * g.lda, abytes);
+  const __amdgpu_buffer_rsrc_t rBh = ft_rsrc(g.Bh, (long)g.N * g.ldb * 2), rBl = ft_rsrc(g.Bl, (long)g.N * g.ldb * 2);
+  const long xbytes = (long)g.kblocks * 128 * FT_K * 2;
+  const __amdgpu_buffer_rsrc_t rXh = ft_rsrc(g.Xh, xbytes), rXl = ft_rsrc(g.Xl, xbytes);
+
+  // ---- LDS-DMA source addressing: a wave instruction fills 16 rows x 64 B in lane order (row = lane / 4, 16-byte slot =
+  // lane % 4); slot s of row r must hold chunk s ^ ((r >> 2) & 3) (the swizzle the fragment reads apply)
+  const int dr = lane >> 2, ds = lane & 3;
+  const int a_r = 16 * (w & 3) + dr;                                   // A rows 0..63: waves 0-3 fill hi, 4-7 fill lo
+  const unsigned a_src = (unsigned)(((long)a_r * g.lda + 8 * (ds ^ ((a_r >> 2) & 3))) * 2);
+  const int b_r = 16 * w + dr;                                         // B / X rows 0..127
+  const int b_ch = ds ^ ((b_r >> 2) & 3);
+  const unsigned x_src = (unsigned)((b_r * FT_K + 8 * b_ch) * 2);      // within one K-blocked [128][32] block
+
+  // ---- fragment coordinates
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int rb = w & 1, cb = w >> 1;                                   // dW: 64 x 128 tile = 2 x 4 blocks of 32 x 32
+  const int bq = w & 3, hq = w >> 2;                                   // forward: 128 (batch) x 64 (rows of W) = 4 x 2 blocks
+  const int fa_d = 32 * rb + l31, fb_d = 32 * cb + l31;
+  const int fa_f = 32 * bq + l31, fb_f = 32 * hq + l31;
+
+  const float lr = g.ctrl[FXC_LR], bc1 = g.ctrl[FXC_BC1], bc2s = g.ctrl[FXC_BC2_SQRT], coef = g.ctrl[FXC_CLIP_COEF];
+  const float step_size = lr / bc1;
+
+  f32x16 yacc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) yacc[i] = 0.f;
+
+  // Run c takes the column tiles c, c + S, c + 2 S, ...: the S workgroups of a row block sit on ADJACENT tiles at any
+  // moment (a contiguous S x 512-byte window of every row of W / m / v moves along the rows), and all row blocks work on
+  // the same few X tiles at the same time (L2 hits).  Contiguous chunks per run measured like the "slices" copy pattern
+  // (scripts/copybench.hip: 5.3-5.5 TB/s against 6.5 for a moving contiguous window).
+  for (int tn = c; tn < g.tiles_n; tn += g.S) {
+    const int n0 = tn * FT_N;
+    const unsigned b_src = (unsigned)(((long)(n0 + b_r) * g.ldb + 8 * b_ch) * 2);
+    // ================= phase 1: dW tile [64 x 128] = dY^T[m0.., :] . X^T[n0.., :]^T over the batch =================
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#define FT_GLDS_K(stage, kt)                                                                              \
+  {                                                                                                       \
+    __bf16* sb = smem + (stage) * 12288;                                                                  \
+    const unsigned ko = (unsigned)(kt) * (FT_K * 2u);                                                     \
+    if (w < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rAh, LDS_PTR(sb + (w & 3) * 512), 16, a_src + ko, 0, 0, 0);        \
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rAl, LDS_PTR(sb + 2048 + (w & 3) * 512), 16, a_src + ko, 0, 0, 0);       \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rBh, LDS_PTR(sb + 4096 + w * 512), 16, b_src + ko, 0, 0, 0);                  \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rBl, LDS_PTR(sb + 8192 + w * 512), 16, b_src + ko, 0, 0, 0);                  \
+  }
+    FT_GLDS_K(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      __syncthreads();                       // stage kt & 1 has landed (the barrier drains the DMA); the other one is free
+      if (kt + 1 < nk) FT_GLDS_K((kt + 1) & 1, kt + 1);
+      const __bf16* sb = smem + (kt & 1) * 12288;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(sb + ft_swz(fa_d, 2 * ks + kh));
+        const bf16x8 al = *reinterpret_cast<const bf16x8*>(sb + 2048 + ft_swz(fa_d, 2 * ks + kh));
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(sb + 4096 + ft_swz(fb_d, 2 * ks + kh));
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(sb + 8192 + ft_swz(fb_d, 2 * ks + kh));
+        acc = FT_MFMA(al, bh, acc);
+        acc = FT_MFMA(ah, bl, acc);
+        acc = FT_MFMA(ah, bh, acc);
+      }
+    }
+    __syncthreads();                         // every wave is done with the operand stages
+    // ================= phase 2: transpose through LDS (C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
+    float* ct = reinterpret_cast<float*>(smem);                        // [64][128] fp32
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ct[(32 * rb + (r & 3) + 8 * (r >> 2) + 4 * kh) * FT_N + 32 * cb + l31] = acc[r];
+    __syncthreads();
+    // ================= phase 3: Adam on 512-byte row segments; W_new -> bf16 (hi, lo) in LDS =================
+    {
+      u32x4 p4[4], m4[4], v4[4];
+      unsigned off[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int u = tid + FT_T * i, row = u >> 5, c4 = u & 31;
+        const int gn = n0 + 4 * c4;
+        // rows >= rows_valid fall beyond num_records; columns >= N are pushed out of range explicitly
+        off[i] = (unsigned)(((long)row * g.ldw + gn) * 4) | ((gn < g.N) ? 0u : 0xFFFFFFF0u);
+        p4[i] = __builtin_amdgcn_raw_buffer_load_b128(rP, off[i], 0, NT);
+        m4[i] = __builtin_amdgcn_raw_buffer_load_b128(rM, off[i], 0, NT);
+        v4[i] = __builtin_amdgcn_raw_buffer_load_b128(rV, off[i], 0, NT);
+      }
+      __bf16* wn_hi = smem + 16384;
+      __bf16* wn_lo = smem + 24576;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int u = tid + FT_T * i, row = u >> 5, c4 = u & 31;
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(ct + row * FT_N + 4 * c4);
+        const f32x4 pf = __builtin_bit_cast(f32x4, p4[i]), mf = __builtin_bit_cast(f32x4, m4[i]);
+        const f32x4 vf = __builtin_bit_cast(f32x4, v4[i]);
+        f32x4 po, mo, vo;
+        bf16x4 h, l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float gr = g4[j] * coef;
+          const float m2 = mf[j] + (gr - mf[j]) * (1.0f - FX_BETA1);
+          const float v2 = vf[j] * FX_BETA2 + (1.0f - FX_BETA2) * gr * gr;
+          const float denom = sqrtf(v2) / bc2s + FX_ADAM_EPS;
+          po[j] = pf[j] - step_size * (m2 / denom);
+          mo[j] = m2;
+          vo[j] = v2;
+          h[j] = (__bf16)po[j];
+          l[j] = (__bf16)(po[j] - (float)h[j]);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, po), rP, off[i], 0, NT);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mo), rM, off[i], 0, NT);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vo), rV, off[i], 0, NT);
+        // columns 4 c4 .. 4 c4 + 3 of the tile: K-step block c4 >> 3, 16-byte chunk (c4 & 7) >> 1, half (c4 & 1)
+        const int wo = (c4 >> 3) * 2048 + ft_swz(row, (c4 & 7) >> 1) + ((c4 & 1) << 2);
+        *reinterpret_cast<bf16x4*>(wn_hi + wo) = h;
+        *reinterpret_cast<bf16x4*>(wn_lo + wo) = l;
+      }
+    }
+    __syncthreads();                         // W_new (hi, lo) visible; ct is dead -> its space stages the next batch
+    // ================= phase 4: Y[b, m0 + h] += Xn[b, n0 .. n0 + 127] . W_new[h, :]^T =================
+#define FT_GLDS_X(stage, kb)                                                                              \
+  {                                                                                                       \
+    __bf16* xb = smem + (stage) * 8192;                                                                   \
+    const unsigned xo = (unsigned)(n0 / FT_K + (kb)) * (128u * FT_K * 2u) + x_src;                        \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rXh, LDS_PTR(xb + w * 512), 16, xo, 0, 0, 0);                \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rXl, LDS_PTR(xb + 4096 + w * 512), 16, xo, 0, 0, 0);         \
+  }
+    FT_GLDS_X(0, 0);
+#pragma unroll
+    for (int kb = 0; kb < FT_N / FT_K; ++kb) {
+      __syncthreads();
+      if (kb + 1 < FT_N / FT_K) FT_GLDS_X((kb + 1) & 1, kb + 1);
+      const __bf16* xb = smem + (kb & 1) * 8192;
+      const __bf16* wh = smem + 16384 + kb * 2048;
+      const __bf16* wl = smem + 24576 + kb * 2048;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(xb + ft_swz(fa_f, 2 * ks + kh));
+        const bf16x8 al = *reinterpret_cast<const bf16x8*>(xb + 4096 + ft_swz(fa_f, 2 * ks + kh));
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wh + ft_swz(fb_f, 2 * ks + kh));
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wl + ft_swz(fb_f, 2 * ks + kh));
+        yacc = FT_MFMA(al, bh, yacc);
+        yacc = FT_MFMA(ah, bl, yacc);
+        yacc = FT_MFMA(ah, bh, yacc);
+      }
+    }
+    __syncthreads();                         // the next tile's first DMA overwrites the X stages / W_new
+  }
+
+  // ---- the run's partial sums: rows = batch (dropped beyond Mn by the range check), columns = rows of W
+  const __amdgpu_buffer_rsrc_t rY = ft_rsrc(g.Y + (long)c * g.slab_stride, (long)g.Mn * g.M * 4);
+  const int hcol = m0 + 32 * hq + l31;
+  const unsigned oob = (hcol < g.M) ? 0u : 0xFFFFFFF0u;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int b = 32 * bq + (r & 3) + 8 * (r >> 2) + 4 * kh;
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yacc[r]), rY, (unsigned)(((long)b * g.M + hcol) * 4) | oob, 0, 0);
+  }
+}
+
+static inline bool ft_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+static int ft_runs(int n_out, int k_in) {
+  const int tiles_m = (n_out + FT_M - 1) / FT_M, tiles_n = (k_in + FT_N - 1) / FT_N;
+  int S = 512 / tiles_m;                                   // ~ one workgroup per resident slot (256 CUs x 2)
+  if (S < 1) S = 1;
+  if (S > tiles_n) S = tiles_n;
+  return S;
+}
+
+extern "C" {
+
+// Number of partial-sum slabs fx_linear_dw_adam_fwd_bf16x3 writes for a weight [n_out, k_in].
+int fx_linear_dw_adam_fwd_bf16x3_slabs(int n_out, int k_in) {
+  if (n_out <= 0 || k_in <= 0) return 0;
+  return ft_runs(n_out, k_in);
+}
+
+int fx_linear_dw_adam_fwd_bf16x3(float* W, float* adam_m, float* adam_v, const void* dyT_hi, const void* dyT_lo,
+                                 const void* xT_hi, const void* xT_lo, int batch_padded, int n_out, int k_in, long lddy,
+                                 long ldx, long ldw, const float* ctrl, const void* xn_hi, const void* xn_lo,
+                                 long xn_rows_padded, int next_rows, float* y_slabs, long y_slabs_bytes, int nt,
+                                 hipStream_t stream) {
+  FX_REQUIRE(W && adam_m && adam_v && dyT_hi && dyT_lo && xT_hi && xT_lo && ctrl && xn_hi && xn_lo && y_slabs,
+             "fx_linear_dw_adam_fwd_bf16x3: null pointer");
+  FX_REQUIRE(batch_padded > 0 && batch_padded % FT_K == 0, "fx_linear_dw_adam_fwd_bf16x3: padded batch %d must be a multiple of %d",
+             batch_padded, FT_K);
+  FX_REQUIRE(n_out > 0 && k_in > 0 && ldw >= k_in && ldw % 4 == 0 && k_in % 4 == 0 && ft_aligned16(W) && ft_aligned16(adam_m) &&
+                 ft_aligned16(adam_v),
+             "fx_linear_dw_adam_fwd_bf16x3: W / m / v must be 16-byte aligned with k_in and ldw multiples of 4");
+  FX_REQUIRE(lddy % 8 == 0 && ldx % 8 == 0 && lddy >= batch_padded && ldx >= batch_padded && ft_aligned16(dyT_hi) &&
+                 ft_aligned16(dyT_lo) && ft_aligned16(xT_hi) && ft_aligned16(xT_lo),
+             "fx_linear_dw_adam_fwd_bf16x3: transposed operands must be 16-byte aligned with ld %% 8 == 0");
+  FX_REQUIRE(xn_rows_padded == 128 && next_rows > 0 && next_rows <= 128 && ft_aligned16(xn_hi) && ft_aligned16(xn_lo),
+             "fx_linear_dw_adam_fwd_bf16x3: the next batch is a K-blocked split of at most 128 rows (rows padded to 128)");
+  FX_REQUIRE((long)k_in * ldx * 2 < 0xF0000000L && (long)FT_M * ldw * 4 < 0xF0000000L && (long)FT_M * lddy * 2 < 0xF0000000L,
+             "fx_linear_dw_adam_fwd_bf16x3: operand row block exceeds 4 GiB");
+  DwAdamFwdArgs g{};
+  g.W = W; g.m = adam_m; g.v = adam_v;
+  g.Ah = (const __bf16*)dyT_hi; g.Al = (const __bf16*)dyT_lo;
+  g.Bh = (const __bf16*)xT_hi; g.Bl = (const __bf16*)xT_lo;
+  g.Xh = (const __bf16*)xn_hi; g.Xl = (const __bf16*)xn_lo;
+  g.Y = y_slabs; g.ctrl = ctrl;
+  g.M = n_out; g.N = k_in; g.K = batch_padded;
+  g.lda = lddy; g.ldb = ldx; g.ldw = ldw;
+  g.Mn = next_rows; g.kblocks = (k_in + FT_K - 1) / FT_K;
+  g.tiles_m = (n_out + FT_M - 1) / FT_M; g.tiles_n = (k_in + FT_N - 1) / FT_N;
+  g.S = ft_runs(n_out, k_in);
+  g.slab_stride = (long)next_rows * n_out;
+  FX_REQUIRE(y_slabs_bytes >= (long)g.S * g.slab_stride * 4, "fx_linear_dw_adam_fwd_bf16x3: slab buffer too small (%ld bytes for %d slabs)",
+             y_slabs_bytes, g.S);
+  const long nblk = (long)g.tiles_m * g.S;
+  FX_REQUIRE(nblk < (1L << 31), "fx_linear_dw_adam_fwd_bf16x3: grid too large");
+  if (nt) hipLaunchKernelGGL((fx_dw_adam_fwd_kernel<2>), dim3((unsigned)nblk), dim3(FT_T), 0, stream, g);
+  else hipLaunchKernelGGL((fx_dw_adam_fwd_kernel<0>), dim3((unsigned)nblk), dim3(FT_T), 0, stream, g);
+  return fx_check_launch("fx_linear_dw_adam_fwd_bf16x3");
+}
+
+// Y[M, N] = sum_z slabs[z][M][N] (+ bias[N]) in slab order: consumes the partial sums of fx_linear_dw_adam_fwd_bf16x3
+// (and of any other split-K producer that leaves its slabs unreduced).
+int fx_reduce_slabs(float* Y, const float* slabs, const float* bias, int M, int N, long ldy, int n_slabs, long slab_stride,
+                    hipStream_t stream) {
+  FX_REQUIRE(Y && slabs && M > 0 && N > 0 && n_slabs > 0 && ldy >= N && slab_stride >= (long)M * N, "fx_reduce_slabs: bad args");
+  fx_launch_reduce_slabs(Y, slabs, bias, M, N, ldy, n_slabs, slab_stride, 0, stream);
+  return fx_check_launch("fx_reduce_slabs");
+}
+
+}  // extern "C"

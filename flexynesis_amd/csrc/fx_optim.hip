@@ -54,21 +54,14 @@ __global__ void fx_step_begin_kernel(float* ctrl, float lr, int n_batches) {
   }
 }
 
-// Plain streaming copy, 16 bytes per lane, four loads in flight per thread: the box's practical HBM read+write rate,
-// reported by bench.py next to the dominant kernel's (boxes of the pool differ by +-10 %).
+// Plain streaming copy: one 16-byte non-temporal load + store per thread, one thread per element group, huge grid --
+// the pattern that measured fastest on MI355X (scripts/copybench.hip: 6.5 TB/s read+write; grid-stride loops 4.1-5.0,
+// per-block contiguous slices 5.3-5.5, hipMemcpyDtoD 5.1).  bench.py reports it as the box's practical HBM rate next to
+// the dominant kernel's (boxes of the pool differ by +-10 %).
 typedef float fx_f32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void fx_stream_copy_kernel(fx_f32x4* __restrict__ dst, const fx_f32x4* __restrict__ src, long n4) {
-  const long stride = (long)gridDim.x * blockDim.x;
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; i + 3 * stride < n4; i += 4 * stride) {
-    const fx_f32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
-    const fx_f32x4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
-    __builtin_nontemporal_store(a, dst + i);
-    __builtin_nontemporal_store(b, dst + i + stride);
-    __builtin_nontemporal_store(c, dst + i + 2 * stride);
-    __builtin_nontemporal_store(d, dst + i + 3 * stride);
-  }
-  for (; i < n4; i += stride) dst[i] = src[i];
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n4) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
 __global__ __launch_bounds__(256) void fx_fill_kernel(float* __restrict__ y, long n, float value) {
@@ -173,8 +166,8 @@ int fx_step_begin(float* ctrl, float lr, int n_batches, hipStream_t stream) {
 int fx_stream_copy(float* dst, const float* src, long n, hipStream_t stream) {
   FX_REQUIRE(dst && src && n > 0 && n % 4 == 0 && aligned16(dst) && aligned16(src), "fx_stream_copy: n %% 4 == 0 and 16-byte aligned buffers");
   const long n4 = n / 4;
-  long b = (n4 + 256L * 4 - 1) / (256L * 4);
-  if (b > 256L * 16) b = 256L * 16;
+  const long b = (n4 + 255) / 256;
+  FX_REQUIRE(b < (1L << 31), "fx_stream_copy: too many elements for one launch");
   hipLaunchKernelGGL(fx_stream_copy_kernel, dim3((unsigned)b), dim3(256), 0, stream, (fx_f32x4*)dst, (const fx_f32x4*)src, n4);
   return fx_check_launch("fx_stream_copy");
 }

@@ -401,6 +401,39 @@ def linear_dw_adam_bf16x3(rec, W, m, v, dyT_hi, dyT_lo, xT_hi, xT_lo, ctrl):
              xT_hi.data_ptr(), xT_lo.data_ptr(), Bp, N, K, _ld(dyT_hi), _ld(xT_hi), _ld(W), ctrl.data_ptr())
 
 
+def dw_adam_fwd_slabs(n_out: int, k_in: int) -> int:
+    return int(lib.fx_linear_dw_adam_fwd_bf16x3_slabs(int(n_out), int(k_in)))
+
+
+def linear_dw_adam_fwd_bf16x3(rec, W, m, v, dyT_hi, dyT_lo, xT_hi, xT_lo, ctrl, xn_hi, xn_lo, next_rows, y_slabs, nt=True):
+    """W[N,K] <- Adam(clip * dY^T X) as linear_dw_adam_bf16x3, and y_slabs[s] = partial sums of x_next W_new^T
+    (x_next: K-blocked split of the NEXT batch, new_split_kb(next_rows, K)); reduce with reduce_slabs."""
+    for t, n in ((W, "W"), (m, "m"), (v, "v")):
+        _chk2d(t, "linear_dw_adam_fwd_bf16x3." + n)
+    N, K = W.shape
+    Bp = dyT_hi.shape[1]
+    if dyT_hi.shape != (N, Bp) or xT_hi.shape != (K, Bp) or dyT_lo.shape != dyT_hi.shape or xT_lo.shape != xT_hi.shape:
+        raise FxError("linear_dw_adam_fwd_bf16x3: shape mismatch")
+    if not (_ld(m) == _ld(W) == _ld(v)):
+        raise FxError("linear_dw_adam_fwd_bf16x3: W/m/v must share a leading dimension")
+    _chk_kb(xn_hi, xn_lo, next_rows, K, "linear_dw_adam_fwd_bf16x3")
+    S = dw_adam_fwd_slabs(N, K)
+    if y_slabs.dtype != torch.float32 or not y_slabs.is_contiguous() or y_slabs.numel() < S * next_rows * N:
+        raise FxError(f"linear_dw_adam_fwd_bf16x3: y_slabs must hold {S} x {next_rows} x {N} fp32")
+    rec.emit("fx_linear_dw_adam_fwd_bf16x3", W.data_ptr(), m.data_ptr(), v.data_ptr(), dyT_hi.data_ptr(), dyT_lo.data_ptr(),
+             xT_hi.data_ptr(), xT_lo.data_ptr(), Bp, N, K, _ld(dyT_hi), _ld(xT_hi), _ld(W), ctrl.data_ptr(), xn_hi.data_ptr(),
+             xn_lo.data_ptr(), xn_hi.shape[1], int(next_rows), y_slabs.data_ptr(), y_slabs.numel() * 4, int(bool(nt)))
+
+
+def reduce_slabs(rec, y, slabs, bias, n_slabs):
+    """y[M,N] = sum of the first n_slabs slabs [n_slabs][M][N] (+ bias), fixed order."""
+    _chk2d(y, "reduce_slabs.y")
+    M, N = y.shape
+    if slabs.numel() < n_slabs * M * N:
+        raise FxError("reduce_slabs: slab buffer too small")
+    rec.emit("fx_reduce_slabs", y.data_ptr(), slabs.data_ptr(), _ptr(bias), M, N, _ld(y), int(n_slabs), M * N)
+
+
 def gemm_slabs(rec, layout, slabs, A, Bm, M, N):
     """Contraction whose split-K partial sums stay in ``slabs`` [splitk, M, N]; returns splitk."""
     _chk2d(A, "gemm_slabs.A")

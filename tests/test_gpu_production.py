@@ -31,6 +31,28 @@ FULL = {
 }
 
 
+def _state_close(got, ref, g, gnorm, lr, what):
+    """A parameter after one Adam step vs the oracle's.  Adam's normalised update m / (sqrt(v) + eps) is O(1) whatever the
+    gradient's size, so a RELATIVE error delta of a gradient element moves the parameter by ~lr * delta.  The split-bf16
+    contractions (and any fp32 reduction order) leave an absolute error of ~3e-5 of the tensor's scale per element, i.e.
+    delta ~ 3e-5 * max|g| / |g|: tight for the elements that carry the gradient, up to a full +-lr step of either sign
+    (2.1 lr apart) for entries at the noise floor -- in particular the biases in front of a BatchNorm, whose true gradient
+    is exactly zero.  Large tensors may additionally hold <= 0.1 % of such outliers (a ReLU gate
+    within rounding of zero changes one row of an upstream gradient discretely)."""
+    got, ref = torch.as_tensor(got).double().cpu().reshape(-1), torch.as_tensor(ref).double().reshape(-1)
+    if g is None:
+        atol = torch.full_like(ref, 3e-6)
+    else:
+        ga = g.double().abs().reshape(-1)
+        delta = 1e-4 * float(ga.max()) / (ga + 1e-30)
+        delta = torch.where(ga < 2e-6 * gnorm, torch.full_like(delta, 2.1), delta)
+        atol = 3e-6 + lr * torch.clamp(delta, max=2.1)
+    bad = (got - ref).abs() > atol + 2e-4 * ref.abs()
+    allowed = int(1e-3 * ref.numel())
+    assert int(bad.sum()) <= allowed, (f"{what}: {int(bad.sum())}/{ref.numel()} off (allowed {allowed}), max err "
+                                       f"{float((got - ref).abs().max()):.3e}")
+
+
 @pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4"])
 def test_fullsize_step_vs_oracle(name):
     """The shapes bench.py times, with supplied draws: named losses <= 1e-4 relative (the north-star gate), grad norm vs
@@ -89,10 +111,8 @@ def test_fullsize_step_vs_oracle(name):
             upd_ref = b_ - st_prev[k].double()
             assert float((a - b_).norm() / upd_ref.norm()) <= 2e-2, f"{name} {k} step{step}: update norm mismatch"
             del a, b_, bad, upd_ref
-        for k in store.small_keys:      # every small parameter too (noise-floor entries: DESIGN.md section 3.1)
-            gk = info["grads"].get(k)
-            atol = 3e-6 if gk is None else torch.where(gk.abs() < 1e-6 * exact, torch.tensor(2.1 * lr), torch.tensor(3e-6))
-            close(sd[k], st[k], 2e-4, atol, f"{name} step{step} state {k}")
+        for k in store.small_keys:      # every small parameter too
+            _state_close(sd[k], st[k], info["grads"].get(k), exact, lr, f"{name} step{step} state {k}")
 
 
 @pytest.mark.parametrize("n_out,k_in,K", [(5000, 20000, 128), (7500, 30000, 384)])
@@ -130,8 +150,9 @@ def test_dominant_kernel_fullsize_vs_fp64(n_out, k_in, K):
     gscale = float(gr.abs().max())
     em = (m[:, :k_in].double() - m_ref).abs().max().item()
     assert em <= 0.1 * 3e-5 * gscale + 1e-9, (em, gscale)          # split-bf16 products: ~2^-16 relative per term
-    ev = ((v[:, :k_in].double() - v_ref).abs() / (v_ref.abs() + 1e-12)).max().item()
-    assert ev <= 1e-3, ev
+    eg = 3e-5 * gscale                                             # bound on the error of one dW element (as for m above)
+    ev = ((v[:, :k_in].double() - v_ref).abs() - 1e-5 * v_ref - 0.001 * (2 * gr.abs() * eg + eg * eg)).max().item()
+    assert ev <= 0, ev
     bad = (W[:, :k_in].double() - W_ref).abs() > 2e-6 + 1e-4 * (W_ref - W0).abs()
     assert float(bad.double().mean()) <= 1e-4, int(bad.sum())
     rel = ((W[:, :k_in].double() - W_ref).norm() / (W_ref - W0).norm()).item()
@@ -142,18 +163,23 @@ def test_dominant_kernel_fullsize_vs_fp64(n_out, k_in, K):
 # ---------------------------------------------------------------------------------------------------------------
 # production RNG mode (Philox in the kernels): what fit() and bench.py actually run
 # ---------------------------------------------------------------------------------------------------------------
-def _bn_out(plan, prefix, rows):
-    """Recompute the BatchNorm output (before ReLU / dropout) of an MLP block from the saved tensors of the plan."""
-    st = plan.store
+def _bn_out(plan, prefix, rows, affine):
+    """Recompute the BatchNorm output (before ReLU / dropout) of an MLP block from the saved tensors of the plan;
+    ``affine`` = the block's (gamma, beta) as they were BEFORE the step (Adam has moved them since)."""
     y1 = plan.buf[prefix + "/y1"][rows].double()
     p = rows.start // plan.B if prefix.startswith("encoders.") else 0
     sm, si = plan.buf[prefix + "/save_mean"][p].double(), plan.buf[prefix + "/save_invstd"][p].double()
-    return (y1 - sm) * si * st.p(prefix + ".batchnorm.weight").double() + st.p(prefix + ".batchnorm.bias").double()
+    return (y1 - sm) * si * affine[prefix][0] + affine[prefix][1]
 
 
-def _mask_of(plan, prefix, rows):
+def _affine_snapshot(store):
+    return {k[:-len(".batchnorm.weight")]: (store.p(k).double().clone(), store.p(k[:-6] + "bias").double().clone())
+            for k in store.param_keys if k.endswith(".batchnorm.weight")}
+
+
+def _mask_of(plan, prefix, rows, affine):
     """(kept, defined): the dropout decision can be read off wherever the ReLU output is safely positive."""
-    bn = _bn_out(plan, prefix, rows)
+    bn = _bn_out(plan, prefix, rows, affine)
     a1 = plan.buf[prefix + "/a1"][rows]
     defined = bn > 1e-3
     kept = a1 != 0
@@ -192,16 +218,17 @@ def test_philox_dropout_statistics_and_independence(model):
         plan.set_batch(x_list=xs, y=y)
     masks = {}
     for step in range(2):
+        affine = _affine_snapshot(store)
         plan.train_step(1e-3)
         torch.cuda.synchronize()
         for i in range(len(layers)):
             for p in range(plan.passes):
-                kept, defined = _mask_of(plan, f"encoders.{i}", slice(p * B, (p + 1) * B))
+                kept, defined = _mask_of(plan, f"encoders.{i}", slice(p * B, (p + 1) * B), affine)
                 n, k = int(defined.sum()), int((kept & defined).sum())
                 _rate_ok(k, n, 0.9, f"encoders.{i} pass {p} step {step}")
                 masks[(step, f"enc{i}", p)] = (kept.clone(), defined.clone())
         for (v, _, _) in variables:
-            kept, defined = _mask_of(plan, f"MLPs.{v}", slice(0, B))
+            kept, defined = _mask_of(plan, f"MLPs.{v}", slice(0, B), affine)
             masks[(step, f"head.{v}", 0)] = (kept.clone(), defined.clone())
         kh = sum(int((masks[(step, f"head.{v}", 0)][0] & masks[(step, f"head.{v}", 0)][1]).sum()) for (v, _, _) in variables)
         nh = sum(int(masks[(step, f"head.{v}", 0)][1].sum()) for (v, _, _) in variables)
@@ -380,10 +407,8 @@ def test_unsupervised_vae_steps_vs_oracle(model):
         exact = sum(float((gv.double() ** 2).sum()) for gv in info["grads"].values()) ** 0.5
         close(store.ctrl[5], exact, 1e-4, 1e-7, f"{model} step{step} grad norm")       # a stale dz shows up here first
         sd = store.state_dict()
-        for k in ("FC_mean.weight", "FC_log_var.weight", "encoders.0.FC_mean.weight"):
-            gk = info["grads"][k]
-            atol = torch.where(gk.abs() < 1e-6 * exact, torch.tensor(2.1 * lr), torch.tensor(3e-6))
-            close(sd[k], st[k], 2e-4, atol, f"{model} step{step} {k}")
+        for k in store.small_keys:
+            _state_close(sd[k], st[k], info["grads"].get(k), exact, lr, f"{model} step{step} {k}")
         assert float(sd["log_vars.mmd_loss"]) == 0.0                                    # single loss term: no gradient
 
 
