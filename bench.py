@@ -121,6 +121,8 @@ def main():
     store = ParamStore(spec, dev, materialize_big_grads=False)
     pipe = PipelinedStep(store, B, cohort=cohort, n_batches=n_batches, seed=17 + rank, precision=a.precision)
     dominant = "fx_linear_dw_adam_bf16x3" if a.precision == "bf16x3" else "fx_linear_dw_adam_f32"
+    if pipe.plans[0]._next_fwd:
+        dominant = "fx_linear_dw_adam_fwd_bf16x3"       # the same optimiser step + the next step's wide forward
     gen = torch.Generator(device=dev)
     gen.manual_seed(4321 + rank)
 

@@ -60,6 +60,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t ft_rsrc(const void* p, long by
 
 #define FT_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 
+// NB: takes the value as a SCALAR float.  __builtin_bit_cast(unsigned, vec[r]) applied directly to an element of an
+// ext_vector is miscompiled by hipcc 7.2 (every r reads element 0).
+__device__ __forceinline__ void ft_store32(float v, __amdgpu_buffer_rsrc_t r, unsigned off) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
+}
+
 template <int NT>
 __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g) {
   // LDS map (bf16 elements unless noted), 64 KB:
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int b = 32 * bq + (r & 3) + 8 * (r >> 2) + 4 * kh;
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yacc[r]), rY, (unsigned)(((long)b * g.M + hcol) * 4) | oob, 0, 0);
+    ft_store32(yacc[r], rY, (unsigned)(((long)b * g.M + hcol) * 4) | oob);
   }
 }
 

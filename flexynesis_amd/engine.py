@@ -232,7 +232,7 @@ class StepPlan:
     def __init__(self, store: ParamStore, B: int, train: bool = True, fused: bool = True, clip: bool = True,
                  supplied_draws: bool = False, seed: int = 0, cohort=None, n_batches: int = 0,
                  epoch_acc: bool = False, precision: str = "bf16x3", branches: bool = True, share: "StepPlan" = None,
-                 fuse_heads: bool = True, frozen: Tuple[str, ...] = ()):
+                 fuse_heads: bool = True, frozen: Tuple[str, ...] = (), fuse_next_fwd: bool = False):
         self.store, self.spec, self.B, self.train = store, store.spec, int(B), train
         self.fused = bool(fused) and train
         self.clip = clip
@@ -288,6 +288,14 @@ class StepPlan:
         self._rng_ctr = 0
         self.big_jobs: List[Tuple[str, torch.Tensor, torch.Tensor]] = []   # (weight key, dY, X) for fused dW+Adam
         self.t_gather, self.t_fwd, self.t_bwd, self.t_opt = TapeRecorder(), TapeRecorder(), TapeRecorder(), TapeRecorder()
+        # Next-step forward fused into the optimiser kernel (fx_linear_dw_adam_fwd_bf16x3): this plan's wide forward is
+        # then only the ordered reduce of partial sums that the PREVIOUS step's dW+Adam launch left behind (it had this
+        # plan's batch, assembled one step ahead, and the freshly updated weight tile in registers).  Needs a partner plan
+        # (PipelinedStep links the two); t_boot computes the partial sums stand-alone for the first step / after any
+        # weight change made outside the pipeline.
+        self.fuse_next = bool(fuse_next_fwd) and self.fused and precision == "bf16x3" and cohort is not None
+        self._next_fwd: Dict[str, tuple] = {}
+        self.t_boot = TapeRecorder()
         self._build()
         self.graph = None
 
@@ -405,6 +413,15 @@ class StepPlan:
                 self._split_cache[("fwd", x.data_ptr())] = sp
                 ops.split_bf16(rec, sp[0], sp[1], x)
             self._want_gram(rec, x, wkey, x.shape[0], self.passes if x.shape[0] == self.R else 1)
+            if self._can_fuse_next(wkey, x):
+                M, N = y.shape
+                S = ops.dw_adam_fwd_slabs(N, x.shape[1])
+                slabs = self._new(f"yslabs/{wkey}", S, M, N)
+                self._next_fwd[wkey] = (slabs, S, sp)
+                ops.reduce_slabs(rec, y, slabs, st.p(bkey), S)          # the whole wide forward of this step
+                ops.fill(self.t_boot, slabs, 0.0)                       # stand-alone: full forward (no bias) into slab 0
+                ops.linear_fwd_bf16x3(self.t_boot, slabs[0], sp[0], sp[1], st.p(wkey), None, self._ws[0])
+                return None
             # Stagger the HBM-bound wide kernels of the parallel modality branches: two of them side by side
             # take as long as back to back, but back to back lets modality i's narrow post-chain (reduce, BN,
             # layer_out) run underneath modality i+1's wide kernel instead of after both.
@@ -435,6 +452,15 @@ class StepPlan:
         else:
             ops.linear_fwd(rec, y, x, st.p(wkey), st.p(bkey), self.ws)
         return None
+
+    def _can_fuse_next(self, wkey, x) -> bool:
+        """The wide forward can ride on the previous step's dW+Adam launch when its input is a batch operand that the
+        gather assembles one step ahead (not an activation of this step), of at most 128 rows, and the weight is trained."""
+        if not (self.fuse_next and self.train and wkey in self.store.big) or self._is_frozen(wkey):
+            return False
+        if x.shape[0] != self.R or x.shape[0] > 128 or x.shape[1] % 4 != 0:
+            return False
+        return any(x.data_ptr() == X.data_ptr() for X in self.X) and ("fwd", x.data_ptr()) in self._split_cache
 
     def _lin_bwd_x(self, rec, dx, dy, wkey):
         """dX = dY . W.  Through a WIDE weight this is a second full read of W (4 B/param on top of the forward's):
@@ -679,8 +705,19 @@ class StepPlan:
             self._build_gnn()
         else:
             self._build_mlp_family()
-        if self.train:
-            self._build_optimizer()
+        if self.train and not self._next_fwd:
+            self._build_optimizer()          # (with fused next-step forwards: built by link_next, once the partner exists)
+
+    def link_next(self, nxt: "StepPlan"):
+        """Record the optimiser tape against the plan that holds the NEXT batch (PipelinedStep's other half): the fused
+        dW+Adam launches multiply every updated weight tile into that plan's split input and leave the partial sums in
+        its slab buffers."""
+        if not self.train:
+            return
+        if set(self._next_fwd) != set(nxt._next_fwd):
+            raise RuntimeError("link_next: the two plans fuse different layers")
+        self.t_opt = TapeRecorder()
+        self._build_optimizer(nxt)
 
     def _build_mlp_family(self):
         """DirectPred (direct_pred.py:107-133, :225-260) and MultiTripletNetwork
@@ -962,9 +999,11 @@ class StepPlan:
             _par_ctx.__exit__(None, None, None)
             self._branch = 0
 
-    def _build_optimizer(self):
+    def _build_optimizer(self, nxt: Optional["StepPlan"] = None):
         """clip_grad_norm_(1.0) + Adam over every parameter (main.py:216-217, direct_pred.py:143)."""
         st, ro = self.store, self.t_opt
+        if self._next_fwd and nxt is None:
+            raise RuntimeError("this plan's wide forward is fused into the partner's optimiser step: use PipelinedStep")
         o = self._slot_o
         if not self.fused:
             for k in st.big_keys:
@@ -989,7 +1028,12 @@ class StepPlan:
             d = st.big[k]
             if self.fused and self.precision == "bf16x3":
                 dy, x, dyt, xt = self._jobs[k]
-                ops.linear_dw_adam_bf16x3(ro, d["W"], d["M"], d["V"], dyt[0], dyt[1], xt[0], xt[1], st.ctrl)
+                if k in self._next_fwd:
+                    nslabs, _, nsp = nxt._next_fwd[k]
+                    ops.linear_dw_adam_fwd_bf16x3(ro, d["W"], d["M"], d["V"], dyt[0], dyt[1], xt[0], xt[1], st.ctrl, nsp[0], nsp[1],
+                                                  nxt.R, nslabs, nt=os.environ.get("FX_NT_ADAM", "1") != "0")
+                else:
+                    ops.linear_dw_adam_bf16x3(ro, d["W"], d["M"], d["V"], dyt[0], dyt[1], xt[0], xt[1], st.ctrl)
             elif self.fused:
                 dy, x, _, _ = self._jobs[k]
                 ops.linear_dw_adam(ro, d["W"], d["M"], d["V"], dy, x, st.ctrl)
@@ -1114,11 +1158,17 @@ class PipelinedStep:
     This is the DataLoader-prefetch of the reference's loop (main.py:289-298, num_workers) moved onto the GPU."""
 
     def __init__(self, store: ParamStore, B: int, *, cohort, n_batches: int, seed: int = 0,
-                 precision: str = "bf16x3", epoch_acc: bool = True, clip: bool = True, frozen: Tuple[str, ...] = ()):
+                 precision: str = "bf16x3", epoch_acc: bool = True, clip: bool = True, frozen: Tuple[str, ...] = (),
+                 fuse_next_fwd: Optional[bool] = None):
+        if fuse_next_fwd is None:            # FX_FUSE_NEXT_FWD=0: A/B switch (separate forward kernel, 28 B/param/step)
+            fuse_next_fwd = os.environ.get("FX_FUSE_NEXT_FWD", "1") != "0"
         kw = dict(train=True, fused=True, supplied_draws=False, seed=seed, cohort=cohort, n_batches=n_batches,
-                  epoch_acc=epoch_acc, precision=precision, clip=clip, frozen=frozen)
+                  epoch_acc=epoch_acc, precision=precision, clip=clip, frozen=frozen, fuse_next_fwd=fuse_next_fwd)
         a = StepPlan(store, B, **kw)
         self.plans = [a, StepPlan(store, B, share=a, **kw)]
+        if a._next_fwd:
+            a.link_next(self.plans[1])
+            self.plans[1].link_next(a)
         self.store, self.n_batches, self.dev = store, int(n_batches), store.device
         self.idx, self.epoch_acc = a.idx, a.epoch_acc
         self.k = 0                       # plan holding the batch of the next step
@@ -1131,6 +1181,13 @@ class PipelinedStep:
         self.store.ctrl[ops.CTRL_CURSOR] = 0.0      # fx_step_begin advances it first: step t assembles row (t + 1) mod n_batches
         self.plans[0].t_gather.run()
         self.k, self.done = 0, 0
+        self.refresh()
+
+    @ops.device_guard
+    def refresh(self):
+        """(Re)compute the wide-forward partial sums of the pending batch with the CURRENT weights: at the start, and
+        after any weight change made outside the pipeline (a partial-batch step, load_state, ...)."""
+        self.plans[self.k].t_boot.run()
 
     def epoch_end_next(self) -> bool:
         """True when the NEXT step is the last of its epoch, i.e. its prefetch reads row 0 of the next epoch's

@@ -201,6 +201,8 @@ def _fit(model, store, dataset, train_idx, val_idx, *, batch_size, epochs, lr, p
                 write_table()
             tail_plan.idx.copy_(tails.pop(0))
             tail_plan.train_step(lr, gather=True)
+            if pipe is not None:
+                pipe.refresh()        # the pending batch's fused wide forward was computed before this step changed the weights
             steps += 1
         epochs_run = epoch + 1
         # epoch means weighted by batch size, like Lightning's on_epoch reduction of the logged losses

@@ -272,10 +272,11 @@ def test_pipelined_step_equals_plain_step(model_name):
             out.append(plan.losses()["total"])
         return out, store.state_dict()
 
-    def piped(graph):
+    def piped(graph, fuse):
         store = ParamStore(spec, dev)
         store.load_state(init)
-        pipe = PipelinedStep(store, B, cohort=cohort, n_batches=nb, seed=9)
+        pipe = PipelinedStep(store, B, cohort=cohort, n_batches=nb, seed=9, fuse_next_fwd=fuse)
+        assert bool(pipe.plans[0]._next_fwd) == (fuse and not trip)      # 3B stacked rows > 128: the triplet forward stays separate
         pipe.idx.copy_(tables[0])
         pipe.prime()
         out, e = [], 0
@@ -293,11 +294,27 @@ def test_pipelined_step_equals_plain_step(model_name):
         return out, store.state_dict()
 
     l0, s0 = plain()
+    # separate forward kernel: the pipelined schedule is the plain step, bit for bit
     for graph in (False, True):
-        l1, s1 = piped(graph)
+        l1, s1 = piped(graph, False)
         assert l1 == l0, (graph, l0, l1)
         for k in s0:
             assert torch.equal(s0[k], s1[k]), (graph, k)
+    # next-step forward fused into dW+Adam: another (fixed) summation order in the wide forward -> rounding-level
+    # differences from the plain step, but graph replay and eager launches of the SAME schedule agree bit for bit
+    lf, sf = piped(False, True)
+    lg, sg = piped(True, True)
+    assert lf == lg
+    for k in sf:
+        assert torch.equal(sf[k], sg[k]), k
+    for a, b in zip(lf, l0):
+        assert abs(a - b) <= 2e-5 * abs(b) + 1e-6, (lf, l0)
+    for k in s0:
+        if s0[k].dtype.is_floating_point:
+            d = (sf[k].double() - s0[k].double()).abs()
+            # Adam turns rounding-level gradient differences of noise-floor entries into +-lr steps
+            assert float((d > 1e-5 + 1e-3 * s0[k].double().abs()).double().mean()) <= 2e-3, k
+            assert float(d.max()) <= 2.1 * lr * steps, k
 
 
 def test_crossmodal_validation_decode_and_fit():

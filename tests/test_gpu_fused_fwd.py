@@ -79,3 +79,69 @@ def test_dw_adam_fwd_argument_checks():
     with pytest.raises(FxError):
         ops.linear_dw_adam_fwd_bf16x3(ops.IMMEDIATE, W[:, :k_in], W.clone()[:, :k_in], W.clone()[:, :k_in], dyt[0], dyt[1],
                                       xt[0], xt[1], ctrl, xn[0], xn[1], B, slabs)
+
+
+@pytest.mark.parametrize("model,layers,B", [
+    ("DirectPred", [("gex", 2600), ("cnv", 2200)], 128),
+    ("DirectPred", [("gex", 4100), ("cnv", 3000)], 37),              # ragged batch: rows padded to 128 / 64
+    ("supervised_vae", [("gex", 2000), ("cnv", 1600)], 64),          # encoders fused, decoders (activations as input) not
+    ("DirectPred", [("gex", 20000), ("cnv", 20000)], 128),           # cfg2: the shape bench.py times
+])
+def test_pipeline_fused_forward_is_the_forward_of_the_next_batch(model, layers, B):
+    """Engine wiring: after step t the slabs of the pending plan, summed, must equal a stand-alone wide forward of the
+    pending batch with the weights as they are NOW (t_boot recomputes exactly that); then the trajectory with the fusion
+    tracks the one without it, and hipGraph replay reproduces eager launches bit for bit."""
+    from flexynesis_amd.arch import ArchSpec
+    from flexynesis_amd.data import synthetic_cohort
+    from flexynesis_amd.engine import ParamStore, PipelinedStep
+    dev = _dev()
+    variables = [("y", "numerical", 1), ("c", "categorical", 4)]
+    spec = ArchSpec(model, layers, 32, 0.25, 16, variables, None, None, True)
+    cohort = synthetic_cohort(layers, 700, dev, seed=3)
+    nb = 4
+    g = torch.Generator().manual_seed(1)
+    tables = [torch.randint(0, 700, (nb * B,), generator=g).to(dev) for _ in range(4)]
+    torch.manual_seed(5)
+    init = ParamStore(spec, dev, materialize_big_grads=False).state_dict()
+
+    def run(fuse, graph, check):
+        store = ParamStore(spec, dev, materialize_big_grads=False)
+        store.load_state(init)
+        pipe = PipelinedStep(store, B, cohort=cohort, n_batches=nb, seed=4, fuse_next_fwd=fuse)
+        fused_keys = sorted(pipe.plans[0]._next_fwd)
+        wide_inputs = sorted(k for k in store.big_keys if k.startswith("encoders."))     # the wide layers fed by the batch itself
+        assert fused_keys == (wide_inputs if fuse else []) and (wide_inputs or not fuse), (fused_keys, store.big_keys)
+        pipe.idx.copy_(tables[0])
+        pipe.prime()
+        losses, e = [], 0
+        for s in range(2 * nb + 1):
+            if pipe.epoch_end_next():
+                e += 1
+                pipe.idx.copy_(tables[e])
+            if graph and pipe.graphs[0] is not None:
+                pipe.replay()
+            else:
+                pipe.step(1e-3)
+                if graph:
+                    pipe.capture(1e-3)
+            losses.append(pipe.last.loss_vec.clone())
+            if check:
+                pend = pipe.plans[pipe.k]
+                got = {k: pend._next_fwd[k][0].sum(0).clone() for k in fused_keys}
+                pipe.refresh()                                   # stand-alone forward of the pending batch, current weights
+                for k in fused_keys:
+                    ref = pend._next_fwd[k][0].sum(0)
+                    assert float((got[k] - ref).norm() / ref.norm()) <= 2e-6, (s, k)
+                    assert float((got[k] - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (s, k)
+        torch.cuda.synchronize()
+        return torch.stack(losses).cpu(), store.state_dict()
+
+    l_check, _ = run(True, False, True)
+    l_f, s_f = run(True, False, False)
+    l_g, s_g = run(True, True, False)
+    l_u, _ = run(False, False, False)
+    assert torch.equal(l_f, l_g)                                   # graph replay == eager, bit for bit
+    for k in s_f:
+        assert torch.equal(s_f[k], s_g[k]), k
+    for a in (l_f, l_check):
+        assert float(((a - l_u).abs() / (l_u.abs() + 1e-6)).max()) <= 1e-4, (a, l_u)

@@ -292,3 +292,97 @@ def test_graph_csr_build_needs_no_gpu_for_weights():
     src, dst, w = G.edge_weights(np.array([[0, 1, 1], [1, 0, 1]]), 3, "GCN")
     assert sorted(zip(src.tolist(), dst.tolist())) == [(0, 0), (0, 1), (1, 0), (1, 1), (2, 2)]
     assert w[(src == 2) & (dst == 2)][0] == 1.0               # isolated node: degree 1 from its self loop
+
+
+# ---- device triplet sampler (fit.TripletSampler; reference data.py:1106-1131) ------------------------------------
+def _triplet_labels():
+    # groups: 0 -> 3 members, 1 -> 2, 2 -> 4, NaN ("NA" group) -> 2; scattered positions
+    return torch.tensor([2., 0., float("nan"), 1., 2., 0., 2., float("nan"), 1., 0., 2.])
+
+
+def test_triplet_sampler_semantics():
+    """positive = another sample with the anchor's label (never the anchor); negative = member of another label group,
+    the NaN samples forming one extra group (reference data.py:1118-1127); anchors = samples with a label (:1102-1104)."""
+    from flexynesis_amd.fit import TripletSampler
+    lab = _triplet_labels()
+    sm = TripletSampler(lab)
+    assert sm.valid.tolist() == [i for i, v in enumerate(lab.tolist()) if v == v]
+    assert sm.n_groups == 4
+    gen = torch.Generator().manual_seed(0)
+    anchors = sm.valid.repeat(4000)
+    pos, neg = sm.sample(anchors, gen)
+    la, lp, ln = lab[anchors], lab[pos], lab[neg]
+    assert bool((pos != anchors).all()) and bool((lp == la).all())
+    assert bool(((ln != la) | torch.isnan(ln)).all())
+    assert bool(torch.isnan(ln).any()), "the NA group must be drawn as a negative label"
+
+    # uniformity: every admissible positive / negative label / member of the drawn group equally likely (4 sigma)
+    def check(counts, p, what):
+        n = int(counts.sum())
+        sigma = (p * (1 - p) / n) ** 0.5
+        assert bool(((counts / n - p).abs() <= 4 * sigma + 1e-9).all()), (what, (counts / n).tolist(), p)
+
+    members = {0.0: [1, 5, 9], 1.0: [3, 8], 2.0: [0, 4, 6, 10], "NA": [2, 7]}
+    for a in sm.valid.tolist():
+        sel = anchors == a
+        key = float(lab[a])
+        others = [i for i in members[key] if i != a]
+        check(torch.bincount(pos[sel], minlength=11)[others].double(), 1.0 / len(others), f"positives of {a}")
+        neg_groups = [k for k in members if k != key]
+        gcount = torch.tensor([float(sum(int((neg[sel] == i).sum()) for i in members[k])) for k in neg_groups])
+        check(gcount, 1.0 / len(neg_groups), f"negative label of {a}")
+        for k in neg_groups:
+            check(torch.bincount(neg[sel], minlength=11)[members[k]].double() / 1.0, gcount[neg_groups.index(k)].item() / int(sel.sum()) / len(members[k]),
+                  f"negatives of {a} inside group {k}") if False else None
+            inside = torch.bincount(neg[sel], minlength=11)[members[k]].double()
+            check(inside, 1.0 / len(members[k]), f"negatives of {a} inside group {k}")
+
+
+def test_triplet_sampler_rejects_what_the_reference_cannot_sample():
+    from flexynesis_amd.fit import TripletSampler
+    gen = torch.Generator().manual_seed(0)
+    with pytest.raises(ValueError):          # one label group only: random.choice(list(set())) raises in the reference
+        TripletSampler(torch.tensor([1., 1., 1.]))
+    sm = TripletSampler(torch.tensor([0., 0., 1., 2., 2.]))
+    with pytest.raises(ValueError):          # a class with a single member: the reference's rejection loop never ends
+        sm.sample(torch.tensor([2]), gen)
+    sm.sample(torch.tensor([0, 1, 3, 4]), gen)
+    # NaN-only "other group": two groups = one label + NA is a legal configuration
+    sm = TripletSampler(torch.tensor([3., 3., float("nan")]))
+    pos, neg = sm.sample(torch.tensor([0, 1, 0, 1]), gen)
+    assert pos.tolist() == [1, 0, 1, 0] and neg.tolist() == [2, 2, 2, 2]
+
+
+@pytest.mark.skipif(not __import__("oracle.ref_shim", fromlist=["x"]).available(), reason="reference only exists in the build container")
+def test_triplet_sampler_matches_the_reference_dataset_distribution():
+    """Live: the reference's TripletMultiOmicDataset.__getitem__ (numpy / random RNG) and the device sampler draw from the
+    same distribution -- per anchor, the empirical frequencies of every (positive, negative) index agree within 5 sigma."""
+    import random
+    from oracle import ref_shim
+    from flexynesis_amd.fit import TripletSampler
+    R = ref_shim.load()
+    lab = _triplet_labels()
+    n = lab.numel()
+    dat = {"a": torch.arange(n, dtype=torch.float32).reshape(n, 1)}           # the feature IS the sample index
+    ds = R.MultiOmicDataset(dat, {"c": lab}, {"c": "categorical"}, {"a": ["f"]}, [f"s{i}" for i in range(n)], {})
+    tds = R.TripletMultiOmicDataset(ds, "c")
+    sm = TripletSampler(lab)
+    assert tds.valid_indices == sm.valid.tolist()
+    np.random.seed(0)
+    random.seed(0)
+    reps = 3000
+    gen = torch.Generator().manual_seed(1)
+    for ai, a in enumerate(tds.valid_indices):
+        ref_pos, ref_neg = torch.zeros(n), torch.zeros(n)
+        for _ in range(reps):
+            anc, p, ng, y = tds[ai]
+            assert int(anc["a"].item()) == a
+            ref_pos[int(p["a"].item())] += 1
+            ref_neg[int(ng["a"].item())] += 1
+        p2, n2 = sm.sample(torch.full((reps,), a), gen)
+        got_pos, got_neg = torch.bincount(p2, minlength=n).float(), torch.bincount(n2, minlength=n).float()
+        for ref, got in ((ref_pos, got_pos), (ref_neg, got_neg)):
+            assert bool(((ref > 0) == (got > 0)).all()), (a, ref.tolist(), got.tolist())       # same support
+            pr = (ref + got) / (2 * reps)
+            sigma = (pr * (1 - pr) * 2 / reps).sqrt()
+            assert bool((((ref - got) / reps).abs() <= 5 * sigma + 1e-9).all()), (a, ref.tolist(), got.tolist())
