@@ -1159,10 +1159,12 @@ class PipelinedStep:
 
     def __init__(self, store: ParamStore, B: int, *, cohort, n_batches: int, seed: int = 0,
                  precision: str = "bf16x3", epoch_acc: bool = True, clip: bool = True, frozen: Tuple[str, ...] = (),
-                 fuse_next_fwd: Optional[bool] = None):
+                 fuse_next_fwd: Optional[bool] = None, supplied_draws: bool = False):
         if fuse_next_fwd is None:            # FX_FUSE_NEXT_FWD=0: A/B switch (separate forward kernel, 28 B/param/step)
             fuse_next_fwd = os.environ.get("FX_FUSE_NEXT_FWD", "1") != "0"
-        kw = dict(train=True, fused=True, supplied_draws=False, seed=seed, cohort=cohort, n_batches=n_batches,
+        # supplied_draws: parity mode -- dropout masks / eps / priors are static buffers the caller fills before each step
+        # (``pending.set_draws``) instead of in-kernel Philox draws; the schedule is otherwise the production one
+        kw = dict(train=True, fused=True, supplied_draws=bool(supplied_draws), seed=seed, cohort=cohort, n_batches=n_batches,
                   epoch_acc=epoch_acc, precision=precision, clip=clip, frozen=frozen, fuse_next_fwd=fuse_next_fwd)
         a = StepPlan(store, B, **kw)
         self.plans = [a, StepPlan(store, B, share=a, **kw)]
@@ -1233,6 +1235,11 @@ class PipelinedStep:
         self.plans[self.k].bump_nbt()
         self.k ^= 1
         self.done += 1
+
+    @property
+    def pending(self) -> StepPlan:
+        """The plan the NEXT step computes from (its batch is already assembled)."""
+        return self.plans[self.k]
 
     @property
     def last(self) -> StepPlan:

@@ -112,24 +112,28 @@ def _eval_loss(model, store, cohort, idx_rows: torch.Tensor, batch_size: int, pa
 def fit(model, dataset, train_idx: Sequence[int], val_idx: Optional[Sequence[int]] = None, *, batch_size: int,
         epochs: int, lr: float, patience: int = 0, seed: int = 0, use_graph: bool = True, device=None,
         verbose: bool = False, clip: bool = True, frozen: Sequence[str] = (), drop_last: bool = True,
-        fresh_optimizer: bool = False) -> FitResult:
+        fresh_optimizer: bool = False, supplied: Optional[dict] = None) -> FitResult:
     """Train ``model`` on ``dataset[train_idx]`` and validate on ``dataset[val_idx]`` once per epoch.
     For MultiTripletNetwork the indices address the valid (non-NaN main label) anchors, like the reference's
     ``TripletMultiOmicDataset`` (data.py:1102-1104).
 
     Defaults = the HPO trainer (main.py:212-225, :289-298: clip 1.0, shuffle, drop_last=True).  The FineTuner's
     trainer (main.py:530-611) is ``clip=False, drop_last=False, frozen=(...)``: state_dict key prefixes with
-    requires_grad=False are neither differentiated nor stepped, and the last partial batch of an epoch is used."""
+    requires_grad=False are neither differentiated nor stepped, and the last partial batch of an epoch is used.
+
+    ``supplied`` (parity tests): {"perms": [per-epoch permutation of range(len(train_idx))], "draws": fn(epoch, batch) ->
+    {name: tensor}} replaces the device shuffle and the in-kernel Philox draws by recorded ones; the schedule (pipelined
+    batch assembly, hipGraph replay, fused kernels) is the production one."""
     store = model._bind(device)
     # streams, events and graph capture are keyed on torch's current device: make it the model's for the whole fit
     with torch.cuda.device(store.device):
         return _fit(model, store, dataset, train_idx, val_idx, batch_size=batch_size, epochs=epochs, lr=lr, patience=patience,
                     seed=seed, use_graph=use_graph, verbose=verbose, clip=clip, frozen=frozen, drop_last=drop_last,
-                    fresh_optimizer=fresh_optimizer)
+                    fresh_optimizer=fresh_optimizer, supplied=supplied)
 
 
 def _fit(model, store, dataset, train_idx, val_idx, *, batch_size, epochs, lr, patience, seed, use_graph, verbose, clip, frozen,
-         drop_last, fresh_optimizer) -> FitResult:
+         drop_last, fresh_optimizer, supplied=None) -> FitResult:
     dev = store.device
     if fresh_optimizer:
         store.reset_optimizer()             # a new torch.optim.Adam per fit (main.py:562-566)
@@ -153,8 +157,10 @@ def _fit(model, store, dataset, train_idx, val_idx, *, batch_size, epochs, lr, p
         raise ValueError(f"batch_size {B} exceeds the training split ({tr.numel()} samples) with drop_last=True")
     frozen = tuple(frozen)
     plan_kw = dict(clip=bool(clip), frozen=frozen)
+    if supplied is not None and (trip or tail):
+        raise ValueError("supplied permutations / draws cover full batches of the non-triplet models only")
     pipe = PipelinedStep(store, B, cohort=cohort, n_batches=n_batches, seed=int(seed) * 7919 + 13, epoch_acc=True,
-                         **plan_kw) if n_batches >= 1 else None
+                         supplied_draws=supplied is not None, **plan_kw) if n_batches >= 1 else None
     tail_plan = StepPlan(store, tail, train=True, fused=True, supplied_draws=False, seed=int(seed) * 7919 + 17, cohort=cohort,
                          n_batches=0, epoch_acc=True, **plan_kw) if tail else None
     names = spec.loss_names()
@@ -169,9 +175,16 @@ def _fit(model, store, dataset, train_idx, val_idx, *, batch_size, epochs, lr, p
         pos, neg = sampler.sample(perm, gen)
         return torch.cat([perm.view(-1, k), pos.view(-1, k), neg.view(-1, k)], dim=1).reshape(-1)
 
+    tables_written = [0]
+
     def write_table():
         """shuffle=True (main.py:289-298): a fresh device permutation of the training split."""
-        perm = tr[torch.randperm(tr.numel(), generator=gen, device=dev)]
+        if supplied is not None:
+            e = min(tables_written[0], len(supplied["perms"]) - 1)      # (the table after the last epoch is never trained on)
+            perm = tr[torch.as_tensor(supplied["perms"][e], dtype=torch.int64).to(dev)]
+        else:
+            perm = tr[torch.randperm(tr.numel(), generator=gen, device=dev)]
+        tables_written[0] += 1
         if pipe is not None:
             pipe.idx.copy_(rows_of(perm[: n_batches * B], B))
         if tail:
@@ -189,6 +202,8 @@ def _fit(model, store, dataset, train_idx, val_idx, *, batch_size, epochs, lr, p
         for b in range(n_batches):
             if pipe.epoch_end_next():
                 write_table()         # the last step of an epoch prefetches row 0 of the next epoch's table
+            if supplied is not None:
+                pipe.pending.set_draws({k: torch.as_tensor(v).to(dev) for k, v in supplied["draws"](epoch, b).items()})
             if use_graph and pipe.graphs[0] is not None:
                 pipe.replay()
             else:
@@ -224,6 +239,9 @@ def _fit(model, store, dataset, train_idx, val_idx, *, batch_size, epochs, lr, p
             print(f"[fit] epoch {epoch}: " + ", ".join(f"{k}={v:.5f}" for k, v in rec.items()), flush=True)
         if va is not None and patience and patience > 0:
             # lightning.pytorch.callbacks.EarlyStopping(monitor='val_loss', patience, mode='min', min_delta=0)
+            if not np.isfinite(rec["val_loss"]):          # EarlyStopping(check_finite=True): a non-finite monitor stops at once
+                stopped_epoch = epoch
+                break
             if rec["val_loss"] < best:
                 best, wait = rec["val_loss"], 0
             else:

@@ -84,7 +84,7 @@ def test_dw_adam_fwd_argument_checks():
 @pytest.mark.parametrize("model,layers,B", [
     ("DirectPred", [("gex", 2600), ("cnv", 2200)], 128),
     ("DirectPred", [("gex", 4100), ("cnv", 3000)], 37),              # ragged batch: rows padded to 128 / 64
-    ("supervised_vae", [("gex", 2000), ("cnv", 1600)], 64),          # encoders fused, decoders (activations as input) not
+    ("supervised_vae", [("gex", 2600), ("cnv", 2200)], 64),          # encoders fused, decoders (activations as input) not
     ("DirectPred", [("gex", 20000), ("cnv", 20000)], 128),           # cfg2: the shape bench.py times
 ])
 def test_pipeline_fused_forward_is_the_forward_of_the_next_batch(model, layers, B):

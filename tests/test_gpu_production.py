@@ -37,9 +37,12 @@ def _state_close(got, ref, g, gnorm, lr, what):
     contractions (and any fp32 reduction order) leave an absolute error of ~3e-5 of the tensor's scale per element, i.e.
     delta ~ 3e-5 * max|g| / |g|: tight for the elements that carry the gradient, up to a full +-lr step of either sign
     (2.1 lr apart) for entries at the noise floor -- in particular the biases in front of a BatchNorm, whose true gradient
-    is exactly zero.  Large tensors may additionally hold <= 0.1 % of such outliers (a ReLU gate
-    within rounding of zero changes one row of an upstream gradient discretely)."""
+    is exactly zero.  Hard bound for every element: two opposite full steps.  Beyond the
+    element-wise rule a tensor may hold max(1, 0.2 %) outliers: a column sum that cancels heavily (BatchNorm / bias
+    gradients) or a ReLU gate within rounding of zero puts single elements at the noise floor without a small |g|."""
     got, ref = torch.as_tensor(got).double().cpu().reshape(-1), torch.as_tensor(ref).double().reshape(-1)
+    err = (got - ref).abs()
+    assert float(err.max()) <= 2.1 * lr + 1e-6 + 2e-4 * float(ref.abs().max()), f"{what}: max err {float(err.max()):.3e}"
     if g is None:
         atol = torch.full_like(ref, 3e-6)
     else:
@@ -47,10 +50,10 @@ def _state_close(got, ref, g, gnorm, lr, what):
         delta = 1e-4 * float(ga.max()) / (ga + 1e-30)
         delta = torch.where(ga < 2e-6 * gnorm, torch.full_like(delta, 2.1), delta)
         atol = 3e-6 + lr * torch.clamp(delta, max=2.1)
-    bad = (got - ref).abs() > atol + 2e-4 * ref.abs()
-    allowed = int(1e-3 * ref.numel())
+    bad = err > atol + 2e-4 * ref.abs()
+    allowed = max(1, int(2e-3 * ref.numel()))
     assert int(bad.sum()) <= allowed, (f"{what}: {int(bad.sum())}/{ref.numel()} off (allowed {allowed}), max err "
-                                       f"{float((got - ref).abs().max()):.3e}")
+                                       f"{float(err.max()):.3e}")
 
 
 @pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4"])
