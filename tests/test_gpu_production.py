@@ -49,7 +49,9 @@ def _state_close(got, ref, g, gnorm, lr, what):
         ga = g.double().abs().reshape(-1)
         delta = 1e-4 * float(ga.max()) / (ga + 1e-30)
         delta = torch.where(ga < 2e-6 * gnorm, torch.full_like(delta, 2.1), delta)
-        atol = 3e-6 + lr * torch.clamp(delta, max=2.1)
+        # floor of 5 % of a step: column-sum gradients (BatchNorm / bias) cancel heavily, so their relative error is set by
+        # the size of the summed terms, not by |g|
+        atol = 3e-6 + lr * torch.clamp(delta, min=0.05, max=2.1)
     bad = err > atol + 2e-4 * ref.abs()
     allowed = max(1, int(2e-3 * ref.numel()))
     assert int(bad.sum()) <= allowed, (f"{what}: {int(bad.sum())}/{ref.numel()} off (allowed {allowed}), max err "
