@@ -249,7 +249,10 @@ class StepPlan:
         self._ws = [Workspace(self.dev)]
         self._branch = 0
         self.branches = bool(branches) and os.environ.get("FX_BRANCHES", "1") != "0"   # per-modality chains as parallel hipGraph branches
-        self.bn_slabs = False                   # fold the wide layer's split-K reduce into BatchNorm (measured: no gain)
+        # FX_BN_SLABS=1 folds the reduction of the wide layer's partial sums (+ bias) into the BatchNorm kernel (one launch
+        # less per wide layer).  Measured twice, no gain: 1.289 vs 1.276 ms/step at cfg2 with the fused next-step forward
+        # (the BatchNorm kernel then re-reads 6 slabs instead of one array), so it stays an A/B switch.
+        self.bn_slabs = os.environ.get("FX_BN_SLABS", "0") == "1"
         # whole encoder-tail backward in one launch (fx_block_bwd); FX_BLOCK_BWD=0 is an A/B switch for benchmarks
         self.block_bwd = os.environ.get("FX_BLOCK_BWD", "1") != "0"
         # all supervisor heads in one launch each way (fx_heads_fwd/bwd); FX_FUSE_HEADS=0 is an A/B switch for benchmarks
@@ -418,17 +421,18 @@ class StepPlan:
                 S = ops.dw_adam_fwd_slabs(N, x.shape[1])
                 slabs = self._new(f"yslabs/{wkey}", S, M, N)
                 self._next_fwd[wkey] = (slabs, S, sp)
-                ops.reduce_slabs(rec, y, slabs, st.p(bkey), S)          # the whole wide forward of this step
+                if not want_slabs:
+                    ops.reduce_slabs(rec, y, slabs, st.p(bkey), S)      # the whole wide forward of this step
                 ops.fill(self.t_boot, slabs, 0.0)                       # stand-alone: full forward (no bias) into slab 0
                 ops.linear_fwd_bf16x3(self.t_boot, slabs[0], sp[0], sp[1], st.p(wkey), None, self._ws[0])
-                return None
+                return (slabs.view(S, M * N), S) if want_slabs else None
             # Stagger the HBM-bound wide kernels of the parallel modality branches: two of them side by side
             # take as long as back to back, but back to back lets modality i's narrow post-chain (reduce, BN,
             # layer_out) run underneath modality i+1's wide kernel instead of after both.
             stagger = self.branches and isinstance(rec, TapeRecorder) and len(rec.segments[-1]) > 1
             if stagger and getattr(self, "_last_wide_ev", None) is not None:
                 rec.wait_event(self._last_wide_ev)
-            if want_slabs:
+            if want_slabs and os.environ.get("FX_BN_SLABS_UNFUSED", "0") == "1":      # (measured: no gain with the stand-alone forward)
                 M, N = y.shape
                 ns = int(ops.lib.fx_linear_fwd_bf16x3_splitk(M, N, x.shape[1]))
                 sbuf = self._new(f"slabs/{wkey}", ns, M * N)
@@ -1173,6 +1177,9 @@ class PipelinedStep:
             self.plans[1].link_next(a)
         self.store, self.n_batches, self.dev = store, int(n_batches), store.device
         self.idx, self.epoch_acc = a.idx, a.epoch_acc
+        # FX_EARLY_GATHER=1 forks the batch assembly of step t+1 at the start of step t instead of after the losses.
+        # Measured slower (1.313 vs 1.276 ms/step at cfg2): the gather / Gram kernels then compete with the forward chain.
+        self.early_gather = bool(a._next_fwd) and os.environ.get("FX_EARLY_GATHER", "0") == "1"
         self.k = 0                       # plan holding the batch of the next step
         self.done = 0                    # steps issued since prime()
         self.graphs = [None, None]
@@ -1199,9 +1206,13 @@ class PipelinedStep:
     def _issue(self, k, lr, timed=None):
         cur, nxt = self.plans[k], self.plans[1 - k]
         ops.step_begin(ops.IMMEDIATE, self.store.ctrl, lr, self.n_batches)
-        cur.t_fwd.run()
         main = torch.cuda.current_stream()
-        used = nxt.t_gather.fork_from(main)               # fork: batch assembly of step t+1 ...
+        if self.early_gather:
+            used = nxt.t_gather.fork_from(main)
+            cur.t_fwd.run()
+        else:
+            cur.t_fwd.run()
+            used = nxt.t_gather.fork_from(main)           # fork: batch assembly of step t+1 ...
         cur.t_bwd.run()                                   # ... overlaps the head / backward chain of step t
         for st in used:
             main.wait_stream(st)                          # join before the HBM-saturating dW+Adam launches

@@ -1,0 +1,138 @@
+// What does the memory system give a kernel with the dW+Adam kernel's traffic -- read + write of three fp32 arrays
+// [H, F] in 16-byte non-temporal accesses -- as a function of the TILE SHAPE a workgroup streams and of how many
+// workgroups a CU holds?  No GEMM: the "gradient" is a constant.   hipcc --offload-arch=gfx950 -O3 scripts/adamprobe.hip
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// one workgroup (512 threads) per tile of R rows x C columns (R * C = 8192 or 16384 elements), tiles walked row-block-fastest
+// (ORDER 0) or column-fastest (ORDER 1); LDSB bytes of dummy LDS limit the workgroups per CU.
+template <int R, int C, int ORDER, int LDSB>
+__global__ __launch_bounds__(512) void adam_tiles(float* __restrict__ W, float* __restrict__ M, float* __restrict__ V, int H, int F, long ld) {
+  __shared__ char pad[LDSB];
+  if (threadIdx.x == 9999) pad[threadIdx.x % LDSB] = 1;
+  const int tiles_m = (H + R - 1) / R, tiles_n = (F + C - 1) / C;
+  int tm, tn;
+  if (ORDER == 0) { tm = blockIdx.x % tiles_m; tn = blockIdx.x / tiles_m; } else { tn = blockIdx.x % tiles_n; tm = blockIdx.x / tiles_n; }
+  constexpr int UPR = C / 4, UNITS = R * UPR, PER = UNITS / 512;
+  f4 p[PER], m[PER], v[PER];
+  long off[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int u = threadIdx.x + 512 * i, r = u / UPR, c4 = u % UPR;
+    const int row = tm * R + r, col = tn * C + 4 * c4;
+    off[i] = (row < H && col < F) ? ((long)row * ld + col) / 4 : -1;
+    if (off[i] >= 0) {
+      p[i] = __builtin_nontemporal_load((const f4*)W + off[i]);
+      m[i] = __builtin_nontemporal_load((const f4*)M + off[i]);
+      v[i] = __builtin_nontemporal_load((const f4*)V + off[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    if (off[i] < 0) continue;
+    f4 po, mo, vo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float g = 1e-3f;
+      const float m2 = m[i][j] + (g - m[i][j]) * 0.1f;
+      const float v2 = v[i][j] * 0.999f + 0.001f * g * g;
+      po[j] = p[i][j] - 1e-3f * (m2 / (sqrtf(v2) + 1e-8f));
+      mo[j] = m2; vo[j] = v2;
+    }
+    __builtin_nontemporal_store(po, (f4*)W + off[i]);
+    __builtin_nontemporal_store(mo, (f4*)M + off[i]);
+    __builtin_nontemporal_store(vo, (f4*)V + off[i]);
+  }
+}
+
+// persistent: workgroup (tm, c) walks the column tiles c, c + S, ... of its 64-row block (the fused kernel's schedule)
+template <int LDSB>
+__global__ __launch_bounds__(512) void adam_runs(float* __restrict__ W, float* __restrict__ M, float* __restrict__ V, int H, int F, long ld, int S, int contiguous) {
+  __shared__ char pad[LDSB];
+  if (threadIdx.x == 9999) pad[threadIdx.x % LDSB] = 1;
+  constexpr int R = 64, C = 128, UPR = 32, PER = 4;
+  const int tiles_m = (H + R - 1) / R, tiles_n = (F + C - 1) / C;
+  const int tm = blockIdx.x % tiles_m, c = blockIdx.x / tiles_m;
+  int t0 = c, t1 = tiles_n, ts = S;
+  if (contiguous) { t0 = (int)((long)c * tiles_n / S); t1 = (int)((long)(c + 1) * tiles_n / S); ts = 1; }
+  for (int tn = t0; tn < t1; tn += ts) {
+    f4 p[PER], m[PER], v[PER];
+    long off[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int u = threadIdx.x + 512 * i, r = u / UPR, c4 = u % UPR;
+      const int row = tm * R + r, col = tn * C + 4 * c4;
+      off[i] = (row < H && col < F) ? ((long)row * ld + col) / 4 : -1;
+      if (off[i] >= 0) {
+        p[i] = __builtin_nontemporal_load((const f4*)W + off[i]);
+        m[i] = __builtin_nontemporal_load((const f4*)M + off[i]);
+        v[i] = __builtin_nontemporal_load((const f4*)V + off[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      if (off[i] < 0) continue;
+      f4 po, mo, vo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float g = 1e-3f;
+        const float m2 = m[i][j] + (g - m[i][j]) * 0.1f;
+        const float v2 = v[i][j] * 0.999f + 0.001f * g * g;
+        po[j] = p[i][j] - 1e-3f * (m2 / (sqrtf(v2) + 1e-8f));
+        mo[j] = m2; vo[j] = v2;
+      }
+      __builtin_nontemporal_store(po, (f4*)W + off[i]);
+      __builtin_nontemporal_store(mo, (f4*)M + off[i]);
+      __builtin_nontemporal_store(vo, (f4*)V + off[i]);
+    }
+  }
+}
+
+int main() {
+  const int H = 5000, F = 20000; const long ld = 20000;
+  float *W, *M, *V;
+  const size_t bytes = (size_t)H * ld * 4;
+  CK(hipMalloc(&W, bytes)); CK(hipMalloc(&M, bytes)); CK(hipMalloc(&V, bytes));
+  CK(hipMemset(W, 0, bytes)); CK(hipMemset(M, 0, bytes)); CK(hipMemset(V, 0, bytes));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  auto run = [&](const char* name, auto launch) {
+    for (int i = 0; i < 2; ++i) launch();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    const int it = 10;
+    for (int i = 0; i < it; ++i) launch();
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-64s %8.1f us  %6.3f TB/s\n", name, ms / it * 1e3, 6.0 * H * F * 4 / (ms / it * 1e-3) / 1e12);
+  };
+#define TILES(R, C, ORDER, LDSB, label) run(label, [&] { const int g = ((H + R - 1) / R) * ((F + C - 1) / C); \
+    hipLaunchKernelGGL((adam_tiles<R, C, ORDER, LDSB>), dim3(g), dim3(512), 0, 0, W, M, V, H, F, ld); });
+  TILES(128, 128, 0, 65536, "tile 128x128 (512 B segs), rows fastest, 2 WG/CU")
+  TILES(128, 128, 1, 65536, "tile 128x128 (512 B segs), cols fastest, 2 WG/CU")
+  TILES(64, 128, 0, 65536, "tile  64x128 (512 B segs), rows fastest, 2 WG/CU")
+  TILES(64, 128, 1, 65536, "tile  64x128 (512 B segs), cols fastest, 2 WG/CU")
+  TILES(64, 128, 1, 32768, "tile  64x128 (512 B segs), cols fastest, 4 WG/CU")
+  TILES(64, 128, 0, 32768, "tile  64x128 (512 B segs), rows fastest, 4 WG/CU")
+  TILES(32, 256, 1, 65536, "tile  32x256 (1 KB segs),  cols fastest, 2 WG/CU")
+  TILES(32, 256, 0, 65536, "tile  32x256 (1 KB segs),  rows fastest, 2 WG/CU")
+  TILES(16, 512, 1, 65536, "tile  16x512 (2 KB segs),  cols fastest, 2 WG/CU")
+  TILES(16, 512, 0, 65536, "tile  16x512 (2 KB segs),  rows fastest, 2 WG/CU")
+  TILES(8, 1024, 1, 65536, "tile   8x1024 (4 KB segs), cols fastest, 2 WG/CU")
+  TILES(4, 2048, 1, 65536, "tile   4x2048 (8 KB segs), cols fastest, 2 WG/CU")
+  TILES(4, 2048, 1, 16384, "tile   4x2048 (8 KB segs), cols fastest, 4+ WG/CU")
+  TILES(64, 128, 1, 16384, "tile  64x128 (512 B segs), cols fastest, 4+ WG/CU")
+  for (int S : {6, 12}) for (int contiguous : {0, 1}) {
+    char nm[128];
+    snprintf(nm, 128, "persistent runs 64x128, S=%d, %s, 2 WG/CU", S, contiguous ? "contiguous chunks" : "interleaved tiles");
+    run(nm, [&] { hipLaunchKernelGGL((adam_runs<65536>), dim3(79 * S), dim3(512), 0, 0, W, M, V, H, F, ld, S, contiguous); });
+  }
+  for (int S : {12, 24}) {
+    char nm[128];
+    snprintf(nm, 128, "persistent runs 64x128, S=%d, interleaved, 4 WG/CU", S);
+    run(nm, [&] { hipLaunchKernelGGL((adam_runs<32768>), dim3(79 * S), dim3(512), 0, 0, W, M, V, H, F, ld, S, 0); });
+  }
+  return 0;
+}
