@@ -27,6 +27,7 @@ U64 = C.c_ulonglong
 PROTOTYPES = {
     "fx_last_error_string": (C.c_char_p, []),
     "fx_version": (I, []),
+    "fx_source_hash": (C.c_char_p, []),
     "fx_gather_rows": (I, [P, P, P, I, I, L, L, P, L, P]),
     "fx_gemm_workspace_bytes": (L, [I, I, I]),
     "fx_gemm_f32": (I, [I, P, P, P, P, I, I, I, L, L, L, I, P, L, P]),
@@ -49,6 +50,8 @@ PROTOTYPES = {
     "fx_linear_fwd_bf16x3_workspace_bytes": (L, [I, I, I]),
     "fx_linear_fwd_bf16x3": (I, [P, P, P, P, P, I, I, I, L, L, L, P, L, P]),
     "fx_linear_dw_adam_bf16x3": (I, [P, P, P, P, P, P, P, I, I, I, L, L, L, P, P]),
+    "fx_linear_dw_adam_bf16x3_ex": (I, [P, P, P, P, P, P, P, I, I, I, L, L, L, P, I, I, I, P]),
+    "fx_linear_fwd_bf16x3_ex": (I, [P, P, P, P, P, I, I, I, L, L, L, P, L, I, I, I, I, P]),
     "fx_linear_dw_adam_fwd_bf16x3_slabs": (I, [I, I]),
     "fx_linear_dw_adam_fwd_bf16x3": (I, [P, P, P, P, P, P, P, I, I, I, L, L, L, P, P, P, L, I, P, L, I, P]),
     "fx_reduce_slabs": (I, [P, P, P, I, I, L, I, L, P]),

@@ -24,8 +24,6 @@
 // branch around every load and drain vmcnt(0) each time -- measured 4x slower; cdna guide section 5 trap
 // (c)).  LDS rows are 64 B (32 bf16); the 16-byte chunk index is XOR-swizzled with (row>>2)&3 so the
 // 16-lane groups of ds_read_b128 hit 16 distinct 4-bank slots (conflict-free) without padding.
-#include <stdlib.h>
-
 #include "fx_common.h"
 #include "fx_reduce.h"
 
@@ -161,7 +159,12 @@ __global__ __launch_bounds__(128 * WN) void fx_gemm_bf16x3_kernel(XGemmArgs g) {
   // ---- buffer descriptors: rows >= M (or >= N) fall beyond num_records and read as zero
   const long a_bytes = g.a_rp ? (long)g.K * g.a_rp * 2 : (long)g.M * g.lda * 2;
   const __amdgpu_buffer_rsrc_t rAh = fx_rsrc(g.Ahi, a_bytes), rAl = fx_rsrc(g.Alo, a_bytes);
-  const __amdgpu_buffer_rsrc_t rB0 = B_F32 ? fx_rsrc(g.Bf, (long)(B_KN ? g.Ktrue : g.N) * g.ldb * 4) : fx_rsrc(g.Bhi, (long)g.N * g.ldb * 2);
+  // The fp32 weight operand is addressed through a descriptor REBASED to this workgroup's rows (row-major [N, K]: the
+  // N tile; [K, N]: the K slice), so the 32-bit buffer offsets only span one tile / slice and the weight itself may
+  // exceed 4 GiB (config.py:7-15 allows hidden_dim_factor 0.5: 50000 features -> a 5 GB layer_1.weight).
+  const long brow0 = B_KN ? (long)k_begin : (long)n0;
+  const long brows = B_KN ? (long)max(min(g.Ktrue, k_end) - k_begin, 0) : (long)max(min(TN, g.N - n0), 0);
+  const __amdgpu_buffer_rsrc_t rB0 = B_F32 ? fx_rsrc(g.Bf + brow0 * g.ldb, brows * g.ldb * 4) : fx_rsrc(g.Bhi, (long)g.N * g.ldb * 2);
   const __amdgpu_buffer_rsrc_t rB1 = B_F32 ? rB0 : fx_rsrc(g.Blo, (long)g.N * g.ldb * 2);
 
   // ---- per-thread constant addressing (bytes) and LDS destinations (elements)
@@ -183,8 +186,8 @@ __global__ __launch_bounds__(128 * WN) void fx_gemm_bf16x3_kernel(XGemmArgs g) {
     b_lds1 = b_lds0 + 4;
   } else if (B_F32) {  // TN rows x 8 float4 per row; thread handles (n = tid>>3, k4 = tid&7) and n + TN/2
     const int n = tid >> 3, k4 = tid & 7;
-    b_off0 = (unsigned)(((long)(n0 + n) * g.ldb + 4 * k4) * 4);
-    b_off1 = (unsigned)(((long)(n0 + n + TN / 2) * g.ldb + 4 * k4) * 4);
+    b_off0 = (unsigned)(((long)n * g.ldb + 4 * k4) * 4);                 // rows relative to the rebased descriptor
+    b_off1 = (unsigned)(((long)(n + TN / 2) * g.ldb + 4 * k4) * 4);
     b_lds0 = swz(n, k4 >> 1) + ((k4 & 1) << 2);
     b_lds1 = swz(n + TN / 2, k4 >> 1) + ((k4 & 1) << 2);
   } else {      // TN rows x 4 chunks: one 16-byte chunk of hi and of lo per thread
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(128 * WN) void fx_gemm_bf16x3_kernel(XGemmArgs g) {
   const unsigned a_step = g.a_rp ? (unsigned)g.a_rp * (TK * 2u) : TK * 2u;
   const unsigned b_step = B_KN ? (unsigned)(TK * g.ldb * 4) : TK * (B_F32 ? 4u : 2u);
   const unsigned a_kb = (unsigned)(k_begin / TK) * a_step;
-  const unsigned b_kb = B_KN ? (unsigned)((long)k_begin * g.ldb * 4) : (unsigned)k_begin * (B_F32 ? 4u : 2u);
+  const unsigned b_kb = B_KN ? 0u : (unsigned)k_begin * (B_F32 ? 4u : 2u);        // [K, N]: the descriptor starts at k_begin
   const unsigned b_row = (unsigned)(g.ldb * 4);      // B_KN: bytes between consecutive k
 
   // ---- two register stages (named: no arrays, no references -> nothing can land in scratch)
@@ -319,8 +322,10 @@ __global__ __launch_bounds__(128 * WN) void fx_gemm_bf16x3_kernel(XGemmArgs g) {
       }
     }
   } else {
-    const long bytes = (long)g.M * g.ldc * 4;
-    const __amdgpu_buffer_rsrc_t rP = fx_rsrc(g.C, bytes), rM = fx_rsrc(g.adam_m, bytes), rV = fx_rsrc(g.adam_v, bytes);
+    // descriptors rebased to the tile's first row: offsets stay below TM * ldc * 4 bytes whatever the weight's size
+    const long bytes = (long)max(min(TM, g.M - m0), 0) * g.ldc * 4;
+    const long rbase = (long)m0 * g.ldc;
+    const __amdgpu_buffer_rsrc_t rP = fx_rsrc(g.C + rbase, bytes), rM = fx_rsrc(g.adam_m + rbase, bytes), rV = fx_rsrc(g.adam_v + rbase, bytes);
     const float lr = g.ctrl[FXC_LR], bc1 = g.ctrl[FXC_BC1], bc2s = g.ctrl[FXC_BC2_SQRT];
     const float coef = g.ctrl[FXC_CLIP_COEF];
     const float step_size = lr / bc1;
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(128 * WN) void fx_gemm_bf16x3_kernel(XGemmArgs g) {
           const int u = tid + T * (half * 4 + i), row = u / UPR, c4 = u % UPR;
           const int gn = n0 + 4 * c4;
           lidx[i] = row * TN + 4 * c4;
-          off[i] = (unsigned)(((long)(m0 + row) * g.ldc + gn) * 4) | ((gn < g.N) ? 0u : 0xFFFFFFF0u);
+          off[i] = (unsigned)(((long)row * g.ldc + gn) * 4) | ((gn < g.N) ? 0u : 0xFFFFFFF0u);
           p4[i] = bld128<NT>(rP, off[i]);
           m4[i] = bld128<NT>(rM, off[i]);
           v4[i] = bld128<NT>(rV, off[i]);
@@ -379,7 +384,7 @@ __global__ __launch_bounds__(128 * WN) void fx_gemm_bf16x3_kernel(XGemmArgs g) {
       // generic path (weight width not a multiple of 4): dword accesses in the MFMA C/D layout
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk) {
-        const int mbase = m0 + wr * 64 + blk * 32 + 4 * (lane >> 5);
+        const int mbase = wr * 64 + blk * 32 + 4 * (lane >> 5);      // relative to the rebased descriptors
         float pv[16], mv[16], vv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -431,14 +436,14 @@ __global__ __launch_bounds__(512) void fx_fwd_bf16x3_mt_kernel(XGemmArgs g) {
   const int k_end = min(g.K, k_begin + g.kchunk);
   const int nk = (k_end > k_begin) ? (k_end - k_begin) / TK : 0;
   const __amdgpu_buffer_rsrc_t rAh = fx_rsrc(g.Ahi, (long)g.K * g.a_rp * 2), rAl = fx_rsrc(g.Alo, (long)g.K * g.a_rp * 2);
-  const __amdgpu_buffer_rsrc_t rB = fx_rsrc(g.Bf, (long)g.N * g.ldb * 4);
+  const __amdgpu_buffer_rsrc_t rB = fx_rsrc(g.Bf + (long)n0 * g.ldb, (long)max(min(TN, g.N - n0), 0) * g.ldb * 4);   // rebased: W may exceed 4 GiB
   const int a_row = tid >> 2, a_c = tid & 3;
   const unsigned a_off = (unsigned)(((long)(m0 + a_row) * TK + 8 * a_c) * 2);
   const unsigned a_tile = TM * TK * 2u;                         // bytes between M tiles of one K-step (K-blocked X)
   const unsigned a_step = (unsigned)g.a_rp * (TK * 2u), a_kb = (unsigned)(k_begin / TK) * a_step;
   const int bn = tid >> 3, k4 = tid & 7;
-  const unsigned b_off0 = (unsigned)(((long)(n0 + bn) * g.ldb + 4 * k4) * 4);
-  const unsigned b_off1 = (unsigned)(((long)(n0 + bn + 64) * g.ldb + 4 * k4) * 4);
+  const unsigned b_off0 = (unsigned)(((long)bn * g.ldb + 4 * k4) * 4);
+  const unsigned b_off1 = (unsigned)(((long)(bn + 64) * g.ldb + 4 * k4) * 4);
   const unsigned b_kb = (unsigned)k_begin * 4u, b_step = TK * 4u;
   const int a_lds = swz(a_row, a_c);
   const int b_lds0 = swz(bn, k4 >> 1) + ((k4 & 1) << 2), b_lds1 = swz(bn + 64, k4 >> 1) + ((k4 & 1) << 2);
@@ -583,23 +588,18 @@ __global__ __launch_bounds__(256) void fx_split_bf16_t_kernel(__bf16* __restrict
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
-
-// wave-column count of the forward kernel: 4 (128x128 tile) unless overridden for experiments
-static int fwd_wn() { return env_int("FX_FWD_WN", 4) == 2 ? 2 : 4; }
-static int adam_wn() { return env_int("FX_ADAM_WN", 4) == 2 ? 2 : 4; }
+// Tuning knobs of the wide kernels.  They are ARGUMENTS of the *_ex entry points (0 = the shipped choice); the library
+// itself reads no environment variable and keeps no mutable state (include/fxhip.h).
+struct FwdTune { int splitk, wn, mt, nt; };      // forced split-K (0 auto) | 2 or 4 wave columns (0 -> 4) | 1 = no multi-M-tile kernel | non-temporal W loads
+static inline int fwd_wn(const FwdTune& t) { return t.wn == 2 ? 2 : 4; }
 
 // split-K so that the grid fills the chip about once: 256 CUs x (3 workgroups of 256 threads | 2 of 512)
 // M > 128 takes fx_fwd_bf16x3_mt_kernel: MT M-tiles per workgroup, one workgroup (64 KB LDS, ~190 VGPRs) per CU
 static int fwd_mt(int M) { return M > 2 * TM ? 3 : (M > TM ? 2 : 1); }
 
-static int pick_splitk_x(int M, int N, int K, int wn) {
-  const int forced = env_int("FX_SPLITK", 0);
-  if (forced > 0) return forced;
-  if (wn == 4 && M > TM && env_int("FX_FWD_MT", 1)) {
+static int pick_splitk_x(int M, int N, int K, int wn, const FwdTune& t) {
+  if (t.splitk > 0) return t.splitk;
+  if (wn == 4 && M > TM && t.mt != 1) {
     const int mt = fwd_mt(M);
     const long tiles = (long)((M + mt * TM - 1) / (mt * TM)) * ((N + 127) / 128);
     if (tiles >= 128 || K <= 8 * TK) return 1;
@@ -646,18 +646,20 @@ int fx_split_bf16_t(void* hiT, void* loT, const float* x, int R, int C, long ldx
 
 long fx_linear_fwd_bf16x3_workspace_bytes(int M, int N, int K) {
   const int Kp = (K + TK - 1) / TK * TK;
-  int s = pick_splitk_x(M, N, Kp, 2), s4 = pick_splitk_x(M, N, Kp, 4);
+  const FwdTune t{};
+  int s = pick_splitk_x(M, N, Kp, 2, t), s4 = pick_splitk_x(M, N, Kp, 4, t);
   if (s4 > s) s = s4;
   return (long)s * M * N * (long)sizeof(float);  // always goes through slabs (bias is added by the reduce)
 }
 
 int fx_linear_fwd_bf16x3_splitk(int M, int N, int K) {
-  return pick_splitk_x(M, N, (K + TK - 1) / TK * TK, fwd_wn());
+  const FwdTune t{};
+  return pick_splitk_x(M, N, (K + TK - 1) / TK * TK, fwd_wn(t), t);
 }
 
 static int fwd_bf16x3_impl(float* Y, const void* xhi, const void* xlo, const float* W, const float* bias, int M, int N,
                            int K, long ldx, long ldw, long ldy, void* workspace, long workspace_bytes, bool reduce,
-                           hipStream_t stream, bool kn = false);
+                           hipStream_t stream, bool kn = false, FwdTune tune = FwdTune{});
 
 // Y[M,N] = X[M,K] . W[N,K]^T + bias ; X given as K-BLOCKED split bf16 (fx_split_bf16 / fx_gather_split layout:
 // [ceil(K/32)][ldx rows][32], ldx = rows padded to a multiple of 128, padding zero)
@@ -665,6 +667,17 @@ int fx_linear_fwd_bf16x3(float* Y, const void* xhi, const void* xlo, const float
                          long ldx, long ldw, long ldy, void* workspace, long workspace_bytes, hipStream_t stream) {
   FX_REQUIRE(Y != nullptr, "fx_linear_fwd_bf16x3: null output");
   return fwd_bf16x3_impl(Y, xhi, xlo, W, bias, M, N, K, ldx, ldw, ldy, workspace, workspace_bytes, true, stream);
+}
+
+// The same with explicit tuning (A/B experiments; every variant computes the same contraction): splitk 0 = auto
+// (workspace must hold splitk slabs), wave_cols 0|4 = 128x128 tile, 2 = 128x64; no_mt 1 = one workgroup per M tile even
+// for M > 128; nt 1 = non-temporal W loads.
+int fx_linear_fwd_bf16x3_ex(float* Y, const void* xhi, const void* xlo, const float* W, const float* bias, int M, int N, int K,
+                            long ldx, long ldw, long ldy, void* workspace, long workspace_bytes, int splitk, int wave_cols,
+                            int no_mt, int nt, hipStream_t stream) {
+  FX_REQUIRE(Y != nullptr, "fx_linear_fwd_bf16x3_ex: null output");
+  return fwd_bf16x3_impl(Y, xhi, xlo, W, bias, M, N, K, ldx, ldw, ldy, workspace, workspace_bytes, true, stream, false,
+                         FwdTune{splitk, wave_cols, no_mt ? 1 : 0, nt});
 }
 
 // Same, but the fx_linear_fwd_bf16x3_splitk(M,N,K) partial-sum slabs ([s][M][N]) are left in `slabs` (no bias) for
@@ -688,14 +701,17 @@ int fx_linear_bwd_x_bf16x3(float* dX, const void* dyhi, const void* dylo, const 
 
 static int fwd_bf16x3_impl(float* Y, const void* xhi, const void* xlo, const float* W, const float* bias, int M, int N,
                            int K, long ldx, long ldw, long ldy, void* workspace, long workspace_bytes, bool reduce,
-                           hipStream_t stream, bool kn) {
+                           hipStream_t stream, bool kn, FwdTune tune) {
   FX_REQUIRE(xhi && xlo && W && M > 0 && N > 0 && K > 0, "fx_linear_fwd_bf16x3: bad args");
   const int Kp = (K + TK - 1) / TK * TK;
   FX_REQUIRE(ldx >= M && ldx % 128 == 0 && aligned16(xhi) && aligned16(xlo),
              "fx_linear_fwd_bf16x3: X must be a K-blocked split with rows padded to a multiple of 128 (got %ld for M=%d)", ldx, M);
-  FX_REQUIRE((long)(kn ? K : N) * ldw * 4 < 0xF0000000L && (long)Kp * ldx * 2 < 0xF0000000L, "fx_linear_fwd_bf16x3: operand exceeds 4 GiB");
-  const int wn = kn ? 4 : fwd_wn(), tn = 32 * wn;
-  const int s = pick_splitk_x(M, N, Kp, wn);
+  const int wn = kn ? 4 : fwd_wn(tune), tn = 32 * wn;
+  const int s = pick_splitk_x(M, N, Kp, wn, tune);
+  // W is addressed per N tile (or per K slice when stored [K, N]) through a rebased descriptor: only that block must
+  // stay below 4 GiB, not the weight
+  FX_REQUIRE((kn ? (long)(((Kp / TK + s - 1) / s) * TK + 4 * TK) : (long)tn) * ldw * 4 < 0xF0000000L && (long)Kp * ldx * 2 < 0xF0000000L,
+             "fx_linear_fwd_bf16x3: operand block exceeds 4 GiB");
   FX_REQUIRE(workspace && workspace_bytes >= (long)s * M * N * (long)sizeof(float), "fx_linear_fwd_bf16x3: workspace too small");
   XGemmArgs g{};
   g.Ahi = (const __bf16*)xhi; g.Alo = (const __bf16*)xlo;
@@ -708,8 +724,8 @@ static int fwd_bf16x3_impl(float* Y, const void* xhi, const void* xlo, const flo
   g.slab_stride = (long)M * N;
   const long nblk = (long)((M + TM - 1) / TM) * ((N + tn - 1) / tn) * s;
   FX_REQUIRE(nblk < (1L << 31), "fx_linear_fwd_bf16x3: grid too large");
-  const int nt = env_int("FX_NT_FWD", 0);
-  if (!kn && wn == 4 && M > TM && env_int("FX_FWD_MT", 1)) {
+  const int nt = tune.nt;
+  if (!kn && wn == 4 && M > TM && tune.mt != 1) {
     const int mt = fwd_mt(M);
     const long nb = (long)((M + mt * TM - 1) / (mt * TM)) * ((N + 127) / 128) * s;
     FX_REQUIRE(nb < (1L << 31), "fx_linear_fwd_bf16x3: grid too large");
@@ -732,15 +748,19 @@ static int fwd_bf16x3_impl(float* Y, const void* xhi, const void* xlo, const flo
 
 extern "C" {
 
-int fx_linear_dw_adam_bf16x3(float* W, float* adam_m, float* adam_v, const void* dyT_hi, const void* dyT_lo,
-                             const void* xT_hi, const void* xT_lo, int batch_padded, int n_out, int k_in, long lddy,
-                             long ldx, long ldw, const float* ctrl, hipStream_t stream) {
+static int dw_adam_bf16x3_impl(float* W, float* adam_m, float* adam_v, const void* dyT_hi, const void* dyT_lo,
+                               const void* xT_hi, const void* xT_lo, int batch_padded, int n_out, int k_in, long lddy,
+                               long ldx, long ldw, const float* ctrl, int tile_order, int wave_cols, int plain_loads,
+                               hipStream_t stream) {
   FX_REQUIRE(W && adam_m && adam_v && dyT_hi && dyT_lo && xT_hi && xT_lo && ctrl, "fx_linear_dw_adam_bf16x3: null pointer");
   FX_REQUIRE(batch_padded > 0 && batch_padded % TK == 0, "fx_linear_dw_adam_bf16x3: padded batch %d must be a multiple of %d",
              batch_padded, TK);
   FX_REQUIRE(lddy % 8 == 0 && ldx % 8 == 0 && aligned16(dyT_hi) && aligned16(dyT_lo) && aligned16(xT_hi) && aligned16(xT_lo),
              "fx_linear_dw_adam_bf16x3: operands must be 16-byte aligned with ld %% 8 == 0");
-  FX_REQUIRE((long)n_out * ldw * 4 < 0xF0000000L && (long)k_in * ldx * 2 < 0xF0000000L, "fx_linear_dw_adam_bf16x3: weight exceeds 4 GiB");
+  // W / m / v are addressed per 128-row tile through rebased descriptors: the weight itself may exceed 4 GiB
+  FX_REQUIRE((long)TM * ldw * 4 < 0xF0000000L && (long)n_out * lddy * 2 < 0xF0000000L && (long)k_in * ldx * 2 < 0xF0000000L,
+             "fx_linear_dw_adam_bf16x3: operand block exceeds 4 GiB");
+  FX_REQUIRE(tile_order >= 0 && tile_order <= 2, "fx_linear_dw_adam_bf16x3: tile_order is 0 (auto), 1 (linear) or 2 (XCD-partitioned)");
   XGemmArgs g{};
   g.Ahi = (const __bf16*)dyT_hi; g.Alo = (const __bf16*)dyT_lo;
   g.Bhi = (const __bf16*)xT_hi; g.Blo = (const __bf16*)xT_lo;
@@ -750,17 +770,16 @@ int fx_linear_dw_adam_bf16x3(float* W, float* adam_m, float* adam_v, const void*
   g.splitk = 1; g.kchunk = batch_padded;
   g.n_fast = n_out > k_in;
   g.adam_m = adam_m; g.adam_v = adam_v; g.ctrl = ctrl;
-  const int wn = adam_wn(), tn = 32 * wn;
+  const int wn = wave_cols == 2 ? 2 : 4, tn = 32 * wn;
   long nblk = (long)((n_out + TM - 1) / TM) * ((k_in + tn - 1) / tn);
-  const int xcd_mode = env_int("FX_ADAM_XCD", 1);      // 0 = linear order, 1 = XCD order when it pays, 2 = always (tests)
-  if (xcd_mode) {
+  if (tile_order != 1) {
     const int tiles_m = (n_out + TM - 1) / TM, tiles_n = (k_in + tn - 1) / tn;
     const int longer = tiles_n >= tiles_m ? tiles_n : tiles_m, shorter = tiles_n >= tiles_m ? tiles_m : tiles_n;
     // group size: the group's operand rows (tile rows x K x (hi + lo)) should fill about 1.5 MB of the 4 MB L2
     const long tile_bytes = (long)(tiles_n >= tiles_m ? TM : tn) * batch_padded * 4;
     // Only when the shorter dimension's whole operand does not fit one L2 anyway (measured: cfg2 / cfg3 shapes, 2.5 MB,
     // are as fast or faster in the linear order; cfg4's 11.5 MB operand costs 9.0 instead of 5.9 GB of HBM traffic)
-    if (longer >= 16 && (xcd_mode == 2 || (long)shorter * tile_bytes > (3L << 20))) {
+    if (longer >= 16 && (tile_order == 2 || (long)shorter * tile_bytes > (3L << 20))) {
       int G = (int)((3L << 19) / tile_bytes);
       if (G < 1) G = 1;
       if (G > shorter) G = shorter;
@@ -770,15 +789,31 @@ int fx_linear_dw_adam_bf16x3(float* W, float* adam_m, float* adam_v, const void*
     }
   }
   FX_REQUIRE(nblk < (1L << 31), "fx_linear_dw_adam_bf16x3: grid too large");
-  const int nt = env_int("FX_NT_ADAM", 1);
   if (wn == 4) {
-    if (nt) hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<false, XEPI_ADAM, 2, 4>), dim3((unsigned)nblk), dim3(512), 0, stream, g);
+    if (!plain_loads) hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<false, XEPI_ADAM, 2, 4>), dim3((unsigned)nblk), dim3(512), 0, stream, g);
     else hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<false, XEPI_ADAM, 0, 4>), dim3((unsigned)nblk), dim3(512), 0, stream, g);
   } else {
-    if (nt) hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<false, XEPI_ADAM, 2, 2>), dim3((unsigned)nblk), dim3(256), 0, stream, g);
+    if (!plain_loads) hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<false, XEPI_ADAM, 2, 2>), dim3((unsigned)nblk), dim3(256), 0, stream, g);
     else hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<false, XEPI_ADAM, 0, 2>), dim3((unsigned)nblk), dim3(256), 0, stream, g);
   }
   return fx_check_launch("fx_linear_dw_adam_bf16x3");
+}
+
+int fx_linear_dw_adam_bf16x3(float* W, float* adam_m, float* adam_v, const void* dyT_hi, const void* dyT_lo,
+                             const void* xT_hi, const void* xT_lo, int batch_padded, int n_out, int k_in, long lddy,
+                             long ldx, long ldw, const float* ctrl, hipStream_t stream) {
+  return dw_adam_bf16x3_impl(W, adam_m, adam_v, dyT_hi, dyT_lo, xT_hi, xT_lo, batch_padded, n_out, k_in, lddy, ldx, ldw, ctrl, 0, 0,
+                             0, stream);
+}
+
+// The same with explicit tuning: tile_order 0 = auto, 1 = linear, 2 = XCD-partitioned / L2-blocked (bit-identical results);
+// wave_cols 0|4 = 128x128 tile, 2 = 128x64; plain_loads 1 = default cache policy instead of non-temporal W / m / v accesses.
+int fx_linear_dw_adam_bf16x3_ex(float* W, float* adam_m, float* adam_v, const void* dyT_hi, const void* dyT_lo,
+                                const void* xT_hi, const void* xT_lo, int batch_padded, int n_out, int k_in, long lddy,
+                                long ldx, long ldw, const float* ctrl, int tile_order, int wave_cols, int plain_loads,
+                                hipStream_t stream) {
+  return dw_adam_bf16x3_impl(W, adam_m, adam_v, dyT_hi, dyT_lo, xT_hi, xT_lo, batch_padded, n_out, k_in, lddy, ldx, ldw, ctrl,
+                             tile_order, wave_cols, plain_loads, stream);
 }
 
 }  // extern "C"

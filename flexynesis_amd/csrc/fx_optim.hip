@@ -155,7 +155,17 @@ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0;
 extern "C" {
 
 const char* fx_last_error_string(void) { return g_err; }
-int fx_version(void) { return 100; }  // 0.1.0
+int fx_version(void) { return 200; }  // 0.2.0
+
+// SHA-256 of the sources this library was built from (csrc/build.py defines FX_SOURCE_HASH); build.py finds the literal
+// in the binary behind the marker and rebuilds when the sources have changed.
+#ifndef FX_SOURCE_HASH
+#define FX_SOURCE_HASH "unknown"
+#endif
+const char* fx_source_hash(void) {
+  static const char marked[] = "FXSRCHASH:" FX_SOURCE_HASH;
+  return marked + 10;
+}
 
 int fx_step_begin(float* ctrl, float lr, int n_batches, hipStream_t stream) {
   FX_REQUIRE(ctrl != nullptr, "fx_step_begin: null ctrl");

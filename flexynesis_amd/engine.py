@@ -1035,7 +1035,7 @@ class StepPlan:
                 if k in self._next_fwd:
                     nslabs, _, nsp = nxt._next_fwd[k]
                     ops.linear_dw_adam_fwd_bf16x3(ro, d["W"], d["M"], d["V"], dyt[0], dyt[1], xt[0], xt[1], st.ctrl, nsp[0], nsp[1],
-                                                  nxt.R, nslabs, nt=os.environ.get("FX_NT_ADAM", "1") != "0")
+                                                  nxt.R, nslabs, nt=not ops.TUNE["adam_plain"])
                 else:
                     ops.linear_dw_adam_bf16x3(ro, d["W"], d["M"], d["V"], dyt[0], dyt[1], xt[0], xt[1], st.ctrl)
             elif self.fused:

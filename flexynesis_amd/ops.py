@@ -21,6 +21,24 @@ CTRL_FLOATS = 64
 CTRL_STEP, CTRL_LR, CTRL_CLIP_COEF, CTRL_GNORM, CTRL_CURSOR, CTRL_STEP_HI = 0, 1, 4, 5, 8, 10
 
 
+def _env_int(name: str, default: int) -> int:
+    import os
+    try:
+        return int(os.environ.get(name, default))
+    except ValueError:
+        return default
+
+
+# A/B switches of the wide kernels (benchmark experiments; every variant computes the same thing).  They are read HERE,
+# once at import, and handed to the library as explicit arguments of its *_ex entry points -- libfxhip itself reads no
+# environment variables.  FX_ADAM_XCD: 0 linear tile order, 1 auto (default), 2 always XCD-partitioned.
+TUNE = {
+    "fwd_splitk": _env_int("FX_SPLITK", 0), "fwd_wn": _env_int("FX_FWD_WN", 0), "fwd_no_mt": int(_env_int("FX_FWD_MT", 1) == 0),
+    "fwd_nt": _env_int("FX_NT_FWD", 0), "adam_order": {0: 1, 1: 0, 2: 2}.get(_env_int("FX_ADAM_XCD", 1), 0),
+    "adam_wn": _env_int("FX_ADAM_WN", 0), "adam_plain": int(_env_int("FX_NT_ADAM", 1) == 0),
+}
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -368,6 +386,13 @@ def linear_fwd_bf16x3(rec, y, xhi, xlo, W, b, ws):
         raise FxError("linear_fwd_bf16x3: shape mismatch")
     _chk_kb(xhi, xlo, M, K, "linear_fwd_bf16x3")
     need = int(lib.fx_linear_fwd_bf16x3_workspace_bytes(M, N, K))
+    t = TUNE
+    if t["fwd_splitk"] or t["fwd_wn"] or t["fwd_no_mt"] or t["fwd_nt"]:
+        need = max(need, max(t["fwd_splitk"], 1) * M * N * 4)
+        ws.reserve(need)
+        rec.emit("fx_linear_fwd_bf16x3_ex", y.data_ptr(), xhi.data_ptr(), xlo.data_ptr(), W.data_ptr(), _ptr(b), M, N, K,
+                 xhi.shape[1], _ld(W), _ld(y), ws.buf.data_ptr(), ws.nbytes, t["fwd_splitk"], t["fwd_wn"], t["fwd_no_mt"], t["fwd_nt"])
+        return
     ws.reserve(need)
     rec.emit("fx_linear_fwd_bf16x3", y.data_ptr(), xhi.data_ptr(), xlo.data_ptr(), W.data_ptr(), _ptr(b), M, N, K,
              xhi.shape[1], _ld(W), _ld(y), ws.buf.data_ptr(), ws.nbytes)
@@ -387,8 +412,9 @@ def linear_bwd_x_bf16x3(rec, dx, dyhi, dylo, W, ws: Workspace):
              _ld(W), _ld(dx), ws.buf.data_ptr(), ws.nbytes)
 
 
-def linear_dw_adam_bf16x3(rec, W, m, v, dyT_hi, dyT_lo, xT_hi, xT_lo, ctrl):
-    """W[N,K] <- Adam(clip * dY^T X) with dY^T [N, Bp] and X^T [K, Bp] pre-split."""
+def linear_dw_adam_bf16x3(rec, W, m, v, dyT_hi, dyT_lo, xT_hi, xT_lo, ctrl, tile_order=None):
+    """W[N,K] <- Adam(clip * dY^T X) with dY^T [N, Bp] and X^T [K, Bp] pre-split.  tile_order: None = the process-wide
+    choice (TUNE), 0 auto, 1 linear, 2 XCD-partitioned (bit-identical results)."""
     for t, n in ((W, "W"), (m, "m"), (v, "v")):
         _chk2d(t, "linear_dw_adam_bf16x3." + n)
     N, K = W.shape
@@ -397,6 +423,12 @@ def linear_dw_adam_bf16x3(rec, W, m, v, dyT_hi, dyT_lo, xT_hi, xT_lo, ctrl):
         raise FxError("linear_dw_adam_bf16x3: shape mismatch")
     if not (_ld(m) == _ld(W) == _ld(v)):
         raise FxError("linear_dw_adam_bf16x3: W/m/v must share a leading dimension")
+    order = TUNE["adam_order"] if tile_order is None else int(tile_order)
+    if order or TUNE["adam_wn"] or TUNE["adam_plain"]:
+        rec.emit("fx_linear_dw_adam_bf16x3_ex", W.data_ptr(), m.data_ptr(), v.data_ptr(), dyT_hi.data_ptr(), dyT_lo.data_ptr(),
+                 xT_hi.data_ptr(), xT_lo.data_ptr(), Bp, N, K, _ld(dyT_hi), _ld(xT_hi), _ld(W), ctrl.data_ptr(), order,
+                 TUNE["adam_wn"], TUNE["adam_plain"])
+        return
     rec.emit("fx_linear_dw_adam_bf16x3", W.data_ptr(), m.data_ptr(), v.data_ptr(), dyT_hi.data_ptr(), dyT_lo.data_ptr(),
              xT_hi.data_ptr(), xT_lo.data_ptr(), Bp, N, K, _ld(dyT_hi), _ld(xT_hi), _ld(W), ctrl.data_ptr())
 

@@ -48,6 +48,8 @@ typedef struct ihipStream_t* fx_stream_t; /* == hipStream_t */
 
 const char* fx_last_error_string(void);
 int fx_version(void);
+/* SHA-256 (hex) of the HIP sources the library was built from; csrc/build.py rebuilds when it no longer matches */
+const char* fx_source_hash(void);
 
 /* ---- data: replaces MultiOmicDataset.__getitem__ + default_collate + per-batch H2D
  *      (data.py:980-995, main.py:289-298).  dst[r,:] = src[idx[r],:]; idx int64 on device.
@@ -83,6 +85,12 @@ int fx_split_bf16_t(void* hiT, void* loT, const float* x, int R, int C, long ldx
 long fx_linear_fwd_bf16x3_workspace_bytes(int M, int N, int K);
 int fx_linear_fwd_bf16x3(float* Y, const void* xhi, const void* xlo, const float* W, const float* bias, int M, int N, int K,
                          long ldx, long ldw, long ldy, void* workspace, long workspace_bytes, fx_stream_t stream);
+/* fx_linear_fwd_bf16x3 with explicit tuning (A/B experiments; same contraction): splitk 0 = auto, wave_cols 0|4 = 128x128
+ * tile / 2 = 128x64, no_mt 1 = one workgroup per 128-row M tile even for M > 128, nt 1 = non-temporal W loads.  The library
+ * reads no environment variables: callers that want A/B switches pass them here. */
+int fx_linear_fwd_bf16x3_ex(float* Y, const void* xhi, const void* xlo, const float* W, const float* bias, int M, int N, int K,
+                            long ldx, long ldw, long ldy, void* workspace, long workspace_bytes, int splitk, int wave_cols,
+                            int no_mt, int nt, fx_stream_t stream);
 /* dX[M,N] = dY[M,K] . W[K,N] with W = the weight [out = K, in = N] as stored: autograd's data-gradient mm through a WIDE
  * layer (the decoders' FC_output of supervised_vae / CrossModalPred, modules.py:89,101).  dY as a K-blocked split. */
 int fx_linear_bwd_x_bf16x3(float* dX, const void* dyhi, const void* dylo, const float* W, int M, int N, int K,
@@ -90,6 +98,12 @@ int fx_linear_bwd_x_bf16x3(float* dX, const void* dyhi, const void* dylo, const 
 int fx_linear_dw_adam_bf16x3(float* W, float* adam_m, float* adam_v, const void* dyT_hi, const void* dyT_lo,
                              const void* xT_hi, const void* xT_lo, int batch_padded, int n_out, int k_in, long lddy,
                              long ldx, long ldw, const float* ctrl, fx_stream_t stream);
+/* fx_linear_dw_adam_bf16x3 with explicit tuning: tile_order 0 = auto, 1 = linear, 2 = XCD-partitioned / L2-blocked (results are
+ * bit-identical); wave_cols 0|4 = 128x128 tile, 2 = 128x64; plain_loads 1 = default cache policy for W / m / v. */
+int fx_linear_dw_adam_bf16x3_ex(float* W, float* adam_m, float* adam_v, const void* dyT_hi, const void* dyT_lo,
+                                const void* xT_hi, const void* xT_lo, int batch_padded, int n_out, int k_in, long lddy,
+                                long ldx, long ldw, const float* ctrl, int tile_order, int wave_cols, int plain_loads,
+                                fx_stream_t stream);
 /* The same optimiser step for one wide weight PLUS the wide-layer forward of the FOLLOWING training step
  * (nn.Linear of modules.py:145 / :28 applied to the next batch, main.py:289-298's next DataLoader item): while a tile of
  * W_new is in registers it is multiplied into the next batch xn (K-blocked split of <= 128 rows, xn_rows_padded = 128),

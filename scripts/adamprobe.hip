@@ -91,6 +91,50 @@ __global__ __launch_bounds__(512) void adam_runs(float* __restrict__ W, float* _
   }
 }
 
+// non-persistent short runs: workgroup = (row block tm, run q) handles column tiles q*r .. q*r + r - 1; consecutive workgroups =
+// consecutive runs of the SAME row block (column-fastest), so the resident set covers a few row blocks at full width
+template <int LDSB>
+__global__ __launch_bounds__(512) void adam_short_runs(float* __restrict__ W, float* __restrict__ M, float* __restrict__ V, int H, int F, long ld, int r, int rot) {
+  __shared__ char pad[LDSB];
+  if (threadIdx.x == 9999) pad[threadIdx.x % LDSB] = 1;
+  constexpr int R = 64, C = 128, UPR = 32, PER = 4;
+  const int tiles_n = (F + C - 1) / C, runs = (tiles_n + r - 1) / r;
+  const int q = blockIdx.x % runs, tm = blockIdx.x / runs;
+  for (int i0 = 0; i0 < r; ++i0) {
+    const int tn = q * r + (rot ? (i0 + tm) % r : i0);
+    if (tn >= tiles_n) continue;
+    f4 p[PER], m[PER], v[PER];
+    long off[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int u = threadIdx.x + 512 * i, rr = u / UPR, c4 = u % UPR;
+      const int row = tm * R + rr, col = tn * C + 4 * c4;
+      off[i] = (row < H && col < F) ? ((long)row * ld + col) / 4 : -1;
+      if (off[i] >= 0) {
+        p[i] = __builtin_nontemporal_load((const f4*)W + off[i]);
+        m[i] = __builtin_nontemporal_load((const f4*)M + off[i]);
+        v[i] = __builtin_nontemporal_load((const f4*)V + off[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      if (off[i] < 0) continue;
+      f4 po, mo, vo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float g = 1e-3f;
+        const float m2 = m[i][j] + (g - m[i][j]) * 0.1f;
+        const float v2 = v[i][j] * 0.999f + 0.001f * g * g;
+        po[j] = p[i][j] - 1e-3f * (m2 / (sqrtf(v2) + 1e-8f));
+        mo[j] = m2; vo[j] = v2;
+      }
+      __builtin_nontemporal_store(po, (f4*)W + off[i]);
+      __builtin_nontemporal_store(mo, (f4*)M + off[i]);
+      __builtin_nontemporal_store(vo, (f4*)V + off[i]);
+    }
+  }
+}
+
 int main() {
   const int H = 5000, F = 20000; const long ld = 20000;
   float *W, *M, *V;
@@ -133,6 +177,12 @@ int main() {
     char nm[128];
     snprintf(nm, 128, "persistent runs 64x128, S=%d, interleaved, 4 WG/CU", S);
     run(nm, [&] { hipLaunchKernelGGL((adam_runs<32768>), dim3(79 * S), dim3(512), 0, 0, W, M, V, H, F, ld, S, 0); });
+  }
+  for (int r : {1, 2, 4, 8, 13, 26}) {
+    char nm[128];
+    snprintf(nm, 128, "short runs of %d tiles 64x128, column-fastest, 2 WG/CU", r);
+    const int runs = (157 + r - 1) / r;
+    run(nm, [&] { hipLaunchKernelGGL((adam_short_runs<65536>), dim3(79 * runs), dim3(512), 0, 0, W, M, V, H, F, ld, r, 0); });
   }
   return 0;
 }

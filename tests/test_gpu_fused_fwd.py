@@ -145,3 +145,59 @@ def test_pipeline_fused_forward_is_the_forward_of_the_next_batch(model, layers, 
         assert torch.equal(s_f[k], s_g[k]), k
     for a in (l_f, l_check):
         assert float(((a - l_u).abs() / (l_u.abs() + 1e-6)).max()) <= 1e-4, (a, l_u)
+
+
+def test_wide_weight_beyond_4GiB():
+    """A layer_1.weight larger than 4 GiB (reference config.py:7-15 allows hidden_dim_factor 0.5: 50000 features -> [25000,
+    50000] = 5 GB): every wide kernel addresses W / m / v through descriptors rebased per row block, so the 32-bit buffer
+    offsets never span the whole weight.  The rows past the 4 GiB mark are the ones an un-rebased kernel would drop."""
+    import math
+    from flexynesis_amd import ops
+    dev = _dev()
+    n_out, k_in, B = 22000, 50000, 64
+    ldw = ops.pad32(k_in)
+    assert n_out * ldw * 4 > (1 << 32)
+    first_beyond = (1 << 32) // (ldw * 4) + 1
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    dy = torch.randn(B, n_out, generator=g, device=dev) * 1e-2
+    x = torch.randn(B, k_in, generator=g, device=dev)
+    xn = torch.randn(B, k_in, generator=g, device=dev)
+    W0 = torch.randn(n_out, ldw, generator=g, device=dev) / k_in ** 0.5
+    ctrl = torch.zeros(64, device=dev)
+    lr = 1e-3
+    ops.step_begin(ops.IMMEDIATE, ctrl, lr)          # t = 1: m = 0.1 g, v = 0.001 g^2, update = lr * sign-ish
+    dyt, xt = ops.new_split(n_out, B, dev), ops.new_split(k_in, B, dev)
+    ops.split_bf16_t(ops.IMMEDIATE, dyt[0], dyt[1], dy)
+    ops.split_bf16_t(ops.IMMEDIATE, xt[0], xt[1], x)
+    xnh, xnl = ops.new_split_kb(B, k_in, dev)
+    ops.split_bf16(ops.IMMEDIATE, xnh, xnl, xn)
+    res = []
+    for fused in (False, True):
+        W, m, v = W0.clone(), torch.zeros_like(W0), torch.zeros_like(W0)
+        y = torch.empty(B, n_out, device=dev)
+        if fused:
+            S = ops.dw_adam_fwd_slabs(n_out, k_in)
+            slabs = torch.zeros(S, B, n_out, device=dev)
+            ops.linear_dw_adam_fwd_bf16x3(ops.IMMEDIATE, W[:, :k_in], m[:, :k_in], v[:, :k_in], dyt[0], dyt[1], xt[0], xt[1], ctrl,
+                                          xnh, xnl, B, slabs)
+            ops.reduce_slabs(ops.IMMEDIATE, y, slabs, None, S)
+        else:
+            ops.linear_dw_adam_bf16x3(ops.IMMEDIATE, W[:, :k_in], m[:, :k_in], v[:, :k_in], dyt[0], dyt[1], xt[0], xt[1], ctrl)
+            ops.linear_fwd_bf16x3(ops.IMMEDIATE, y, xnh, xnl, W[:, :k_in], None, ops.Workspace(dev))
+        torch.cuda.synchronize()
+        res.append((W, m, v, y))
+    (W1, m1, v1, y1), (W2, m2, v2, y2) = res
+    assert torch.equal(W1, W2) and torch.equal(m1, m2) and torch.equal(v1, v2)
+    for rows in (slice(0, 70), slice(first_beyond - 3, first_beyond + 70), slice(n_out - 130, n_out)):
+        gr = dy[:, rows].double().t() @ x.double()                       # clip coefficient 1
+        assert float(gr.abs().max()) > 0
+        mref = 0.1 * gr
+        err = (m1[rows, :k_in].double() - mref).abs().max().item()
+        assert err <= 0.1 * 3e-5 * float(gr.abs().max()), (rows, err)
+        assert bool((m1[rows, :k_in] != 0).any(dim=1).all()), f"rows {rows} were not updated"
+        Wn = W1[rows, :k_in].double()
+        ref = xn.double() @ Wn.t()
+        for y in (y1, y2):
+            assert float((y[:, rows].double() - ref).norm() / ref.norm()) <= 1e-5, rows
+    assert float((W1[:, :k_in] - W0[:, :k_in]).abs().max()) <= 1.001 * lr and torch.equal(W1[:, k_in:], W0[:, k_in:])

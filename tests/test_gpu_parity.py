@@ -466,7 +466,7 @@ def test_engine_vs_oracle_three_steps(model, layers, B):
 @pytest.mark.parametrize("n_out,k_in,B", [(1100, 2500, 96), (2600, 700, 64), (130, 2100, 32), (2050, 2050, 128)])
 def test_dw_adam_xcd_tile_order_is_bit_identical(n_out, k_in, B):
     """The XCD-partitioned, L2-blocked tile order of the fused dW+Adam kernel (used when an operand outgrows one L2) only
-    changes WHICH workgroup computes a tile: forced on (FX_ADAM_XCD=2) it must reproduce the linear order bit for bit,
+    changes WHICH workgroup computes a tile: forced on (tile_order = 2) it must reproduce the linear order bit for bit,
     including ragged edges and the padded part of the index space."""
     import os
     from flexynesis_amd import ops
@@ -485,19 +485,12 @@ def test_dw_adam_xcd_tile_order_is_bit_identical(n_out, k_in, B):
     ops.split_bf16_t(ops.IMMEDIATE, dyt[0], dyt[1], dy)
     ops.split_bf16_t(ops.IMMEDIATE, xt[0], xt[1], x)
     outs = []
-    old = os.environ.get("FX_ADAM_XCD")
-    try:
-        for mode in ("0", "2"):
-            os.environ["FX_ADAM_XCD"] = mode
-            W, m, v = W0.clone(), m0.clone(), v0.clone()
-            ops.linear_dw_adam_bf16x3(ops.IMMEDIATE, W[:, :k_in], m[:, :k_in], v[:, :k_in], dyt[0], dyt[1], xt[0], xt[1], ctrl)
-            torch.cuda.synchronize()
-            outs.append((W, m, v))
-    finally:
-        if old is None:
-            os.environ.pop("FX_ADAM_XCD", None)
-        else:
-            os.environ["FX_ADAM_XCD"] = old
+    for order in (1, 2):              # 1 = linear, 2 = XCD-partitioned: explicit arguments of fx_linear_dw_adam_bf16x3_ex
+        W, m, v = W0.clone(), m0.clone(), v0.clone()
+        ops.linear_dw_adam_bf16x3(ops.IMMEDIATE, W[:, :k_in], m[:, :k_in], v[:, :k_in], dyt[0], dyt[1], xt[0], xt[1], ctrl,
+                                  tile_order=order)
+        torch.cuda.synchronize()
+        outs.append((W, m, v))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
     assert not torch.equal(outs[0][0][:, :k_in], W0[:, :k_in])            # the step did something

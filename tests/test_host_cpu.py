@@ -386,3 +386,12 @@ def test_triplet_sampler_matches_the_reference_dataset_distribution():
             pr = (ref + got) / (2 * reps)
             sigma = (pr * (1 - pr) * 2 / reps).sqrt()
             assert bool((((ref - got) / reps).abs() <= 5 * sigma + 1e-9).all()), (a, ref.tolist(), got.tolist())
+
+
+def test_library_carries_the_hash_of_its_sources():
+    """csrc/build.py rebuilds on a SOURCE-HASH mismatch, not on file times: the shipped libfxhip.so must have been built from
+    exactly the sources in the tree."""
+    from flexynesis_amd import _lib
+    from flexynesis_amd.csrc import build
+    assert not build.needs_build()
+    assert _lib.lib.fx_source_hash().decode() == build.source_hash() == build.built_hash()
