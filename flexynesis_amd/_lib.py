@@ -58,6 +58,7 @@ PROTOTYPES = {
     "fx_linear_bwd_x_bf16x3": (I, [P, P, P, P, I, I, I, L, L, L, P, L, P]),
     "fx_bn_act_fwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, L, L, I, I, I, F, U64, U64, P, P]),
     "fx_bn_act_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, L, L, L, L, I, I, F, I, P]),
+    "fx_bn_eval_bwd": (I, [P, P, P, P, P, P, I, I, L, L, L, L, I, I, P]),
     "fx_sigmoid": (I, [P, P, L, P]),
     "fx_reparam": (I, [P, P, P, P, P, L, U64, U64, P, P]),
     "fx_mul": (I, [P, P, P, L, P]),

@@ -270,6 +270,38 @@ int fx_bn_act_bwd(float* dx, float* dgamma, float* dbeta, float* dbias, const fl
   return fx_check_launch("fx_bn_act_bwd");
 }
 
+// EVAL-mode backward of the same blocks, with respect to the block input only (attribution: d output / d input through
+// model.eval(); reference direct_pred.py:418-431 under Captum).  BatchNorm is the affine map of its running statistics:
+//   MLP      out = relu(bn(x))           dx = dout * [out > 0] * gamma / sqrt(running_var + eps)
+//   Enc/Dec  out = bn(leaky(x))          dx = dout * gamma / sqrt(running_var + eps) * (x > 0 ? 1 : 0.2)
+__global__ __launch_bounds__(256) void fx_bn_eval_bwd_kernel(float* __restrict__ dx, const float* __restrict__ dout,
+                                                             const float* __restrict__ x, const float* __restrict__ out,
+                                                             const float* __restrict__ gamma, const float* __restrict__ rvar,
+                                                             int B, int C, long ldx, long ldo, long lddo, long lddx,
+                                                             int pre_act, int post_act) {
+  const int c = blockIdx.x * COLS + (threadIdx.x & (COLS - 1)), ry = threadIdx.x / COLS;
+  if (c >= C) return;
+  const float k = gamma[c] / sqrtf(rvar[c] + FX_BN_EPS);
+  for (int r = blockIdx.y * RGRP + ry; r < B; r += gridDim.y * RGRP) {
+    float g = dout[(long)r * lddo + c] * k;
+    if (post_act == ACT_RELU) g = out[(long)r * ldo + c] > 0.f ? g : 0.f;
+    if (pre_act == ACT_LEAKY) g = x[(long)r * ldx + c] > 0.f ? g : g * LEAKY_SLOPE;
+    dx[(long)r * lddx + c] = g;
+  }
+}
+
+int fx_bn_eval_bwd(float* dx, const float* dout, const float* x, const float* out, const float* gamma, const float* running_var,
+                   int B, int C, long ldx, long ldo, long lddo, long lddx, int pre_act, int post_act, hipStream_t stream) {
+  FX_REQUIRE(dx && dout && gamma && running_var && B > 0 && C > 0, "fx_bn_eval_bwd: bad args");
+  FX_REQUIRE(post_act != ACT_RELU || out, "fx_bn_eval_bwd: ReLU gating needs the block output");
+  FX_REQUIRE(pre_act != ACT_LEAKY || x, "fx_bn_eval_bwd: the LeakyReLU slope needs the block input");
+  int gy = (B + RGRP - 1) / RGRP;
+  if (gy > 16) gy = 16;
+  hipLaunchKernelGGL(fx_bn_eval_bwd_kernel, dim3((C + COLS - 1) / COLS, gy), dim3(256), 0, stream, dx, dout, x, out, gamma,
+                     running_var, B, C, ldx, ldo, lddo, lddx, pre_act, post_act);
+  return fx_check_launch("fx_bn_eval_bwd");
+}
+
 int fx_colsum(float* out, const float* x, int B, int C, long ldx, hipStream_t stream) {
   FX_REQUIRE(out && x && B > 0 && C > 0, "fx_colsum: bad args");
   hipLaunchKernelGGL(fx_colsum_kernel, dim3((C + COLS - 1) / COLS), dim3(256), 0, stream, out, x, B, C, ldx);

@@ -232,7 +232,8 @@ class StepPlan:
     def __init__(self, store: ParamStore, B: int, train: bool = True, fused: bool = True, clip: bool = True,
                  supplied_draws: bool = False, seed: int = 0, cohort=None, n_batches: int = 0,
                  epoch_acc: bool = False, precision: str = "bf16x3", branches: bool = True, share: "StepPlan" = None,
-                 fuse_heads: bool = True, frozen: Tuple[str, ...] = (), fuse_next_fwd: bool = False):
+                 fuse_heads: bool = True, frozen: Tuple[str, ...] = (), fuse_next_fwd: bool = False,
+                 attribution: bool = False):
         self.store, self.spec, self.B, self.train = store, store.spec, int(B), train
         self.fused = bool(fused) and train
         self.clip = clip
@@ -299,6 +300,12 @@ class StepPlan:
         self.fuse_next = bool(fuse_next_fwd) and self.fused and precision == "bf16x3" and cohort is not None
         self._next_fwd: Dict[str, tuple] = {}
         self.t_boot = TapeRecorder()
+        # attribution (eval plans): input-gradient tapes d head_output / d X for IntegratedGradients / GradientShap
+        self.attribution = bool(attribution) and not train
+        self.t_attr_head: Dict[str, TapeRecorder] = {}
+        self.t_attr_common = TapeRecorder()
+        self.attr_dout: Dict[str, torch.Tensor] = {}
+        self.dX: List[torch.Tensor] = []
         self._build()
         self.graph = None
 
@@ -751,6 +758,8 @@ class StepPlan:
         self._head_losses(rf, emb[:B])
         self._total(rf)
         if not self.train:
+            if self.attribution:
+                self._build_mlp_attr(n, L)
             return
         # ---- backward
         self._head_bwd(rb, emb[:B], demb[:B], first_accumulate=trip)
@@ -770,6 +779,49 @@ class StepPlan:
                 self._enter_branch(par, i)
                 self._mlp_bwd(rb, f"encoders.{i}", self.X[i], decat[:, i * L:(i + 1) * L], R, self.passes)
         self._branch = 0
+
+    def _build_mlp_attr(self, n, L):
+        """Eval-mode input-gradient tapes of the MLP family: d out_v[:, c] / d X_i for a head v, the upstream gradient
+        ``attr_dout[v]`` [B, C_v] being set by the caller (a one-hot column selects class c).  This is the gradient that
+        Captum's IntegratedGradients / GradientShap evaluate on ``forward_target`` (reference direct_pred.py:418-431,
+        :476-555) with the model in eval mode: BatchNorm = affine map of the running statistics, no dropout, ReLU gates
+        from the forward's saved outputs.  Only the anchor rows [:B] carry a gradient (triplet: heads see emb[:B])."""
+        spec, st, B = self.spec, self.store, self.B
+        demb = self._new("attr/demb", B, L)
+        for (v, kind, C) in spec.variables:
+            ra = self.t_attr_head[v] = TapeRecorder()
+            pre = "MLPs." + v
+            S = st.shapes[pre + ".layer_1.weight"][0]
+            do = self.attr_dout[v] = self._new(f"attr/dout.{v}", B, C)
+            da1 = self._new(f"attr/{pre}/da1", B, S)
+            ops.linear_bwd_x(ra, da1, do, st.p(pre + ".layer_out.weight"), self._ws[0])
+            ops.bn_eval_bwd(ra, da1, da1, None, self.buf[pre + "/a1"][:B], st.p(pre + ".batchnorm.weight"),
+                            st.b(pre + ".batchnorm.running_var"), ACT_NONE, ACT_RELU)
+            ops.linear_bwd_x(ra, demb, da1, st.p(pre + ".layer_1.weight"), self._ws[0])
+        rc = self.t_attr_common
+        if n > 1:
+            decat = self._new("attr/decat", B, n * L)
+            ops.linear_bwd_x(rc, decat, demb, st.p("fusion_block.weight"), self._ws[0])
+        else:
+            decat = demb
+        for i in range(n):
+            p = f"encoders.{i}"
+            H = st.shapes[p + ".layer_1.weight"][0]
+            da1 = self._new(f"attr/{p}/da1", B, H)
+            ops.linear_bwd_x(rc, da1, decat[:, i * L:(i + 1) * L], st.p(p + ".layer_out.weight"), self._ws[0])
+            ops.bn_eval_bwd(rc, da1, da1, None, self.buf[p + "/a1"][:B], st.p(p + ".batchnorm.weight"),
+                            st.b(p + ".batchnorm.running_var"), ACT_NONE, ACT_RELU)
+            dx = self._new(f"attr/dX.{i}", B, spec.layers[i][1])
+            self._branch = 0
+            self._lin_bwd_x(rc, dx, da1, p + ".layer_1.weight")
+            self.dX.append(dx)
+
+    def input_gradient(self, var: str):
+        """Run the input-gradient tapes for head ``var`` (after forward(); attr_dout[var] set): fills self.dX."""
+        if not self.attribution:
+            raise RuntimeError("build the plan with attribution=True")
+        self.t_attr_head[var].run()
+        self.t_attr_common.run()
 
     def _build_gnn(self):
         """GNN (models/gnn_early.py:142-198): flexGCN encoder (modules.py:251-262: per layer conv -> BatchNorm1d over the
@@ -1079,6 +1131,8 @@ class StepPlan:
     def bump_nbt(self):
         for k in self.store.nbt:
             self.store.nbt[k] += self.passes if k.startswith("encoders.") and self.passes > 1 else 1
+
+    input_gradient = ops.device_guard(input_gradient)
 
     @ops.device_guard
     def forward(self):

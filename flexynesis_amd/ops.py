@@ -626,6 +626,15 @@ def bn_act_bwd(rec, dx, dgamma, dbeta, dbias, dout, x, out, gamma, save_mean, sa
              float(drop_p), int(accumulate))
 
 
+def bn_eval_bwd(rec, dx, dout, x, out, gamma, running_var, pre_act, post_act):
+    """Input gradient of a BatchNorm block in eval mode (running statistics, no dropout); dx may alias dout."""
+    for t, n in ((dx, "dx"), (dout, "dout")):
+        _chk2d(t, "bn_eval_bwd." + n)
+    B, Cc = dout.shape
+    rec.emit("fx_bn_eval_bwd", dx.data_ptr(), dout.data_ptr(), _ptr(x), _ptr(out), gamma.data_ptr(), running_var.data_ptr(), B, Cc,
+             _ld(x) if x is not None else 0, _ld(out) if out is not None else 0, _ld(dout), _ld(dx), pre_act, post_act)
+
+
 def gather_rows(rec, dst, src, idx, ctrl_cursor=None, cursor_stride=0):
     """dst[r,:] = src[idx[r],:]; 1-D src (labels) is treated as [N,1]."""
     if src.dim() == 1:

@@ -199,6 +199,12 @@ int fx_bn_act_bwd(float* dx, float* dgamma, float* dbeta, float* dbias, const fl
                   long ldx, long ldo, long lddo, long lddx, int pre_act, int post_act, float drop_p, int accumulate,
                   fx_stream_t stream);
 
+/* Eval-mode backward of the two blocks with respect to the block INPUT only (BatchNorm = affine map of its running
+ * statistics, no dropout): the input-gradient path of the attributions the reference computes through Captum
+ * (direct_pred.py:418-590: IntegratedGradients / GradientShap of forward_target under model.eval()). */
+int fx_bn_eval_bwd(float* dx, const float* dout, const float* x, const float* out, const float* gamma, const float* running_var,
+                   int B, int C, long ldx, long ldo, long lddo, long lddx, int pre_act, int post_act, fx_stream_t stream);
+
 /* ---- elementwise pieces of supervised_vae (supervised_vae.py:187-200; modules.py:101-102) */
 int fx_sigmoid(float* y, const float* x, long n, fx_stream_t stream);
 int fx_reparam(float* z, float* eps_out, const float* mean, const float* log_var, const float* eps, long n,

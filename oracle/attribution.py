@@ -1,0 +1,58 @@
+"""CPU restatement of the reference's gradient attributions -- test infrastructure (see oracle/restate.py's header).
+
+Reference: ``compute_feature_importance`` / ``forward_target`` (models/direct_pred.py:418-590): Captum's
+IntegratedGradients or GradientShap of the head output, all-zero baselines, the whole DataLoader batch folded into ONE
+Captum example ([1, batch, F] inputs), |attribution| summed over the batch, divided by the number of samples.
+
+Captum is un-vendored and not installed here: its two rules are restated from its documentation -- PARITY UNPINNED for
+  * IntegratedGradients(method="gausslegendre", n_steps): attr = (x - x0) * sum_i w_i dF(x0 + a_i (x - x0))/dx with
+    (a_i, w_i) the n-point Gauss-Legendre rule on [0, 1];
+  * GradientShap(n_samples, stdevs=0): NoiseTunnel("smoothgrad") over InputBaselineXGradient: one alpha ~ U(0, 1) per
+    expanded example -- i.e. per draw, shared by the folded batch -- a baseline drawn from the (identical, zero)
+    baselines; attr = mean_i (x - x0) * dF(x0 + a_i (x - x0))/dx.
+The differentiated function is the pinned oracle's eval-mode forward (restate.py) under torch autograd."""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import restate as O
+
+
+def head_output(spec: O.Spec, st, x_list: List[torch.Tensor], var: str) -> torch.Tensor:
+    """forward(x_list)[var] in eval mode (direct_pred.py:107-133), differentiable in x_list."""
+    emb = O.directpred_embed(spec, st, x_list, False, {}, None)
+    return O.mlp_forward(st, "MLPs." + var, emb, False, None, None)
+
+
+def quadrature(n_steps: int):
+    xs, ws = np.polynomial.legendre.leggauss(int(n_steps))
+    return (0.5 * (1.0 + xs)).tolist(), (0.5 * ws).tolist()
+
+
+def feature_importance(spec: O.Spec, st, dat: Dict[str, torch.Tensor], var: str, kind: str, num_class: int, method: str,
+                       n: int, batch_size: int = 512, alphas: Optional[Sequence[float]] = None, dtype=torch.float64):
+    """{class: [importance vector per layer]} = mean over samples of |attribution|."""
+    st = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in st.items()}
+    names = [nm for nm, _ in spec.layers]
+    N = dat[names[0]].shape[0]
+    out = {c: [torch.zeros(dat[nm].shape[1], dtype=dtype) for nm in names] for c in range(num_class)}
+    for s0 in range(0, N, batch_size):
+        xs = [dat[nm][s0:s0 + batch_size].to(dtype) for nm in names]
+        if method == "IntegratedGradients":
+            al, wt = quadrature(n)
+        else:
+            al, wt = list(alphas), [1.0 / n] * n
+        for c in range(num_class):
+            acc = [torch.zeros_like(x) for x in xs]
+            for a, w in zip(al, wt):
+                pts = [(x * a).requires_grad_(True) for x in xs]
+                o = head_output(spec, st, pts, var)
+                grads = torch.autograd.grad(o[:, c if num_class > 1 else 0].sum(), pts)
+                for j, g in enumerate(grads):
+                    acc[j] += w * g
+            for j in range(len(names)):
+                out[c][j] += (acc[j] * xs[j]).abs().sum(0)
+    return {c: [v / N for v in out[c]] for c in out}

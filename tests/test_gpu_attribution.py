@@ -1,0 +1,78 @@
+"""compute_feature_importance on the engine (eval forward + input-gradient tapes on the HIP kernels) against the restated
+reference computation (oracle/attribution.py; reference models/direct_pred.py:418-590).  GPU, -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(model_name, layers, n=150, seed=0, big=False):
+    from flexynesis_amd import models as M
+    from flexynesis_amd.data import MultiOmicDataset
+    from oracle import restate as O
+    g = torch.Generator().manual_seed(seed)
+    dat = {k: torch.randn(n, F, generator=g) for k, F in layers}
+    ann = {"y": torch.randn(n, generator=g), "c": torch.randint(0, 3, (n,), generator=g).float()}
+    feats = {k: [f"{k}_{j}" for j in range(F)] for k, F in layers}
+    ds = MultiOmicDataset(dat, ann, {"y": "numerical", "c": "categorical"}, feats, [f"s{i}" for i in range(n)],
+                          {"c": {0: "zero", 1: "one", 2: "two"}})
+    cfg = {"latent_dim": 16, "hidden_dim_factor": 0.5, "lr": 1e-3, "supervisor_hidden_dim": 8, "epochs": 1, "batch_size": 32}
+    cls = getattr(M, model_name)
+    torch.manual_seed(seed + 1)
+    m = cls(cfg, ds, ["c", "y"] if model_name == "MultiTripletNetwork" else ["y", "c"], device_type="cuda")
+    # non-trivial running statistics (a freshly initialised BatchNorm is the identity in eval mode)
+    sd = m.state_dict()
+    for k in sd:
+        if k.endswith("running_mean"):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.3
+        elif k.endswith("running_var"):
+            sd[k] = torch.rand(sd[k].shape, generator=g) + 0.5
+    m.load_state_dict(sd)
+    variables = [("c", "categorical", 3), ("y", "numerical", 1)] if model_name == "MultiTripletNetwork" else \
+        [("y", "numerical", 1), ("c", "categorical", 3)]
+    ospec = O.Spec(model_name, layers, 16, 0.5, 8, variables)
+    st = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    return m, ds, ospec, st, dat
+
+
+@pytest.mark.parametrize("model_name,layers", [
+    ("DirectPred", [("gex", 300), ("cnv", 220)]),
+    ("DirectPred", [("all", 2500)]),                       # early fusion; hidden 1250 x 2500 weight -> the wide (split-bf16) dX path
+    ("MultiTripletNetwork", [("gex", 260), ("cnv", 180)]),
+])
+@pytest.mark.parametrize("method", ["IntegratedGradients", "GradientShap"])
+def test_feature_importance_matches_restated_reference(model_name, layers, method):
+    from oracle import attribution as A
+    m, ds, ospec, st, dat = _setup(model_name, layers)
+    alphas = [0.13, 0.42, 0.58, 0.77, 0.91]
+    for var, kind, C in (("y", "numerical", 1), ("c", "categorical", 3)):
+        df = m.compute_feature_importance(ds, var, method=method, steps_or_samples=5, batch_size=64, alphas=alphas)
+        assert df is m.feature_importances[var]
+        assert list(df.columns) == ["target_variable", "target_class", "target_class_label", "layer", "name", "importance"]
+        assert len(df) == C * sum(F for _, F in layers)
+        ref = A.feature_importance(ospec, st, dat, var, kind, C, method, 5, batch_size=64, alphas=alphas)
+        for c in range(C):
+            for j, (lname, F) in enumerate(layers):
+                got = df[(df.target_class == c) & (df.layer == lname)]
+                assert list(got.name) == ds.features[lname]
+                if kind == "categorical":
+                    assert set(got.target_class_label) == {ds.label_mappings["c"][c]}
+                a, b = torch.as_tensor(got.importance.to_numpy()).double(), ref[c][j]
+                scale = float(b.abs().max())
+                assert float((a - b).abs().max()) <= 2e-4 * scale + 1e-9, (var, c, lname, float((a - b).abs().max()), scale)
+                assert float((a - b).norm() / b.norm()) <= 1e-4
+
+
+def test_feature_importance_argument_checks_and_batching():
+    m, ds, _, _, _ = _setup("DirectPred", [("gex", 120), ("cnv", 90)], n=70)
+    with pytest.raises(ValueError):
+        m.compute_feature_importance(ds, "y", method="Saliency")
+    with pytest.raises(KeyError):
+        m.compute_feature_importance(ds, "nope")
+    # IntegratedGradients is deterministic and independent of how the samples are batched (eval mode: samples independent)
+    a = m.compute_feature_importance(ds, "y", steps_or_samples=4, batch_size=512).importance.to_numpy()
+    b = m.compute_feature_importance(ds, "y", steps_or_samples=4, batch_size=17).importance.to_numpy()
+    assert np.allclose(a, b, rtol=1e-5, atol=1e-9) and a.min() >= 0 and a.max() > 0
+    # the model is back in a usable state for training / prediction
+    assert set(m.predict(ds)) == {"y", "c"}

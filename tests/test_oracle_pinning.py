@@ -310,3 +310,38 @@ def test_trial_loop_early_stopping_semantics():
         assert out["epochs"] == (want if want else G["epochs"])
         assert len(out["history"]) == (want + 1 if want else G["epochs"])
         assert [r["val_loss"] for r in out["history"]] == curve[:len(out["history"])]
+
+
+def test_attribution_restatement_properties():
+    """oracle/attribution.py (Captum absent: the rule is restated) -- completeness of IntegratedGradients: with enough
+    Gauss-Legendre nodes the attributions of a sample sum to F(x) - F(0); GradientShap with the quadrature's nodes and
+    uniform weights is the same computation with other weights."""
+    from oracle import attribution as A
+    spec = O.Spec("DirectPred", [("a", 30), ("b", 18)], 6, 0.5, 5, [("y", "numerical", 1), ("c", "categorical", 3)])
+    st = {k: v.double() if v.is_floating_point() else v for k, v in O.init_state(spec, seed=4).items()}
+    g = torch.Generator().manual_seed(0)
+    for k in st:                                   # non-trivial running statistics
+        if k.endswith("running_mean"):
+            st[k] = torch.randn(st[k].shape, generator=g).double() * 0.3
+        if k.endswith("running_var"):
+            st[k] = torch.rand(st[k].shape, generator=g).double() + 0.5
+    xs = [torch.randn(5, 30, generator=g).double(), torch.randn(5, 18, generator=g).double()]
+    al, wt = A.quadrature(64)
+    assert abs(sum(wt) - 1.0) < 1e-12 and all(0 < a < 1 for a in al)
+    for var, c in (("y", 0), ("c", 2)):
+        f1 = A.head_output(spec, st, xs, var)[:, c]
+        f0 = A.head_output(spec, st, [torch.zeros_like(x) for x in xs], var)[:, c]
+        tot = torch.zeros(5, dtype=torch.float64)
+        for a, w in zip(al, wt):
+            pts = [(x * a).requires_grad_(True) for x in xs]
+            o = A.head_output(spec, st, pts, var)[:, c].sum()
+            gr = torch.autograd.grad(o, pts)
+            tot += w * sum((g_ * x).sum(1) for g_, x in zip(gr, xs))
+        close(tot, f1 - f0, rtol=2e-2, atol=1.5e-3, what=f"IG completeness {var}")     # piecewise-linear net: the ReLU kinks limit the quadrature
+    dat = {"a": xs[0], "b": xs[1]}
+    imp = A.feature_importance(spec, st, dat, "c", "categorical", 3, "IntegratedGradients", 5, batch_size=2)
+    assert set(imp) == {0, 1, 2} and imp[0][0].shape == (30,) and imp[0][1].shape == (18,)
+    assert all(float(v.min()) >= 0 for c in imp for v in imp[c])
+    al5, _ = A.quadrature(5)
+    gs = A.feature_importance(spec, st, dat, "c", "categorical", 3, "GradientShap", 5, batch_size=5, alphas=al5)
+    assert gs[1][0].shape == (30,) and not torch.allclose(gs[1][0], imp[1][0])        # same nodes, uniform weights
