@@ -75,6 +75,7 @@ PROTOTYPES = {
     "fx_total_loss": (I, [P, I, I, P, P, P, P, P]),
     "fx_step_begin": (I, [P, F, I, P]),
     "fx_fill": (I, [P, L, F, P]),
+    "fx_scale_by": (I, [P, L, P, P]),
     "fx_stream_copy": (I, [P, P, L, P]),
     "fx_sumsq_blocks": (I, [L]),
     "fx_sumsq": (I, [P, P, L, P]),

@@ -64,6 +64,14 @@ __global__ __launch_bounds__(256) void fx_stream_copy_kernel(fx_f32x4* __restric
   if (i < n4) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
+// x *= s[0] with the scalar read on the device: a no-op pass (every block returns after one load) when s[0] == 1, which
+// is what loss.backward() hands down -- the drop-in autograd bridge applies the upstream gradient without a host sync
+__global__ __launch_bounds__(256) void fx_scale_by_kernel(float* __restrict__ x, long n, const float* __restrict__ s) {
+  const float k = s[0];
+  if (k == 1.0f) return;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] *= k;
+}
+
 __global__ __launch_bounds__(256) void fx_fill_kernel(float* __restrict__ y, long n, float value) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = value;
 }
@@ -180,6 +188,13 @@ int fx_stream_copy(float* dst, const float* src, long n, hipStream_t stream) {
   FX_REQUIRE(b < (1L << 31), "fx_stream_copy: too many elements for one launch");
   hipLaunchKernelGGL(fx_stream_copy_kernel, dim3((unsigned)b), dim3(256), 0, stream, (fx_f32x4*)dst, (const fx_f32x4*)src, n4);
   return fx_check_launch("fx_stream_copy");
+}
+
+int fx_scale_by(float* x, long n, const float* scale, hipStream_t stream) {
+  FX_REQUIRE(x && scale && n > 0, "fx_scale_by: bad args");
+  long b = (n + 256L * 8 - 1) / (256L * 8);
+  hipLaunchKernelGGL(fx_scale_by_kernel, dim3((unsigned)(b > 2048 ? 2048 : b)), dim3(256), 0, stream, x, n, scale);
+  return fx_check_launch("fx_scale_by");
 }
 
 int fx_fill(float* y, long n, float value, hipStream_t stream) {

@@ -59,9 +59,11 @@ def resolve_device(device_type) -> torch.device:
 
 
 class _PlanLoss(torch.autograd.Function):
-    """Connects a recorded StepPlan to autograd: forward has already run the forward tape; backward runs
-    the backward tape (hand-written HIP kernels, gradients materialised in the arenas) and hands a copy
-    of each gradient to autograd so that ``loss.backward()`` / Lightning / torch optimisers work."""
+    """Connects a recorded StepPlan to autograd: forward has already run the forward tape; backward runs the backward
+    tape (hand-written HIP kernels, gradients materialised in the arenas) and hands autograd VIEWS of those arenas, so
+    ``loss.backward()`` / Lightning / torch optimisers see ``param.grad`` without another pass over the 0.8 GB of
+    gradients.  The upstream gradient (1 for a plain ``loss.backward()``) is applied by a device-side scaling pass that
+    reads the scalar on the GPU and returns at once when it is 1 -- no host synchronisation."""
 
     @staticmethod
     def forward(ctx, model, plan, *params):
@@ -73,7 +75,11 @@ class _PlanLoss(torch.autograd.Function):
     def backward(ctx, gout):
         model, plan = ctx.model, ctx.plan
         plan.backward()
-        scale = gout.reshape(-1)[0]
+        st = model._store
+        scale = gout.reshape(-1)[:1].to(torch.float32).contiguous()
+        ops.scale_by(ops.IMMEDIATE, st.G, scale)
+        for k in st.big_keys:
+            ops.scale_by(ops.IMMEDIATE, st.big[k]["_G"].view(-1), scale)
         grads = []
         weighted = plan.spec.weighted
         for key, p in model._param_items():
@@ -83,8 +89,60 @@ class _PlanLoss(torch.autograd.Function):
             if key.startswith("log_vars.") and not weighted:
                 grads.append(None)          # reference: log_vars get no grad with a single loss term
                 continue
-            grads.append(model._store.g(key).clone() * scale)
+            grads.append(st.g(key))          # a view into the gradient arena (overwritten by the next backward)
         return (None, None, *grads)
+
+
+class FxAdam(torch.optim.Optimizer):
+    """``torch.optim.Adam(model.parameters(), lr)`` (reference models/direct_pred.py:135-144) for a model whose
+    parameters and gradients live in the engine's arenas: ``step()`` is one ``fx_adam_flat`` launch over the
+    small-parameter arena plus one per wide weight, instead of torch's multi-tensor passes.  Same update rule and
+    defaults (betas 0.9 / 0.999, eps 1e-8, no weight decay); parameters whose ``.grad`` is None are skipped, like torch's.
+    Gradients are whatever ``param.grad`` holds when ``step()`` is called -- i.e. after Lightning's
+    ``clip_grad_norm_`` -- because ``param.grad`` IS the arena."""
+
+    def __init__(self, model, lr):
+        self.model = model
+        super().__init__(list(model.parameters()), dict(lr=float(lr)))
+        self._mask_sig = None
+        self._mask = None
+        self._ctrl = None          # this optimiser's own step-control block: t counts optimizer.step() calls (the model's
+                                   # block counts training_step calls for the dropout streams; they differ under
+                                   # gradient accumulation)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        m = self.model
+        st = m._bind()
+        lr = float(self.param_groups[0]["lr"])
+        with torch.cuda.device(st.device):
+            items = m._param_items()
+            # a gradient that is not the arena view (e.g. autograd had to clone a row-padded wide gradient, or a user set
+            # it) is copied into its arena slot first
+            live = []
+            for key, p in items:
+                has = p.grad is not None
+                live.append(has)
+                if has and p.grad.data_ptr() != st.g(key).data_ptr():
+                    st.g(key).copy_(p.grad)
+            sig = tuple(live)
+            if sig != self._mask_sig:
+                mask = torch.zeros_like(st.P)
+                for (key, p), has in zip(items, live):
+                    if has and key not in st.big:
+                        st._view(mask, key).fill_(1.0)
+                self._mask, self._mask_sig = mask, sig
+            if self._ctrl is None or self._ctrl.device != st.device:
+                self._ctrl = torch.zeros(ops.CTRL_FLOATS, dtype=torch.float32, device=st.device)
+            ctrl = self._ctrl
+            ops.step_begin(ops.IMMEDIATE, ctrl, lr, 0)               # t += 1, bias corrections; clip coefficient = 1
+            ops.adam_flat(ops.IMMEDIATE, st.P, st.G, st.M, st.V, ctrl, None if all(live) else self._mask)
+            for (key, p), has in zip(items, live):
+                if has and key in st.big:
+                    d = st.big[key]
+                    ops.adam_flat(ops.IMMEDIATE, d["_W"].view(-1), d["_G"].view(-1), d["_M"].view(-1), d["_V"].view(-1), ctrl)
+        return loss
 
 
 class FxModel(_Base):
@@ -228,12 +286,20 @@ class FxModel(_Base):
 
     # -- LightningModule protocol ------------------------------------------------------------------------------
     def configure_optimizers(self):
-        """Adam(lr) as the reference (models/direct_pred.py:135-144); it updates the arena views in place."""
-        return torch.optim.Adam(self.parameters(), lr=self.config["lr"])
+        """Adam(lr) as the reference (models/direct_pred.py:135-144), as a ``torch.optim.Optimizer`` whose ``step()``
+        runs on the arenas (``FxAdam``).  ``torch.optim.Adam(model.parameters(), lr)`` works too (it updates the arena
+        views in place); pass ``FX_TORCH_ADAM=1`` to get it from here."""
+        import os
+        if os.environ.get("FX_TORCH_ADAM", "0") == "1" or not torch.cuda.is_available():
+            return torch.optim.Adam(self.parameters(), lr=self.config["lr"])
+        return FxAdam(self, self.config["lr"])
 
     def training_step(self, train_batch, batch_idx, log=True):
         plan = self._plan(self._batch_size(train_batch), train=True, fused=False)
         self._feed(plan, train_batch)
+        # the in-kernel dropout / eps / prior draws are keyed on the step counter of the control block: advance it once per
+        # training_step (an external optimiser never touches it, and the same masks would be drawn every step)
+        ops.step_begin(ops.IMMEDIATE, plan.store.ctrl, float(self.config.get("lr", 0.0)), 0)
         plan.forward()
         plan.bump_nbt()
         self._sync_nbt()

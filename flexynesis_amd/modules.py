@@ -16,6 +16,14 @@ from .ops import ACT_LEAKY, ACT_NONE, ACT_RELU, IMMEDIATE, Workspace
 __all__ = ["Encoder", "Decoder", "MLP", "cox_ph_loss"]
 
 _WS = {}
+_DRAWS = [0]
+
+
+def _next_seed() -> int:
+    """Philox seed of one dropout call: torch's global seed mixed with a per-process call counter -- reproducible under
+    torch.manual_seed and free of any tensor op (the previous torch.randint(...).item() cost ~10 us per block)."""
+    _DRAWS[0] += 1
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _DRAWS[0] * 0xD1B54A32D192ED03) & 0x7FFFFFFFFFFFFFFF
 
 
 def _ws(device) -> Workspace:
@@ -69,7 +77,7 @@ class _BnActFn(torch.autograd.Function):
         out = torch.empty_like(x)
         sm = torch.empty(C, device=x.device)
         si = torch.empty(C, device=x.device)
-        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if (training and drop_p > 0 and mask is None) else 0
+        seed = _next_seed() if (training and drop_p > 0 and mask is None) else 0
         ops.bn_act_fwd(IMMEDIATE, out, x, _f32c(gamma), _f32c(beta), bn.running_mean, bn.running_var, sm, si, pre_act,
                        post_act, training, drop_p if training else 0.0, mask=mask, seed=seed, offset=0)
         if training:

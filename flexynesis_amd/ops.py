@@ -708,6 +708,11 @@ def fill(rec, y, value=0.0):
     rec.emit("fx_fill", y.data_ptr(), y.numel(), float(value))
 
 
+def scale_by(rec, x, scale):
+    """x *= scale[0] (device scalar; no-op when it is 1)."""
+    rec.emit("fx_scale_by", x.data_ptr(), x.numel(), scale.data_ptr())
+
+
 def stream_copy(rec, dst, src):
     rec.emit("fx_stream_copy", dst.data_ptr(), src.data_ptr(), src.numel())
 

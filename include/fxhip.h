@@ -237,6 +237,9 @@ int fx_total_loss(float* total_out, int n, int weighted, const float* const* los
 
 /* ---- optimiser: Lightning's clip_grad_norm_(1.0) + torch.optim.Adam(lr) (main.py:212-225, direct_pred.py:143) */
 int fx_step_begin(float* ctrl, float lr, int n_batches, fx_stream_t stream);
+/* x[0..n) *= scale[0], the scalar read on the device (nothing is written when it is 1): applies the upstream gradient
+ * of loss.backward() to the materialised gradients without a host synchronisation */
+int fx_scale_by(float* x, long n, const float* scale, fx_stream_t stream);
 /* y[0..n) = value (zero_grad of an accumulator that no kernel of the step overwrites first) */
 int fx_fill(float* y, long n, float value, fx_stream_t stream);
 /* dst[0..n) = src[0..n): plain 16-byte-per-lane streaming copy (n % 4 == 0, 16-byte aligned).  bench.py times it to

@@ -448,3 +448,44 @@ def test_run_trial_crossmodal_takes_layer_lists():
                                          input_layers=["cnv"], output_layers=["gex"])
     assert "error" not in info and np.isfinite(val) and epochs == 3
     assert model.input_layers == ["cnv"] and model.output_layers == ["gex"] and len(model.encoders) == 1
+
+
+def test_drop_in_fx_adam_equals_torch_adam_and_masks_change():
+    """Level-1 drop-in (Lightning protocol): configure_optimizers() returns FxAdam, whose step() runs fx_adam_flat on the
+    arenas that param.grad already views; it must follow torch.optim.Adam on the same gradients.  The dropout masks of
+    training_step are keyed on a step counter that training_step itself advances: they change from step to step with
+    either optimiser (an external optimiser never touches the engine's control block)."""
+    import flexynesis_amd.models as M
+    from flexynesis_amd.models.base import FxAdam
+    g = Golden("directpred_2omics_multitask")
+    m, ds = _model_from_golden(g, M.DirectPred)
+    m.load_state_dict(g.state0())
+    m.to(DEV)
+    ma, mb = copy.deepcopy(m), copy.deepcopy(m)
+    oa, ob = ma.configure_optimizers(), torch.optim.Adam(mb.parameters(), lr=ma.config["lr"])
+    assert isinstance(oa, FxAdam) and isinstance(oa, torch.optim.Optimizer)
+    b = g.batch(0)
+    batch = ({n: x.to(DEV) for (n, _), x in zip(g.spec.layers, b["x"])}, {k: v.to(DEV) for k, v in b["y"].items()},
+             tuple(f"s{i}" for i in range(8)))
+    patterns = {0: [], 1: []}
+    for it in range(6):
+        for j, (mm, oo) in enumerate(((ma, oa), (mb, ob))):
+            mm.train()
+            oo.zero_grad()
+            loss = mm.training_step(batch, it)
+            loss.backward()
+            plan = mm._plans[(8, True, False)]
+            patterns[j].append((plan.buf["encoders.0/a1"] == 0).clone())
+            # param.grad is the arena itself: no copy was made on the way to autograd
+            pk = "encoders.0.layer_out.weight"
+            assert dict(mm.named_parameters())[pk].grad.data_ptr() == mm._store.g(pk).data_ptr()
+            torch.nn.utils.clip_grad_norm_(mm.parameters(), 1.0)
+            oo.step()
+    for j in (0, 1):
+        assert not torch.equal(patterns[j][0], patterns[j][1]) and not torch.equal(patterns[j][1], patterns[j][2])
+        assert torch.equal(patterns[0][j], patterns[1][j])            # same seeds, same counters: both models drew the same masks
+    sa, sb = ma.state_dict(), mb.state_dict()
+    for k in sa:
+        if sa[k].dtype.is_floating_point:
+            assert float((sa[k] - sb[k]).abs().max()) <= 2e-6 + 1e-5 * float(sb[k].abs().max()), k
+    assert float((sa["encoders.0.layer_1.weight"] - g.state0()["encoders.0.layer_1.weight"].to(DEV)).abs().max()) > 1e-4
