@@ -159,3 +159,46 @@ def test_gnn_training_step_matches_reference(conv):
             assert int(st2[k]) == int(v)
         else:
             torch.testing.assert_close(st2[k], v.detach(), rtol=2e-4, atol=2.2e-3 if k.endswith("bias") else 2e-5)
+
+
+# ---- independent dense-adjacency formulation of the three graph convolutions -------------------------------------
+@pytest.mark.parametrize("conv", ["GC", "SAGE", "GCN"])
+def test_conv_restatement_matches_dense_adjacency_formulation(conv):
+    """torch_geometric is absent, so oracle.restate.gnn_edges / gnn_conv (edge-list form, restated from PyG's docs) cannot
+    be pinned to PyG itself.  This is a second, independently written statement of the same layers straight from the
+    papers, as dense matrix algebra in fp64 -- Kipf & Welling 2017 (GCN: A_hat = D~^-1/2 (A + I) D~^-1/2), Hamilton et al.
+    2017 (GraphSAGE mean aggregator), Morris et al. 2019 (GraphConv: W_root x_i + W_rel sum_j x_j) -- on multigraphs with
+    duplicate edges, self loops, hubs and isolated nodes.  Agreement removes the single-author risk, not the PyG gap."""
+    g = torch.Generator().manual_seed({"GC": 1, "SAGE": 2, "GCN": 3}[conv])
+    n, cin, cout, B, E = 23, 3, 5, 4, 90
+    src = torch.randint(0, n - 2, (E,), generator=g)           # the last two nodes stay isolated
+    dst = torch.randint(0, n - 2, (E,), generator=g)
+    src[:6], dst[:6] = torch.tensor([0, 0, 1, 1, 2, 5]), torch.tensor([0, 0, 1, 3, 2, 5])      # self loops (one doubled)
+    src[6:10], dst[6:10] = torch.tensor([4, 4, 4, 7]), torch.tensor([9, 9, 9, 9])               # duplicate edges, a hub
+    ei = torch.stack([src, dst])
+    x = torch.randn(B, n, cin, generator=g, dtype=torch.float64)
+    W1 = torch.randn(cout, cin, generator=g, dtype=torch.float64)
+    W2 = torch.randn(cout, cin, generator=g, dtype=torch.float64)
+    b = torch.randn(cout, generator=g, dtype=torch.float64)
+    A = torch.zeros(n, n, dtype=torch.float64)                 # A[i, j] = number of edges j -> i (messages flow source -> target)
+    for s_, d_ in zip(src.tolist(), dst.tolist()):
+        A[d_, s_] += 1.0
+    if conv == "GC":
+        st = {"c.lin_rel.weight": W1, "c.lin_rel.bias": b, "c.lin_root.weight": W2}
+        want = torch.einsum("ij,bjc->bic", A, x) @ W1.t() + b + x @ W2.t()
+    elif conv == "SAGE":
+        st = {"c.lin_l.weight": W1, "c.lin_l.bias": b, "c.lin_r.weight": W2}
+        deg = A.sum(1)
+        Dinv = torch.where(deg > 0, 1.0 / deg, torch.zeros_like(deg))
+        want = torch.einsum("ij,bjc->bic", Dinv[:, None] * A, x) @ W1.t() + b + x @ W2.t()
+    else:
+        st = {"c.lin.weight": W1, "c.bias": b}
+        At = A.clone()
+        At.fill_diagonal_(0.0)                                 # renormalisation trick: A~ = A + I (existing self loops are replaced)
+        At = At + torch.eye(n, dtype=torch.float64)
+        d = At.sum(1)
+        Ahat = d.pow(-0.5)[:, None] * At * d.pow(-0.5)[None, :]
+        want = torch.einsum("ij,bjc->bic", Ahat, x @ W1.t()) + b
+    got = O.gnn_conv(st, "c", x, O.gnn_edges(ei, n, conv), conv)
+    assert torch.allclose(got, want, rtol=1e-12, atol=1e-12), float((got - want).abs().max())
+    assert float(want[:, -2:].abs().sum()) > 0 or conv == "GC"           # isolated nodes still get the root / bias / self-loop term

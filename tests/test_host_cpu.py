@@ -395,3 +395,50 @@ def test_library_carries_the_hash_of_its_sources():
     from flexynesis_amd.csrc import build
     assert not build.needs_build()
     assert _lib.lib.fx_source_hash().decode() == build.source_hash() == build.built_hash()
+
+
+def test_model_builds_from_the_inference_namespace():
+    """reference inference.py:116-122 rebuilds a model from saved artefacts with a SimpleNamespace in place of the dataset:
+    ``dat`` values are None, ``ann[var]`` is the category LIST (or a dummy array for numerical targets)."""
+    from types import SimpleNamespace
+    import flexynesis_amd.models as M
+    ns = SimpleNamespace(layers=["gex", "cnv"], features={"gex": [f"g{i}" for i in range(40)], "cnv": [f"c{i}" for i in range(24)]},
+                         dat={"gex": None, "cnv": None}, variable_types={"c": "categorical", "y": "numerical"},
+                         ann={"c": ["A", "B", "C"], "y": np.array([0.0])})
+    cfg = {"latent_dim": 6, "hidden_dim_factor": 0.5, "lr": 1e-3, "supervisor_hidden_dim": 4, "epochs": 1, "batch_size": 8}
+    for cls in (M.DirectPred, M.supervised_vae):
+        m = cls(cfg, ns, ["y", "c"], device_type="cpu")
+        sd = m.state_dict()
+        assert sd["MLPs.c.layer_out.weight"].shape == (3, 4) and sd["MLPs.y.layer_out.weight"].shape == (1, 4)
+        assert m.layers == ["gex", "cnv"] and m.input_dims == [40, 24]
+        first = "encoders.0.layer_1.weight" if cls is M.DirectPred else "encoders.0.hidden_layers.0.weight"
+        assert sd[first].shape == (20, 40)
+
+
+@pytest.mark.skipif(not __import__("oracle.ref_shim", fromlist=["x"]).available(), reason="reference only exists in the build container")
+@pytest.mark.parametrize("name", ["DirectPred", "supervised_vae", "MultiTripletNetwork", "CrossModalPred"])
+def test_state_dict_loads_into_the_reference_model(name):
+    """The other direction of the checkpoint ABI: a state_dict produced by the engine's model class loads STRICTLY into
+    the reference's class (same keys, shapes and dtypes, incl. the int64 num_batches_tracked buffers), so weights trained
+    here can be handed to the reference's inference / attribution code."""
+    import flexynesis_amd.models as M
+    from oracle import ref_capture, ref_shim
+    from oracle import restate as O
+    from oracle.gen_goldens import make_cohort
+    R = ref_shim.load()
+    kw = dict(input_layers=["a"], output_layers=["b", "a"]) if name == "CrossModalPred" else {}
+    spec = O.Spec(name, [("a", 30), ("b", 18)], 6, 0.4, 3, [("c", "categorical", 3), ("y", "numerical", 1)], **kw)
+    dat, ann, vt = make_cohort(spec, 30, seed=2, missing=False)
+    cfg = {"latent_dim": 6, "hidden_dim_factor": 0.4, "lr": 1e-3, "supervisor_hidden_dim": 3, "epochs": 1, "batch_size": 6}
+    ref = ref_capture.build_reference_model(R, spec, ref_capture.make_dataset(R, dat, ann, vt), cfg)
+    from flexynesis_amd.data import MultiOmicDataset
+    ds = MultiOmicDataset(dat, ann, vt, {k: [f"{k}_{j}" for j in range(v.shape[1])] for k, v in dat.items()},
+                          [f"s{i}" for i in range(30)], {})
+    torch.manual_seed(5)
+    mine = getattr(M, name)(cfg, ds, ["c", "y"], device_type="cpu", **kw)
+    sd = mine.state_dict()
+    sd["encoders.0." + ("layer_1" if name in ("DirectPred", "MultiTripletNetwork") else "hidden_layers.0") + ".weight"] += 0.25
+    res = ref.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    for k, v in ref.state_dict().items():
+        assert v.dtype == sd[k].dtype and torch.equal(v, sd[k]), k
