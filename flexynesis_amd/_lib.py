@@ -60,6 +60,8 @@ PROTOTYPES = {
     "fx_bn_act_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, L, L, L, L, I, I, F, I, P]),
     "fx_bn_eval_bwd": (I, [P, P, P, P, P, P, I, I, L, L, L, L, I, I, P]),
     "fx_sigmoid": (I, [P, P, L, P]),
+    "fx_sigmoid_bwd": (I, [P, P, P, L, P]),
+    "fx_softmax_rows": (I, [P, P, I, I, L, L, P]),
     "fx_reparam": (I, [P, P, P, P, P, L, U64, U64, P, P]),
     "fx_mul": (I, [P, P, P, L, P]),
     "fx_fill_normal": (I, [P, L, U64, U64, P, P]),

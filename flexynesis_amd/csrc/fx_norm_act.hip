@@ -205,6 +205,22 @@ __global__ void fx_sigmoid_kernel(float* __restrict__ y, const float* __restrict
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     y[i] = 1.0f / (1.0f + expf(-x[i]));
 }
+// dx = dy * y * (1 - y)   (backward of y = sigmoid(x) from its saved output)
+__global__ void fx_sigmoid_bwd_kernel(float* __restrict__ dx, const float* __restrict__ dy, const float* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dx[i] = dy[i] * y[i] * (1.0f - y[i]);
+}
+// row-wise softmax of a small [B, C] logit matrix (predict(): class probabilities of a categorical head), one thread per row
+__global__ void fx_softmax_rows_kernel(float* __restrict__ y, const float* __restrict__ x, int B, int C, long ldx, long ldy) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= B) return;
+  const float* xr = x + (long)r * ldx;
+  float mx = xr[0];
+  for (int c = 1; c < C; ++c) mx = fmaxf(mx, xr[c]);
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s += expf(xr[c] - mx);
+  for (int c = 0; c < C; ++c) y[(long)r * ldy + c] = expf(xr[c] - mx) / s;
+}
 // z = mean + log_var * eps (reference supervised_vae.py:198-199: log_var is used directly as the scale)
 __global__ void fx_reparam_kernel(float* __restrict__ z, float* __restrict__ eps_out, const float* __restrict__ mean,
                                   const float* __restrict__ log_var, const float* __restrict__ eps, long n,
@@ -312,6 +328,18 @@ int fx_sigmoid(float* y, const float* x, long n, hipStream_t stream) {
   FX_REQUIRE(y && x && n > 0, "fx_sigmoid: bad args");
   hipLaunchKernelGGL(fx_sigmoid_kernel, dim3(grid_for(n)), dim3(256), 0, stream, y, x, n);
   return fx_check_launch("fx_sigmoid");
+}
+
+int fx_sigmoid_bwd(float* dx, const float* dy, const float* y, long n, hipStream_t stream) {
+  FX_REQUIRE(dx && dy && y && n > 0, "fx_sigmoid_bwd: bad args");
+  hipLaunchKernelGGL(fx_sigmoid_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, stream, dx, dy, y, n);
+  return fx_check_launch("fx_sigmoid_bwd");
+}
+
+int fx_softmax_rows(float* y, const float* x, int B, int C, long ldx, long ldy, hipStream_t stream) {
+  FX_REQUIRE(y && x && B > 0 && C > 0 && ldx >= C && ldy >= C, "fx_softmax_rows: bad args");
+  hipLaunchKernelGGL(fx_softmax_rows_kernel, dim3((B + 127) / 128), dim3(128), 0, stream, y, x, B, C, ldx, ldy);
+  return fx_check_launch("fx_softmax_rows");
 }
 
 int fx_reparam(float* z, float* eps_out, const float* mean, const float* log_var, const float* eps, long n,

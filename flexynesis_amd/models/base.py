@@ -354,7 +354,9 @@ class FxModel(_Base):
             for v in self.variables:
                 o = plan.buf[f"MLPs.{v}/out"].detach()
                 if dataset.variable_types[v] == "categorical":
-                    o = torch.softmax(o, dim=1)
+                    pr = torch.empty_like(o)
+                    ops.softmax_rows(ops.IMMEDIATE, pr, o)
+                    o = pr
                 preds[v].extend(o.cpu().numpy())
         return {v: np.array(a) for v, a in preds.items()}
 

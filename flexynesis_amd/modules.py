@@ -67,6 +67,25 @@ class _LinearFn(torch.autograd.Function):
         return dx, dW, db
 
 
+class _SigmoidFn(torch.autograd.Function):
+    """y = sigmoid(x) (fx_sigmoid); backward dy * y * (1 - y) from the saved output (fx_sigmoid_bwd)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32c(x)
+        y = torch.empty_like(x)
+        ops.sigmoid(IMMEDIATE, y, x)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dx = torch.empty_like(y)
+        ops.sigmoid_bwd(IMMEDIATE, dx, _f32c(dy), y)
+        return dx
+
+
 class _BnActFn(torch.autograd.Function):
     """[LeakyReLU ->] BatchNorm1d [-> ReLU -> Dropout] in one kernel each way (fx_bn_act_fwd/bwd)."""
 
@@ -179,7 +198,7 @@ class Decoder(nn.Module):
     def forward(self, x):
         _require_gpu(x, "Decoder")
         h = _run_hidden(self.hidden_layers, x, self.training)
-        return torch.sigmoid(_LinearFn.apply(h, self.FC_output.weight, self.FC_output.bias))
+        return _SigmoidFn.apply(_LinearFn.apply(h, self.FC_output.weight, self.FC_output.bias))
 
 
 class _CoxFn(torch.autograd.Function):

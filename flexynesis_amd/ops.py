@@ -747,6 +747,16 @@ def sigmoid(rec, y, x):
     rec.emit("fx_sigmoid", y.data_ptr(), x.data_ptr(), x.numel())
 
 
+def sigmoid_bwd(rec, dx, dy, y):
+    rec.emit("fx_sigmoid_bwd", dx.data_ptr(), dy.data_ptr(), y.data_ptr(), y.numel())
+
+
+def softmax_rows(rec, y, x):
+    _chk2d(x, "softmax_rows.x")
+    _chk2d(y, "softmax_rows.y")
+    rec.emit("fx_softmax_rows", y.data_ptr(), x.data_ptr(), x.shape[0], x.shape[1], _ld(x), _ld(y))
+
+
 def reparam(rec, z, mean, log_var, eps=None, eps_out=None, seed=0, offset=0, ctrl=None):
     rec.emit("fx_reparam", z.data_ptr(), _ptr(eps_out), mean.data_ptr(), log_var.data_ptr(), _ptr(eps), z.numel(),
              int(seed), int(offset), _ptr(ctrl))

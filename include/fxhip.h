@@ -207,6 +207,9 @@ int fx_bn_eval_bwd(float* dx, const float* dout, const float* x, const float* ou
 
 /* ---- elementwise pieces of supervised_vae (supervised_vae.py:187-200; modules.py:101-102) */
 int fx_sigmoid(float* y, const float* x, long n, fx_stream_t stream);
+int fx_sigmoid_bwd(float* dx, const float* dy, const float* y, long n, fx_stream_t stream);     /* dx = dy * y * (1 - y) */
+/* y[r, :] = softmax(x[r, :]) for a small [B, C] logit matrix: predict()'s class probabilities (direct_pred.py:330-337) */
+int fx_softmax_rows(float* y, const float* x, int B, int C, long ldx, long ldy, fx_stream_t stream);
 int fx_reparam(float* z, float* eps_out, const float* mean, const float* log_var, const float* eps, long n,
                unsigned long long seed, unsigned long long offset, const float* ctrl, fx_stream_t stream);
 int fx_mul(float* y, const float* a, const float* b, long n, fx_stream_t stream);
