@@ -233,7 +233,7 @@ class StepPlan:
                  supplied_draws: bool = False, seed: int = 0, cohort=None, n_batches: int = 0,
                  epoch_acc: bool = False, precision: str = "bf16x3", branches: bool = True, share: "StepPlan" = None,
                  fuse_heads: bool = True, frozen: Tuple[str, ...] = (), fuse_next_fwd: bool = False,
-                 attribution: bool = False, early_enc: bool = False):
+                 attribution: bool = False):
         self.store, self.spec, self.B, self.train = store, store.spec, int(B), train
         self.fused = bool(fused) and train
         self.clip = clip
@@ -298,17 +298,6 @@ class StepPlan:
         # (PipelinedStep links the two); t_boot computes the partial sums stand-alone for the first step / after any
         # weight change made outside the pipeline.
         self.fuse_next = bool(fuse_next_fwd) and self.fused and precision == "bf16x3" and cohort is not None
-        # Early encoder chains (PipelinedStep): the forward chain of input layer i -- wide Linear (or the reduce of its
-        # fused partial sums) -> BatchNorm block -> small Linear(s) -- depends only on the batch, assembled one step ahead,
-        # and on encoder i's parameters.  It is recorded as its own tape t_enc[i]; the pipeline issues the NEXT plan's chain
-        # i on a side stream as soon as this step's optimiser has updated encoder i, so it overlaps the HBM-bound dW+Adam
-        # launches of the other wide weights (which leave the matrix cores idle) instead of opening the next step.
-        # The chain then runs BEFORE the next fx_step_begin: its Philox offsets carry a +1 step bias, so the draws are the
-        # ones the in-order schedule makes.
-        self.early_enc = bool(early_enc) and self.fused and train and cohort is not None
-        self.t_enc: List[TapeRecorder] = []
-        self.t_opt_big: List[Tuple[str, TapeRecorder]] = []
-        self._rng_bias = 0
         self._next_fwd: Dict[str, tuple] = {}
         self.t_boot = TapeRecorder()
         # attribution (eval plans): input-gradient tapes d head_output / d X for IntegratedGradients / GradientShap
@@ -328,7 +317,7 @@ class StepPlan:
 
     def _rng(self):
         self._rng_ctr += 1
-        return self.seed, (self._rng_ctr << 32) + self._rng_bias
+        return self.seed, (self._rng_ctr << 32)
 
     def _draw(self, name, *shape):
         """Supplied-randomness slot (parity mode): a static buffer the caller fills."""
@@ -739,7 +728,6 @@ class StepPlan:
         if set(self._next_fwd) != set(nxt._next_fwd):
             raise RuntimeError("link_next: the two plans fuse different layers")
         self.t_opt = TapeRecorder()
-        self.t_opt_big = []
         self._build_optimizer(nxt)
 
     def _build_mlp_family(self):
@@ -750,18 +738,11 @@ class StepPlan:
         trip = spec.model == "MultiTripletNetwork"
         tags = ["@a", "@p", "@n"] if trip else [""]
         ecat = self._new("ecat", R, n * L)
-        if self.early_enc:
-            for i in range(n):                                   # one tape per modality, issued by the pipeline (see __init__)
-                rec_i = self._begin_chain(i)
-                self._mlp_fwd(rec_i, f"encoders.{i}", self.X[i], ecat[:, i * L:(i + 1) * L], R, self.passes,
+        with rf.parallel(n if self.branches else 1) as par:      # one graph branch per modality
+            for i in range(n):
+                self._enter_branch(par, i)
+                self._mlp_fwd(rf, f"encoders.{i}", self.X[i], ecat[:, i * L:(i + 1) * L], R, self.passes,
                               [f"encoders.{i}{t}" for t in tags])
-                self._end_chain()
-        else:
-            with rf.parallel(n if self.branches else 1) as par:      # one graph branch per modality
-                for i in range(n):
-                    self._enter_branch(par, i)
-                    self._mlp_fwd(rf, f"encoders.{i}", self.X[i], ecat[:, i * L:(i + 1) * L], R, self.passes,
-                                  [f"encoders.{i}{t}" for t in tags])
         self._branch = 0
         if n > 1:
             emb = self._new("emb", R, L)
@@ -937,21 +918,6 @@ class StepPlan:
                 ops.rowlin_wgrad(rb, st.g(wr) if wr else None, st.g(ba), dy, h_in, scratch_w)
         self.buf["gnn/events"] = [j[0] for j in jobs]
 
-    def _begin_chain(self, i) -> TapeRecorder:
-        """Start recording the early forward chain of input layer i (own tape, own split-K scratch, +1 step RNG bias)."""
-        rec = TapeRecorder()
-        self.t_enc.append(rec)
-        self._branch = i
-        self._last_wide_ev = None
-        while len(self._ws) <= i:
-            self._ws.append(Workspace(self.dev))
-        self._rng_bias = 1 << 44
-        return rec
-
-    def _end_chain(self):
-        self._rng_bias = 0
-        self._branch = 0
-
     def _enter_branch(self, par, i):
         """Route subsequent emits to graph branch i (with its own split-K scratch)."""
         b = i if self.branches else 0
@@ -976,24 +942,15 @@ class StepPlan:
         mcat, vcat = self._new("mcat", B, n * L), self._new("vcat", B, n * L)
         hs = []
         vae_par = self.branches and os.environ.get("FX_VAE_BRANCHES", "1") != "0"
-        def enc_chain(rec, i):
-            p = f"encoders.{i}"
-            h = self._hidden_fwd(rec, p, self.X[enc[i]], B)
-            hs.append(h)
-            ops.linear_fwd(rec, mcat[:, i * L:(i + 1) * L], h, st.p(p + ".FC_mean.weight"), st.p(p + ".FC_mean.bias"), self.ws)
-            ops.linear_fwd(rec, vcat[:, i * L:(i + 1) * L], h, st.p(p + ".FC_var.weight"), st.p(p + ".FC_var.bias"), self.ws)
-
-        if self.early_enc:
+        with rf.parallel(n if vae_par else 1) as par:       # one graph branch per encoder (wide kernels staggered)
             for i in range(n):
-                rec_i = self._begin_chain(i)
-                enc_chain(rec_i, i)
-                self._end_chain()
-        else:
-            with rf.parallel(n if vae_par else 1) as par:       # one graph branch per encoder (wide kernels staggered)
-                for i in range(n):
-                    if vae_par:
-                        self._enter_branch(par, i)
-                    enc_chain(rf, i)
+                if vae_par:
+                    self._enter_branch(par, i)
+                p = f"encoders.{i}"
+                h = self._hidden_fwd(rf, p, self.X[enc[i]], B)
+                hs.append(h)
+                ops.linear_fwd(rf, mcat[:, i * L:(i + 1) * L], h, st.p(p + ".FC_mean.weight"), st.p(p + ".FC_mean.bias"), self.ws)
+                ops.linear_fwd(rf, vcat[:, i * L:(i + 1) * L], h, st.p(p + ".FC_var.weight"), st.p(p + ".FC_var.bias"), self.ws)
         self._branch = 0
         mean, logv, z = self._new("mean", B, L), self._new("log_var", B, L), self._new("z", B, L)
         ops.linear_fwd(rf, mean, mcat, st.p("FC_mean.weight"), st.p("FC_mean.bias"), self.ws)
@@ -1125,9 +1082,6 @@ class StepPlan:
             if self._is_frozen(k):
                 continue
             d = st.big[k]
-            if self.early_enc:                 # one tape per wide weight: the pipeline forks the next plan's chains between them
-                ro = TapeRecorder()
-                self.t_opt_big.append((k, ro))
             if self.fused and self.precision == "bf16x3":
                 dy, x, dyt, xt = self._jobs[k]
                 if k in self._next_fwd:
@@ -1180,24 +1134,8 @@ class StepPlan:
 
     input_gradient = ops.device_guard(input_gradient)
 
-    def _run_opt(self, timed=None):
-        for tape in [self.t_opt] + [t for _, t in self.t_opt_big]:
-            if timed is None:
-                tape.run()
-            else:
-                tape.run_timed(*timed)
-
-    @ops.device_guard
-    def run_chains(self):
-        """Issue the early encoder chains in order on the current stream (first step, or a plan run outside the pipeline).
-        Must come BEFORE the fx_step_begin of the step they belong to (their draws are keyed on step + 1)."""
-        for t in self.t_enc:
-            t.run()
-
     @ops.device_guard
     def forward(self):
-        if self.early_enc:
-            raise RuntimeError("a plan with early encoder chains is driven by PipelinedStep (run_chains + the step)")
         self.t_fwd.run()
 
     @ops.device_guard
@@ -1207,19 +1145,17 @@ class StepPlan:
     @ops.device_guard
     def optimizer_step(self, lr: float):
         ops.step_begin(ops.IMMEDIATE, self.store.ctrl, lr, 0)
-        self._run_opt()
+        self.t_opt.run()
 
     @ops.device_guard
     def train_step(self, lr: float, gather: bool = False):
         """One full optimisation step (eager launch of the recorded tapes)."""
         ops.step_begin(ops.IMMEDIATE, self.store.ctrl, lr, self.n_batches)
-        if self.early_enc:
-            raise RuntimeError("a plan with early encoder chains is driven by PipelinedStep")
         if gather:
             self.t_gather.run()
         self.t_fwd.run()
         self.t_bwd.run()
-        self._run_opt()
+        self.t_opt.run()
         self.bump_nbt()
 
     @ops.device_guard
@@ -1249,7 +1185,7 @@ class StepPlan:
             self.t_gather.run()
         self.t_fwd.run()
         self.t_bwd.run()
-        self._run_opt()
+        self.t_opt.run()
 
     @ops.device_guard
     def replay(self):
@@ -1257,8 +1193,7 @@ class StepPlan:
         self.bump_nbt()
 
     def n_launches(self):
-        return (len(self.t_gather) + len(self.t_fwd) + len(self.t_bwd) + len(self.t_opt) + sum(len(t) for t in self.t_enc) +
-                sum(len(t) for _, t in self.t_opt_big) + 1)
+        return len(self.t_gather) + len(self.t_fwd) + len(self.t_bwd) + len(self.t_opt) + 1
 
     def losses(self) -> Dict[str, float]:
         vals = self.loss_vec.detach().cpu().tolist()
@@ -1282,28 +1217,18 @@ class PipelinedStep:
 
     def __init__(self, store: ParamStore, B: int, *, cohort, n_batches: int, seed: int = 0,
                  precision: str = "bf16x3", epoch_acc: bool = True, clip: bool = True, frozen: Tuple[str, ...] = (),
-                 fuse_next_fwd: Optional[bool] = None, supplied_draws: bool = False, early_enc: Optional[bool] = None):
+                 fuse_next_fwd: Optional[bool] = None, supplied_draws: bool = False):
         if fuse_next_fwd is None:            # FX_FUSE_NEXT_FWD=0: A/B switch (separate forward kernel, 28 B/param/step)
             fuse_next_fwd = os.environ.get("FX_FUSE_NEXT_FWD", "1") != "0"
-        if early_enc is None:                # FX_EARLY_ENC=0: A/B switch (encoder forward chains open the step instead)
-            early_enc = os.environ.get("FX_EARLY_ENC", "1") != "0"
-        early_enc = bool(early_enc) and store.spec.model != "GNN"
         # supplied_draws: parity mode -- dropout masks / eps / priors are static buffers the caller fills before each step
         # (``pending.set_draws``) instead of in-kernel Philox draws; the schedule is otherwise the production one
         kw = dict(train=True, fused=True, supplied_draws=bool(supplied_draws), seed=seed, cohort=cohort, n_batches=n_batches,
-                  epoch_acc=epoch_acc, precision=precision, clip=clip, frozen=frozen, fuse_next_fwd=fuse_next_fwd,
-                  early_enc=early_enc)
+                  epoch_acc=epoch_acc, precision=precision, clip=clip, frozen=frozen, fuse_next_fwd=fuse_next_fwd)
         a = StepPlan(store, B, **kw)
         self.plans = [a, StepPlan(store, B, share=a, **kw)]
         if a._next_fwd:
             a.link_next(self.plans[1])
             self.plans[1].link_next(a)
-        self.early_enc = a.early_enc
-        # encoder index whose chain may start once a given wide weight has been updated (None: not an encoder's weight)
-        self._enc_of = {}
-        for key, _ in a.t_opt_big:
-            m = key.split(".")
-            self._enc_of[key] = int(m[1]) if m[0] == "encoders" and m[1].isdigit() and int(m[1]) < len(a.t_enc) else None
         self.store, self.n_batches, self.dev = store, int(n_batches), store.device
         self.idx, self.epoch_acc = a.idx, a.epoch_acc
         # FX_EARLY_GATHER=1 forks the batch assembly of step t+1 at the start of step t instead of after the losses.
@@ -1319,21 +1244,13 @@ class PipelinedStep:
         self.store.ctrl[ops.CTRL_CURSOR] = 0.0      # fx_step_begin advances it first: step t assembles row (t + 1) mod n_batches
         self.plans[0].t_gather.run()
         self.k, self.done = 0, 0
-        self.refresh()                       # wide-forward partial sums (+ early encoder chains) of batch 0
+        self.refresh()
 
     @ops.device_guard
-    def refresh(self, first: bool = True):
+    def refresh(self):
         """(Re)compute the wide-forward partial sums of the pending batch with the CURRENT weights: at the start, and
-        after any weight change made outside the pipeline (a partial-batch step, load_state, ...).  With early encoder
-        chains the pending plan's chains are (re)issued too; they update BatchNorm running statistics, so this is only
-        legal when they have not run yet for this batch (``prime``) -- fit() builds pipelines that need mid-run refreshes
-        without early chains."""
-        pend = self.plans[self.k]
-        pend.t_boot.run()
-        if self.early_enc:
-            if self.done:
-                raise RuntimeError("refresh() after the first step is not possible with early encoder chains")
-            pend.run_chains()
+        after any weight change made outside the pipeline (a partial-batch step, load_state, ...)."""
+        self.plans[self.k].t_boot.run()
 
     def epoch_end_next(self) -> bool:
         """True when the NEXT step is the last of its epoch, i.e. its prefetch reads row 0 of the next epoch's
@@ -1353,41 +1270,10 @@ class PipelinedStep:
         cur.t_bwd.run()                                   # ... overlaps the head / backward chain of step t
         for st in used:
             main.wait_stream(st)                          # join before the HBM-saturating dW+Adam launches
-        if not self.early_enc:
-            cur._run_opt(timed)
-            return
-        # small parameters first (norm, clip coefficient, flat Adam), then one launch per wide weight; the NEXT plan's
-        # forward chain of encoder i forks as soon as encoder i's parameters are final and overlaps the remaining launches
         if timed is None:
             cur.t_opt.run()
         else:
             cur.t_opt.run_timed(*timed)
-        waiting = set(range(len(nxt.t_enc)))
-        gated = {e for e in self._enc_of.values() if e is not None}
-        side = ops.side_streams(len(nxt.t_enc), group=0) if nxt.t_enc else []
-        forked = []
-
-        def fork(i):
-            waiting.discard(i)
-            side[i].wait_stream(main)
-            with torch.cuda.stream(side[i]):
-                nxt.t_enc[i].run()
-            forked.append(side[i])
-
-        for i in sorted(waiting - gated):                 # encoders without a wide weight of their own
-            fork(i)
-        for key, tape in cur.t_opt_big:
-            if timed is None:
-                tape.run()
-            else:
-                tape.run_timed(*timed)
-            e = self._enc_of.get(key)
-            if e is not None and e in waiting:
-                fork(e)
-        for i in sorted(waiting):
-            fork(i)
-        for st in forked:
-            main.wait_stream(st)
 
     @ops.device_guard
     def step(self, lr: float, timed=None):
@@ -1429,4 +1315,5 @@ class PipelinedStep:
         return self.last.losses()
 
     def n_launches(self):
-        return self.plans[0].n_launches()
+        p = self.plans[0]
+        return len(p.t_gather) + len(p.t_fwd) + len(p.t_bwd) + len(p.t_opt) + 1

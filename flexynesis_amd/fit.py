@@ -160,10 +160,7 @@ def _fit(model, store, dataset, train_idx, val_idx, *, batch_size, epochs, lr, p
     if supplied is not None and (trip or tail):
         raise ValueError("supplied permutations / draws cover full batches of the non-triplet models only")
     pipe = PipelinedStep(store, B, cohort=cohort, n_batches=n_batches, seed=int(seed) * 7919 + 13, epoch_acc=True,
-                         supplied_draws=supplied is not None, early_enc=False if (tail or supplied is not None) else None,
-                         **plan_kw) if n_batches >= 1 else None
-    # (early encoder chains consume the NEXT step's draws one step ahead and cannot be refreshed after a partial-batch step
-    # between epochs: both cases keep the encoder chains inside their own step)
+                         supplied_draws=supplied is not None, **plan_kw) if n_batches >= 1 else None
     tail_plan = StepPlan(store, tail, train=True, fused=True, supplied_draws=False, seed=int(seed) * 7919 + 17, cohort=cohort,
                          n_batches=0, epoch_acc=True, **plan_kw) if tail else None
     names = spec.loss_names()
