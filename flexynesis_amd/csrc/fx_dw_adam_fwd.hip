@@ -9,7 +9,8 @@
 //
 //   W [M = n_out, N = k_in] (+ m, v)        fp32, row-major, rows padded (ldw)
 //   dY^T [M, K], X^T [N, K]                  split bf16 (hi, lo), K = padded batch (fx_split_bf16_t / fx_gather_split)
-//   Xn  K-blocked [ceil(N/32)][128][32]      split bf16 of the NEXT batch (fx_gather_split / fx_split_bf16), <= 128 rows
+//   Xn  K-blocked [ceil(N/32)][Rp][32]       split bf16 of the NEXT batch (fx_gather_split / fx_split_bf16); Rp = 128 MT rows,
+//                                            MT = 1..3 M-tiles (the triplet network stacks anchor / positive / negative: 3 B rows)
 //   Y slabs [S][Mn][M]                       partial sums of Xn . W_new^T; fx_reduce_slabs adds them (+ bias) in order
 //
 // Work decomposition.  A workgroup (512 threads) owns one 64-row block of W and a RUN of consecutive 128-column tiles;
@@ -49,6 +50,7 @@ struct DwAdamFwdArgs {
   int Mn, kblocks;
   int tiles_m, tiles_n, S;
   long slab_stride;
+  int xcd_group;                            // 1: the S runs of a row block share an XCD (block id -> (XCD, row block, run))
 };
 
 __device__ __forceinline__ int ft_swz(int row, int chunk) { return row * FT_K + ((chunk ^ ((row >> 2) & 3)) << 3); }
@@ -66,7 +68,9 @@ __device__ __forceinline__ void ft_store32(float v, __amdgpu_buffer_rsrc_t r, un
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
 }
 
-template <int NT>
+// MT = M-tiles of the next batch (rows / 128); UNITS = 16-byte W / m / v units per thread in flight in the Adam phase
+// (4 for MT = 1; 2 for MT > 1, whose MT accumulator sets need the registers).
+template <int NT, int MT, int UNITS>
 __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g) {
   // LDS map (bf16 elements unless noted), 64 KB:
   //   phase 1 (dW K-loop)   stage s at s*12288: A hi [64][32] | A lo | B hi [128][32] | B lo          (2 x 24 KB)
@@ -75,7 +79,19 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
   __shared__ __attribute__((aligned(16))) __bf16 smem[32768];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave id, scalar
-  const int tm = blockIdx.x % g.tiles_m, c = blockIdx.x / g.tiles_m;
+  int tm, c;
+  if (g.xcd_group) {
+    // Workgroup ids go round-robin over the 8 XCDs.  Here every row block lives on ONE XCD with all its S runs, so its
+    // dY^T tile (64 rows x K, re-read for every column tile) is shared in that XCD's L2: with K = 3 B = 384 the tiles of
+    // the ~59 workgroups of an XCD would otherwise outgrow the 4 MB L2 (5.8 MB) and be re-fetched for every tile.
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    tm = (j / g.S) * 8 + xcd;
+    c = j % g.S;
+    if (tm >= g.tiles_m) return;                       // padding of the index space (before any barrier)
+  } else {
+    tm = blockIdx.x % g.tiles_m;
+    c = blockIdx.x / g.tiles_m;
+  }
   const int m0 = tm * FT_M;
   const int rows_valid = min(FT_M, g.M - m0);
   const int nk = g.K / FT_K;
@@ -87,7 +103,7 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
   const long abytes = (long)rows_valid * g.lda * 2;
   const __amdgpu_buffer_rsrc_t rAh = ft_rsrc(g.Ah + (long)m0 * g.lda, abytes), rAl = ft_rsrc(g.Al + (long)m0 * g.lda, abytes);
   const __amdgpu_buffer_rsrc_t rBh = ft_rsrc(g.Bh, (long)g.N * g.ldb * 2), rBl = ft_rsrc(g.Bl, (long)g.N * g.ldb * 2);
-  const long xbytes = (long)g.kblocks * 128 * FT_K * 2;
+  const long xbytes = (long)g.kblocks * (128 * MT) * FT_K * 2;
   const __amdgpu_buffer_rsrc_t rXh = ft_rsrc(g.Xh, xbytes), rXl = ft_rsrc(g.Xl, xbytes);
 
   // ---- LDS-DMA source addressing: a wave instruction fills 16 rows x 64 B in lane order (row = lane / 4, 16-byte slot =
@@ -97,7 +113,7 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
   const unsigned a_src = (unsigned)(((long)a_r * g.lda + 8 * (ds ^ ((a_r >> 2) & 3))) * 2);
   const int b_r = 16 * w + dr;                                         // B / X rows 0..127
   const int b_ch = ds ^ ((b_r >> 2) & 3);
-  const unsigned x_src = (unsigned)((b_r * FT_K + 8 * b_ch) * 2);      // within one K-blocked [128][32] block
+  const unsigned x_src = (unsigned)((b_r * FT_K + 8 * b_ch) * 2);      // within one M-tile of a K-blocked [128 MT][32] block
 
   // ---- fragment coordinates
   const int l31 = lane & 31, kh = lane >> 5;
@@ -109,9 +125,11 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
   const float lr = g.ctrl[FXC_LR], bc1 = g.ctrl[FXC_BC1], bc2s = g.ctrl[FXC_BC2_SQRT], coef = g.ctrl[FXC_CLIP_COEF];
   const float step_size = lr / bc1;
 
-  f32x16 yacc;
+  f32x16 yacc[MT];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) yacc[i] = 0.f;
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) yacc[m][i] = 0.f;
 
   // Run c takes the column tiles c, c + S, c + 2 S, ...: the S workgroups of a row block sit on ADJACENT tiles at any
   // moment (a contiguous S x 512-byte window of every row of W / m / v moves along the rows), and all row blocks work on
@@ -156,12 +174,15 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
     for (int r = 0; r < 16; ++r) ct[(32 * rb + (r & 3) + 8 * (r >> 2) + 4 * kh) * FT_N + 32 * cb + l31] = acc[r];
     __syncthreads();
     // ================= phase 3: Adam on 512-byte row segments; W_new -> bf16 (hi, lo) in LDS =================
-    {
-      u32x4 p4[4], m4[4], v4[4];
-      unsigned off[4];
+    __bf16* wn_hi = smem + 16384;
+    __bf16* wn_lo = smem + 24576;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int u = tid + FT_T * i, row = u >> 5, c4 = u & 31;
+    for (int pass = 0; pass < 4 / UNITS; ++pass) {
+      u32x4 p4[UNITS], m4[UNITS], v4[UNITS];
+      unsigned off[UNITS];
+#pragma unroll
+      for (int i = 0; i < UNITS; ++i) {
+        const int u = tid + FT_T * (pass * UNITS + i), row = u >> 5, c4 = u & 31;
         const int gn = n0 + 4 * c4;
         // rows >= rows_valid fall beyond num_records; columns >= N are pushed out of range explicitly
         off[i] = (unsigned)(((long)row * g.ldw + gn) * 4) | ((gn < g.N) ? 0u : 0xFFFFFFF0u);
@@ -169,11 +190,9 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
         m4[i] = __builtin_amdgcn_raw_buffer_load_b128(rM, off[i], 0, NT);
         v4[i] = __builtin_amdgcn_raw_buffer_load_b128(rV, off[i], 0, NT);
       }
-      __bf16* wn_hi = smem + 16384;
-      __bf16* wn_lo = smem + 24576;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int u = tid + FT_T * i, row = u >> 5, c4 = u & 31;
+      for (int i = 0; i < UNITS; ++i) {
+        const int u = tid + FT_T * (pass * UNITS + i), row = u >> 5, c4 = u & 31;
         const f32x4 g4 = *reinterpret_cast<const f32x4*>(ct + row * FT_N + 4 * c4);
         const f32x4 pf = __builtin_bit_cast(f32x4, p4[i]), mf = __builtin_bit_cast(f32x4, m4[i]);
         const f32x4 vf = __builtin_bit_cast(f32x4, v4[i]);
@@ -202,19 +221,21 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
     }
     __syncthreads();                         // W_new (hi, lo) visible; ct is dead -> its space stages the next batch
     // ================= phase 4: Y[b, m0 + h] += Xn[b, n0 .. n0 + 127] . W_new[h, :]^T =================
-#define FT_GLDS_X(stage, kb)                                                                              \
+    // sub-step q = m * 4 + kb: M-tile m of the next batch against K-step block kb of the tile
+#define FT_GLDS_X(stage, q)                                                                               \
   {                                                                                                       \
     __bf16* xb = smem + (stage) * 8192;                                                                   \
-    const unsigned xo = (unsigned)(n0 / FT_K + (kb)) * (128u * FT_K * 2u) + x_src;                        \
+    const unsigned xo = (unsigned)(n0 / FT_K + ((q) & 3)) * (128u * MT * FT_K * 2u) + (unsigned)((q) >> 2) * (128u * FT_K * 2u) + x_src; \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rXh, LDS_PTR(xb + w * 512), 16, xo, 0, 0, 0);                \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rXl, LDS_PTR(xb + 4096 + w * 512), 16, xo, 0, 0, 0);         \
   }
     FT_GLDS_X(0, 0);
 #pragma unroll
-    for (int kb = 0; kb < FT_N / FT_K; ++kb) {
+    for (int q = 0; q < 4 * MT; ++q) {
       __syncthreads();
-      if (kb + 1 < FT_N / FT_K) FT_GLDS_X((kb + 1) & 1, kb + 1);
-      const __bf16* xb = smem + (kb & 1) * 8192;
+      if (q + 1 < 4 * MT) FT_GLDS_X((q + 1) & 1, q + 1);
+      const int kb = q & 3, m = q >> 2;
+      const __bf16* xb = smem + (q & 1) * 8192;
       const __bf16* wh = smem + 16384 + kb * 2048;
       const __bf16* wl = smem + 24576 + kb * 2048;
 #pragma unroll
@@ -223,9 +244,9 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
         const bf16x8 al = *reinterpret_cast<const bf16x8*>(xb + 4096 + ft_swz(fa_f, 2 * ks + kh));
         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wh + ft_swz(fb_f, 2 * ks + kh));
         const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wl + ft_swz(fb_f, 2 * ks + kh));
-        yacc = FT_MFMA(al, bh, yacc);
-        yacc = FT_MFMA(ah, bl, yacc);
-        yacc = FT_MFMA(ah, bh, yacc);
+        yacc[m] = FT_MFMA(al, bh, yacc[m]);
+        yacc[m] = FT_MFMA(ah, bl, yacc[m]);
+        yacc[m] = FT_MFMA(ah, bh, yacc[m]);
       }
     }
     __syncthreads();                         // the next tile's first DMA overwrites the X stages / W_new
@@ -236,10 +257,12 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
   const int hcol = m0 + 32 * hq + l31;
   const unsigned oob = (hcol < g.M) ? 0u : 0xFFFFFFF0u;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int b = 32 * bq + (r & 3) + 8 * (r >> 2) + 4 * kh;
-    ft_store32(yacc[r], rY, (unsigned)(((long)b * g.M + hcol) * 4) | oob);
-  }
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int b = 128 * m + 32 * bq + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      ft_store32(yacc[m][r], rY, (unsigned)(((long)b * g.M + hcol) * 4) | oob);
+    }
 }
 
 static inline bool ft_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -263,7 +286,7 @@ int fx_linear_dw_adam_fwd_bf16x3_slabs(int n_out, int k_in) {
 int fx_linear_dw_adam_fwd_bf16x3(float* W, float* adam_m, float* adam_v, const void* dyT_hi, const void* dyT_lo,
                                  const void* xT_hi, const void* xT_lo, int batch_padded, int n_out, int k_in, long lddy,
                                  long ldx, long ldw, const float* ctrl, const void* xn_hi, const void* xn_lo,
-                                 long xn_rows_padded, int next_rows, float* y_slabs, long y_slabs_bytes, int nt,
+                                 long xn_rows_padded, int next_rows, float* y_slabs, long y_slabs_bytes, int flags,
                                  hipStream_t stream) {
   FX_REQUIRE(W && adam_m && adam_v && dyT_hi && dyT_lo && xT_hi && xT_lo && ctrl && xn_hi && xn_lo && y_slabs,
              "fx_linear_dw_adam_fwd_bf16x3: null pointer");
@@ -275,8 +298,10 @@ int fx_linear_dw_adam_fwd_bf16x3(float* W, float* adam_m, float* adam_v, const v
   FX_REQUIRE(lddy % 8 == 0 && ldx % 8 == 0 && lddy >= batch_padded && ldx >= batch_padded && ft_aligned16(dyT_hi) &&
                  ft_aligned16(dyT_lo) && ft_aligned16(xT_hi) && ft_aligned16(xT_lo),
              "fx_linear_dw_adam_fwd_bf16x3: transposed operands must be 16-byte aligned with ld %% 8 == 0");
-  FX_REQUIRE(xn_rows_padded == 128 && next_rows > 0 && next_rows <= 128 && ft_aligned16(xn_hi) && ft_aligned16(xn_lo),
-             "fx_linear_dw_adam_fwd_bf16x3: the next batch is a K-blocked split of at most 128 rows (rows padded to 128)");
+  FX_REQUIRE((xn_rows_padded == 128 || xn_rows_padded == 256 || xn_rows_padded == 384) && next_rows > 0 &&
+                 next_rows <= xn_rows_padded && ft_aligned16(xn_hi) && ft_aligned16(xn_lo),
+             "fx_linear_dw_adam_fwd_bf16x3: the next batch is a K-blocked split of at most 384 rows (rows padded to 128 / 256 / 384)");
+  FX_REQUIRE((long)((k_in + FT_K - 1) / FT_K) * xn_rows_padded * FT_K * 2 < 0xF0000000L, "fx_linear_dw_adam_fwd_bf16x3: next batch exceeds 4 GiB");
   FX_REQUIRE((long)k_in * ldx * 2 < 0xF0000000L && (long)FT_M * ldw * 4 < 0xF0000000L && (long)FT_M * lddy * 2 < 0xF0000000L,
              "fx_linear_dw_adam_fwd_bf16x3: operand row block exceeds 4 GiB");
   DwAdamFwdArgs g{};
@@ -291,12 +316,21 @@ int fx_linear_dw_adam_fwd_bf16x3(float* W, float* adam_m, float* adam_v, const v
   g.tiles_m = (n_out + FT_M - 1) / FT_M; g.tiles_n = (k_in + FT_N - 1) / FT_N;
   g.S = ft_runs(n_out, k_in);
   g.slab_stride = (long)next_rows * n_out;
+  // flags: bit 0 = non-temporal W / m / v accesses; bits 1-2 = block mapping: 0 auto (XCD-grouped row blocks when the
+  // dY^T tiles of an XCD's workgroups would outgrow its L2), 1 = plain, 2 = XCD-grouped
+  const int nt = flags & 1, map = (flags >> 1) & 3;
+  g.xcd_group = map == 2 || (map == 0 && (long)FT_M * batch_padded * 4 * 60 > (3L << 20));
   FX_REQUIRE(y_slabs_bytes >= (long)g.S * g.slab_stride * 4, "fx_linear_dw_adam_fwd_bf16x3: slab buffer too small (%ld bytes for %d slabs)",
              y_slabs_bytes, g.S);
-  const long nblk = (long)g.tiles_m * g.S;
+  const long nblk = g.xcd_group ? 8L * ((g.tiles_m + 7) / 8) * g.S : (long)g.tiles_m * g.S;
   FX_REQUIRE(nblk < (1L << 31), "fx_linear_dw_adam_fwd_bf16x3: grid too large");
-  if (nt) hipLaunchKernelGGL((fx_dw_adam_fwd_kernel<2>), dim3((unsigned)nblk), dim3(FT_T), 0, stream, g);
-  else hipLaunchKernelGGL((fx_dw_adam_fwd_kernel<0>), dim3((unsigned)nblk), dim3(FT_T), 0, stream, g);
+  const dim3 grid((unsigned)nblk), blk(FT_T);
+  const int mt = (int)(xn_rows_padded / 128);
+#define FT_LAUNCH(NTV, MTV, UV) hipLaunchKernelGGL((fx_dw_adam_fwd_kernel<NTV, MTV, UV>), grid, blk, 0, stream, g)
+  if (mt == 1) { if (nt) FT_LAUNCH(2, 1, 4); else FT_LAUNCH(0, 1, 4); }
+  else if (mt == 2) { if (nt) FT_LAUNCH(2, 2, 2); else FT_LAUNCH(0, 2, 2); }
+  else { if (nt) FT_LAUNCH(2, 3, 2); else FT_LAUNCH(0, 3, 2); }
+#undef FT_LAUNCH
   return fx_check_launch("fx_linear_dw_adam_fwd_bf16x3");
 }
 

@@ -466,10 +466,11 @@ class StepPlan:
 
     def _can_fuse_next(self, wkey, x) -> bool:
         """The wide forward can ride on the previous step's dW+Adam launch when its input is a batch operand that the
-        gather assembles one step ahead (not an activation of this step), of at most 128 rows, and the weight is trained."""
+        gather assembles one step ahead (not an activation of this step), of at most 384 rows (three 128-row M-tiles: the
+        triplet network's stacked anchor / positive / negative rows at B <= 128), and the weight is trained."""
         if not (self.fuse_next and self.train and wkey in self.store.big) or self._is_frozen(wkey):
             return False
-        if x.shape[0] != self.R or x.shape[0] > 128 or x.shape[1] % 4 != 0:
+        if x.shape[0] != self.R or x.shape[0] > 384 or x.shape[1] % 4 != 0:
             return False
         return any(x.data_ptr() == X.data_ptr() for X in self.X) and ("fwd", x.data_ptr()) in self._split_cache
 

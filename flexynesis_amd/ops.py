@@ -437,7 +437,8 @@ def dw_adam_fwd_slabs(n_out: int, k_in: int) -> int:
     return int(lib.fx_linear_dw_adam_fwd_bf16x3_slabs(int(n_out), int(k_in)))
 
 
-def linear_dw_adam_fwd_bf16x3(rec, W, m, v, dyT_hi, dyT_lo, xT_hi, xT_lo, ctrl, xn_hi, xn_lo, next_rows, y_slabs, nt=True):
+def linear_dw_adam_fwd_bf16x3(rec, W, m, v, dyT_hi, dyT_lo, xT_hi, xT_lo, ctrl, xn_hi, xn_lo, next_rows, y_slabs, nt=True,
+                              mapping=0):
     """W[N,K] <- Adam(clip * dY^T X) as linear_dw_adam_bf16x3, and y_slabs[s] = partial sums of x_next W_new^T
     (x_next: K-blocked split of the NEXT batch, new_split_kb(next_rows, K)); reduce with reduce_slabs."""
     for t, n in ((W, "W"), (m, "m"), (v, "v")):
@@ -454,7 +455,8 @@ def linear_dw_adam_fwd_bf16x3(rec, W, m, v, dyT_hi, dyT_lo, xT_hi, xT_lo, ctrl, 
         raise FxError(f"linear_dw_adam_fwd_bf16x3: y_slabs must hold {S} x {next_rows} x {N} fp32")
     rec.emit("fx_linear_dw_adam_fwd_bf16x3", W.data_ptr(), m.data_ptr(), v.data_ptr(), dyT_hi.data_ptr(), dyT_lo.data_ptr(),
              xT_hi.data_ptr(), xT_lo.data_ptr(), Bp, N, K, _ld(dyT_hi), _ld(xT_hi), _ld(W), ctrl.data_ptr(), xn_hi.data_ptr(),
-             xn_lo.data_ptr(), xn_hi.shape[1], int(next_rows), y_slabs.data_ptr(), y_slabs.numel() * 4, int(bool(nt)))
+             xn_lo.data_ptr(), xn_hi.shape[1], int(next_rows), y_slabs.data_ptr(), y_slabs.numel() * 4,
+             int(bool(nt)) | ((int(mapping) & 3) << 1))
 
 
 def reduce_slabs(rec, y, slabs, bias, n_slabs):

@@ -106,16 +106,18 @@ int fx_linear_dw_adam_bf16x3_ex(float* W, float* adam_m, float* adam_v, const vo
                                 fx_stream_t stream);
 /* The same optimiser step for one wide weight PLUS the wide-layer forward of the FOLLOWING training step
  * (nn.Linear of modules.py:145 / :28 applied to the next batch, main.py:289-298's next DataLoader item): while a tile of
- * W_new is in registers it is multiplied into the next batch xn (K-blocked split of <= 128 rows, xn_rows_padded = 128),
- * so the next step does not read W again (24 instead of 28 bytes per parameter and step).  The partial sums land in
+ * W_new is in registers it is multiplied into the next batch xn (K-blocked split of <= 384 rows -- the triplet network
+ * stacks anchor / positive / negative --, xn_rows_padded = 128, 256 or 384), so the next step does not read W again (24
+ * instead of 28 bytes per parameter and step).  The partial sums land in
  * y_slabs [fx_linear_dw_adam_fwd_bf16x3_slabs(n_out, k_in)][next_rows][n_out]; fx_reduce_slabs adds them (+ bias) in a
- * fixed order.  W, m, v results are bit-identical to fx_linear_dw_adam_bf16x3.  nt != 0: non-temporal W / m / v accesses.
- * k_in % 4 == 0; descriptors are rebased per row block, so the weight itself may exceed 4 GiB. */
+ * fixed order.  W, m, v results are bit-identical to fx_linear_dw_adam_bf16x3.
+ * flags: bit 0 = non-temporal W / m / v accesses; bits 1-2 = workgroup mapping (0 auto, 1 plain, 2 row blocks grouped per
+ * XCD).  k_in % 4 == 0; descriptors are rebased per row block, so the weight itself may exceed 4 GiB. */
 int fx_linear_dw_adam_fwd_bf16x3_slabs(int n_out, int k_in);
 int fx_linear_dw_adam_fwd_bf16x3(float* W, float* adam_m, float* adam_v, const void* dyT_hi, const void* dyT_lo,
                                  const void* xT_hi, const void* xT_lo, int batch_padded, int n_out, int k_in, long lddy,
                                  long ldx, long ldw, const float* ctrl, const void* xn_hi, const void* xn_lo,
-                                 long xn_rows_padded, int next_rows, float* y_slabs, long y_slabs_bytes, int nt,
+                                 long xn_rows_padded, int next_rows, float* y_slabs, long y_slabs_bytes, int flags,
                                  fx_stream_t stream);
 /* Y[M,N] = sum_z slabs[z][M][N] (+ bias[N]), summed in slab order (deterministic) */
 int fx_reduce_slabs(float* Y, const float* slabs, const float* bias, int M, int N, long ldy, int n_slabs, long slab_stride,

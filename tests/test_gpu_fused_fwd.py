@@ -16,6 +16,9 @@ pytestmark = pytest.mark.gpu
     (1250, 5000, 64, 64),         # cfg1 shape
     (2050, 2052, 128, 37),        # row-block and column remainders of 2 / 4
     (5000, 20000, 128, 128),      # cfg2 shape (what bench.py runs)
+    (700, 1500, 96, 200),         # two M-tiles of the next batch (rows padded to 256), K = 96
+    (1875, 3000, 384, 384),       # triplet: 3 B stacked rows = three M-tiles, K = 384 (XCD-grouped row blocks)
+    (7500, 30000, 384, 384),      # cfg4 shape
 ])
 def test_dw_adam_fwd_matches_the_kernels_it_replaces(n_out, k_in, B, Bn):
     from flexynesis_amd import ops
@@ -51,6 +54,13 @@ def test_dw_adam_fwd_matches_the_kernels_it_replaces(n_out, k_in, B, Bn):
     slabs = torch.full((S, Bn, n_out), float("nan"), device=dev)
     ops.linear_dw_adam_fwd_bf16x3(ops.IMMEDIATE, W2[:, :k_in], m2[:, :k_in], v2[:, :k_in], dyt[0], dyt[1], xt[0], xt[1], ctrl,
                                   xnh, xnl, Bn, slabs)
+    if n_out == 1875:             # both workgroup mappings give the same bits
+        W3, m3, v3 = W0.clone(), m0.clone(), v0.clone()
+        slabs3 = torch.full((S, Bn, n_out), float("nan"), device=dev)
+        ops.linear_dw_adam_fwd_bf16x3(ops.IMMEDIATE, W3[:, :k_in], m3[:, :k_in], v3[:, :k_in], dyt[0], dyt[1], xt[0], xt[1], ctrl,
+                                      xnh, xnl, Bn, slabs3, mapping=1)
+        torch.cuda.synchronize()
+        assert torch.equal(W3, W2) and torch.equal(slabs3, slabs)
     y2 = torch.empty(Bn, n_out, device=dev)
     ops.reduce_slabs(ops.IMMEDIATE, y2, slabs, bias, S)
     torch.cuda.synchronize()
@@ -86,6 +96,7 @@ def test_dw_adam_fwd_argument_checks():
     ("DirectPred", [("gex", 4100), ("cnv", 3000)], 37),              # ragged batch: rows padded to 128 / 64
     ("supervised_vae", [("gex", 2600), ("cnv", 2200)], 64),          # encoders fused, decoders (activations as input) not
     ("DirectPred", [("gex", 20000), ("cnv", 20000)], 128),           # cfg2: the shape bench.py times
+    ("MultiTripletNetwork", [("gex", 2600), ("cnv", 2200)], 96),     # 3 B = 288 stacked rows: three M-tiles
 ])
 def test_pipeline_fused_forward_is_the_forward_of_the_next_batch(model, layers, B):
     """Engine wiring: after step t the slabs of the pending plan, summed, must equal a stand-alone wide forward of the
@@ -95,12 +106,13 @@ def test_pipeline_fused_forward_is_the_forward_of_the_next_batch(model, layers, 
     from flexynesis_amd.data import synthetic_cohort
     from flexynesis_amd.engine import ParamStore, PipelinedStep
     dev = _dev()
-    variables = [("y", "numerical", 1), ("c", "categorical", 4)]
+    trip = model == "MultiTripletNetwork"
+    variables = [("c", "categorical", 4), ("y", "numerical", 1)] if trip else [("y", "numerical", 1), ("c", "categorical", 4)]
     spec = ArchSpec(model, layers, 32, 0.25, 16, variables, None, None, True)
     cohort = synthetic_cohort(layers, 700, dev, seed=3)
     nb = 4
     g = torch.Generator().manual_seed(1)
-    tables = [torch.randint(0, 700, (nb * B,), generator=g).to(dev) for _ in range(4)]
+    tables = [torch.randint(0, 700, (nb * B * (3 if trip else 1),), generator=g).to(dev) for _ in range(4)]
     torch.manual_seed(5)
     init = ParamStore(spec, dev, materialize_big_grads=False).state_dict()
 
