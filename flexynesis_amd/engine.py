@@ -470,7 +470,12 @@ class StepPlan:
         triplet network's stacked anchor / positive / negative rows at B <= 128), and the weight is trained."""
         if not (self.fuse_next and self.train and wkey in self.store.big) or self._is_frozen(wkey):
             return False
-        if x.shape[0] != self.R or x.shape[0] > 384 or x.shape[1] % 4 != 0:
+        # The kernel handles up to three 128-row M-tiles of the next batch (the triplet network's 3 B stacked rows), but beyond
+        # one tile it is slower than the separate kernels: at cfg4 (K = 3 B = 384, 3 M-tiles) 1.92 ms per weight against
+        # 1.18 + 0.59 ms -- 24 dependent LDS-DMA steps per tile in 64 KB of LDS leave it latency-bound (FX_FUSE_NEXT_MT=1
+        # enables it for measurements).
+        max_rows = 384 if os.environ.get("FX_FUSE_NEXT_MT", "0") == "1" else 128
+        if x.shape[0] != self.R or x.shape[0] > max_rows or x.shape[1] % 4 != 0:
             return False
         return any(x.data_ptr() == X.data_ptr() for X in self.X) and ("fwd", x.data_ptr()) in self._split_cache
 

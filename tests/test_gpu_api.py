@@ -276,7 +276,7 @@ def test_pipelined_step_equals_plain_step(model_name):
         store = ParamStore(spec, dev)
         store.load_state(init)
         pipe = PipelinedStep(store, B, cohort=cohort, n_batches=nb, seed=9, fuse_next_fwd=fuse)
-        assert bool(pipe.plans[0]._next_fwd) == fuse
+        assert bool(pipe.plans[0]._next_fwd) == (fuse and rows <= 128)   # (more than one M-tile: the separate forward is faster)
         pipe.idx.copy_(tables[0])
         pipe.prime()
         out, e = [], 0

@@ -98,7 +98,7 @@ def test_dw_adam_fwd_argument_checks():
     ("DirectPred", [("gex", 20000), ("cnv", 20000)], 128),           # cfg2: the shape bench.py times
     ("MultiTripletNetwork", [("gex", 2600), ("cnv", 2200)], 96),     # 3 B = 288 stacked rows: three M-tiles
 ])
-def test_pipeline_fused_forward_is_the_forward_of_the_next_batch(model, layers, B):
+def test_pipeline_fused_forward_is_the_forward_of_the_next_batch(model, layers, B, monkeypatch):
     """Engine wiring: after step t the slabs of the pending plan, summed, must equal a stand-alone wide forward of the
     pending batch with the weights as they are NOW (t_boot recomputes exactly that); then the trajectory with the fusion
     tracks the one without it, and hipGraph replay reproduces eager launches bit for bit."""
@@ -106,6 +106,7 @@ def test_pipeline_fused_forward_is_the_forward_of_the_next_batch(model, layers, 
     from flexynesis_amd.data import synthetic_cohort
     from flexynesis_amd.engine import ParamStore, PipelinedStep
     dev = _dev()
+    monkeypatch.setenv("FX_FUSE_NEXT_MT", "1")          # exercise the multi-M-tile path too (off by default: slower)
     trip = model == "MultiTripletNetwork"
     variables = [("c", "categorical", 4), ("y", "numerical", 1)] if trip else [("y", "numerical", 1), ("c", "categorical", 4)]
     spec = ArchSpec(model, layers, 32, 0.25, 16, variables, None, None, True)
