@@ -185,10 +185,11 @@ def main():
             # in separate rocprofv3 --pmc passes of this same command and committed under profiles/.
             traffic = None
             try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_cfg2.json")))
-                if a.config == "cfg2" and B == 128 and a.precision == "bf16x3":
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic_cfg2.json")))
+                if a.config == "cfg2" and B == 128 and a.precision == "bf16x3" and not a.features:
+                    want = "fx_dw_adam_fwd_kernel" if dominant.endswith("_fwd_bf16x3") else "fx_gemm_bf16x3_kernel<false, 1"
                     for kname, d in pm["kernels"].items():
-                        if kname.startswith("fx_gemm_bf16x3_kernel<false, 1"):
+                        if kname.startswith(want):
                             traffic = d["hbm_bytes_per_launch_corrected"]
             except Exception:
                 traffic = None
