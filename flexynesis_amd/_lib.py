@@ -58,6 +58,8 @@ PROTOTYPES = {
     "fx_linear_bwd_x_bf16x3": (I, [P, P, P, P, I, I, I, L, L, L, P, L, P]),
     "fx_bn_act_fwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, L, L, I, I, I, F, U64, U64, P, P]),
     "fx_bn_act_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, L, L, L, L, I, I, F, I, P]),
+    "fx_small_linear_fwd": (I, [P, P, P, P, I, I, I, L, L, P]),
+    "fx_small_linear_bwd": (I, [P, P, P, P, P, P, I, I, I, L, L, L, I, P]),
     "fx_bn_eval_bwd": (I, [P, P, P, P, P, P, I, I, L, L, L, L, I, I, P]),
     "fx_sigmoid": (I, [P, P, L, P]),
     "fx_sigmoid_bwd": (I, [P, P, P, L, P]),
@@ -76,6 +78,7 @@ PROTOTYPES = {
     "fx_mmd_finalize": (I, [P, P, I, I, P, I, F, F, I, P]),
     "fx_total_loss": (I, [P, I, I, P, P, P, P, P]),
     "fx_step_begin": (I, [P, F, I, P]),
+    "fx_adam_flat_clip": (I, [P, P, P, P, L, P, P, P, I, F, P]),
     "fx_fill": (I, [P, L, F, P]),
     "fx_scale_by": (I, [P, L, P, P]),
     "fx_stream_copy": (I, [P, P, L, P]),

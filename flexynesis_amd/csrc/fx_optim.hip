@@ -139,6 +139,42 @@ __global__ __launch_bounds__(256) void fx_adam_flat_kernel(float* __restrict__ p
   }
 }
 
+// fx_clip_finalize + fx_adam_flat in one launch: EVERY workgroup adds up the norm slots itself (a few hundred doubles from
+// L2, the same fixed order, so all workgroups get the same bits), derives the clip coefficient and applies Adam to its part
+// of the arena; workgroup 0 also publishes the norm and the coefficient in the control block for the wide-weight kernels
+// that follow.  One dependent launch less between the backward and the dW+Adam kernels.
+__global__ __launch_bounds__(256) void fx_adam_flat_clip_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                                float* __restrict__ m, float* __restrict__ v, long n,
+                                                                float* __restrict__ ctrl, const float* __restrict__ trainable,
+                                                                const double* __restrict__ slots, int n_slots, float max_norm) {
+  __shared__ double sm[16];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n_slots; i += blockDim.x) acc += slots[i];
+  acc = fx_block_sum_d(acc, sm);
+  const float total = (float)sqrt(acc);
+  float coef = 1.0f;
+  if (max_norm > 0.f) {
+    coef = max_norm / (total + 1e-6f);
+    coef = coef > 1.0f ? 1.0f : coef;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    ctrl[FXC_GNORM] = total;
+    ctrl[FXC_CLIP_COEF] = coef;
+  }
+  const float lr = ctrl[FXC_LR], bc1 = ctrl[FXC_BC1], bc2s = ctrl[FXC_BC2_SQRT];
+  const float step_size = lr / bc1;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    if (trainable && trainable[i] == 0.f) continue;
+    const float gr = g[i] * coef;
+    const float m2 = m[i] + (gr - m[i]) * (1.0f - FX_BETA1);
+    const float v2 = v[i] * FX_BETA2 + (1.0f - FX_BETA2) * gr * gr;
+    const float denom = sqrtf(v2) / bc2s + FX_ADAM_EPS;
+    p[i] = p[i] - step_size * (m2 / denom);
+    m[i] = m2;
+    v[i] = v2;
+  }
+}
+
 // ---- cohort gather: dst[r, :] = src[idx[r], :]  (16-byte coalesced row copies) -------------------------
 __global__ __launch_bounds__(256) void fx_gather_rows_kernel(float* __restrict__ dst, const float* __restrict__ src,
                                                              const long* __restrict__ idx, int n_rows, int n_cols,
@@ -236,6 +272,16 @@ int fx_adam_flat(float* p, const float* g, float* m, float* v, long n, const flo
   if (b > 4096) b = 4096;
   hipLaunchKernelGGL(fx_adam_flat_kernel, dim3((unsigned)b), dim3(256), 0, stream, p, g, m, v, n, ctrl, trainable);
   return fx_check_launch("fx_adam_flat");
+}
+
+int fx_adam_flat_clip(float* p, const float* g, float* m, float* v, long n, float* ctrl, const float* trainable,
+                      const double* slots, int n_slots, float max_norm, hipStream_t stream) {
+  FX_REQUIRE(p && g && m && v && ctrl && slots && n > 0 && n_slots > 0, "fx_adam_flat_clip: bad args");
+  long b = (n + 255) / 256;
+  if (b > 1024) b = 1024;
+  hipLaunchKernelGGL(fx_adam_flat_clip_kernel, dim3((unsigned)b), dim3(256), 0, stream, p, g, m, v, n, ctrl, trainable, slots,
+                     n_slots, max_norm);
+  return fx_check_launch("fx_adam_flat_clip");
 }
 
 int fx_gather_rows(float* dst, const float* src, const long* idx, int n_rows, int n_cols, long ld_src, long ld_dst,

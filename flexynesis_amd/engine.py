@@ -258,6 +258,7 @@ class StepPlan:
         self.block_bwd = os.environ.get("FX_BLOCK_BWD", "1") != "0"
         # all supervisor heads in one launch each way (fx_heads_fwd/bwd); FX_FUSE_HEADS=0 is an A/B switch for benchmarks
         self.fuse_heads = bool(fuse_heads) and os.environ.get("FX_FUSE_HEADS", "1") != "0"
+        self.small_linear = os.environ.get("FX_SMALL_LINEAR", "1") != "0"
         self._gram_x: Dict[int, tuple] = {}
         self._jobs: Dict[str, tuple] = {}
         self._slot_o = 0
@@ -490,6 +491,28 @@ class StepPlan:
             ops.split_bf16(rec, sp[0], sp[1], dy)
             ops.linear_bwd_x_bf16x3(rec, dx, sp[0], sp[1], W, self.ws)
         else:
+            ops.linear_bwd_x(rec, dx, dy, W, self.ws)
+
+    def _small_fwd(self, rec, y, x, wkey, bkey):
+        """A small dense layer on the critical chain (fusion layer, VAE FC_mean / FC_log_var): one latency-lean launch
+        (fx_small_linear_fwd) instead of the tiled MFMA GEMM (FX_SMALL_LINEAR=0: A/B switch)."""
+        st = self.store
+        W = st.p(wkey)
+        if self.small_linear and wkey not in st.big and ops.small_linear_ok(x, W):
+            ops.small_linear_fwd(rec, y, x, W, st.p(bkey))
+        else:
+            ops.linear_fwd(rec, y, x, W, st.p(bkey), self.ws)
+
+    def _small_bwd(self, rec, dx, dy, x, wkey, bkey, need_dx=True):
+        """All three gradients of such a layer in one launch (weight, bias, data) instead of three."""
+        st = self.store
+        W = st.p(wkey)
+        if self.small_linear and wkey not in st.big and not self._is_frozen(wkey) and ops.small_linear_ok(x, W):
+            ops.small_linear_bwd(rec, dx if need_dx else None, st.g(wkey), st.g(bkey), dy, x, W)
+            return
+        self._weight_grad(rec, wkey, dy, x)
+        ops.colsum(rec, st.g(bkey), dy)
+        if need_dx:
             ops.linear_bwd_x(rec, dx, dy, W, self.ws)
 
     def _is_frozen(self, key: str) -> bool:
@@ -752,7 +775,7 @@ class StepPlan:
         self._branch = 0
         if n > 1:
             emb = self._new("emb", R, L)
-            ops.linear_fwd(rf, emb, ecat, st.p("fusion_block.weight"), st.p("fusion_block.bias"), self.ws)
+            self._small_fwd(rf, emb, ecat, "fusion_block.weight", "fusion_block.bias")
         else:
             emb = ecat
         self.embeddings = emb[:B]
@@ -772,10 +795,7 @@ class StepPlan:
         enc_frozen = self._is_frozen("encoders.0.layer_1.weight")
         if n > 1:
             decat = self._new("decat", R, n * L)
-            self._weight_grad(rb, "fusion_block.weight", demb, ecat)
-            ops.colsum(rb, st.g("fusion_block.bias"), demb)
-            if not enc_frozen:
-                ops.linear_bwd_x(rb, decat, demb, st.p("fusion_block.weight"), self.ws)
+            self._small_bwd(rb, decat, demb, ecat, "fusion_block.weight", "fusion_block.bias", need_dx=not enc_frozen)
         else:
             decat = demb
         if enc_frozen:
@@ -959,8 +979,8 @@ class StepPlan:
                 ops.linear_fwd(rf, vcat[:, i * L:(i + 1) * L], h, st.p(p + ".FC_var.weight"), st.p(p + ".FC_var.bias"), self.ws)
         self._branch = 0
         mean, logv, z = self._new("mean", B, L), self._new("log_var", B, L), self._new("z", B, L)
-        ops.linear_fwd(rf, mean, mcat, st.p("FC_mean.weight"), st.p("FC_mean.bias"), self.ws)
-        ops.linear_fwd(rf, logv, vcat, st.p("FC_log_var.weight"), st.p("FC_log_var.bias"), self.ws)
+        self._small_fwd(rf, mean, mcat, "FC_mean.weight", "FC_mean.bias")
+        self._small_fwd(rf, logv, vcat, "FC_log_var.weight", "FC_log_var.bias")
         eps = self._draw("eps", B, L) if self.supplied else None
         eps_used = self._new("eps_used", B, L)
         seed, off = self._rng()
@@ -1027,14 +1047,11 @@ class StepPlan:
         dlv = self._new("dlog_var", B, L)
         ops.mul(rb, dlv, dz, eps_used)
         dmcat, dvcat = self._new("dmcat", B, n * L), self._new("dvcat", B, n * L)
-        self._weight_grad(rb, "FC_mean.weight", dz, mcat)
-        ops.colsum(rb, st.g("FC_mean.bias"), dz)
-        self._weight_grad(rb, "FC_log_var.weight", dlv, vcat)
-        ops.colsum(rb, st.g("FC_log_var.bias"), dlv)
-        if self._is_frozen("encoders.0.FC_mean.weight"):
-            return          # FineTuner "encoders": True -- the encoders need no gradient
-        ops.linear_bwd_x(rb, dmcat, dz, st.p("FC_mean.weight"), self.ws)
-        ops.linear_bwd_x(rb, dvcat, dlv, st.p("FC_log_var.weight"), self.ws)
+        enc_frozen = self._is_frozen("encoders.0.FC_mean.weight")    # FineTuner "encoders": True -- the encoders need no gradient
+        self._small_bwd(rb, dmcat, dz, mcat, "FC_mean.weight", "FC_mean.bias", need_dx=not enc_frozen)
+        self._small_bwd(rb, dvcat, dlv, vcat, "FC_log_var.weight", "FC_log_var.bias", need_dx=not enc_frozen)
+        if enc_frozen:
+            return
         enc_par = vae_par and self._block_ok(B, 1)
         if enc_par:
             _par_ctx = rb.parallel(n)
@@ -1075,7 +1092,6 @@ class StepPlan:
         ops.sumsq(ro, self.slots[o:], st.G)
         o += ops.sumsq_blocks(st.n_small)
         assert o <= self.slots.numel(), (o, self.slots.numel())
-        ops.clip_finalize(ro, st.ctrl, self.slots, self.slots.numel(), CLIP_MAX_NORM if self.clip else 0.0)
         trainable = None
         if self.frozen:             # 0/1 mask over the small-parameter arena: frozen tensors are skipped by Adam
             trainable = torch.ones_like(st.P)
@@ -1083,7 +1099,12 @@ class StepPlan:
                 if self._is_frozen(k):
                     st._view(trainable, k).zero_()
             self.buf["trainable_mask"] = trainable
-        ops.adam_flat(ro, st.P, st.G, st.M, st.V, st.ctrl, trainable)
+        if os.environ.get("FX_ADAM_CLIP_FUSED", "1") != "0":        # norm -> clip coefficient -> flat Adam in one launch
+            ops.adam_flat_clip(ro, st.P, st.G, st.M, st.V, st.ctrl, self.slots, self.slots.numel(),
+                               CLIP_MAX_NORM if self.clip else 0.0, trainable)
+        else:
+            ops.clip_finalize(ro, st.ctrl, self.slots, self.slots.numel(), CLIP_MAX_NORM if self.clip else 0.0)
+            ops.adam_flat(ro, st.P, st.G, st.M, st.V, st.ctrl, trainable)
         for k in st.big_keys:
             if self._is_frozen(k):
                 continue

@@ -314,6 +314,38 @@ def linear_bwd_w(rec, dW, dy, x, ws, accumulate=False):
     gemm(rec, GEMM_TN, dW, dy, x, None, ws, accumulate)
 
 
+SMALL_LINEAR_MAX = 4096
+
+
+def small_linear_ok(x, W) -> bool:
+    return max(x.shape[0], W.shape[0], W.shape[1]) <= SMALL_LINEAR_MAX and W.is_contiguous()
+
+
+def small_linear_fwd(rec, y, x, W, b):
+    """y = x W^T + b for the small layers on the critical chain (one latency-lean launch; include/fxhip.h)."""
+    for t, n in ((y, "y"), (x, "x"), (W, "W")):
+        _chk2d(t, "small_linear_fwd." + n)
+    R, K = x.shape
+    O = W.shape[0]
+    if W.shape != (O, K) or y.shape != (R, O) or not W.is_contiguous():
+        raise FxError("small_linear_fwd: shape mismatch")
+    rec.emit("fx_small_linear_fwd", y.data_ptr(), x.data_ptr(), W.data_ptr(), _ptr(b), R, O, K, _ld(x), _ld(y))
+
+
+def small_linear_bwd(rec, dx, gW, gb, dy, x, W, dx_accumulate=False):
+    """dx (+)= dy W (dx may be None), gW = dy^T x, gb = colsum(dy) (gb may be None) in ONE launch."""
+    for t, n in ((dy, "dy"), (x, "x"), (W, "W"), (gW, "gW")):
+        _chk2d(t, "small_linear_bwd." + n)
+    R, K = x.shape
+    O = W.shape[0]
+    if W.shape != (O, K) or dy.shape != (R, O) or gW.shape != W.shape or not (W.is_contiguous() and gW.is_contiguous()):
+        raise FxError("small_linear_bwd: shape mismatch")
+    if dx is not None and dx.shape != (R, K):
+        raise FxError("small_linear_bwd: dx shape mismatch")
+    rec.emit("fx_small_linear_bwd", _ptr(dx), gW.data_ptr(), _ptr(gb), dy.data_ptr(), x.data_ptr(), W.data_ptr(), R, O, K,
+             _ld(x), _ld(dy), _ld(dx) if dx is not None else K, int(bool(dx_accumulate)))
+
+
 def linear_dw_adam(rec, W, m, v, dy, x, ctrl):
     for t, n in ((W, "W"), (m, "m"), (v, "v"), (dy, "dY"), (x, "X")):
         _chk2d(t, "linear_dw_adam." + n)
@@ -743,6 +775,12 @@ def adam_flat(rec, p, g, m, v, ctrl, trainable=None):
     """``trainable``: optional 0/1 fp32 mask over the arena; elements with 0 are left untouched (frozen groups)."""
     rec.emit("fx_adam_flat", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), ctrl.data_ptr(),
              _ptr(trainable))
+
+
+def adam_flat_clip(rec, p, g, m, v, ctrl, slots, n_slots, max_norm, trainable=None):
+    """clip_finalize + adam_flat in one launch (see include/fxhip.h)."""
+    rec.emit("fx_adam_flat_clip", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), ctrl.data_ptr(),
+             _ptr(trainable), slots.data_ptr(), int(n_slots), float(max_norm))
 
 
 def sigmoid(rec, y, x):

@@ -191,6 +191,14 @@ int fx_block_bwd(const float* const* dE, const long* ldE, const float* const* W,
                  long ldt, const float* gram_x, double* slots, int B, int C, long ldx, long ldo, int pre_act, int post_act,
                  float drop_p, fx_stream_t stream);
 
+/* ---- small dense layers on the critical chain (fusion layer direct_pred.py:87-93,121-124; VAE FC_mean / FC_log_var
+ *      supervised_vae.py:104-107,172-176): one forward launch, and ONE backward launch for the data, weight and bias
+ *      gradients (autograd's two mm + sum).  W / gW contiguous [O, K]; R, O, K <= 4096; fixed summation order. */
+int fx_small_linear_fwd(float* y, const float* x, const float* W, const float* b, int R, int O, int K, long ldx, long ldy,
+                        fx_stream_t stream);
+int fx_small_linear_bwd(float* dx, float* gW, float* gb, const float* dy, const float* x, const float* W, int R, int O, int K,
+                        long ldx, long lddy, long lddx, int dx_accumulate, fx_stream_t stream);
+
 /* ---- BatchNorm1d (+LeakyReLU before | +ReLU+Dropout after), train & eval (modules.py:25-34,145-148) */
 int fx_bn_act_fwd(float* out, const float* x, const float* gamma, const float* beta, float* running_mean,
                   float* running_var, float* save_mean, float* save_invstd, const float* mask, float* mask_out, int B,
@@ -257,6 +265,11 @@ int fx_clip_finalize(float* ctrl, const double* slots, int n_slots, float max_no
 int fx_adam_flat(float* p, const float* g, float* m, float* v, long n, const float* ctrl,
                  const float* trainable /* optional 0/1 per element: 0 = requires_grad False, skipped (main.py:530-539,562-566) */,
                  fx_stream_t stream);
+
+/* fx_clip_finalize and fx_adam_flat in ONE launch (every workgroup reduces the norm slots in the same fixed order; workgroup 0
+ * publishes FXC_GNORM / FXC_CLIP_COEF in ctrl for the wide-weight kernels that follow): same results, one launch less */
+int fx_adam_flat_clip(float* p, const float* g, float* m, float* v, long n, float* ctrl, const float* trainable,
+                      const double* slots, int n_slots, float max_norm, fx_stream_t stream);
 
 /* ---- device-side ingest of a raw omics matrix.  x is the matrix as the reference's HDF5
  *      importer reads it: contiguous [n_samples, n_features], samples as rows (h5_dataloader.py:88-116,

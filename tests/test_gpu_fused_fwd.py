@@ -214,3 +214,35 @@ def test_wide_weight_beyond_4GiB():
         for y in (y1, y2):
             assert float((y[:, rows].double() - ref).norm() / ref.norm()) <= 1e-5, rows
     assert float((W1[:, :k_in] - W0[:, :k_in]).abs().max()) <= 1.001 * lr and torch.equal(W1[:, k_in:], W0[:, k_in:])
+
+
+@pytest.mark.parametrize("R,O,K", [(128, 64, 128), (37, 5, 3), (384, 128, 384), (100, 70, 130), (1, 1, 1), (200, 16, 17)])
+def test_small_linear_kernels_vs_fp64(R, O, K):
+    """fx_small_linear_fwd / _bwd (fusion layer, VAE FC_mean / FC_log_var) against fp64, strided operands included."""
+    from flexynesis_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(R * 7 + O * 3 + K)
+    xbig = torch.randn(R, K + 5, generator=g).to(dev)
+    x = xbig[:, 2:2 + K]                                   # a strided view (like ecat slices)
+    W = torch.randn(O, K, generator=g).to(dev)
+    b = torch.randn(O, generator=g).to(dev)
+    ybig = torch.full((R, O + 3), float("nan"), device=dev)
+    y = ybig[:, 1:1 + O]
+    ops.small_linear_fwd(ops.IMMEDIATE, y, x, W, b)
+    ref = x.double() @ W.double().t() + b.double()
+    close(y, ref, 1e-5, 1e-5, "small_linear_fwd")
+    assert bool(torch.isnan(ybig[:, 0]).all()) and bool(torch.isnan(ybig[:, 1 + O:]).all())
+    dy = torch.randn(R, O, generator=g).to(dev)
+    dx = torch.full((R, K), float("nan"), device=dev)
+    gW = torch.full((O, K), float("nan"), device=dev)
+    gb = torch.full((O,), float("nan"), device=dev)
+    ops.small_linear_bwd(ops.IMMEDIATE, dx, gW, gb, dy, x, W)
+    close(dx, dy.double() @ W.double(), 1e-5, 2e-5, "dx")
+    close(gW, dy.double().t() @ x.double(), 1e-5, 2e-5 * R ** 0.5, "gW")
+    close(gb, dy.double().sum(0), 1e-5, 2e-5 * R ** 0.5, "gb")
+    gW2 = torch.empty_like(gW)
+    ops.small_linear_bwd(ops.IMMEDIATE, None, gW2, None, dy, x, W)        # frozen upstream / bias-free layer
+    assert torch.equal(gW2, gW)
+    dx2 = torch.ones(R, K, device=dev)
+    ops.small_linear_bwd(ops.IMMEDIATE, dx2, gW2, gb, dy, x, W, dx_accumulate=True)
+    close(dx2, 1.0 + dy.double() @ W.double(), 1e-5, 2e-5, "dx accumulate")
