@@ -230,7 +230,7 @@ def test_small_linear_kernels_vs_fp64(R, O, K):
     y = ybig[:, 1:1 + O]
     ops.small_linear_fwd(ops.IMMEDIATE, y, x, W, b)
     ref = x.double() @ W.double().t() + b.double()
-    close(y, ref, 1e-5, 1e-5, "small_linear_fwd")
+    close(y, ref, 1e-5, 1e-5 * K ** 0.5, "small_linear_fwd")
     assert bool(torch.isnan(ybig[:, 0]).all()) and bool(torch.isnan(ybig[:, 1 + O:]).all())
     dy = torch.randn(R, O, generator=g).to(dev)
     dx = torch.full((R, K), float("nan"), device=dev)
