@@ -842,6 +842,42 @@ class StepPlan:
             self._lin_bwd_x(rc, dx, da1, p + ".layer_1.weight")
             self.dX.append(dx)
 
+    def _build_svae_attr(self, enc, hs, mcat, vcat, eps_used, L):
+        """Eval-mode input-gradient tapes of the VAE family: d out_v[:, c] / d X_i through z = mean + log_var * eps (the
+        reference's forward_target differentiates its full forward, supervised_vae.py:553-563, :187-200: the latent is the
+        SAMPLED z even in eval mode), the top-level FC_mean / FC_log_var, every encoder's FC_mean / FC_var and its
+        Linear -> LeakyReLU -> BatchNorm block.  dX[j] belongs to input layer enc[j] (CrossModalPred: its input_layers)."""
+        spec, st, B, n = self.spec, self.store, self.B, len(enc)
+        dz = self._new("attr/dz", B, L)
+        for (v, kind, C) in spec.variables:
+            ra = self.t_attr_head[v] = TapeRecorder()
+            pre = "MLPs." + v
+            S = st.shapes[pre + ".layer_1.weight"][0]
+            do = self.attr_dout[v] = self._new(f"attr/dout.{v}", B, C)
+            da1 = self._new(f"attr/{pre}/da1", B, S)
+            ops.linear_bwd_x(ra, da1, do, st.p(pre + ".layer_out.weight"), self._ws[0])
+            ops.bn_eval_bwd(ra, da1, da1, None, self.buf[pre + "/a1"][:B], st.p(pre + ".batchnorm.weight"),
+                            st.b(pre + ".batchnorm.running_var"), ACT_NONE, ACT_RELU)
+            ops.linear_bwd_x(ra, dz, da1, st.p(pre + ".layer_1.weight"), self._ws[0])
+        rc = self.t_attr_common
+        dlv = self._new("attr/dlog_var", B, L)
+        ops.mul(rc, dlv, dz, eps_used)                                    # z = mean + log_var * eps
+        dmcat, dvcat = self._new("attr/dmcat", B, n * L), self._new("attr/dvcat", B, n * L)
+        ops.linear_bwd_x(rc, dmcat, dz, st.p("FC_mean.weight"), self._ws[0])
+        ops.linear_bwd_x(rc, dvcat, dlv, st.p("FC_log_var.weight"), self._ws[0])
+        for i in range(n):
+            p = f"encoders.{i}"
+            H = st.shapes[p + ".hidden_layers.0.weight"][0]
+            dh = self._new(f"attr/{p}/dh", B, H)
+            ops.linear_bwd_x(rc, dh, dmcat[:, i * L:(i + 1) * L], st.p(p + ".FC_mean.weight"), self._ws[0])
+            ops.linear_bwd_x(rc, dh, dvcat[:, i * L:(i + 1) * L], st.p(p + ".FC_var.weight"), self._ws[0], accumulate=True)
+            ops.bn_eval_bwd(rc, dh, dh, self.buf[p + "/y"][:B], None, st.p(p + ".hidden_layers.2.weight"),
+                            st.b(p + ".hidden_layers.2.running_var"), ACT_LEAKY, ACT_NONE)
+            dx = self._new(f"attr/dX.{i}", B, spec.layers[enc[i]][1])
+            self._branch = 0
+            self._lin_bwd_x(rc, dx, dh, p + ".hidden_layers.0.weight")
+            self.dX.append(dx)
+
     def input_gradient(self, var: str):
         """Run the input-gradient tapes for head ``var`` (after forward(); attr_dout[var] set): fills self.dX."""
         if not self.attribution:
@@ -1034,6 +1070,8 @@ class StepPlan:
             ops.mmd_finalize(rf, self.loss_vec[0:1], row_sums, MMD_PRIOR, B, rec_part, nblk, float(B * F), 1.0 / nd, i > 0)
         self._total(rf)
         if not self.train:
+            if self.attribution:
+                self._build_svae_attr(enc, hs, mcat, vcat, eps_used, L)
             return
         # ---- backward through decoders (dlogits live in logits[i]) -> dz, then latent, then encoders
         for i in range(nd):

@@ -380,7 +380,7 @@ class FxModel(_Base):
         return (0.5 * (1.0 + xs)).tolist(), (0.5 * ws).tolist()
 
     def compute_feature_importance(self, dataset, target_var, method="IntegratedGradients", steps_or_samples=5,
-                                   batch_size=512, alphas=None):
+                                   batch_size=512, alphas=None, eps=None):
         """Mean absolute attribution of every input feature for ``target_var`` (one row set per class of a categorical
         target), as the reference computes it through Captum with all-zero baselines:
 
@@ -389,12 +389,14 @@ class FxModel(_Base):
 
         where F is the eval-mode head output (logit of the class / the regression output).  The forward passes and the
         input gradients run on the HIP kernels (eval plans with input-gradient tapes); the result has the reference's
-        DataFrame layout and is stored in ``self.feature_importances[target_var]``.  ``alphas`` overrides the
-        GradientShap draws (tests).  Captum is not installed in this image: the quadrature / sampling rule is restated
+        DataFrame layout and is stored in ``self.feature_importances[target_var]``.  The VAE family differentiates through
+        the SAMPLED latent z = mean + log_var * eps like the reference (a fresh eps per forward; CrossModalPred attributes
+        its input layers).  ``alphas`` overrides the GradientShap draws and ``eps(batch, chunk_start, draw, rows)`` the
+        reparameterisation draws (tests).  Captum is not installed in this image: the quadrature / sampling rule is restated
         from its documentation (parity unpinned for that part; oracle/attribution.py)."""
         import pandas as pd
-        if self.MODEL not in ("DirectPred", "MultiTripletNetwork"):
-            raise NotImplementedError(f"compute_feature_importance is implemented for the MLP-encoder models, not {self.MODEL}")
+        if self.MODEL == "GNN":
+            raise NotImplementedError("compute_feature_importance is not implemented for the GNN model")
         if method not in ("IntegratedGradients", "GradientShap"):
             raise ValueError(f"Unsupported method '{method}'. Choose 'IntegratedGradients' or 'GradientShap'.")
         if target_var not in self.variables:
@@ -405,7 +407,10 @@ class FxModel(_Base):
         else:
             num_class = len(np.unique(np.asarray(dataset.ann[target_var])))
         self.eval()
-        layers = list(dataset.dat.keys())
+        all_layers = list(dataset.dat.keys())
+        vae = self.spec.is_vae
+        # the layers that are differentiated: every layer, or the VAE family's encoder inputs (CrossModalPred: input_layers)
+        layers = [all_layers[i] for i in self.spec.enc_idx] if vae else all_layers
         store = self._bind()
         dev = store.device
         gen = torch.Generator().manual_seed(self._seed)
@@ -422,23 +427,28 @@ class FxModel(_Base):
             for c0 in range(0, len(rows), CH):
                 idx = rows[c0:c0 + CH]
                 B = len(idx)
-                key = (B, "attr")
+                key = (B, "attr", eps is not None)
                 if key not in self._plans:
                     for k, b in self.named_buffers():
                         if k.endswith("num_batches_tracked"):
                             store.nbt[k] = int(b)
-                    self._plans[key] = StepPlan(store, B, train=False, attribution=True, seed=self._seed + 4242)
+                    self._plans[key] = StepPlan(store, B, train=False, attribution=True, seed=self._seed + 4242,
+                                                supplied_draws=eps is not None)
                 plan = self._plans[key]
-                xs = [torch.stack([torch.as_tensor(dataset.dat[l][i]) for i in idx]).to(dev, torch.float32) for l in layers]
+                xall = [torch.stack([torch.as_tensor(dataset.dat[l][i]) for i in idx]).to(dev, torch.float32) for l in all_layers]
+                xs = [xall[all_layers.index(l)] for l in layers]
                 for t in plan.y.values():
                     t.fill_(float("nan"))
                 acc = [[torch.zeros_like(x) for x in xs] for _ in range(num_class)]
-                for a_i, w_i in zip(al, wt):
-                    scaled = [x * float(a_i) for x in xs]
+                for di, (a_i, w_i) in enumerate(zip(al, wt)):
+                    # the interpolation point: the differentiated layers scaled by alpha (the others are not read by the heads)
+                    scaled = [x * float(a_i) if l in layers else x for l, x in zip(all_layers, xall)]
                     if self.MODEL == "MultiTripletNetwork":
                         plan.set_batch(parts=[scaled, scaled, scaled], y=None)
                     else:
                         plan.set_batch(x_list=scaled, y=None)
+                    if eps is not None:                       # parity tests: the reparameterisation draw of this forward
+                        plan.set_draws({"eps": torch.as_tensor(eps(s0 // int(batch_size), c0, di, B)).to(dev)})
                     plan.forward()
                     for c in range(num_class):
                         do = plan.attr_dout[target_var]

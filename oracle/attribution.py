@@ -21,9 +21,21 @@ import torch
 from . import restate as O
 
 
-def head_output(spec: O.Spec, st, x_list: List[torch.Tensor], var: str) -> torch.Tensor:
-    """forward(x_list)[var] in eval mode (direct_pred.py:107-133), differentiable in x_list."""
-    emb = O.directpred_embed(spec, st, x_list, False, {}, None)
+def head_output(spec: O.Spec, st, x_list: List[torch.Tensor], var: str, eps: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """forward(x_list)[var] in eval mode, differentiable in x_list.  MLP family: direct_pred.py:107-133.  VAE family
+    (supervised_vae.py:132-200, crossmodal_pred.py:79-132): x_list = the encoder inputs; the heads see the SAMPLED latent
+    z = mean + log_var * eps even in eval mode (``eps`` supplied)."""
+    if spec.is_vae:
+        means, lvs = [], []
+        for j in range(len(spec.enc_idx)):
+            m, lv = O.encoder_forward(st, f"encoders.{j}", x_list[j], False, None)
+            means.append(m)
+            lvs.append(lv)
+        mean = O.linear(torch.cat(means, 1), st["FC_mean.weight"], st["FC_mean.bias"])
+        log_var = O.linear(torch.cat(lvs, 1), st["FC_log_var.weight"], st["FC_log_var.bias"])
+        emb = mean + log_var * eps
+    else:
+        emb = O.directpred_embed(spec, st, x_list, False, {}, None)
     return O.mlp_forward(st, "MLPs." + var, emb, False, None, None)
 
 
@@ -33,10 +45,12 @@ def quadrature(n_steps: int):
 
 
 def feature_importance(spec: O.Spec, st, dat: Dict[str, torch.Tensor], var: str, kind: str, num_class: int, method: str,
-                       n: int, batch_size: int = 512, alphas: Optional[Sequence[float]] = None, dtype=torch.float64):
-    """{class: [importance vector per layer]} = mean over samples of |attribution|."""
+                       n: int, batch_size: int = 512, alphas: Optional[Sequence[float]] = None, dtype=torch.float64,
+                       eps=None):
+    """{class: [importance vector per differentiated layer]} = mean over samples of |attribution|.  VAE family: the
+    differentiated layers are the encoder inputs; ``eps(batch_index, draw, rows)`` supplies each forward's draw."""
     st = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in st.items()}
-    names = [nm for nm, _ in spec.layers]
+    names = [spec.layers[i][0] for i in spec.enc_idx] if spec.is_vae else [nm for nm, _ in spec.layers]
     N = dat[names[0]].shape[0]
     out = {c: [torch.zeros(dat[nm].shape[1], dtype=dtype) for nm in names] for c in range(num_class)}
     for s0 in range(0, N, batch_size):
@@ -47,9 +61,10 @@ def feature_importance(spec: O.Spec, st, dat: Dict[str, torch.Tensor], var: str,
             al, wt = list(alphas), [1.0 / n] * n
         for c in range(num_class):
             acc = [torch.zeros_like(x) for x in xs]
-            for a, w in zip(al, wt):
+            for di, (a, w) in enumerate(zip(al, wt)):
                 pts = [(x * a).requires_grad_(True) for x in xs]
-                o = head_output(spec, st, pts, var)
+                e = torch.as_tensor(eps(s0 // batch_size, di, xs[0].shape[0])).to(dtype) if eps is not None else None
+                o = head_output(spec, st, pts, var, e)
                 grads = torch.autograd.grad(o[:, c if num_class > 1 else 0].sum(), pts)
                 for j, g in enumerate(grads):
                     acc[j] += w * g

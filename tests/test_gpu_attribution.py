@@ -77,3 +77,60 @@ def test_feature_importance_argument_checks_and_batching():
     assert np.allclose(a, b, rtol=1e-5, atol=1e-9) and a.min() >= 0 and a.max() > 0
     # the model is back in a usable state for training / prediction
     assert set(m.predict(ds)) == {"y", "c"}
+
+
+@pytest.mark.parametrize("model_name", ["supervised_vae", "CrossModalPred"])
+@pytest.mark.parametrize("method", ["IntegratedGradients", "GradientShap"])
+def test_vae_family_feature_importance_matches_restated_reference(model_name, method):
+    """The VAE family differentiates its heads through the SAMPLED latent z = mean + log_var * eps (reference
+    supervised_vae.py:553-563): same eps draws on both sides.  CrossModalPred attributes its input layers."""
+    from flexynesis_amd import models as M
+    from flexynesis_amd.data import MultiOmicDataset
+    from oracle import attribution as A
+    from oracle import restate as O
+    g = torch.Generator().manual_seed(5)
+    n = 90
+    layers = [("gex", 2400), ("cnv", 300), ("meth", 200)]            # gex: 1200 x 2400 weight -> the wide (split-bf16) dX path
+    dat = {k: torch.randn(n, F, generator=g) for k, F in layers}
+    ann = {"y": torch.randn(n, generator=g), "c": torch.randint(0, 3, (n,), generator=g).float()}
+    feats = {k: [f"{k}_{j}" for j in range(F)] for k, F in layers}
+    ds = MultiOmicDataset(dat, ann, {"y": "numerical", "c": "categorical"}, feats, [f"s{i}" for i in range(n)], {})
+    cfg = {"latent_dim": 16, "hidden_dim_factor": 0.5, "lr": 1e-3, "supervisor_hidden_dim": 8, "epochs": 1, "batch_size": 32}
+    kw = dict(input_layers=["gex", "meth"], output_layers=["cnv", "gex"]) if model_name == "CrossModalPred" else {}
+    torch.manual_seed(2)
+    m = getattr(M, model_name)(cfg, ds, ["y", "c"], device_type="cuda", **kw)
+    sd = m.state_dict()
+    for k in sd:
+        if k.endswith("running_mean"):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.3
+        elif k.endswith("running_var"):
+            sd[k] = torch.rand(sd[k].shape, generator=g) + 0.5
+    m.load_state_dict(sd)
+    ospec = O.Spec(model_name, layers, 16, 0.5, 8, [("y", "numerical", 1), ("c", "categorical", 3)],
+                   input_layers=kw.get("input_layers"), output_layers=kw.get("output_layers"))
+    st = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    alphas = [0.2, 0.5, 0.9]
+    draws = {}
+
+    def eps_of(b, di, rows):
+        key = (b, di)
+        if key not in draws:
+            draws[key] = torch.randn(rows, 16, generator=torch.Generator().manual_seed(100 * b + di))
+        return draws[key]
+
+    in_layers = kw.get("input_layers", ["gex", "cnv", "meth"])
+    for var, kind, C in (("y", "numerical", 1), ("c", "categorical", 3)):
+        df = m.compute_feature_importance(ds, var, method=method, steps_or_samples=3, batch_size=64, alphas=alphas,
+                                          eps=lambda b, c0, di, rows: eps_of(b, di, rows))
+        assert sorted(set(df.layer)) == sorted(in_layers)
+        ref = A.feature_importance(ospec, st, dat, var, kind, C, method, 3, batch_size=64, alphas=alphas, eps=eps_of)
+        names = [ospec.layers[i][0] for i in ospec.enc_idx]
+        for c in range(C):
+            for j, lname in enumerate(names):
+                a = torch.as_tensor(df[(df.target_class == c) & (df.layer == lname)].importance.to_numpy()).double()
+                b = ref[c][j]
+                assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()) + 1e-9, (var, c, lname)
+                assert float((a - b).norm() / b.norm()) <= 3e-4
+    # production mode draws its own eps per forward and still returns finite, non-negative importances
+    df = m.compute_feature_importance(ds, "y", steps_or_samples=2, batch_size=64)
+    assert np.isfinite(df.importance.to_numpy()).all() and df.importance.min() >= 0
