@@ -1152,7 +1152,7 @@ class StepPlan:
                 if k in self._next_fwd:
                     nslabs, _, nsp = nxt._next_fwd[k]
                     ops.linear_dw_adam_fwd_bf16x3(ro, d["W"], d["M"], d["V"], dyt[0], dyt[1], xt[0], xt[1], st.ctrl, nsp[0], nsp[1],
-                                                  nxt.R, nslabs, nt=not ops.TUNE["adam_plain"])
+                                                  nxt.R, nslabs, nt=not ops.TUNE["adam_plain"], mapping=ops.TUNE["fused_map"])
                 else:
                     ops.linear_dw_adam_bf16x3(ro, d["W"], d["M"], d["V"], dyt[0], dyt[1], xt[0], xt[1], st.ctrl)
             elif self.fused:

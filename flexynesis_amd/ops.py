@@ -36,6 +36,7 @@ TUNE = {
     "fwd_splitk": _env_int("FX_SPLITK", 0), "fwd_wn": _env_int("FX_FWD_WN", 0), "fwd_no_mt": int(_env_int("FX_FWD_MT", 1) == 0),
     "fwd_nt": _env_int("FX_NT_FWD", 0), "adam_order": {0: 1, 1: 0, 2: 2}.get(_env_int("FX_ADAM_XCD", 1), 0),
     "adam_wn": _env_int("FX_ADAM_WN", 0), "adam_plain": int(_env_int("FX_NT_ADAM", 1) == 0),
+    "fused_map": _env_int("FX_FUSED_MAP", 0),     # fx_linear_dw_adam_fwd_bf16x3 workgroup mapping: 0 auto, 1 plain, 2 XCD-grouped
 }
 
 
