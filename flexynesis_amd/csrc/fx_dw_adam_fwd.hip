@@ -315,6 +315,10 @@ int fx_linear_dw_adam_fwd_bf16x3(float* W, float* adam_m, float* adam_v, const v
   g.Mn = next_rows; g.kblocks = (k_in + FT_K - 1) / FT_K;
   g.tiles_m = (n_out + FT_M - 1) / FT_M; g.tiles_n = (k_in + FT_N - 1) / FT_N;
   g.S = ft_runs(n_out, k_in);
+  if ((flags >> 8) & 0xFF) {                       // bits 8-15: explicit number of runs per row block (experiments)
+    g.S = (flags >> 8) & 0xFF;
+    if (g.S > g.tiles_n) g.S = g.tiles_n;
+  }
   g.slab_stride = (long)next_rows * n_out;
   // flags: bit 0 = non-temporal W / m / v accesses; bits 1-2 = block mapping: 0 auto (XCD-grouped row blocks when the
   // dY^T tiles of an XCD's workgroups would outgrow its L2), 1 = plain, 2 = XCD-grouped

@@ -36,6 +36,7 @@ TUNE = {
     "fwd_splitk": _env_int("FX_SPLITK", 0), "fwd_wn": _env_int("FX_FWD_WN", 0), "fwd_no_mt": int(_env_int("FX_FWD_MT", 1) == 0),
     "fwd_nt": _env_int("FX_NT_FWD", 0), "adam_order": {0: 1, 1: 0, 2: 2}.get(_env_int("FX_ADAM_XCD", 1), 0),
     "adam_wn": _env_int("FX_ADAM_WN", 0), "adam_plain": int(_env_int("FX_NT_ADAM", 1) == 0),
+    "fused_runs": _env_int("FX_FUSED_RUNS", 0),   # runs (= partial-sum slabs) per row block; 0 = the library's choice
     "fused_map": _env_int("FX_FUSED_MAP", 0),     # fx_linear_dw_adam_fwd_bf16x3 workgroup mapping: 0 auto, 1 plain, 2 XCD-grouped
 }
 
@@ -467,6 +468,9 @@ def linear_dw_adam_bf16x3(rec, W, m, v, dyT_hi, dyT_lo, xT_hi, xT_lo, ctrl, tile
 
 
 def dw_adam_fwd_slabs(n_out: int, k_in: int) -> int:
+    s = TUNE["fused_runs"]
+    if s > 0:
+        return min(s, (int(k_in) + 127) // 128)
     return int(lib.fx_linear_dw_adam_fwd_bf16x3_slabs(int(n_out), int(k_in)))
 
 
@@ -489,7 +493,7 @@ def linear_dw_adam_fwd_bf16x3(rec, W, m, v, dyT_hi, dyT_lo, xT_hi, xT_lo, ctrl, 
     rec.emit("fx_linear_dw_adam_fwd_bf16x3", W.data_ptr(), m.data_ptr(), v.data_ptr(), dyT_hi.data_ptr(), dyT_lo.data_ptr(),
              xT_hi.data_ptr(), xT_lo.data_ptr(), Bp, N, K, _ld(dyT_hi), _ld(xT_hi), _ld(W), ctrl.data_ptr(), xn_hi.data_ptr(),
              xn_lo.data_ptr(), xn_hi.shape[1], int(next_rows), y_slabs.data_ptr(), y_slabs.numel() * 4,
-             int(bool(nt)) | ((int(mapping) & 3) << 1))
+             int(bool(nt)) | ((int(mapping) & 3) << 1) | ((TUNE["fused_runs"] & 0xFF) << 8))
 
 
 def reduce_slabs(rec, y, slabs, bias, n_slabs):

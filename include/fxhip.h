@@ -112,7 +112,8 @@ int fx_linear_dw_adam_bf16x3_ex(float* W, float* adam_m, float* adam_v, const vo
  * y_slabs [fx_linear_dw_adam_fwd_bf16x3_slabs(n_out, k_in)][next_rows][n_out]; fx_reduce_slabs adds them (+ bias) in a
  * fixed order.  W, m, v results are bit-identical to fx_linear_dw_adam_bf16x3.
  * flags: bit 0 = non-temporal W / m / v accesses; bits 1-2 = workgroup mapping (0 auto, 1 plain, 2 row blocks grouped per
- * XCD).  k_in % 4 == 0; descriptors are rebased per row block, so the weight itself may exceed 4 GiB. */
+ * XCD); bits 8-15 = runs per row block (0 = fx_linear_dw_adam_fwd_bf16x3_slabs(); the slab buffer must hold that many).
+ * k_in % 4 == 0; descriptors are rebased per row block, so the weight itself may exceed 4 GiB. */
 int fx_linear_dw_adam_fwd_bf16x3_slabs(int n_out, int k_in);
 int fx_linear_dw_adam_fwd_bf16x3(float* W, float* adam_m, float* adam_v, const void* dyT_hi, const void* dyT_lo,
                                  const void* xT_hi, const void* xT_lo, int batch_padded, int n_out, int k_in, long lddy,
