@@ -135,6 +135,47 @@ __global__ __launch_bounds__(512) void adam_short_runs(float* __restrict__ W, fl
   }
 }
 
+// TILE-MAJOR storage: every 64 x 128 tile is one contiguous 32 KB chunk per array.  mode 0: non-persistent, workgroup b = chunk b
+// (the flat pattern); mode 1: persistent, chunks stored row-block-major [tm][tn], workgroup (tm, c) walks tn = c, c + S, ...;
+// mode 2: persistent, chunks stored step-major [k][tm][c] (tile (tm, tn) at ((tn / S) * tiles_m + tm) * S + tn % S), so that at
+// any instant the whole grid reads ONE contiguous window of each array.
+template <int LDSB>
+__global__ __launch_bounds__(512) void adam_chunks(float* __restrict__ W, float* __restrict__ M, float* __restrict__ V, long n_chunks, int tiles_m, int tiles_n, int S, int mode, unsigned long long* cnt) {
+  __shared__ char pad[LDSB];
+  if (threadIdx.x == 9999) pad[threadIdx.x % LDSB] = 1;
+  constexpr int PER = 4;
+  long c0 = blockIdx.x, cstep = S, cend = n_chunks;
+  if (mode == 0) { c0 = blockIdx.x; cstep = 1; cend = c0 + 1; }
+  else if (mode == 1) { const int tm = blockIdx.x % tiles_m, c = blockIdx.x / tiles_m; c0 = (long)tm * tiles_n + c; cstep = S; cend = (long)(tm + 1) * tiles_n; }
+  for (long ch = c0; ch < cend; ch += cstep) {
+    if (cnt && threadIdx.x == 0) atomicAdd(cnt, 1ull);
+    f4 p[PER], m[PER], v[PER];
+    long off[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      off[i] = ch * 2048 + threadIdx.x + 512 * i;
+      p[i] = __builtin_nontemporal_load((const f4*)W + off[i]);
+      m[i] = __builtin_nontemporal_load((const f4*)M + off[i]);
+      v[i] = __builtin_nontemporal_load((const f4*)V + off[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      f4 po, mo, vo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float g = 1e-3f;
+        const float m2 = m[i][j] + (g - m[i][j]) * 0.1f;
+        const float v2 = v[i][j] * 0.999f + 0.001f * g * g;
+        po[j] = p[i][j] - 1e-3f * (m2 / (sqrtf(v2) + 1e-8f));
+        mo[j] = m2; vo[j] = v2;
+      }
+      __builtin_nontemporal_store(po, (f4*)W + off[i]);
+      __builtin_nontemporal_store(mo, (f4*)M + off[i]);
+      __builtin_nontemporal_store(vo, (f4*)V + off[i]);
+    }
+  }
+}
+
 int main() {
   const int H = 5000, F = 20000; const long ld = 20000;
   float *W, *M, *V;
@@ -148,6 +189,7 @@ int main() {
     CK(hipEventRecord(e0));
     const int it = 10;
     for (int i = 0; i < it; ++i) launch();
+    CK(hipGetLastError());
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     printf("%-64s %8.1f us  %6.3f TB/s\n", name, ms / it * 1e3, 6.0 * H * F * 4 / (ms / it * 1e-3) / 1e12);
@@ -183,6 +225,22 @@ int main() {
     snprintf(nm, 128, "short runs of %d tiles 64x128, column-fastest, 2 WG/CU", r);
     const int runs = (157 + r - 1) / r;
     run(nm, [&] { hipLaunchKernelGGL((adam_short_runs<65536>), dim3(79 * runs), dim3(512), 0, 0, W, M, V, H, F, ld, r, 0); });
+  }
+  {
+    const int tiles_m = 78, tiles_n = 156;                      // 78 * 156 * 8192 = 99.68 M elements <= H * F
+    const long n_chunks = (long)tiles_m * tiles_n;
+    unsigned long long* cnt; CK(hipMalloc(&cnt, 8)); CK(hipMemset(cnt, 0, 8));
+    auto chunks = [&](const char* nm, int grid, int S, int mode) {
+      run(nm, [&] { hipLaunchKernelGGL((adam_chunks<65536>), dim3(grid), dim3(512), 0, 0, W, M, V, n_chunks, tiles_m, tiles_n, S, mode, cnt); });
+      unsigned long long h = 0; CK(hipMemcpy(&h, cnt, 8, hipMemcpyDeviceToHost)); printf("   chunks visited so far: %llu (12 launches of %ld expected per line)\n", h, n_chunks);
+    };
+    // note: TB/s printed assumes H*F elements; these touch 79*156*8192 (0.9908 of it) -- scale by 0.997
+    chunks("tile-major chunks, non-persistent (flat), 2 WG/CU  [x0.997]", (int)n_chunks, 0, 0);
+    chunks("tile-major [tm][tn], persistent S=6, 2 WG/CU       [x0.997]", 78 * 6, 6, 1);
+    chunks("tile-major [tm][tn], persistent S=12, 2 WG/CU      [x0.997]", 78 * 12, 12, 1);
+    chunks("tile-major [k][tm][c], persistent grid 468, 2 WG/CU [x0.997]", 468, 468, 2);
+    chunks("tile-major [k][tm][c], persistent grid 512, 2 WG/CU [x0.997]", 512, 512, 2);
+    chunks("tile-major [k][tm][c], persistent grid 948, 2 WG/CU [x0.997]", 948, 948, 2);
   }
   return 0;
 }
