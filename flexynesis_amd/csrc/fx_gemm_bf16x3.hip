@@ -65,6 +65,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t fx_rsrc(const void* p, long by
 }
 // AUX = cache-policy bits of the buffer instruction: 0 = default, 2 = nt (data streamed exactly once should
 // not displace the L2-resident activation operand).
+// the same for a descriptor the compiler cannot prove wave-uniform on its own (it would wrap every load in a
+// readfirstlane "waterfall" loop): base and size are made scalar explicitly
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t fx_rsrc_uniform(const void* p, long bytes) {
+  const unsigned long long a = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  const unsigned n = __builtin_amdgcn_readfirstlane(bytes > 0xFFFFFFF0L ? 0xFFFFFFF0u : (unsigned)bytes);
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, n, 0x00020000);
+}
 template <int AUX = 0>
 __device__ __forceinline__ u32x4 bld128(__amdgpu_buffer_rsrc_t r, unsigned off) {
   return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, AUX);
@@ -544,6 +552,190 @@ __global__ __launch_bounds__(512) void fx_fwd_bf16x3_mt_kernel(XGemmArgs g) {
     }
 }
 
+// ---- multi-M-tile forward, W in registers ------------------------------------------------------------------
+// The same contraction as fx_fwd_bf16x3_mt_kernel, rebuilt around what bounds it (scripts/bench_fwd_mt.py with parts of the
+// kernel switched off, cfg4 shape 384 x 30000 -> 7500): the MFMA work alone takes ~270 us, the operand traffic alone ~400 us
+// (a CU draws ~50 GB/s from the L2 whatever the pattern; X is re-read by all 59 column tiles: 2.7 GB against 0.9 GB of W) --
+// and the staged kernel took their SUM, 650 us: every wave issued its loads in one burst after the barrier, a burst the
+// memory pipeline accepts no faster than it serves it, and an in-order wave cannot issue MFMAs behind a blocked load.
+//  * W is loaded COALESCED (8 lanes x 16 B = the 128 bytes a row contributes to a K-step), four K-steps ahead, into two
+//    registers per thread; at the top of its K-step it is split into (hi, lo) and written to a single 16 KB LDS tile between
+//    two barriers.  (Loading W straight into the MFMA operand layout -- 32 rows x two 16-byte pieces per instruction -- needs no
+//    LDS but touches 64 different 64-byte sectors per wave instruction: measured 570 us against 341 us without the W loads.)
+//  * X: three LDS stages of [MT x 128 rows][32 k] (hi | lo) filled by LDS-DMA two K-steps ahead -- no
+//    register staging, no ds_write.
+//  * The ten load instructions of a K-step are SPREAD between its MFMAs (sched_group_barrier), fragment reads run one
+//    product ahead, and an accumulator comes round every 2 MT MFMAs.
+//  * One raw s_barrier per K-step with an explicit vmcnt (a __syncthreads would drain the two K-steps in flight).
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+__device__ __forceinline__ void split8(const u32x4 a, const u32x4 b, bf16x8& h, bf16x8& l) {
+  const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);   // whole-vector casts (see split_store4)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float va = fa[j], vb = fb[j];
+    h[j] = (__bf16)va;
+    l[j] = (__bf16)(va - (float)h[j]);
+    h[4 + j] = (__bf16)vb;
+    l[4 + j] = (__bf16)(vb - (float)h[4 + j]);
+  }
+}
+
+template <int MT, int NT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void fx_fwd_bf16x3_wreg_kernel(XGemmArgs g) {
+  constexpr int ROWS = MT * TM;                 // batch rows per workgroup
+  constexpr int HALF = ROWS * TK;               // bf16 elements of the hi (or lo) array of one stage
+  constexpr int STAGE = 2 * HALF;
+  __shared__ __attribute__((aligned(16))) __bf16 smem[3 * STAGE + 8192];   // 3 x 48 KB at MT = 3 + 16 KB of W fragments = all 160 KB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w & 1, wc = w >> 1;
+  const int groups_m = (g.M + ROWS - 1) / ROWS;
+  int lin = blockIdx.x;
+  const int z = lin % g.splitk;
+  lin /= g.splitk;
+  const int gm = lin % groups_m, tn = lin / groups_m;
+  const int m0 = gm * ROWS, n0 = tn * 128;
+  const int k_begin = z * g.kchunk;
+  const int k_end = min(g.K, k_begin + g.kchunk);
+  const int nk = (k_end > k_begin) ? (k_end - k_begin) / TK : 0;
+  const __amdgpu_buffer_rsrc_t rAh = fx_rsrc(g.Ahi, (long)g.K * g.a_rp * 2), rAl = fx_rsrc(g.Alo, (long)g.K * g.a_rp * 2);
+  const __amdgpu_buffer_rsrc_t rB = fx_rsrc_uniform(g.Bf + (long)n0 * g.ldb, (long)max(min(128, g.N - n0), 0) * g.ldb * 4);   // rebased: W may exceed 4 GiB
+  // LDS-DMA: one wave instruction fills 16 rows x 64 B in lane order (row = lane / 4, slot = lane % 4); slot s of row r
+  // must hold chunk s ^ ((r >> 2) & 3).  Wave w fills rows 16 w .. 16 w + 15 of every M tile, hi and lo.
+  const int dr = lane >> 2, dsl = lane & 3;
+  const unsigned a_src = (unsigned)(((long)(m0 + 16 * w + dr) * TK + 8 * (dsl ^ ((dr >> 2) & 3))) * 2);
+  const unsigned a_tile = TM * TK * 2u;
+  const unsigned a_step = (unsigned)g.a_rp * (TK * 2u), a_kb = (unsigned)(k_begin / TK) * a_step;
+  const int l31 = lane & 31, kh = lane >> 5;
+  // W: coalesced -- 8 lanes x 16 B cover the 128 bytes one row contributes to a K-step; thread t loads rows t / 8 and t / 8 + 64
+  const int bn = tid >> 3, k4 = tid & 7;
+  const unsigned b_off = (unsigned)(((long)bn * g.ldb + 4 * k4) * 4), b_row64 = (unsigned)((long)64 * g.ldb * 4);
+  const int b_lds0 = swz(bn, k4 >> 1) + ((k4 & 1) << 2), b_lds1 = swz(bn + 64, k4 >> 1) + ((k4 & 1) << 2);
+  const unsigned b_kb = (unsigned)k_begin * 4u, b_step = TK * 4u;
+#define WR_ISSUE_X(kt_, stage_)                                                                                    \
+  {                                                                                                                \
+    const unsigned past = ((kt_) < nk) ? 0u : 0xFFFFFFF0u;                                                         \
+    const unsigned ka = a_kb + (unsigned)(kt_) * a_step;                                                           \
+    __bf16* sb = smem + (stage_) * STAGE + 16 * w * TK;                                                            \
+    _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                               \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rAh, LDS_PTR(sb + m * TM * TK), 16, (a_src + m * a_tile + ka) | past, 0, 0, 0);        \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rAl, LDS_PTR(sb + HALF + m * TM * TK), 16, (a_src + m * a_tile + ka) | past, 0, 0, 0); \
+    }                                                                                                              \
+  }
+#define WR_ISSUE_W(P, kt_)                                                                                         \
+  {                                                                                                                \
+    const unsigned past = ((kt_) < nk) ? 0u : 0xFFFFFFF0u;                                                         \
+    const unsigned kb = b_off + b_kb + (unsigned)(kt_) * b_step;                                                   \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) P[j] = bld128<NT>(rB, (kb + j * b_row64) | past);                \
+  }
+  f32x16 acc[MT][2];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc[m][0][i] = 0.f; acc[m][1][i] = 0.f; }
+  // fragment offsets (elements) of sub-step ks within a stage: row = wr * 64 + l31 (+ 32, + 128 m), chunk 2 ks + kh
+  const int arow = wr * 64 + l31;
+  const int f_off0 = swz(arow, kh), f_off1 = swz(arow, 2 + kh);
+  const int fb_off0 = swz(wc * 32 + l31, kh), fb_off1 = swz(wc * 32 + l31, 2 + kh);
+// fragments of sub-step ks: F[2 m + blk] = rows wr * 64 + 32 blk + l31 of M tile m, the hi (half = 0) or lo (half = 1) array
+#define WR_RD(F, xs, ks, half)                                                                          \
+  {                                                                                                     \
+    const __bf16* fp = (xs) + ((ks) ? f_off1 : f_off0) + (half) * HALF;                                 \
+    _Pragma("unroll") for (int i = 0; i < 2 * MT; ++i)                                                  \
+      F[i] = *reinterpret_cast<const bf16x8*>(fp + (i >> 1) * TM * TK + (i & 1) * 32 * TK);             \
+  }
+// one of the three products against all 2 MT accumulators
+#define WR_P(F, B)                                                                                      \
+  {                                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < 2 * MT; ++i) acc[i >> 1][i & 1] = MFMA_BF16(F[i], B, acc[i >> 1][i & 1]); \
+  }
+// schedule of one K-step: 0x008 = MFMA, 0x100 = LDS read, 0x020 = VMEM read.  Six products of 2 MT MFMAs (lo x hi, hi x lo,
+// hi x hi of sub-step 0, then of sub-step 1); the next product's fragment reads go one per MFMA, the K-step's 2 MT + 4 load
+// instructions one every third MFMA.
+#define WR_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0);
+#define WR_STEP(P, kt_)                                                                                 \
+  {                                                                                                     \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * MT + 4) : "memory"); /* X of K-step kt_ (this wave's pieces) has landed: all but the W loads issued with it and the whole next group */ \
+    asm volatile("s_barrier" ::: "memory");            /* everyone's has; stage st - 1 and the W fragments are free again */ \
+    split_store4(P[0], wfr + b_lds0, wfr + 4096 + b_lds0);     /* W of this K-step: (hi, lo) [128][32], swizzled like X */ \
+    split_store4(P[1], wfr + b_lds1, wfr + 4096 + b_lds1);                                              \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                  \
+    asm volatile("s_barrier" ::: "memory");            /* the W tile is complete */                     \
+    bf16x8 bh[2], bl[2];                                                                                \
+    bh[0] = *reinterpret_cast<const bf16x8*>(wfr + fb_off0);                                            \
+    bl[0] = *reinterpret_cast<const bf16x8*>(wfr + 4096 + fb_off0);                                     \
+    bh[1] = *reinterpret_cast<const bf16x8*>(wfr + fb_off1);                                            \
+    bl[1] = *reinterpret_cast<const bf16x8*>(wfr + 4096 + fb_off1);                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    const __bf16* xs = smem + st * STAGE;                                                               \
+    bf16x8 al0[2 * MT], ah0[2 * MT], al1[2 * MT], ah1[2 * MT];                                          \
+    WR_RD(al0, xs, 0, 1);                                                                               \
+    WR_RD(ah0, xs, 0, 0);                                                                               \
+    WR_ISSUE_X((kt_) + 2, st >= 1 ? st - 1 : 2);               /* X two K-steps ahead (L2) ... */        \
+    WR_ISSUE_W(P, (kt_) + 4);                                  /* ... W four (HBM), issued AFTER it: vmcnt retires in order */ \
+    WR_P(al0, bh[0]);                                                                                   \
+    WR_RD(al1, xs, 1, 1);                                                                               \
+    WR_P(ah0, bl[0]);                                                                                   \
+    WR_P(ah0, bh[0]);                                                                                   \
+    WR_RD(ah1, xs, 1, 0);                                                                               \
+    WR_P(al1, bh[1]);                                                                                   \
+    WR_P(ah1, bl[1]);                                                                                   \
+    WR_P(ah1, bh[1]);                                                                                   \
+    WR_SGB(0x100, 2 * MT)                                                                  /* lo fragments of sub-step 0 */ \
+    _Pragma("unroll") for (int u = 0; u < 2 * MT; ++u) { WR_SGB(0x100, 1) WR_SGB(0x008, 1) }  /* hi fragments of 0 | lo x hi */ \
+    _Pragma("unroll") for (int u = 0; u < 2 * MT; ++u) { WR_SGB(0x008, 1) WR_SGB(0x020, 1) }  /* hi x lo | the X pieces of K-step kt + 2 */ \
+    _Pragma("unroll") for (int u = 0; u < 2 * MT; ++u) { WR_SGB(0x008, 1) WR_SGB(0x100, 1) }  /* hi x hi | lo fragments of sub-step 1 */ \
+    _Pragma("unroll") for (int u = 0; u < 2 * MT; ++u) { WR_SGB(0x008, 1) WR_SGB(0x100, 1) }  /* lo x hi of 1 | hi fragments of 1 */ \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) { WR_SGB(0x008, 1) WR_SGB(0x020, 1) }       /* hi x lo | the W loads of K-step kt + 2 */ \
+    WR_SGB(0x008, 4 * MT - 2)                                                              /* hi x hi */ \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    st = st == 2 ? 0 : st + 1;                                                                          \
+  }
+  // the stages start as zeros: a K-step past the slice must find finite numbers whatever an out-of-range DMA leaves behind
+  {
+    const u32x4 zz = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < (3 * STAGE * 2) / (512 * 16); ++i) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(smem) + (i * 512 + tid) * 16) = zz;
+    __syncthreads();
+  }
+  __bf16* wfr = smem + 3 * STAGE;      // W of the current K-step: hi [128][32] | lo [128][32]
+  u32x4 q0[2], q1[2], q2[2], q3[2];
+  int st = 0;
+  // issue order = the vmcnt bookkeeping: per K-step the X pieces, then the W loads that are issued with them
+  WR_ISSUE_W(q0, 0);
+  WR_ISSUE_W(q1, 1);
+  __builtin_amdgcn_sched_barrier(0);
+  WR_ISSUE_X(0, 0);
+  WR_ISSUE_W(q2, 2);
+  __builtin_amdgcn_sched_barrier(0);
+  WR_ISSUE_X(1, 1);
+  WR_ISSUE_W(q3, 3);
+  __builtin_amdgcn_sched_barrier(0);
+  // K-steps in fours without an exit in between (one basic block, so that the compiler's own vmcnt bookkeeping for the W
+  // registers stays exact): K-steps past the slice multiply zeros (their loads are out of range)
+  for (int kt = 0; kt < nk; kt += 4) {
+    WR_STEP(q0, kt);
+    WR_STEP(q1, kt + 1);
+    WR_STEP(q2, kt + 2);
+    WR_STEP(q3, kt + 3);
+  }
+  const int n = n0 + wc * 32 + l31;
+  const unsigned oob = (n < g.N) ? 0u : 0xFFFFFFF0u;
+  const __amdgpu_buffer_rsrc_t rC = fx_rsrc(g.C + (long)z * g.slab_stride, (long)g.M * g.ldc * 4);
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      const int mbase = m0 + m * TM + wr * 64 + blk * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int mm = mbase + (r & 3) + 8 * (r >> 2);
+        const unsigned off = (unsigned)(((long)mm * g.ldc + n) * 4) | oob;       // rows >= M fall outside the slab
+        bst32f(acc[m][blk][r], rC, off);
+      }
+    }
+}
+
 // ---- operand splitting ----------------------------------------------------------------------------------
 // hi/lo K-BLOCKED [Cp/32][Rp][32] from x [R, C]: element (r, c) at ((c/32)*Rp + r)*32 + c%32; columns C..Cp-1 are
 // written as zeros (Cp = C rounded up to 32); rows R..Rp-1 are never written (the caller allocates them as zeros)
@@ -670,14 +862,14 @@ int fx_linear_fwd_bf16x3(float* Y, const void* xhi, const void* xlo, const float
 }
 
 // The same with explicit tuning (A/B experiments; every variant computes the same contraction): splitk 0 = auto
-// (workspace must hold splitk slabs), wave_cols 0|4 = 128x128 tile, 2 = 128x64; no_mt 1 = one workgroup per M tile even
+// (workspace must hold splitk slabs), wave_cols 0|4 = 128x128 tile, 2 = 128x64; no_mt 1 = one workgroup per M tile (2 = LDS-staged multi-M-tile kernel) even
 // for M > 128; nt 1 = non-temporal W loads.
 int fx_linear_fwd_bf16x3_ex(float* Y, const void* xhi, const void* xlo, const float* W, const float* bias, int M, int N, int K,
                             long ldx, long ldw, long ldy, void* workspace, long workspace_bytes, int splitk, int wave_cols,
                             int no_mt, int nt, hipStream_t stream) {
   FX_REQUIRE(Y != nullptr, "fx_linear_fwd_bf16x3_ex: null output");
   return fwd_bf16x3_impl(Y, xhi, xlo, W, bias, M, N, K, ldx, ldw, ldy, workspace, workspace_bytes, true, stream, false,
-                         FwdTune{splitk, wave_cols, no_mt ? 1 : 0, nt});
+                         FwdTune{splitk, wave_cols, no_mt, nt});
 }
 
 // Same, but the fx_linear_fwd_bf16x3_splitk(M,N,K) partial-sum slabs ([s][M][N]) are left in `slabs` (no bias) for
@@ -729,8 +921,16 @@ static int fwd_bf16x3_impl(float* Y, const void* xhi, const void* xlo, const flo
     const int mt = fwd_mt(M);
     const long nb = (long)((M + mt * TM - 1) / (mt * TM)) * ((N + 127) / 128) * s;
     FX_REQUIRE(nb < (1L << 31), "fx_linear_fwd_bf16x3: grid too large");
-    if (mt == 3) hipLaunchKernelGGL((fx_fwd_bf16x3_mt_kernel<3>), dim3((unsigned)nb), dim3(512), 0, stream, g);
-    else hipLaunchKernelGGL((fx_fwd_bf16x3_mt_kernel<2>), dim3((unsigned)nb), dim3(512), 0, stream, g);
+    if (tune.mt == 2) {                                   // A/B: both operands staged through the LDS
+      if (mt == 3) hipLaunchKernelGGL((fx_fwd_bf16x3_mt_kernel<3>), dim3((unsigned)nb), dim3(512), 0, stream, g);
+      else hipLaunchKernelGGL((fx_fwd_bf16x3_mt_kernel<2>), dim3((unsigned)nb), dim3(512), 0, stream, g);
+    } else if (mt == 3) {
+      if (nt) hipLaunchKernelGGL((fx_fwd_bf16x3_wreg_kernel<3, 2>), dim3((unsigned)nb), dim3(512), 0, stream, g);
+      else hipLaunchKernelGGL((fx_fwd_bf16x3_wreg_kernel<3, 0>), dim3((unsigned)nb), dim3(512), 0, stream, g);
+    } else {
+      if (nt) hipLaunchKernelGGL((fx_fwd_bf16x3_wreg_kernel<2, 2>), dim3((unsigned)nb), dim3(512), 0, stream, g);
+      else hipLaunchKernelGGL((fx_fwd_bf16x3_wreg_kernel<2, 0>), dim3((unsigned)nb), dim3(512), 0, stream, g);
+    }
   } else if (kn) {
     hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<true, XEPI_STORE, 0, 4, true>), dim3((unsigned)nblk), dim3(512), 0, stream, g);
   } else if (wn == 4) {
