@@ -552,21 +552,22 @@ __global__ __launch_bounds__(512) void fx_fwd_bf16x3_mt_kernel(XGemmArgs g) {
     }
 }
 
-// ---- multi-M-tile forward, W in registers ------------------------------------------------------------------
-// The same contraction as fx_fwd_bf16x3_mt_kernel, rebuilt around what bounds it (scripts/bench_fwd_mt.py with parts of the
-// kernel switched off, cfg4 shape 384 x 30000 -> 7500): the MFMA work alone takes ~270 us, the operand traffic alone ~400 us
-// (a CU draws ~50 GB/s from the L2 whatever the pattern; X is re-read by all 59 column tiles: 2.7 GB against 0.9 GB of W) --
-// and the staged kernel took their SUM, 650 us: every wave issued its loads in one burst after the barrier, a burst the
-// memory pipeline accepts no faster than it serves it, and an in-order wave cannot issue MFMAs behind a blocked load.
-//  * W is loaded COALESCED (8 lanes x 16 B = the 128 bytes a row contributes to a K-step), four K-steps ahead, into two
-//    registers per thread; at the top of its K-step it is split into (hi, lo) and written to a single 16 KB LDS tile between
-//    two barriers.  (Loading W straight into the MFMA operand layout -- 32 rows x two 16-byte pieces per instruction -- needs no
-//    LDS but touches 64 different 64-byte sectors per wave instruction: measured 570 us against 341 us without the W loads.)
-//  * X: three LDS stages of [MT x 128 rows][32 k] (hi | lo) filled by LDS-DMA two K-steps ahead -- no
-//    register staging, no ds_write.
-//  * The ten load instructions of a K-step are SPREAD between its MFMAs (sched_group_barrier), fragment reads run one
-//    product ahead, and an accumulator comes round every 2 MT MFMAs.
-//  * One raw s_barrier per K-step with an explicit vmcnt (a __syncthreads would drain the two K-steps in flight).
+// ---- multi-M-tile forward, second design: X by LDS-DMA, loads dealt out between the MFMAs -------------------
+// The same contraction as fx_fwd_bf16x3_mt_kernel.  What that kernel's 650 us at the cfg4 shape (384 x 30000 -> 7500) are made
+// of was measured by switching parts of THIS kernel off (1 x MI355X, fwd + slab reduce, us):
+//     fragment reads + barriers + loop only 254 | + MFMA 320 | + MFMA + X 341 | + MFMA + W 427 | + X + W (no MFMA) 366 | all 570
+//     MFMA alone (no LDS reads, loads, barriers) 282; scripts/mfmaprobe.hip: the same MFMA mix sustains 2.0-2.1 PFLOP/s = 260 us
+// MFMA, LDS fragment reads and the X stream (2.7 GB from the L2: X is re-read by all 59 column tiles) overlap well; what does
+// not is the 0.9 GB HBM stream of W on top of them (+ 230 us), whatever its form -- straight into MFMA operand layout or
+// coalesced, two or four K-steps ahead, temporal or non-temporal all measure 565-590 us.  The kernel is ~12 % faster than the
+// first design (cfg4 step 6.31 -> 6.0 ms) because
+//  * X goes global -> LDS by DMA, two K-steps ahead in three stages: no register staging, no ds_write;
+//  * W is loaded coalesced (8 lanes x 16 B = the 128 bytes a row contributes to a K-step) four K-steps ahead into two
+//    registers per thread, split into (hi, lo) at the top of its K-step and written to a single 16 KB tile between two barriers;
+//  * the K-step's load instructions are dealt out between its MFMAs instead of issued in one burst after the barrier (an
+//    in-order wave cannot issue MFMAs behind a load the memory pipeline has not accepted yet), the fragment reads run one
+//    product ahead, and an accumulator comes round every 2 MT MFMAs;
+//  * one raw s_barrier pair per K-step with an explicit vmcnt (a __syncthreads would drain the K-steps in flight).
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 __device__ __forceinline__ void split8(const u32x4 a, const u32x4 b, bf16x8& h, bf16x8& l) {
   const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);   // whole-vector casts (see split_store4)
@@ -581,7 +582,7 @@ __device__ __forceinline__ void split8(const u32x4 a, const u32x4 b, bf16x8& h, 
 }
 
 template <int MT, int NT>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void fx_fwd_bf16x3_wreg_kernel(XGemmArgs g) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void fx_fwd_bf16x3_dma_kernel(XGemmArgs g) {
   constexpr int ROWS = MT * TM;                 // batch rows per workgroup
   constexpr int HALF = ROWS * TK;               // bf16 elements of the hi (or lo) array of one stage
   constexpr int STAGE = 2 * HALF;
@@ -862,7 +863,7 @@ int fx_linear_fwd_bf16x3(float* Y, const void* xhi, const void* xlo, const float
 }
 
 // The same with explicit tuning (A/B experiments; every variant computes the same contraction): splitk 0 = auto
-// (workspace must hold splitk slabs), wave_cols 0|4 = 128x128 tile, 2 = 128x64; no_mt 1 = one workgroup per M tile (2 = LDS-staged multi-M-tile kernel) even
+// (workspace must hold splitk slabs), wave_cols 0|4 = 128x128 tile, 2 = 128x64; no_mt 1 = one workgroup per M tile (2 = the first multi-M-tile kernel) even
 // for M > 128; nt 1 = non-temporal W loads.
 int fx_linear_fwd_bf16x3_ex(float* Y, const void* xhi, const void* xlo, const float* W, const float* bias, int M, int N, int K,
                             long ldx, long ldw, long ldy, void* workspace, long workspace_bytes, int splitk, int wave_cols,
@@ -921,15 +922,15 @@ static int fwd_bf16x3_impl(float* Y, const void* xhi, const void* xlo, const flo
     const int mt = fwd_mt(M);
     const long nb = (long)((M + mt * TM - 1) / (mt * TM)) * ((N + 127) / 128) * s;
     FX_REQUIRE(nb < (1L << 31), "fx_linear_fwd_bf16x3: grid too large");
-    if (tune.mt == 2) {                                   // A/B: both operands staged through the LDS
+    if (tune.mt == 2) {                                   // A/B: the first design, both operands staged through registers
       if (mt == 3) hipLaunchKernelGGL((fx_fwd_bf16x3_mt_kernel<3>), dim3((unsigned)nb), dim3(512), 0, stream, g);
       else hipLaunchKernelGGL((fx_fwd_bf16x3_mt_kernel<2>), dim3((unsigned)nb), dim3(512), 0, stream, g);
     } else if (mt == 3) {
-      if (nt) hipLaunchKernelGGL((fx_fwd_bf16x3_wreg_kernel<3, 2>), dim3((unsigned)nb), dim3(512), 0, stream, g);
-      else hipLaunchKernelGGL((fx_fwd_bf16x3_wreg_kernel<3, 0>), dim3((unsigned)nb), dim3(512), 0, stream, g);
+      if (nt) hipLaunchKernelGGL((fx_fwd_bf16x3_dma_kernel<3, 2>), dim3((unsigned)nb), dim3(512), 0, stream, g);
+      else hipLaunchKernelGGL((fx_fwd_bf16x3_dma_kernel<3, 0>), dim3((unsigned)nb), dim3(512), 0, stream, g);
     } else {
-      if (nt) hipLaunchKernelGGL((fx_fwd_bf16x3_wreg_kernel<2, 2>), dim3((unsigned)nb), dim3(512), 0, stream, g);
-      else hipLaunchKernelGGL((fx_fwd_bf16x3_wreg_kernel<2, 0>), dim3((unsigned)nb), dim3(512), 0, stream, g);
+      if (nt) hipLaunchKernelGGL((fx_fwd_bf16x3_dma_kernel<2, 2>), dim3((unsigned)nb), dim3(512), 0, stream, g);
+      else hipLaunchKernelGGL((fx_fwd_bf16x3_dma_kernel<2, 0>), dim3((unsigned)nb), dim3(512), 0, stream, g);
     }
   } else if (kn) {
     hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<true, XEPI_STORE, 0, 4, true>), dim3((unsigned)nblk), dim3(512), 0, stream, g);
