@@ -176,12 +176,27 @@ __global__ __launch_bounds__(512) void adam_chunks(float* __restrict__ W, float*
   }
 }
 
-int main() {
+__global__ void fill_random(float* p, long n, unsigned seed) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    unsigned x = (unsigned)i * 2654435761u + seed; x ^= x >> 15; x *= 2246822519u; x ^= x >> 13; x *= 3266489917u; x ^= x >> 16;
+    p[i] = (float)(x >> 8) * (1.0f / 16777216.0f) * 0.02f + 1e-4f;
+  }
+}
+
+int main(int argc, char** argv) {
   const int H = 5000, F = 20000; const long ld = 20000;
+  const bool random_data = argc > 1;
   float *W, *M, *V;
   const size_t bytes = (size_t)H * ld * 4;
   CK(hipMalloc(&W, bytes)); CK(hipMalloc(&M, bytes)); CK(hipMalloc(&V, bytes));
   CK(hipMemset(W, 0, bytes)); CK(hipMemset(M, 0, bytes)); CK(hipMemset(V, 0, bytes));
+  if (random_data) {   // the arrays hold noise instead of zeros (data-dependent power: zeros are the easy case)
+    hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, W, (long)H * ld, 1u);
+    hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, M, (long)H * ld, 2u);
+    hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, V, (long)H * ld, 3u);
+    CK(hipDeviceSynchronize());
+  }
+  printf("data: %s\n", random_data ? "random" : "zeros");
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   auto run = [&](const char* name, auto launch) {
     for (int i = 0; i < 2; ++i) launch();
