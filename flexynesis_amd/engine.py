@@ -233,10 +233,11 @@ class StepPlan:
                  supplied_draws: bool = False, seed: int = 0, cohort=None, n_batches: int = 0,
                  epoch_acc: bool = False, precision: str = "bf16x3", branches: bool = True, share: "StepPlan" = None,
                  fuse_heads: bool = True, frozen: Tuple[str, ...] = (), fuse_next_fwd: bool = False,
-                 attribution: bool = False):
+                 attribution: bool = False, clip_norm: float = CLIP_MAX_NORM):
         self.store, self.spec, self.B, self.train = store, store.spec, int(B), train
         self.fused = bool(fused) and train
         self.clip = clip
+        self.clip_norm = float(clip_norm)       # gradient_clip_val of the caller's Trainer (the reference uses 1.0)
         # FineTuner (reference main.py:530-539): state_dict key prefixes with requires_grad=False, e.g. ("encoders.",)
         # or ("MLPs.",).  Frozen parameters get no gradient work and are skipped by Adam; BatchNorm buffers of frozen
         # blocks still update.  The reference never clips while fine-tuning (its Trainer has no gradient_clip_val).
@@ -759,6 +760,23 @@ class StepPlan:
         self.t_opt = TapeRecorder()
         self._build_optimizer(nxt)
 
+    def set_clip(self, max_norm: Optional[float]):
+        """Re-record the optimiser tape for another gradient_clip_val (None / 0 = no clipping).  For plans driven by an
+        external loop (FxAdam under the Lightning protocol), where the clip value is only known when the trainer calls
+        configure_gradient_clipping."""
+        clip = bool(max_norm) and float(max_norm) > 0.0
+        norm = float(max_norm) if clip else self.clip_norm
+        if not self.train or (clip == self.clip and norm == self.clip_norm):
+            return
+        if self._next_fwd:
+            raise RuntimeError("set_clip: this plan's optimiser tape belongs to a PipelinedStep")
+        if self.frozen and clip:
+            raise ValueError("frozen parameter groups train without gradient clipping")
+        self.clip, self.clip_norm = clip, norm
+        self.t_opt = TapeRecorder()
+        self._build_optimizer()
+        self.graph = None
+
     def _build_mlp_family(self):
         """DirectPred (direct_pred.py:107-133, :225-260) and MultiTripletNetwork
         (triplet_encoder.py:125-166, :276-330; anchor/positive/negative stacked as 3B rows)."""
@@ -1139,9 +1157,9 @@ class StepPlan:
             self.buf["trainable_mask"] = trainable
         if os.environ.get("FX_ADAM_CLIP_FUSED", "1") != "0":        # norm -> clip coefficient -> flat Adam in one launch
             ops.adam_flat_clip(ro, st.P, st.G, st.M, st.V, st.ctrl, self.slots, self.slots.numel(),
-                               CLIP_MAX_NORM if self.clip else 0.0, trainable)
+                               self.clip_norm if self.clip else 0.0, trainable)
         else:
-            ops.clip_finalize(ro, st.ctrl, self.slots, self.slots.numel(), CLIP_MAX_NORM if self.clip else 0.0)
+            ops.clip_finalize(ro, st.ctrl, self.slots, self.slots.numel(), self.clip_norm if self.clip else 0.0)
             ops.adam_flat(ro, st.P, st.G, st.M, st.V, st.ctrl, trainable)
         for k in st.big_keys:
             if self._is_frozen(k):

@@ -15,6 +15,8 @@ import copy
 from typing import Dict, List, Optional
 
 import numpy as np
+import os
+
 import torch
 from torch import nn
 
@@ -78,8 +80,15 @@ class _PlanLoss(torch.autograd.Function):
         st = model._store
         scale = gout.reshape(-1)[:1].to(torch.float32).contiguous()
         ops.scale_by(ops.IMMEDIATE, st.G, scale)
-        for k in st.big_keys:
-            ops.scale_by(ops.IMMEDIATE, st.big[k]["_G"].view(-1), scale)
+        if plan.fused:
+            # fused optimiser mode: the wide weights' gradients are never formed (FxAdam.step() runs the engine's clip +
+            # dW+Adam launches on the saved dY / X operands); their .grad stays None.  An upstream gradient other than 1
+            # cannot be applied to a gradient that does not exist: checked one step late, without a host sync.
+            model._fused_check_scale(scale)
+            model._fused_ready = plan
+        else:
+            for k in st.big_keys:
+                ops.scale_by(ops.IMMEDIATE, st.big[k]["_G"].view(-1), scale)
         grads = []
         weighted = plan.spec.weighted
         for key, p in model._param_items():
@@ -88,6 +97,9 @@ class _PlanLoss(torch.autograd.Function):
                 continue
             if key.startswith("log_vars.") and not weighted:
                 grads.append(None)          # reference: log_vars get no grad with a single loss term
+                continue
+            if plan.fused and key in st.big:
+                grads.append(None)
                 continue
             grads.append(st.g(key))          # a view into the gradient arena (overwritten by the next backward)
         return (None, None, *grads)
@@ -101,9 +113,16 @@ class FxAdam(torch.optim.Optimizer):
     Gradients are whatever ``param.grad`` holds when ``step()`` is called -- i.e. after Lightning's
     ``clip_grad_norm_`` -- because ``param.grad`` IS the arena."""
 
-    def __init__(self, model, lr):
+    def __init__(self, model, lr, fused=False):
         self.model = model
         super().__init__(list(model.parameters()), dict(lr=float(lr)))
+        # fused=True: the engine's own optimiser step -- gradient norm from the Gram identity, clip coefficient and Adam
+        # for the small parameters in one launch, dW + clip + Adam per wide weight in one launch each (24 B/param, dW is
+        # never stored).  Clipping then happens INSIDE step(): max_norm is set by FxModel.configure_gradient_clipping
+        # (the hook Lightning's Trainer calls with its gradient_clip_val) or by hand.  Needs exactly one
+        # loss.backward() per step() with unit upstream gradient (no gradient accumulation, no loss scaling).
+        self.fused = bool(fused)
+        self.max_norm = None
         self._mask_sig = None
         self._mask = None
         self._ctrl = None          # this optimiser's own step-control block: t counts optimizer.step() calls (the model's
@@ -116,6 +135,17 @@ class FxAdam(torch.optim.Optimizer):
         m = self.model
         st = m._bind()
         lr = float(self.param_groups[0]["lr"])
+        if self.fused:
+            plan = m._fused_ready
+            if plan is None:                       # no backward since the last step: nothing to apply (torch skips None grads)
+                return loss
+            with torch.cuda.device(st.device):
+                plan.set_clip(self.max_norm)
+                if lr != m._ctrl_lr:               # training_step put config['lr'] into the control block; a scheduler may differ
+                    st.ctrl[ops.CTRL_LR:ops.CTRL_LR + 1].fill_(lr)
+                plan.t_opt.run()
+            m._fused_ready = None
+            return loss
         with torch.cuda.device(st.device):
             items = m._param_items()
             # a gradient that is not the arena view (e.g. autograd had to clone a row-padded wide gradient, or a user set
@@ -185,6 +215,12 @@ class FxModel(_Base):
         self._store: Optional[ParamStore] = None
         self._plans: Dict[tuple, StepPlan] = {}
         self._seed = int(torch.initial_seed() % (2 ** 31))
+        # Level-1 fast path (see FxAdam): FX_LEVEL1_FUSED=1 or model.fused_optimizer = True before configure_optimizers()
+        self.fused_optimizer = os.environ.get("FX_LEVEL1_FUSED", "0") == "1"
+        self._fused_ready: Optional[StepPlan] = None
+        self._fused_scale_host = None
+        self._fused_scale_event = None
+        self._ctrl_lr = None
         keys = [k for k, _ in self.state_dict().items()]
         want = list(self.spec.state_shapes().keys())
         assert sorted(keys) == sorted(want), (set(keys) ^ set(want))
@@ -292,11 +328,45 @@ class FxModel(_Base):
         import os
         if os.environ.get("FX_TORCH_ADAM", "0") == "1" or not torch.cuda.is_available():
             return torch.optim.Adam(self.parameters(), lr=self.config["lr"])
-        return FxAdam(self, self.config["lr"])
+        opt = FxAdam(self, self.config["lr"], fused=self.fused_optimizer)
+        self._fx_optimizer = opt
+        return opt
+
+    def configure_gradient_clipping(self, optimizer, gradient_clip_val=None, gradient_clip_algorithm=None):
+        """The hook Lightning's Trainer calls between backward and optimizer.step() with its ``gradient_clip_val``
+        (reference main.py:216: 1.0).  With a fused FxAdam the norm clip is part of step() itself (the wide gradients it
+        would have to read do not exist); otherwise the usual torch clipping."""
+        opt = getattr(optimizer, "optimizer", optimizer)          # Lightning wraps optimisers in LightningOptimizer
+        if isinstance(opt, FxAdam) and opt.fused:
+            if gradient_clip_algorithm not in (None, "norm"):
+                raise ValueError("the fused FxAdam clips by global norm only (gradient_clip_algorithm='norm')")
+            opt.max_norm = float(gradient_clip_val) if gradient_clip_val else None
+            return
+        if not gradient_clip_val:
+            return
+        if gradient_clip_algorithm == "value":
+            torch.nn.utils.clip_grad_value_(self.parameters(), gradient_clip_val)
+        else:
+            torch.nn.utils.clip_grad_norm_(self.parameters(), gradient_clip_val)
+
+    def _fused_check_scale(self, scale):
+        """Fused optimiser mode supports only loss.backward() with upstream gradient 1.  The value is copied to pinned host
+        memory asynchronously and looked at when the NEXT backward arrives (no host synchronisation in the step)."""
+        if self._fused_scale_host is None:
+            self._fused_scale_host = torch.ones(1, dtype=torch.float32).pin_memory()
+            self._fused_scale_event = torch.cuda.Event()
+        elif self._fused_scale_event.query() and float(self._fused_scale_host[0]) != 1.0:
+            raise RuntimeError("fused FxAdam: loss.backward() was called with an upstream gradient of "
+                               f"{float(self._fused_scale_host[0])} (loss scaling / gradient accumulation): set "
+                               "model.fused_optimizer = False for such loops")
+        self._fused_scale_host.copy_(scale, non_blocking=True)
+        self._fused_scale_event.record()
 
     def training_step(self, train_batch, batch_idx, log=True):
-        plan = self._plan(self._batch_size(train_batch), train=True, fused=False)
+        fused = bool(self.fused_optimizer) and isinstance(getattr(self, "_fx_optimizer", None), FxAdam) and self._fx_optimizer.fused
+        plan = self._plan(self._batch_size(train_batch), train=True, fused=fused)
         self._feed(plan, train_batch)
+        self._ctrl_lr = float(self.config.get("lr", 0.0))
         # the in-kernel dropout / eps / prior draws are keyed on the step counter of the control block: advance it once per
         # training_step (an external optimiser never touches it, and the same masks would be drawn every step)
         ops.step_begin(ops.IMMEDIATE, plan.store.ctrl, float(self.config.get("lr", 0.0)), 0)

@@ -3,7 +3,10 @@ optimizer.step()) on the model class with torch-side batches, at cfg2 (2 x 20000
 loop (fit / bench.py).  Gradients are materialised (36 B/param/step instead of 24) and torch's clip_grad_norm_ makes two
 more passes over them; this is the price of running under an unmodified external loop.
 
-    python scripts/bench_dropin.py [fx|torch]"""
+    python scripts/bench_dropin.py [fx|torch|fused]
+
+"fused": model.fused_optimizer = True -- FxAdam runs the engine's clip + dW+Adam launches (24 B/param, no wide gradients); the
+clip value reaches it through the configure_gradient_clipping hook, as under Lightning's Trainer."""
 import json
 import sys
 import time
@@ -29,7 +32,8 @@ def main():
     m = M.DirectPred(cfg, ds, ["y"], device_type="cuda")
     m.to(dev)
     m.train()
-    opt = m.configure_optimizers() if kind == "fx" else torch.optim.Adam(m.parameters(), lr=1e-3)
+    m.fused_optimizer = kind == "fused"
+    opt = m.configure_optimizers() if kind in ("fx", "fused") else torch.optim.Adam(m.parameters(), lr=1e-3)
     perm = torch.randperm(n, generator=g, device=dev)
 
     def step(i):
@@ -38,7 +42,7 @@ def main():
         opt.zero_grad()
         loss = m.training_step(batch, i, log=False)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        m.configure_gradient_clipping(opt, 1.0, "norm")      # Lightning's hook: torch clip_grad_norm_ unless the optimiser clips itself
         opt.step()
         return loss
 
@@ -51,7 +55,7 @@ def main():
         loss = step(5 + i)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(json.dumps({"path": "Lightning protocol (level-1 drop-in)", "optimizer": type(opt).__name__, "ms_per_step": round(1e3 * dt / K, 3),
+    print(json.dumps({"path": "Lightning protocol (level-1 drop-in)", "optimizer": type(opt).__name__ + (" (fused)" if getattr(opt, "fused", False) else ""), "ms_per_step": round(1e3 * dt / K, 3),
                       "samples_per_s": round(K * B / dt, 1), "loss": float(loss)}))
 
 

@@ -490,3 +490,69 @@ def test_drop_in_fx_adam_equals_torch_adam_and_masks_change():
         if sa[k].dtype.is_floating_point and not k.endswith(noise):
             assert float((sa[k] - sb[k]).abs().max()) <= 2e-6 + 1e-5 * float(sb[k].abs().max()), k
     assert float((sa["encoders.0.layer_1.weight"] - g.state0()["encoders.0.layer_1.weight"].to(DEV)).abs().max()) > 1e-4
+
+
+def test_level1_fused_optimizer_follows_materialised_path():
+    """Level-1 fast path: model.fused_optimizer = True makes configure_optimizers() return a fused FxAdam -- backward forms
+    no wide gradients (their .grad stays None), the trainer's gradient_clip_val arrives through the
+    configure_gradient_clipping hook, and step() runs the engine's clip + dW+Adam launches.  It must follow the default
+    level-1 path (materialised gradients, torch's clip_grad_norm_, FxAdam on the arenas) to rounding."""
+    import flexynesis_amd.models as M
+    from flexynesis_amd.models.base import FxAdam
+    torch.manual_seed(5)
+    ds = _synthetic_ds(n=256, F=(8192, 4100), seed=3)
+    cfg = {"latent_dim": 32, "hidden_dim_factor": 0.25, "lr": 1e-3, "supervisor_hidden_dim": 8, "epochs": 1, "batch_size": 64}
+    m = M.DirectPred(cfg, ds, ["y", "c"], device_type="cuda")
+    m.to(DEV)
+    ma, mb = copy.deepcopy(m), copy.deepcopy(m)
+    ma.fused_optimizer = True
+    oa, ob = ma.configure_optimizers(), mb.configure_optimizers()
+    assert isinstance(oa, FxAdam) and oa.fused and not ob.fused
+    lr, steps, B = cfg["lr"], 5, 64
+    losses = {0: [], 1: []}
+    for it in range(steps):
+        idx = torch.arange(it * 32, it * 32 + B) % 256
+        batch = ({k: v[idx].to(DEV) for k, v in ds.dat.items()}, {k: torch.as_tensor(v)[idx].to(DEV) for k, v in ds.ann.items()}, None)
+        for j, (mm, oo) in enumerate(((ma, oa), (mb, ob))):
+            mm.train()
+            oo.zero_grad()
+            loss = mm.training_step(batch, it, log=False)
+            loss.backward()
+            big = [k for k in mm._store.big_keys]
+            assert len(big) == 2
+            grads = dict(mm.named_parameters())
+            if j == 0:
+                assert all(grads[k].grad is None for k in big)                 # never formed
+                assert grads["encoders.0.layer_out.weight"].grad is not None
+            else:
+                assert all(grads[k].grad is not None for k in big)
+            mm.configure_gradient_clipping(oo, 1.0, "norm")                     # what Lightning's Trainer calls
+            oo.step()
+            losses[j].append(float(loss))
+    assert oa.max_norm == 1.0
+    for a, b in zip(losses[0], losses[1]):
+        assert abs(a - b) <= 2e-5 * abs(b) + 1e-6, (losses[0], losses[1])
+    assert losses[0][-1] < losses[0][0]
+    sa, sb = ma.state_dict(), mb.state_dict()
+    noise = (".layer_1.bias", ".layer_out.bias", "fusion_block.bias", ".running_mean")
+    moved = 0.0
+    for k in sa:
+        if sa[k].dtype.is_floating_point:
+            d = (sa[k].double() - sb[k].double()).abs()
+            assert float(d.max()) <= 2.1 * lr * steps, k
+            if not k.endswith(noise):
+                assert float((d > 1e-5 + 1e-3 * sb[k].double().abs()).double().mean()) <= 5e-3, k
+    w0 = m.state_dict()["encoders.0.layer_1.weight"]
+    assert float((sa["encoders.0.layer_1.weight"] - w0).abs().max()) > 1e-4       # the wide weights did move
+    # a second step() without a backward in between applies nothing
+    before = sa["encoders.0.layer_1.weight"].clone()
+    oa.step()
+    assert torch.equal(ma.state_dict()["encoders.0.layer_1.weight"], before)
+    # an upstream gradient other than 1 is refused (detected one backward late, without a host sync in the step)
+    ma.train()
+    loss = ma.training_step(batch, 99, log=False)
+    (2.0 * loss).backward()
+    torch.cuda.synchronize()
+    loss = ma.training_step(batch, 100, log=False)
+    with pytest.raises(RuntimeError, match="upstream gradient"):
+        loss.backward()
