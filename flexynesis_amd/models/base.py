@@ -177,6 +177,14 @@ class FxAdam(torch.optim.Optimizer):
 
 class FxModel(_Base):
     MODEL = None  # "DirectPred" | "supervised_vae" | "MultiTripletNetwork" | "CrossModalPred"
+    # run-time state that belongs to one bound instance: never copied, pickled or kept across .to()
+    _RUNTIME = {"_store": None, "_plans": dict, "_fused_ready": None, "_fused_scale_host": None, "_fused_scale_event": None,
+                "_fx_optimizer": None}
+
+    def _reset_runtime(self, target=None):
+        d = self.__dict__ if target is None else target
+        for k, v in self._RUNTIME.items():
+            d[k] = v() if callable(v) else v
 
     def __init__(self, config, dataset, target_variables, batch_variables=None, surv_event_var=None,
                  surv_time_var=None, use_loss_weighting=True, device_type=None, **spec_kw):
@@ -253,8 +261,11 @@ class FxModel(_Base):
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
-        # .to()/.cuda()/.cpu() replace parameter storage: the arenas are stale after any such move
-        self._store, self._plans = None, {}
+        # .to()/.cuda()/.cpu() replace parameter storage: the arenas are stale after any such move (the optimiser stays:
+        # it holds the same Parameter objects)
+        opt = self.__dict__.get("_fx_optimizer")
+        self._reset_runtime()
+        self.__dict__["_fx_optimizer"] = opt
         return out
 
     def __deepcopy__(self, memo):
@@ -262,10 +273,10 @@ class FxModel(_Base):
         new = cls.__new__(cls)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            if k in ("_store", "_plans"):
+            if k in self._RUNTIME:
                 continue
             setattr(new, k, copy.deepcopy(v, memo))
-        new._store, new._plans = None, {}
+        new._reset_runtime()
         # cloned parameters may still alias one cloned arena; give each its own storage
         for p in new.parameters():
             p.data = p.data.clone()
@@ -275,7 +286,7 @@ class FxModel(_Base):
 
     def __getstate__(self):
         st = dict(self.__dict__)
-        st["_store"], st["_plans"] = None, {}
+        self._reset_runtime(st)
         return st
 
     def _sync_nbt(self):

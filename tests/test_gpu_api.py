@@ -548,6 +548,22 @@ def test_level1_fused_optimizer_follows_materialised_path():
     before = sa["encoders.0.layer_1.weight"].clone()
     oa.step()
     assert torch.equal(ma.state_dict()["encoders.0.layer_1.weight"], before)
+    # copies and pickles of a model that has trained in this mode carry no run-time state (plans, events, the optimiser)
+    import io
+    mc = copy.deepcopy(ma)
+    assert mc._fused_ready is None and mc._fx_optimizer is None and mc.fused_optimizer
+    buf = io.BytesIO()
+    torch.save(ma, buf)
+    buf.seek(0)
+    md = torch.load(buf, weights_only=False)
+    assert torch.equal(md.state_dict()["encoders.0.layer_1.weight"].cpu(), before.cpu()) and md._fx_optimizer is None
+    oc = mc.configure_optimizers()
+    mc.train()
+    oc.zero_grad()
+    mc.training_step(batch, 7, log=False).backward()
+    mc.configure_gradient_clipping(oc, 1.0, "norm")
+    oc.step()
+    assert not torch.equal(mc.state_dict()["encoders.0.layer_1.weight"], before)
     # an upstream gradient other than 1 is refused (detected one backward late, without a host sync in the step)
     ma.train()
     loss = ma.training_step(batch, 99, log=False)
