@@ -572,3 +572,61 @@ def test_level1_fused_optimizer_follows_materialised_path():
     loss = ma.training_step(batch, 100, log=False)
     with pytest.raises(RuntimeError, match="upstream gradient"):
         loss.backward()
+
+
+@pytest.mark.parametrize("name,targets,surv", [("supervised_vae", ["c"], False), ("MultiTripletNetwork", ["c", "y"], False),
+                                               ("CrossModalPred", ["y"], True)])
+def test_level1_fused_optimizer_other_families(name, targets, surv):
+    """The fused level-1 mode on the VAE family and the triplet network: wide weights (encoders and decoders) move without
+    ever having a .grad, and the run follows the default level-1 mode (same seeds -> same in-kernel draws) to rounding."""
+    import flexynesis_amd.models as M
+    from flexynesis_amd.data import TripletMultiOmicDataset
+    torch.manual_seed(2)
+    ds = _synthetic_ds(n=192, F=(8192, 4100), seed=4)
+    cfg = {"latent_dim": 24, "hidden_dim_factor": 0.25, "lr": 2e-3, "supervisor_hidden_dim": 8, "epochs": 1, "batch_size": 32}
+    kw = dict(surv_event_var="event", surv_time_var="time") if surv else {}
+    if name == "CrossModalPred":
+        kw.update(input_layers=["gex", "cnv"], output_layers=["cnv"])
+    m = getattr(M, name)(cfg, ds, targets, device_type="cuda", **kw)
+    m.to(DEV)
+    w0 = {k: v.clone() for k, v in m.state_dict().items()}
+    ma, mb = copy.deepcopy(m), copy.deepcopy(m)
+    ma.fused_optimizer = True
+    oa, ob = ma.configure_optimizers(), mb.configure_optimizers()
+    tds = TripletMultiOmicDataset(ds, "c") if name == "MultiTripletNetwork" else None
+    g = torch.Generator().manual_seed(0)
+    losses = {0: [], 1: []}
+    steps, lr = 4, cfg["lr"]
+    for it in range(steps):
+        idx = torch.randperm(192, generator=g)[:32].tolist()
+        if tds is not None:
+            items = [tds[i] for i in idx]
+            col = lambda j: {k: torch.stack([torch.as_tensor(t[j][k]) for t in items]).to(DEV) for k in items[0][j]}
+            batch = (col(0), col(1), col(2), col(3))
+        else:
+            batch = ({k: v[idx].to(DEV) for k, v in ds.dat.items()}, {k: torch.as_tensor(v)[idx].to(DEV) for k, v in ds.ann.items()}, None)
+        for j, (mm, oo) in enumerate(((ma, oa), (mb, ob))):
+            mm.train()
+            oo.zero_grad()
+            loss = mm.training_step(batch, it, log=False)
+            loss.backward()
+            mm.configure_gradient_clipping(oo, 1.0, "norm")
+            oo.step()
+            losses[j].append(float(loss.detach()))
+    big = list(ma._store.big_keys)
+    assert len(big) >= 2
+    params = dict(ma.named_parameters())
+    assert all(params[k].grad is None for k in big)
+    sa, sb = ma.state_dict(), mb.state_dict()
+    for k in big:
+        assert float((sa[k] - w0[k]).abs().max()) > 1e-4, k
+    for a, b in zip(losses[0], losses[1]):
+        assert abs(a - b) <= 1e-4 * abs(b) + 1e-6, (losses[0], losses[1])
+    noise = (".layer_1.bias", ".layer_out.bias", "fusion_block.bias", ".running_mean", ".bias")
+    for k in sa:
+        if sa[k].dtype.is_floating_point:
+            assert bool(torch.isfinite(sa[k]).all()), k
+            d = (sa[k].double() - sb[k].double()).abs()
+            assert float(d.max()) <= 2.1 * lr * steps, k
+            if not k.endswith(noise):
+                assert float((d > 1e-5 + 2e-3 * sb[k].double().abs()).double().mean()) <= 1e-2, k
