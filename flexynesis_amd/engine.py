@@ -896,6 +896,46 @@ class StepPlan:
             self._lin_bwd_x(rc, dx, dh, p + ".hidden_layers.0.weight")
             self.dX.append(dx)
 
+    def _build_gnn_attr(self, layers, h_last, gop, g, L):
+        """Eval-mode input-gradient tapes of the GNN (reference gnn_early.py:427-438 under Captum): heads -> embedding -> fc ->
+        for every conv layer, last to first: BatchNorm as the affine map of its running statistics with the ReLU gate of the
+        saved output, then dL/dh_in = A^T (dY Wa) + dY Wr -- the training backward's message-passing chain, here carried
+        through the FIRST layer too (training never needs the gradient of the node features)."""
+        spec, st, B = self.spec, self.store, self.B
+        if g["act"] != "relu":
+            raise NotImplementedError("GNN attributions are implemented for act='relu' (the reference's default)")
+        nodes, C = int(g["nodes"]), int(g["embedding_dim"])
+        demb = self._new("attr/demb", B, L)
+        for (v, kind, Cv) in spec.variables:
+            ra = self.t_attr_head[v] = TapeRecorder()
+            pre = "MLPs." + v
+            S = st.shapes[pre + ".layer_1.weight"][0]
+            do = self.attr_dout[v] = self._new(f"attr/dout.{v}", B, Cv)
+            da1 = self._new(f"attr/{pre}/da1", B, S)
+            ops.linear_bwd_x(ra, da1, do, st.p(pre + ".layer_out.weight"), self._ws[0])
+            ops.bn_eval_bwd(ra, da1, da1, None, self.buf[pre + "/a1"][:B], st.p(pre + ".batchnorm.weight"),
+                            st.b(pre + ".batchnorm.running_var"), ACT_NONE, ACT_RELU)
+            ops.linear_bwd_x(ra, demb, da1, st.p(pre + ".layer_1.weight"), self._ws[0])
+        rc = self.t_attr_common
+        dh = self._new("attr/gnn/dh", B, nodes * C)
+        self._branch = 0
+        self._lin_bwd_x(rc, dh, demb, "encoders.0.fc.weight")
+        da = dh.view(B, nodes, C)
+        outs = [lay[0] for lay in layers[1:]] + [h_last]           # layer k's output = layer k + 1's input
+        for k in reversed(range(len(layers))):
+            h_in, y, sm, si, mask, seed, off, wa, ba, wr, bnp, agg = layers[k]
+            d2, a2 = da.view(B * nodes, C), outs[k].view(B * nodes, C)
+            ops.bn_eval_bwd(rc, d2, d2, None, a2, st.p(bnp + ".weight"), st.b(bnp + ".running_var"), ACT_NONE, ACT_RELU)
+            cin = h_in.shape[2]
+            t = self._new(f"attr/gnn/t{k}", B, nodes, cin)
+            ops.rowlin2(rc, t, da, st.p(wa), trans=True)
+            dx = self._new(f"attr/gnn/dx{k}", B, nodes, cin)
+            ops.spmm_rows(rc, dx, t, gop.s_rowptr, gop.s_idx, gop.s_w)
+            if wr:
+                ops.rowlin2(rc, dx, da, st.p(wr), trans=True, accumulate=True)
+            da = dx
+        self.dX.append(da.view(B, nodes * da.shape[2]))
+
     def input_gradient(self, var: str):
         """Run the input-gradient tapes for head ``var`` (after forward(); attr_dout[var] set): fills self.dX."""
         if not self.attribution:
@@ -950,6 +990,8 @@ class StepPlan:
         self._head_losses(rf, emb)
         self._total(rf)
         if not self.train:
+            if self.attribution:
+                self._build_gnn_attr(layers, h, gop, g, L)
             return
         # ---- backward
         demb = self._new("demb", B, L)

@@ -472,12 +472,10 @@ class FxModel(_Base):
         input gradients run on the HIP kernels (eval plans with input-gradient tapes); the result has the reference's
         DataFrame layout and is stored in ``self.feature_importances[target_var]``.  The VAE family differentiates through
         the SAMPLED latent z = mean + log_var * eps like the reference (a fresh eps per forward; CrossModalPred attributes
-        its input layers).  ``alphas`` overrides the GradientShap draws and ``eps(batch, chunk_start, draw, rows)`` the
+        its input layers; the GNN attributes its node features and reports them per omics layer and node).  ``alphas`` overrides the GradientShap draws and ``eps(batch, chunk_start, draw, rows)`` the
         reparameterisation draws (tests).  Captum is not installed in this image: the quadrature / sampling rule is restated
         from its documentation (parity unpinned for that part; oracle/attribution.py)."""
         import pandas as pd
-        if self.MODEL == "GNN":
-            raise NotImplementedError("compute_feature_importance is not implemented for the GNN model")
         if method not in ("IntegratedGradients", "GradientShap"):
             raise ValueError(f"Unsupported method '{method}'. Choose 'IntegratedGradients' or 'GradientShap'.")
         if target_var not in self.variables:
@@ -542,6 +540,22 @@ class FxModel(_Base):
                     for j in range(len(layers)):
                         sums[c][j] += (acc[c][j] * xs[j]).abs().sum(0).double()
         df_list = []
+        if self.MODEL == "GNN":
+            # reference gnn_early.py:599-631: one row set per omics layer of the underlying dataset, names = the graph's nodes,
+            # column layer_idx of the [nodes, node_features] importances -- the reference enumerates multiomic_dataset.dat in
+            # its own key order while the node features are stacked in SORTED layer order (data.py:1219); reproduced as is
+            omics = list(getattr(dataset, "multiomic_dataset", dataset).dat.keys())
+            F = int(self.spec.gnn["node_features"])
+            for c in range(num_class):
+                label = dataset.label_mappings[target_var].get(c) if target_var in getattr(dataset, "label_mappings", {}) else ""
+                imp = (sums[c][0] / n).float().cpu().numpy().reshape(-1, F)
+                for li, lname in enumerate(omics):
+                    col = imp[:, 0] if F == 1 else imp[:, li]
+                    df_list.append(pd.DataFrame({"target_variable": target_var, "target_class": c, "target_class_label": label,
+                                                 "layer": lname, "name": dataset.common_features, "importance": col}))
+            df_imp = pd.concat(df_list, ignore_index=True)
+            self.feature_importances[target_var] = df_imp
+            return df_imp
         for c in range(num_class):
             for j, l in enumerate(layers):
                 label = dataset.label_mappings[target_var].get(c) if target_var in getattr(dataset, "label_mappings", {}) else ""

@@ -34,6 +34,11 @@ def head_output(spec: O.Spec, st, x_list: List[torch.Tensor], var: str, eps: Opt
         mean = O.linear(torch.cat(means, 1), st["FC_mean.weight"], st["FC_mean.bias"])
         log_var = O.linear(torch.cat(lvs, 1), st["FC_log_var.weight"], st["FC_log_var.bias"])
         emb = mean + log_var * eps
+    elif spec.model == "GNN":
+        # gnn_early.py:427-438 (forward_target) -> :142-158: the single pseudo-layer holds [B, nodes * node_features]
+        g = spec.gnn
+        xg = x_list[0].reshape(-1, int(g["nodes"]), int(g["node_features"]))
+        emb = O.flexgcn_forward(spec, st, "encoders.0", xg, False, {}, None)
     else:
         emb = O.directpred_embed(spec, st, x_list, False, {}, None)
     return O.mlp_forward(st, "MLPs." + var, emb, False, None, None)
