@@ -42,7 +42,7 @@ PROTOTYPES = {
     "fx_gram_hadamard": (I, [P, P, I, P, I, L, P]),
     "fx_gather_split": (I, [P, P, P, P, P, P, P, I, I, L, L, L, L, P, L, P]),
     "fx_block_bwd_blocks": (I, [I]),
-    "fx_block_bwd": (I, [P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, P, P, P, L, P, P, I, I, L, L, I, I, F, P]),
+    "fx_block_bwd": (I, [P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, P, P, P, L, P, P, I, I, L, L, I, I, F, I, P]),
     "fx_heads_fwd": (I, [P, I, P, L, I, I, I, F, P, P]),
     "fx_heads_bwd": (I, [P, I, P, L, P, L, I, I, I, F, P, P]),
     "fx_split_bf16": (I, [P, P, P, I, I, L, L, P]),

@@ -43,6 +43,7 @@ struct BlockBwdArgs {
   double* slots;
   int B, C; long ldx, ldo;
   int pre_act, post_act; float drop_p;
+  int accumulate;          // parameter gradients (gW, gb, dgamma, dbeta, dbias) are ADDED to: a further BatchNorm pass over the same weights
 };
 
 __device__ __forceinline__ float bb_colsum(float v, float (*red)[BB_COLS], int cx, int ry) {
@@ -59,7 +60,8 @@ __device__ __forceinline__ float bb_colsum(float v, float (*red)[BB_COLS], int c
 // Plain pointer arguments: indexing the kernel-argument arrays with a runtime k put the whole struct in scratch.
 __device__ __forceinline__ void bb_upstream(const float* __restrict__ dE, long ldE, const float* __restrict__ W,
                                             float* __restrict__ gW, float* __restrict__ gb, int L, int B, int C, int c0, int cc,
-                                            int r0, float* dEs, float (*T)[132], float (*Ws)[BB_COLS], float da[BB_RPT]) {
+                                            int r0, float* dEs, float (*T)[132], float (*Ws)[BB_COLS], float da[BB_RPT],
+                                            int accumulate) {
   const int t = threadIdx.x;
   // the upstream width L (latent size: any integer) is processed in chunks of 64 rows of W / columns of dE
   for (int lc0 = 0; lc0 < L; lc0 += BB_MAXL) {
@@ -135,13 +137,16 @@ __device__ __forceinline__ void bb_upstream(const float* __restrict__ dE, long l
       if (l < Lc) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if (c0 + cg * 4 + j < C) gW[(long)(lc0 + l) * C + c0 + cg * 4 + j] = g[j];
+          if (c0 + cg * 4 + j < C) {
+            float* dst = gW + (long)(lc0 + l) * C + c0 + cg * 4 + j;      // every element has exactly one owner thread
+            *dst = accumulate ? *dst + g[j] : g[j];
+          }
       }
       if (gb && blockIdx.x == 0 && t < Lc) {   // bias gradient = column sums of dE_k
         float sg = 0.f;
 #pragma unroll 8
         for (int r = 0; r < 128; ++r) sg += dEs[r * BB_MAXL + t];
-        gb[lc0 + t] = sg;
+        gb[lc0 + t] = accumulate ? gb[lc0 + t] + sg : sg;
       }
     }
   }
@@ -177,8 +182,8 @@ __global__ __launch_bounds__(BB_T) void fx_block_bwd_kernel(BlockBwdArgs a) {
   float da[BB_RPT];
 #pragma unroll
   for (int i = 0; i < BB_RPT; ++i) da[i] = 0.f;
-  bb_upstream(a.dE[0], a.ldE[0], a.W[0], a.gW[0], a.gb[0], a.L[0], B, a.C, c0, cc, r0, dEs, T, Ws, da);
-  if (a.n_up > 1) bb_upstream(a.dE[1], a.ldE[1], a.W[1], a.gW[1], a.gb[1], a.L[1], B, a.C, c0, cc, r0, dEs, T, Ws, da);
+  bb_upstream(a.dE[0], a.ldE[0], a.W[0], a.gW[0], a.gb[0], a.L[0], B, a.C, c0, cc, r0, dEs, T, Ws, da, a.accumulate);
+  if (a.n_up > 1) bb_upstream(a.dE[1], a.ldE[1], a.W[1], a.gW[1], a.gb[1], a.L[1], B, a.C, c0, cc, r0, dEs, T, Ws, da, a.accumulate);
   // ---- gate (ReLU + dropout in one test on the saved output) and BatchNorm backward (fx_bn_bwd_kernel's expressions)
   const float gate_scale = 1.0f / (1.0f - a.drop_p);
   float s1 = 0.f, s2 = 0.f;
@@ -211,9 +216,9 @@ __global__ __launch_bounds__(BB_T) void fx_block_bwd_kernel(BlockBwdArgs a) {
   }
   const float sum_dx = bb_colsum(sb, red, cx, ry);     // (its barriers also order the last reads of T above)
   if (cok && ry == 0) {
-    a.dgamma[c] = sum_dy_xh;
-    a.dbeta[c] = sum_dy;
-    if (a.dbias) a.dbias[c] = sum_dx;
+    a.dgamma[c] = a.accumulate ? a.dgamma[c] + sum_dy_xh : sum_dy_xh;
+    a.dbeta[c] = a.accumulate ? a.dbeta[c] + sum_dy : sum_dy;
+    if (a.dbias) a.dbias[c] = a.accumulate ? a.dbias[c] + sum_dx : sum_dx;
   }
   if (a.dy && cok) {
 #pragma unroll
@@ -285,12 +290,12 @@ int fx_block_bwd(const float* const* dE, const long* ldE, const float* const* W,
                  const int* L, int n_up, const float* x, const float* out, const float* gamma, const float* save_mean,
                  const float* save_invstd, float* dgamma, float* dbeta, float* dbias, float* dy, void* dyT_hi, void* dyT_lo,
                  long ldt, const float* gram_x, double* slots, int B, int C, long ldx, long ldo, int pre_act, int post_act,
-                 float drop_p, hipStream_t stream) {
+                 float drop_p, int accumulate, hipStream_t stream) {
   FX_REQUIRE(dE && ldE && W && gW && gb && L && n_up >= 1 && n_up <= 2, "fx_block_bwd: 1 or 2 upstream Linears");
   FX_REQUIRE(x && out && gamma && save_mean && save_invstd && dgamma && dbeta, "fx_block_bwd: null pointer");
   FX_REQUIRE(B > 1 && B <= 128 && C > 0, "fx_block_bwd: B=%d must be in 2..128", B);
-  FX_REQUIRE(!dyT_hi || (dyT_lo && ldt % 8 == 0 && ldt >= (B + 31) / 32 * 32 && ldt <= 128),
-             "fx_block_bwd: dyT needs hi and lo, ld %% 8 == 0, round32(B) <= ld <= 128 (got %ld)", ldt);
+  FX_REQUIRE(!dyT_hi || (dyT_lo && ldt % 8 == 0 && ldt >= (B + 31) / 32 * 32),
+             "fx_block_bwd: dyT needs hi and lo, ld %% 8 == 0, ld >= round32(B) (got %ld)", ldt);
   FX_REQUIRE(!gram_x || slots, "fx_block_bwd: gram_x needs the norm slots");
   BlockBwdArgs a{};
   for (int k = 0; k < n_up; ++k) {
@@ -304,6 +309,7 @@ int fx_block_bwd(const float* const* dE, const long* ldE, const float* const* W,
   a.dyT_hi = (__bf16*)dyT_hi; a.dyT_lo = (__bf16*)dyT_lo; a.ldt = ldt;
   a.gram_x = gram_x; a.slots = slots;
   a.B = B; a.C = C; a.ldx = ldx; a.ldo = ldo; a.pre_act = pre_act; a.post_act = post_act; a.drop_p = drop_p;
+  a.accumulate = accumulate ? 1 : 0;
   hipLaunchKernelGGL(fx_block_bwd_kernel, dim3(fx_block_bwd_blocks(C)), dim3(BB_T), 0, stream, a);
   return fx_check_launch("fx_block_bwd");
 }

@@ -223,44 +223,78 @@ __global__ __launch_bounds__(256) void fx_gram_hadamard_kernel(double* __restric
   if (threadIdx.x == 0) slots[blockIdx.x] = acc;
 }
 
-// One 32(batch rows) x 32(features) tile per workgroup: gather the cohort rows, emit
-//   x [R,F] fp32 (optional), hi/lo [R, ldo] bf16, hiT/loT [F, ldt] bf16 (transposed through LDS).
+// One 32 (batch rows) x 128 (features) tile per workgroup: gather the cohort rows, emit
+//   x [R,F] fp32 (optional), hi/lo K-blocked [Fp/32][ldo rows][32] bf16, hiT/loT [F, ldt] bf16 (transposed through LDS).
+// 16-byte loads of the source rows (when the row pitch allows), 16-byte stores of x, 8-byte stores of the K-blocked split,
+// 16-byte stores of the transposed split (the first version moved 4 bytes in and 2 bytes out per lane: 156-278 us per
+// modality at cfg4's 384 x 30000 batch, where three of them run beside the backward chain).
 struct GatherSplit {
   float* x; __bf16* hi; __bf16* lo; __bf16* hiT; __bf16* loT;
   const float* src; const long* idx; const float* ctrl; long cursor_stride;
   int R, F; long ld_src, ldx, ldo, ldt;
+  int vec;                 // 1: F % 4 == 0, ld_src % 4 == 0, ldx % 4 == 0 and 16-byte aligned bases -> float4 accesses
 };
+#define GS_COLS 128
+typedef float gs_f4 __attribute__((ext_vector_type(4)));
+typedef __bf16 gs_bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 gs_bf16x8 __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256) void fx_gather_split_kernel(GatherSplit a) {
-  __shared__ float tile[32][33];
+  __shared__ float tile[32][GS_COLS + 1];
   const long* idx = a.idx;
   if (a.ctrl) idx += (long)a.ctrl[FXC_BATCH_CURSOR] * a.cursor_stride;
-  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const int c0 = blockIdx.x * GS_COLS, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 lanes x 4 columns = 128 columns, 8 rows per pass
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int r = r0 + ty + 8 * i, c = c0 + tx;
-    const bool ok = r < a.R && c < a.F;
+    const int rl = ty + 8 * i, r = r0 + rl, c = c0 + 4 * tx;
     const long s = idx[min(r, a.R - 1)];
-    const float v = a.src[s * a.ld_src + min(c, a.F - 1)];
-    const float w = ok ? v : 0.f;
-    tile[ty + 8 * i][tx] = w;
-    if (r < a.R) {          // K-blocked [Fp/32][ldo rows][32]: this workgroup's 32x32 tile is 2 KB contiguous;
-      if (a.x && c < a.F) a.x[(long)r * a.ldx + c] = w;     // columns F..Fp-1 are zero padding
-      const __bf16 h = (__bf16)w;
-      const long o = ((long)blockIdx.x * a.ldo + r) * 32 + tx;
-      a.hi[o] = h;
-      a.lo[o] = (__bf16)(w - (float)h);
+    gs_f4 v;
+    if (a.vec && c + 3 < a.F) {
+      v = *reinterpret_cast<const gs_f4*>(a.src + s * a.ld_src + c);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (c + j < a.F) ? a.src[s * a.ld_src + c + j] : 0.f;
+    }
+    if (r >= a.R) v = gs_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile[rl][4 * tx + j] = v[j];
+    if (r < a.R) {
+      if (a.x) {
+        if (a.vec && c + 3 < a.F) *reinterpret_cast<gs_f4*>(a.x + (long)r * a.ldx + c) = v;
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (c + j < a.F) a.x[(long)r * a.ldx + c + j] = v[j];
+        }
+      }
+      // K-blocked [Fp/32][ldo rows][32]: columns c .. c+3 lie in K-block c / 32 at offset c % 32; columns F..Fp-1 are zero
+      if (c < ((a.F + 31) / 32) * 32) {
+        gs_bf16x4 h, l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { h[j] = (__bf16)v[j]; l[j] = (__bf16)(v[j] - (float)h[j]); }
+        const long o = ((long)(c >> 5) * a.ldo + r) * 32 + (c & 31);
+        *reinterpret_cast<gs_bf16x4*>(a.hi + o) = h;
+        *reinterpret_cast<gs_bf16x4*>(a.lo + o) = l;
+      }
     }
   }
   __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = c0 + ty + 8 * i, r = r0 + tx;   // r < Rp always (grid covers exactly Rp rows)
+  // transposed: thread = (column t >> 1, 16 rows (t & 1) * 16 ..): two 16-byte stores per array
+  {
+    const int cl = threadIdx.x >> 1, rb = (threadIdx.x & 1) * 16, c = c0 + cl;
     if (c < a.F) {
-      const float v = tile[tx][ty + 8 * i];
-      const __bf16 h = (__bf16)v;
-      a.hiT[(long)c * a.ldt + r] = h;
-      a.loT[(long)c * a.ldt + r] = (__bf16)(v - (float)h);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        gs_bf16x8 h, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = tile[rb + 8 * q + j][cl];
+          h[j] = (__bf16)v;
+          l[j] = (__bf16)(v - (float)h[j]);
+        }
+        const long o = (long)c * a.ldt + r0 + rb + 8 * q;     // r0 + 32 <= Rp <= ldt (the grid covers exactly Rp rows)
+        *reinterpret_cast<gs_bf16x8*>(a.hiT + o) = h;
+        *reinterpret_cast<gs_bf16x8*>(a.loT + o) = l;
+      }
     }
   }
 }
@@ -310,9 +344,12 @@ int fx_gather_split(float* x, void* hi, void* lo, void* hiT, void* loT, const fl
   const int Rp = (n_rows + 31) / 32 * 32, Fp = (n_cols + 31) / 32 * 32;
   FX_REQUIRE(ldo >= n_rows && ldo % 128 == 0 && ldt >= Rp,
              "fx_gather_split: hi/lo are K-blocked with rows padded to 128 (got %ld), hiT/loT need ld >= %d (got %ld)", ldo, Rp, ldt);
+  FX_REQUIRE(ldt % 8 == 0 && (((uintptr_t)hiT | (uintptr_t)loT | (uintptr_t)hi | (uintptr_t)lo) & 15) == 0,
+             "fx_gather_split: split outputs must be 16-byte aligned with ldt %% 8 == 0 (got %ld)", ldt);
+  const int vec = (n_cols % 4 == 0) && (ld_src % 4 == 0) && (!x || ldx % 4 == 0) && ((((uintptr_t)src) | ((uintptr_t)x)) & 15) == 0;
   GatherSplit a{x, (__bf16*)hi, (__bf16*)lo, (__bf16*)hiT, (__bf16*)loT, src, idx, ctrl_cursor, cursor_stride,
-                n_rows, n_cols, ld_src, ldx, ldo, ldt};
-  hipLaunchKernelGGL(fx_gather_split_kernel, dim3(Fp / 32, Rp / 32), dim3(256), 0, stream, a);
+                n_rows, n_cols, ld_src, ldx, ldo, ldt, vec};
+  hipLaunchKernelGGL(fx_gather_split_kernel, dim3((Fp + GS_COLS - 1) / GS_COLS, Rp / 32), dim3(256), 0, stream, a);
   return fx_check_launch("fx_gather_split");
 }
 

@@ -257,6 +257,8 @@ class StepPlan:
         self.bn_slabs = os.environ.get("FX_BN_SLABS", "0") == "1"
         # whole encoder-tail backward in one launch (fx_block_bwd); FX_BLOCK_BWD=0 is an A/B switch for benchmarks
         self.block_bwd = os.environ.get("FX_BLOCK_BWD", "1") != "0"
+        self.block_bwd_passes = os.environ.get("FX_BLOCK_BWD_PASSES", "1") != "0"
+        self.gram_bf16x3 = os.environ.get("FX_GRAM_BF16X3", "1") != "0"              # X X^T of stacked rows on the split-bf16 kernel (A/B)    # ... also per pass of stacked rows (A/B)
         # all supervisor heads in one launch each way (fx_heads_fwd/bwd); FX_FUSE_HEADS=0 is an A/B switch for benchmarks
         self.fuse_heads = bool(fuse_heads) and os.environ.get("FX_FUSE_HEADS", "1") != "0"
         self.small_linear = os.environ.get("FX_SMALL_LINEAR", "1") != "0"
@@ -369,11 +371,25 @@ class StepPlan:
                            ACT_NONE, ACT_RELU, DROPOUT_P)
             return
         da1 = self._new(prefix + "/da1", rows, H)           # also holds dy1 (BN backward runs in place)
+        Bp = rows // passes
+        if (dx is None and self.block_bwd and self.train and passes > 1 and Bp <= 128 and self.block_bwd_passes
+                and not self._is_frozen(prefix + ".layer_out.weight")):
+            # stacked BatchNorm passes (triplet: anchor / positive / negative rows): one fx_block_bwd launch per pass, the
+            # parameter gradients accumulated from the second on -- instead of seven dependent per-layer launches
+            bias_key = prefix + ".layer_out.bias"
+            wk = prefix + ".layer_out.weight"
+            for p in range(passes):
+                sl = slice(p * Bp, (p + 1) * Bp)
+                ops.block_bwd(rec, [(dout[sl], st.p(wk), st.g(wk), st.g(bias_key) if bias_key in st.shapes else None)], y1[sl], a1[sl],
+                              st.p(prefix + ".batchnorm.weight"), sm[p], si[p], st.g(prefix + ".batchnorm.weight"),
+                              st.g(prefix + ".batchnorm.bias"), st.g(prefix + ".layer_1.bias"), ACT_NONE, ACT_RELU, DROPOUT_P,
+                              dy=da1[sl], accumulate=p > 0)
+            self._weight_grad(rec, prefix + ".layer_1.weight", da1, x)
+            return
         self._weight_grad(rec, prefix + ".layer_out.weight", dout, a1)
         if prefix + ".layer_out.bias" in st.shapes:
             ops.colsum(rec, st.g(prefix + ".layer_out.bias"), dout)
         ops.linear_bwd_x(rec, da1, dout, st.p(prefix + ".layer_out.weight"), self.ws)
-        Bp = rows // passes
         for p in range(passes):
             sl = slice(p * Bp, (p + 1) * Bp)
             ops.bn_act_bwd(rec, da1[sl], st.g(prefix + ".batchnorm.weight"), st.g(prefix + ".batchnorm.bias"),
@@ -614,9 +630,19 @@ class StepPlan:
         gx = self._gram_x.get(x.data_ptr())
         if gx is None:
             R = x.shape[0]
-            nx = int(ops.lib.fx_gemm_splitk(R, R, x.shape[1]))
-            gx = (self._new(f"gram_x/{x.data_ptr()}", nx, R * R), nx)
-            ops.gemm_slabs(rec, ops.GEMM_NT, gx[0], x, x, R, R)
+            sp = self._split_cache.get(("fwd", x.data_ptr()))
+            if (self.precision == "bf16x3" and sp is not None and R > 128 and x.shape[1] >= 4096 and self.gram_bf16x3
+                    and x.is_contiguous()):
+                # stacked rows (triplet, 3 B = 384): X X^T on the split-bf16 forward kernel -- X's K-blocked split against X
+                # itself as the fp32 "weight" -- instead of the exact-fp32 GEMM: ~200 us per modality of work that ran
+                # beside the backward chain and starved its single-workgroup kernels (heads backward 52 -> 222 us)
+                # (reduced here, in the batch-assembly branch: fx_gram_hadamard on the critical chain then reads one slab, not 85)
+                gx = (self._new(f"gram_x/{x.data_ptr()}", 1, R * R), 1)
+                ops.linear_fwd_bf16x3(rec, gx[0].view(R, R), sp[0], sp[1], x, None, self.ws)
+            else:
+                nx = int(ops.lib.fx_gemm_splitk(R, R, x.shape[1]))
+                gx = (self._new(f"gram_x/{x.data_ptr()}", nx, R * R), nx)
+                ops.gemm_slabs(rec, ops.GEMM_NT, gx[0], x, x, R, R)
             self._gram_x[x.data_ptr()] = gx
         return gx
 

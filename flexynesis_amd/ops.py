@@ -569,7 +569,7 @@ def block_bwd_blocks(C: int) -> int:
 
 
 def block_bwd(rec, ups, x, out, gamma, save_mean, save_invstd, dgamma, dbeta, dbias, pre_act, post_act, drop_p,
-              dy=None, dyT=None, gram_x=None, slots=None):
+              dy=None, dyT=None, gram_x=None, slots=None, accumulate=False):
     """Backward of "wide Linear -> BatchNorm block -> small Linears" in one launch (include/fxhip.h: fx_block_bwd).
     ``ups`` = [(dE [B, L], W [L, C], gW [L, C], gb [L] | None), ...] (1 or 2 entries)."""
     _chk2d(x, "block_bwd.x")
@@ -589,7 +589,7 @@ def block_bwd(rec, ups, x, out, gamma, save_mean, save_invstd, dgamma, dbeta, db
     rec.emit("fx_block_bwd", *[C.addressof(a_) for a_ in arrs], n, x.data_ptr(), out.data_ptr(), gamma.data_ptr(),
              save_mean.data_ptr(), save_invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dbias), _ptr(dy),
              _ptr(dyT[0]) if dyT else None, _ptr(dyT[1]) if dyT else None, _ld(dyT[0]) if dyT else 0, _ptr(gram_x),
-             _ptr(slots), B, Cc, _ld(x), _ld(out), int(pre_act), int(post_act), float(drop_p))
+             _ptr(slots), B, Cc, _ld(x), _ld(out), int(pre_act), int(post_act), float(drop_p), int(bool(accumulate)))
     return arrs
 
 

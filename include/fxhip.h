@@ -184,13 +184,15 @@ int fx_heads_bwd(const fx_head_desc* heads, int n_heads, const float* x, long ld
  *      gram_x = X X^T [B, B] (one double per workgroup into slots[0 .. fx_block_bwd_blocks(C))).
  *      dE / ldE / W / gW / gb / L are HOST arrays of n_up (1 or 2) entries: upstream gradient [B, L_k], weight
  *      [L_k, C], its gradient [L_k, C], bias gradient [L_k] or NULL.  Optional outputs may be NULL (dy, dyT_*, gram_x).
- *      B <= 128. */
+ *      B <= 128 rows per launch: one BatchNorm pass.  Stacked passes through the same weights (the triplet network's anchor /
+ *      positive / negative rows) take one launch per pass on row-offset pointers, with accumulate = 1 from the second on
+ *      (gW, gb, dgamma, dbeta, dbias are then added to; dy / dyT_* rows or columns of the pass are written). */
 int fx_block_bwd_blocks(int C);
 int fx_block_bwd(const float* const* dE, const long* ldE, const float* const* W, float* const* gW, float* const* gb,
                  const int* L, int n_up, const float* x, const float* out, const float* gamma, const float* save_mean,
                  const float* save_invstd, float* dgamma, float* dbeta, float* dbias, float* dy, void* dyT_hi, void* dyT_lo,
                  long ldt, const float* gram_x, double* slots, int B, int C, long ldx, long ldo, int pre_act, int post_act,
-                 float drop_p, fx_stream_t stream);
+                 float drop_p, int accumulate, fx_stream_t stream);
 
 /* ---- small dense layers on the critical chain (fusion layer direct_pred.py:87-93,121-124; VAE FC_mean / FC_log_var
  *      supervised_vae.py:104-107,172-176): one forward launch, and ONE backward launch for the data, weight and bias
