@@ -231,7 +231,7 @@ __global__ __launch_bounds__(BB_T) void fx_block_bwd_kernel(BlockBwdArgs a) {
   __syncthreads();
   if (a.dyT_hi) {      // thread: column t >> 4, rows (t & 15) * 8 .. +8  -> one 16-byte store per array
     const int col = t >> 4, rb = (t & 15) * 8;
-    if (c0 + col < a.C && rb < a.ldt) {
+    if (c0 + col < a.C && rb < ((B + 31) & ~31)) {       // rows B .. round32(B) - 1 are written as zeros; nothing beyond (a pass of stacked rows owns only its columns)
       bf16x8 hi, lo;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {

@@ -377,14 +377,17 @@ class StepPlan:
             # stacked BatchNorm passes (triplet: anchor / positive / negative rows): one fx_block_bwd launch per pass, the
             # parameter gradients accumulated from the second on -- instead of seven dependent per-layer launches
             bias_key = prefix + ".layer_out.bias"
-            wk = prefix + ".layer_out.weight"
+            wk, w1 = prefix + ".layer_out.weight", prefix + ".layer_1.weight"
+            # the wide layer's fused optimiser wants dY as a transposed split [H, rows]: each pass writes its own columns
+            want_t = (self.fused and w1 in st.big and not self._is_frozen(w1) and self.precision == "bf16x3" and Bp % 32 == 0)
+            dyt = ops.new_split(H, rows, self.dev) if want_t else None
             for p in range(passes):
                 sl = slice(p * Bp, (p + 1) * Bp)
                 ops.block_bwd(rec, [(dout[sl], st.p(wk), st.g(wk), st.g(bias_key) if bias_key in st.shapes else None)], y1[sl], a1[sl],
                               st.p(prefix + ".batchnorm.weight"), sm[p], si[p], st.g(prefix + ".batchnorm.weight"),
                               st.g(prefix + ".batchnorm.bias"), st.g(prefix + ".layer_1.bias"), ACT_NONE, ACT_RELU, DROPOUT_P,
-                              dy=da1[sl], accumulate=p > 0)
-            self._weight_grad(rec, prefix + ".layer_1.weight", da1, x)
+                              dy=da1[sl], dyT=(dyt[0][:, p * Bp:], dyt[1][:, p * Bp:]) if want_t else None, accumulate=p > 0)
+            self._weight_grad(rec, w1, da1, x, dyt=dyt)
             return
         self._weight_grad(rec, prefix + ".layer_out.weight", dout, a1)
         if prefix + ".layer_out.bias" in st.shapes:
@@ -535,7 +538,7 @@ class StepPlan:
     def _is_frozen(self, key: str) -> bool:
         return bool(self.frozen) and key.startswith(self.frozen)
 
-    def _weight_grad(self, rec, key, dy, x):
+    def _weight_grad(self, rec, key, dy, x, dyt=None):
         """dW = dY^T X: materialised, or deferred to the fused dW+clip+Adam kernel for wide layers."""
         if self._is_frozen(key):
             return                                       # requires_grad=False: no gradient, not in the optimiser
@@ -553,16 +556,19 @@ class StepPlan:
                 nb = ops.gram_hadamard_blocks(R * R)
                 ops.gram_hadamard(rec, self.slots[self._slot_o:self._slot_o + nb], gx[0], gx[1], gd, nd, R * R)
                 self._slot_o += nb
-            xt = dyt = None
+            xt = None
+            if self.precision != "bf16x3":
+                dyt = None
             if self.precision == "bf16x3":
                 xt = self._split_cache.get(("T", x.data_ptr()))
                 if xt is None:
                     xt = ops.new_split(x.shape[1], x.shape[0], self.dev)
                     self._split_cache[("T", x.data_ptr())] = xt
                     ops.split_bf16_t(rec, xt[0], xt[1], x)
-                dyt = ops.new_split(dy.shape[1], dy.shape[0], self.dev)
+                if dyt is None:                          # (fx_block_bwd may already have written the transposed split)
+                    dyt = ops.new_split(dy.shape[1], dy.shape[0], self.dev)
+                    ops.split_bf16_t(rec, dyt[0], dyt[1], dy)
                 self.buf[f"dyT/{key}"], self.buf[f"dyT_lo/{key}"] = dyt
-                ops.split_bf16_t(rec, dyt[0], dyt[1], dy)
             self._jobs[key] = (dy, x, dyt, xt)
         else:
             ops.linear_bwd_w(rec, self.store.g(key), dy, x, self.ws)
