@@ -579,11 +579,15 @@ def test_train_step_exact_fp32_mode(case):
 # ---------------------------------------------------------------------------------------------------
 # launch-fusion kernels (fx_fused_small.hip)
 # ---------------------------------------------------------------------------------------------------
-def test_gather_split_matches_gather_plus_splits():
+@pytest.mark.parametrize("R,F,src_cols", [(100, 1000, 1000),      # R not a multiple of 32: padded rows must be zero
+                                          (384, 4099, 4099),      # stacked triplet rows; F % 4 != 0: the scalar path, ragged last tile
+                                          (7, 30, 30),            # smaller than one tile
+                                          (128, 996, 1001),       # F % 4 == 0 but the source row pitch is not: scalar loads, vector stores off
+                                          (33, 4224, 4224)])      # F a multiple of the 128-column tile
+def test_gather_split_matches_gather_plus_splits(R, F, src_cols):
     from flexynesis_amd import ops
     dev = _dev()
-    src = torch.randn(300, 1000, device=dev)
-    R, F = 100, 1000                                    # R not a multiple of 32: padded rows must be zero
+    src = torch.randn(300, src_cols, device=dev)[:, :F]
     idx = torch.randint(0, 300, (3 * R,), device=dev)
     ctrl = torch.zeros(64, device=dev)
     ctrl[8] = 1.0
@@ -601,7 +605,7 @@ def test_gather_split_matches_gather_plus_splits():
     rec = ops.unblock(hi, R, F).float() + ops.unblock(lo, R, F).float()
     assert float((rec - ref).abs().max()) <= 2.0 ** -15 * float(ref.abs().max())
     assert torch.equal(ops.unblock(hi, R, F), ref.to(torch.bfloat16))
-    assert float(hi[:, R:].float().abs().sum()) == 0.0 and float(ops.unblock(hi, R, 1024)[:, F:].float().abs().sum()) == 0.0
+    assert float(hi[:, R:].float().abs().sum()) == 0.0 and float(ops.unblock(hi, R, ops.pad32(F))[:, F:].float().abs().sum()) == 0.0
     hit, lot = ops.new_split(F, R, dev)
     ops.split_bf16_t(ops.IMMEDIATE, hit, lot, ref)
     assert torch.equal(spt[0], hit) and torch.equal(spt[1], lot)
