@@ -484,3 +484,33 @@ def test_bench_with_forced_process_group_reports_sweep_object(tmp_path):
     sw = out["sweep"]
     assert "error" not in sw, sw
     assert sw["trials"] == 3 and sw["trials_ok"] == 3 and sw["winner_state_tensors"] > 10 and sw["aggregate_samples_per_s"] > 0
+
+
+def test_integration_md_ctypes_binding_runs_as_written():
+    """INTEGRATION.md section 3 shows the ctypes stub a flexynesis maintainer would add to call one kernel (fx_cox_ph) from the
+    reference's own PyTorch code.  The block is executed verbatim (only the library path is made absolute) and checked
+    against the oracle's restatement of cox_ph_loss and its autograd gradient."""
+    import os
+    import re
+    from oracle import restate as O
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    code = [b for b in blocks if "def cox_ph_loss_hip" in b]
+    assert len(code) == 1
+    src = code[0].replace('"flexynesis_amd/csrc/libfxhip.so"', repr(os.path.join(root, "flexynesis_amd", "csrc", "libfxhip.so")))
+    ns = {}
+    exec(compile(src, "INTEGRATION.md", "exec"), ns)
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    B = 96
+    out = torch.randn(B, 1, generator=g)
+    dur = torch.rand(B, generator=g) * 10
+    ev = (torch.rand(B, generator=g) < 0.6).float()
+    ev[5] = float("nan")                                  # a missing label
+    loss, grad = ns["cox_ph_loss_hip"](out.to(dev), dur.to(dev), ev.to(dev))
+    o = out.double().clone().requires_grad_(True)
+    ref = O.cox_ph(o, dur.double(), ev.double())
+    ref.backward()
+    assert abs(float(loss) - float(ref.detach())) <= 1e-5 * abs(float(ref.detach())) + 1e-7
+    assert torch.allclose(grad.cpu().double(), o.grad, rtol=1e-4, atol=1e-7)
