@@ -808,6 +808,8 @@ class StepPlan:
         self.t_opt = TapeRecorder()
         self._build_optimizer()
         self.graph = None
+        self.__dict__.get("_tape_graph", {}).pop("opt", None)
+        self.__dict__.get("_tape_calls", {}).pop("opt", None)
 
     def _build_mlp_family(self):
         """DirectPred (direct_pred.py:107-133, :225-260) and MultiTripletNetwork
@@ -1291,13 +1293,42 @@ class StepPlan:
 
     input_gradient = ops.device_guard(input_gradient)
 
+    def _run_tape(self, name: str):
+        """Issue one tape; with ``tape_graphs`` (plans driven call by call from an external loop: the Lightning protocol) the
+        second use captures it into a hipGraph and later uses replay that -- ~50 eager launches per step become three graph
+        launches."""
+        tape = getattr(self, "t_" + name)
+        if not getattr(self, "tape_graphs", False):
+            tape.run()
+            return
+        calls = self.__dict__.setdefault("_tape_calls", {})
+        graphs = self.__dict__.setdefault("_tape_graph", {})
+        n = calls.get(name, 0)
+        calls[name] = n + 1
+        g = graphs.get(name)
+        if g is None and n >= 1:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=ops.capture_stream()):
+                tape.run()
+            graphs[name] = g
+        if g is not None:
+            g.replay()
+        else:
+            tape.run()
+
     @ops.device_guard
     def forward(self):
-        self.t_fwd.run()
+        self._run_tape("fwd")
 
     @ops.device_guard
     def backward(self):
-        self.t_bwd.run()
+        self._run_tape("bwd")
+
+    @ops.device_guard
+    def run_optimizer_tape(self):
+        """The recorded clip + Adam launches (the control block must already hold this step's counters: step_begin)."""
+        self._run_tape("opt")
 
     @ops.device_guard
     def eval_pass(self, use_graph: bool = True):

@@ -153,7 +153,7 @@ class FxAdam(torch.optim.Optimizer):
                 plan.set_clip(self.max_norm)
                 if lr != m._ctrl_lr:               # training_step put config['lr'] into the control block; a scheduler may differ
                     st.ctrl[ops.CTRL_LR:ops.CTRL_LR + 1].fill_(lr)
-                plan.t_opt.run()
+                plan.run_optimizer_tape()
             m._fused_ready = None
             return loss
         with torch.cuda.device(st.device):
@@ -315,6 +315,8 @@ class FxModel(_Base):
         if key not in self._plans:
             self._plans[key] = StepPlan(store, B, train=train, fused=fused, supplied_draws=False,
                                         seed=self._seed + len(self._plans))
+            # training plans of the level-1 path are driven tape by tape from an external loop: replay them as hipGraphs
+            self._plans[key].tape_graphs = bool(train) and os.environ.get("FX_LEVEL1_GRAPHS", "1") != "0"
         return self._plans[key]
 
     # -- batch plumbing -------------------------------------------------------------------------------------
