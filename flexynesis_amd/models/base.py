@@ -233,8 +233,11 @@ class FxModel(_Base):
         self._store: Optional[ParamStore] = None
         self._plans: Dict[tuple, StepPlan] = {}
         self._seed = int(torch.initial_seed() % (2 ** 31))
-        # Level-1 fast path (see FxAdam): FX_LEVEL1_FUSED=1 or model.fused_optimizer = True before configure_optimizers()
-        self.fused_optimizer = os.environ.get("FX_LEVEL1_FUSED", "0") == "1"
+        # Level-1 fast path (see FxAdam): FX_LEVEL1_FUSED=1 / model.fused_optimizer = True before configure_optimizers();
+        # None = decide in configure_optimizers() (on when a Lightning Trainer without accumulation / mixed precision drives
+        # the model -- it clips through the configure_gradient_clipping hook; FX_LEVEL1_FUSED=0 turns that off)
+        env = os.environ.get("FX_LEVEL1_FUSED")
+        self.fused_optimizer = None if env is None else env == "1"
         self._fused_ready: Optional[StepPlan] = None
         self._fused_scale_host = None
         self._fused_scale_event = None
@@ -351,9 +354,28 @@ class FxModel(_Base):
         import os
         if os.environ.get("FX_TORCH_ADAM", "0") == "1" or not torch.cuda.is_available():
             return torch.optim.Adam(self.parameters(), lr=self.config["lr"])
+        if self.fused_optimizer is None:
+            self.fused_optimizer = self._trainer_allows_fused()
         opt = FxAdam(self, self.config["lr"], fused=self.fused_optimizer)
         self._fx_optimizer = opt
         return opt
+
+    def _trainer_allows_fused(self) -> bool:
+        """True when a Lightning Trainer is attached whose loop satisfies the fused optimiser's contract: automatic
+        optimisation, one backward per step (no gradient accumulation), full precision (no loss scaling), norm clipping
+        (the Trainer then routes its gradient_clip_val through configure_gradient_clipping).  Hand-written loops keep the
+        default, materialised gradients, unless they opt in."""
+        tr = self.__dict__.get("_trainer", None) or getattr(self, "_fx_trainer_probe", None)
+        if tr is None or not getattr(self, "automatic_optimization", True):
+            return False
+        try:
+            if int(getattr(tr, "accumulate_grad_batches", 1)) != 1:
+                return False
+            if str(getattr(tr, "precision", "32")).lower() not in ("32", "32-true", "64", "64-true"):
+                return False
+            return str(getattr(tr, "gradient_clip_algorithm", None) or "norm").lower() == "norm"
+        except Exception:
+            return False
 
     def configure_gradient_clipping(self, optimizer, gradient_clip_val=None, gradient_clip_algorithm=None):
         """The hook Lightning's Trainer calls between backward and optimizer.step() with its ``gradient_clip_val``

@@ -442,3 +442,26 @@ def test_state_dict_loads_into_the_reference_model(name):
     assert not res.missing_keys and not res.unexpected_keys
     for k, v in ref.state_dict().items():
         assert v.dtype == sd[k].dtype and torch.equal(v, sd[k]), k
+
+
+def test_fused_level1_mode_is_chosen_only_under_a_suitable_trainer():
+    """configure_optimizers() picks the fused FxAdam on its own only when a Lightning Trainer drives the model with one
+    backward per step, full precision and norm clipping (it then clips through the configure_gradient_clipping hook);
+    hand-written loops keep materialised gradients unless they opt in."""
+    import types
+    from flexynesis_amd.models.base import FxModel
+    probe = types.SimpleNamespace(__dict__={}, automatic_optimization=True)
+    f = FxModel._trainer_allows_fused
+    assert f(probe) is False                                                       # no trainer
+    ok = types.SimpleNamespace(accumulate_grad_batches=1, precision="32-true", gradient_clip_algorithm=None)
+    for tr, want in ((ok, True),
+                     (types.SimpleNamespace(accumulate_grad_batches=4, precision="32-true", gradient_clip_algorithm="norm"), False),
+                     (types.SimpleNamespace(accumulate_grad_batches=1, precision="16-mixed", gradient_clip_algorithm="norm"), False),
+                     (types.SimpleNamespace(accumulate_grad_batches=1, precision="bf16-mixed", gradient_clip_algorithm=None), False),
+                     (types.SimpleNamespace(accumulate_grad_batches=1, precision=32, gradient_clip_algorithm="value"), False)):
+        p = types.SimpleNamespace(automatic_optimization=True)
+        p.__dict__["_trainer"] = tr
+        assert f(p) is want, tr
+    p = types.SimpleNamespace(automatic_optimization=False)
+    p.__dict__["_trainer"] = ok
+    assert f(p) is False
