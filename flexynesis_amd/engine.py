@@ -1331,6 +1331,11 @@ class StepPlan:
         self._run_tape("opt")
 
     @ops.device_guard
+    def run_optimizer_tape(self):
+        """The recorded clip + Adam launches (the control block must already hold this step's counters: step_begin)."""
+        self._run_tape("opt")
+
+    @ops.device_guard
     def eval_pass(self, use_graph: bool = True):
         """Batch assembly (cohort mode) + forward of an EVAL plan, for callers that run it many times (per-epoch validation:
         13 chunks x ~27 eager launches cost 2.3 ms of host time per epoch at cfg2, more than the kernels themselves).  The

@@ -99,7 +99,8 @@ def _eval_loss(model, store, cohort, idx_rows: torch.Tensor, batch_size: int, pa
             plan.idx.copy_(torch.cat([rows, pos, neg]))
         else:
             plan.idx.copy_(rows)
-        plan.eval_pass(use_graph=cache.get("use_graph", True))      # batch assembly + forward (eager, then hipGraph replay)
+        plan.t_gather.run()
+        plan.forward()
         k = len(plan.spec.loss_names())
         acc.append((plan.loss_vec[k].clone(), B))
     for v, B in acc:
@@ -164,7 +165,6 @@ def _fit(model, store, dataset, train_idx, val_idx, *, batch_size, epochs, lr, p
                          n_batches=0, epoch_acc=True, **plan_kw) if tail else None
     names = spec.loss_names()
     eval_cache: Dict[int, StepPlan] = {}
-    eval_cache["use_graph"] = bool(use_graph)       # validation chunks replay a hipGraph from their third use on
     history: List[Dict[str, float]] = []
     best, wait, stopped_epoch, steps = float("inf"), 0, 0, 0
     tails: List[torch.Tensor] = []          # tail rows of the epochs whose table has been drawn, oldest first

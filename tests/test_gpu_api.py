@@ -579,9 +579,12 @@ def test_level1_fused_optimizer_follows_materialised_path():
 def test_level1_fused_optimizer_other_families(name, targets, surv):
     """The fused level-1 mode on the VAE family and the triplet network: wide weights (encoders and decoders) move without
     ever having a .grad, and the run follows the default level-1 mode (same seeds -> same in-kernel draws) to rounding."""
+    import random
     import flexynesis_amd.models as M
     from flexynesis_amd.data import TripletMultiOmicDataset
     torch.manual_seed(2)
+    random.seed(2)                      # TripletMultiOmicDataset draws its positives / negatives from the global generators
+    np.random.seed(2)
     ds = _synthetic_ds(n=192, F=(8192, 4100), seed=4)
     cfg = {"latent_dim": 24, "hidden_dim_factor": 0.25, "lr": 2e-3, "supervisor_hidden_dim": 8, "epochs": 1, "batch_size": 32}
     kw = dict(surv_event_var="event", surv_time_var="time") if surv else {}
@@ -627,6 +630,9 @@ def test_level1_fused_optimizer_other_families(name, targets, surv):
         if sa[k].dtype.is_floating_point:
             assert bool(torch.isfinite(sa[k]).all()), k
             d = (sa[k].double() - sb[k].double()).abs()
+            if "running_" in k:            # BatchNorm statistics follow the activations, not the learning rate
+                assert float(d.max()) <= 5e-2 * float(sb[k].double().abs().max()) + 1e-3, k
+                continue
             assert float(d.max()) <= 2.1 * lr * steps, k
             if not k.endswith(noise):
                 assert float((d > 1e-5 + 2e-3 * sb[k].double().abs()).double().mean()) <= 1e-2, k
