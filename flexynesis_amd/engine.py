@@ -1331,35 +1331,6 @@ class StepPlan:
         self._run_tape("opt")
 
     @ops.device_guard
-    def run_optimizer_tape(self):
-        """The recorded clip + Adam launches (the control block must already hold this step's counters: step_begin)."""
-        self._run_tape("opt")
-
-    @ops.device_guard
-    def eval_pass(self, use_graph: bool = True):
-        """Batch assembly (cohort mode) + forward of an EVAL plan, for callers that run it many times (per-epoch validation:
-        13 chunks x ~27 eager launches cost 2.3 ms of host time per epoch at cfg2, more than the kernels themselves).  The
-        first call launches eagerly (loads the code objects), the second captures a hipGraph, later ones replay it."""
-        if self.train:
-            raise RuntimeError("eval_pass is for eval plans")
-        n = getattr(self, "_eval_calls", 0)
-        self._eval_calls = n + 1
-        if use_graph and n >= 1 and getattr(self, "_eval_graph", None) is None:
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=ops.capture_stream()):
-                if self.cohort is not None:
-                    self.t_gather.run()
-                self.t_fwd.run()
-            self._eval_graph = g
-        if use_graph and getattr(self, "_eval_graph", None) is not None:
-            self._eval_graph.replay()
-            return
-        if self.cohort is not None:
-            self.t_gather.run()
-        self.t_fwd.run()
-
-    @ops.device_guard
     def optimizer_step(self, lr: float):
         ops.step_begin(ops.IMMEDIATE, self.store.ctrl, lr, 0)
         self.t_opt.run()
