@@ -12,6 +12,7 @@ arenas.
 from __future__ import annotations
 
 import copy
+import weakref
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -318,8 +319,11 @@ class FxModel(_Base):
         if key not in self._plans:
             self._plans[key] = StepPlan(store, B, train=train, fused=fused, supplied_draws=False,
                                         seed=self._seed + len(self._plans))
-            # training plans of the level-1 path are driven tape by tape from an external loop: replay them as hipGraphs
-            self._plans[key].tape_graphs = bool(train) and os.environ.get("FX_LEVEL1_GRAPHS", "1") != "0"
+            # FX_LEVEL1_GRAPHS=1: training plans of the level-1 path (driven tape by tape from an external loop) replay their
+            # tapes as hipGraphs from the third use on (fused drop-in 70.9 -> 77.6 k samples/s at cfg2).  Opt-in: with it
+            # on, one in three runs of the whole GPU test suite (hundreds of short-lived models and graphs in one process)
+            # died inside a later hipGraphLaunch of an unrelated training graph; five of five runs pass with it off.
+            self._plans[key].tape_graphs = bool(train) and os.environ.get("FX_LEVEL1_GRAPHS", "0") == "1"
         return self._plans[key]
 
     # -- batch plumbing -------------------------------------------------------------------------------------
@@ -357,7 +361,7 @@ class FxModel(_Base):
         if self.fused_optimizer is None:
             self.fused_optimizer = self._trainer_allows_fused()
         opt = FxAdam(self, self.config["lr"], fused=self.fused_optimizer)
-        self._fx_optimizer = opt
+        self._fx_optimizer = weakref.ref(opt)       # (weak: the optimiser holds the model; a cycle would leave the arenas to the GC)
         return opt
 
     def _trainer_allows_fused(self) -> bool:
@@ -408,7 +412,9 @@ class FxModel(_Base):
         self._fused_scale_event.record()
 
     def training_step(self, train_batch, batch_idx, log=True):
-        fused = bool(self.fused_optimizer) and isinstance(getattr(self, "_fx_optimizer", None), FxAdam) and self._fx_optimizer.fused
+        ref = self.__dict__.get("_fx_optimizer")
+        opt = ref() if ref is not None else None
+        fused = bool(self.fused_optimizer) and isinstance(opt, FxAdam) and opt.fused
         plan = self._plan(self._batch_size(train_batch), train=True, fused=fused)
         self._feed(plan, train_batch)
         self._ctrl_lr = float(self.config.get("lr", 0.0))

@@ -638,37 +638,16 @@ def test_level1_fused_optimizer_other_families(name, targets, surv):
                 assert float((d > 1e-5 + 2e-3 * sb[k].double().abs()).double().mean()) <= 1e-2, k
 
 
-@pytest.mark.parametrize("fused", [False, True])
-def test_level1_tape_graphs_equal_eager_launches(fused):
-    """The level-1 plans replay their forward / backward / optimiser tapes as hipGraphs from the third use on; the same
-    run with eager launches must give the same bits."""
-    import flexynesis_amd.models as M
-    torch.manual_seed(9)
-    ds = _synthetic_ds(n=256, F=(8192, 4100), seed=6)
-    cfg = {"latent_dim": 32, "hidden_dim_factor": 0.25, "lr": 1e-3, "supervisor_hidden_dim": 8, "epochs": 1, "batch_size": 64}
-    m = M.DirectPred(cfg, ds, ["y", "c"], device_type="cuda")
-    m.to(DEV)
-    finals = []
-    for graphs in (True, False):
-        mm = copy.deepcopy(m)
-        mm.fused_optimizer = fused
-        oo = mm.configure_optimizers()
-        losses = []
-        for it in range(6):
-            idx = torch.arange(it * 16, it * 16 + 64) % 256
-            batch = ({k: v[idx].to(DEV) for k, v in ds.dat.items()}, {k: torch.as_tensor(v)[idx].to(DEV) for k, v in ds.ann.items()}, None)
-            mm.train()
-            oo.zero_grad()
-            loss = mm.training_step(batch, it, log=False)
-            plan = mm._plans[(64, True, fused)]
-            plan.tape_graphs = graphs
-            loss.backward()
-            mm.configure_gradient_clipping(oo, 1.0, "norm")
-            oo.step()
-            losses.append(float(loss.detach()))
-        if graphs:
-            assert set(plan._tape_graph) == ({"fwd", "bwd", "opt"} if fused else {"fwd", "bwd"})
-        finals.append((losses, {k: v.clone() for k, v in mm.state_dict().items()}))
-    assert finals[0][0] == finals[1][0]
-    for k in finals[0][1]:
-        assert torch.equal(finals[0][1][k], finals[1][1][k]), k
+def test_level1_tape_graphs_equal_eager_launches():
+    """FX_LEVEL1_GRAPHS=1: the level-1 plans replay their forward / backward / optimiser tapes as hipGraphs from the third use
+    on; the same run with eager launches must give the same bits.  Runs in its own process (tests/_level1_graphs_check.py):
+    the switch is opt-in because graphs captured in the middle of a long-lived process made later, unrelated graph
+    launches crash in one of three runs of this whole suite."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FX_LEVEL1_GRAPHS="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "_level1_graphs_check.py")], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "LEVEL1_GRAPHS_OK 2" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
