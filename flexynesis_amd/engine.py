@@ -1309,7 +1309,7 @@ class StepPlan:
         if g is None and n >= 1:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=ops.capture_stream()):
+            with ops.graph_capture(g):
                 tape.run()
             graphs[name] = g
         if g is not None:
@@ -1361,7 +1361,7 @@ class StepPlan:
             torch.cuda.synchronize()
             self.bump_nbt()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=ops.capture_stream()):
+        with ops.graph_capture(g):
             self._step_for_capture(lr, gather)
         self.graph = g
         return g
@@ -1475,7 +1475,7 @@ class PipelinedStep:
         torch.cuda.synchronize()
         for k in (0, 1):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=ops.capture_stream()):
+            with ops.graph_capture(g):
                 self._issue(k, lr)
             self.graphs[k] = g
 

@@ -116,6 +116,31 @@ def capture_stream() -> "torch.cuda.Stream":
     return side_streams(1, group=2)[0]
 
 
+class graph_capture:
+    """``with ops.graph_capture(g): ...`` = ``torch.cuda.graph(g, stream=capture_stream())`` with Python's cyclic garbage
+    collector switched off for the duration: a collection in the middle of a capture can destroy an older CUDAGraph (its
+    private memory pool goes back to the driver), which is not a legal call while a stream is capturing."""
+
+    def __init__(self, g):
+        self._ctx = torch.cuda.graph(g, stream=capture_stream())
+        self._gc = False
+
+    def __enter__(self):
+        import gc
+        self._ctx.__enter__()              # (torch collects garbage and empties the cache before capture_begin)
+        self._gc = gc.isenabled()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        try:
+            return self._ctx.__exit__(*exc)
+        finally:
+            if self._gc:
+                gc.enable()
+
+
 class ImmediateRecorder:
     """Launch each op immediately on the current stream."""
 
