@@ -321,8 +321,11 @@ class FxModel(_Base):
                                         seed=self._seed + len(self._plans))
             # FX_LEVEL1_GRAPHS=1: training plans of the level-1 path (driven tape by tape from an external loop) replay their
             # tapes as hipGraphs from the third use on (fused drop-in 70.9 -> 77.6 k samples/s at cfg2).  Opt-in: with it
-            # on, one in three runs of the whole GPU test suite (hundreds of short-lived models and graphs in one process)
-            # died inside a later hipGraphLaunch of an unrelated training graph; five of five runs pass with it off.
+            # on, three of eight runs of the whole GPU test suite (hundreds of short-lived models and graphs in one process)
+            # died inside a later hipGraphLaunch of an unrelated training graph.  The suspected cause -- models kept alive
+            # by a model <-> optimiser cycle, so that their graphs were destroyed by the cyclic GC, possibly in the middle
+            # of another capture -- is removed (weak reference; ops.graph_capture switches the GC off): five of five runs
+            # pass with the switch on since, ten of ten with it off.  It stays off by default until that has aged.
             self._plans[key].tape_graphs = bool(train) and os.environ.get("FX_LEVEL1_GRAPHS", "0") == "1"
         return self._plans[key]
 
