@@ -141,6 +141,9 @@ int fx_bn_act_fwd_slabs(float* out, float* x_out, const float* slabs, int nslabs
 int fx_gram_hadamard_blocks(long n);
 int fx_gram_hadamard(double* slots, const float* slabs_x, int nslabs_x, const float* slabs_d, int nslabs_d, long n,
                      fx_stream_t stream);
+/* x[r, :] = src[idx[r], :] (x optional) plus both splits in one pass (MultiOmicDataset.__getitem__ + default_collate,
+ * data.py:1015-1027, and the operand preparation of the wide kernels).  hi / lo / hiT / loT 16-byte aligned, ldt % 8 == 0 and
+ * >= n_rows rounded up to 32; 16-byte accesses when n_cols, ld_src and ldx are multiples of 4 (scalar otherwise). */
 int fx_gather_split(float* x, void* hi, void* lo, void* hiT, void* loT, const float* src, const long* idx, int n_rows,
                     int n_cols, long ld_src, long ldx, long ldo /* rows_padded of the K-blocked hi/lo */, long ldt,
                     const float* ctrl_cursor, long cursor_stride, fx_stream_t stream);
