@@ -142,7 +142,10 @@ class FxAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
-        loss = closure() if closure is not None else None
+        loss = None
+        if closure is not None:               # Lightning's automatic optimisation: training_step + backward (+ clipping) run in here
+            with torch.enable_grad():
+                loss = closure()
         m = self.model
         st = m._bind()
         lr = float(self.param_groups[0]["lr"])

@@ -651,3 +651,47 @@ def test_level1_tape_graphs_equal_eager_launches():
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "_level1_graphs_check.py")], env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "LEVEL1_GRAPHS_OK 2" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_fused_fxadam_under_a_lightning_style_closure():
+    """Lightning's automatic optimisation calls ``optimizer.step(closure=...)``: the closure runs training_step, zero_grad,
+    backward and -- after the backward -- the gradient-clipping hook; only then does the optimiser update.  The fused
+    FxAdam must find the backward's plan and the clip value that the closure left behind, and configure_optimizers() must
+    pick the fused mode on its own when such a trainer is attached."""
+    import types
+    import flexynesis_amd.models as M
+    from flexynesis_amd.models.base import FxAdam
+    torch.manual_seed(11)
+    ds = _synthetic_ds(n=256, F=(8192, 4100), seed=8)
+    cfg = {"latent_dim": 32, "hidden_dim_factor": 0.25, "lr": 1e-3, "supervisor_hidden_dim": 8, "epochs": 1, "batch_size": 64}
+    m = M.DirectPred(cfg, ds, ["y", "c"], device_type="cuda")
+    m.to(DEV)
+    ma, mb = copy.deepcopy(m), copy.deepcopy(m)
+    # a trainer as the reference configures it (main.py:212-225): gradient_clip_val=1.0, no accumulation, fp32
+    ma.__dict__["_trainer"] = types.SimpleNamespace(accumulate_grad_batches=1, precision="32-true", gradient_clip_algorithm=None)
+    oa, ob = ma.configure_optimizers(), mb.configure_optimizers()
+    assert isinstance(oa, FxAdam) and oa.fused and ma.fused_optimizer is True
+    assert isinstance(ob, FxAdam) and not ob.fused                      # no trainer attached: materialised gradients
+    for it in range(4):
+        idx = torch.arange(it * 48, it * 48 + 64) % 256
+        batch = ({k: v[idx].to(DEV) for k, v in ds.dat.items()}, {k: torch.as_tensor(v)[idx].to(DEV) for k, v in ds.ann.items()}, None)
+        for mm, oo in ((ma, oa), (mb, ob)):
+            mm.train()
+
+            def closure(mm=mm, oo=oo):
+                loss = mm.training_step(batch, it, log=False)
+                oo.zero_grad()
+                loss.backward()
+                mm.configure_gradient_clipping(oo, 1.0, None)          # precision plugin's _after_closure
+                return loss
+            out = oo.step(closure=closure)
+            assert out is not None and bool(torch.isfinite(out.detach()).all())
+    sa, sb = ma.state_dict(), mb.state_dict()
+    noise = (".layer_1.bias", ".layer_out.bias", "fusion_block.bias", ".running_mean")
+    for k in sa:
+        if sa[k].dtype.is_floating_point and "running_" not in k:
+            d = (sa[k].double() - sb[k].double()).abs()
+            assert float(d.max()) <= 2.1 * 1e-3 * 4, k
+            if not k.endswith(noise):
+                assert float((d > 1e-5 + 1e-3 * sb[k].double().abs()).double().mean()) <= 5e-3, k
+    assert float((sa["encoders.0.layer_1.weight"] - m.state_dict()["encoders.0.layer_1.weight"]).abs().max()) > 1e-4
