@@ -803,10 +803,31 @@ def test_random_configurations_one_step_vs_oracle(seed):
     """Seeded sweep (32 committed seeds; 96 more were run once, all green) over model class x layer count x widths x head layout x batch size: one optimisation step of the
     HIP engine against the CPU oracle from identical state, inputs and random draws (everything is in the small-
     parameter regime here, so all tensors are compared element-wise)."""
+    _one_step_vs_oracle(_random_config(seed), seed)
+
+
+_EXTRA_WIDE = [int(v) for v in __import__("os").environ.get("FX_TEST_EXTRA_SEEDS", "").split(",") if v]      # widen the sweep by hand
+
+
+@pytest.mark.parametrize("seed", list(range(100, 112)) + _EXTRA_WIDE)
+def test_random_wide_configurations_one_step_vs_oracle(seed):
+    """(12 committed seeds; 100 more -- FX_TEST_EXTRA_SEEDS=200..259,300..339 -- were run once, all green.)
+    The same sweep with WIDE layers (2049 .. 9000 features of any residue mod 4 / 32, hidden_dim_factor up to 0.5): the
+    first layers exceed 2^20 elements and take the split-bf16 kernels -- wide forward (1-3 M tiles, the stacked triplet
+    rows through the LDS-DMA kernel), fused dW + clip + Adam, the block backward per BatchNorm pass, the Gram norm, the
+    decoders' data gradient -- at batch sizes that are not multiples of 32."""
+    c = _random_config(seed)
+    rng = np.random.default_rng(seed + 7)
+    c["layers"] = [(n, int(rng.integers(2049, 9001))) for n, _ in c["layers"]]
+    c["factor"] = float(rng.uniform(0.3, 0.5))
+    c["B"] = int(rng.choice([8, 17, 32, 64, 100, 128]))
+    _one_step_vs_oracle(c, seed, expect_big=True)
+
+
+def _one_step_vs_oracle(c, seed, expect_big=False):
     from flexynesis_amd.arch import ArchSpec
     from flexynesis_amd.engine import ParamStore, StepPlan
     from oracle import restate as O
-    c = _random_config(seed)
     dev = _dev()
     aspec = ArchSpec(c["model"], c["layers"], c["latent"], c["factor"], c["sup"], c["heads"], c["surv"][0], c["surv"][1],
                      c["weighting"], c["io"][0], c["io"][1])
@@ -818,6 +839,8 @@ def test_random_configurations_one_step_vs_oracle(seed):
     st0 = O.init_state(ospec, seed=seed + 1)
     store = ParamStore(aspec, dev)
     store.load_state(st0)
+    if expect_big:
+        assert len(store.big_keys) >= 1, "the wide sweep must reach the split-bf16 kernels"
     plan = StepPlan(store, B, train=True, fused=True, supplied_draws=True)
     gen = torch.Generator().manual_seed(seed + 2)
     y = {k: ann[k][:B].clone() for k in plan.y}
@@ -855,7 +878,18 @@ def test_random_configurations_one_step_vs_oracle(seed):
             close(sd[k], st1[k], 1e-4, 1e-6, k)
         elif k in store.big_keys:
             bad = (sd[k].cpu().double() - st1[k].double()).abs() > 2e-5 + 1e-3 * st1[k].double().abs()
-            assert float(bad.double().mean()) <= 1e-3, k
+            assert float(bad.double().mean()) <= (2e-3 if expect_big else 1e-3), k
+        elif expect_big:
+            # Adam's first step moves every entry by lr * sign(g): where |g| is at the rounding level of ITS computation
+            # (split-bf16 contractions upstream: ~1e-5 of the tensor's gradient scale, far above 1e-6 of the global norm)
+            # the sign is implementation-defined -- a few entries per tensor land 2 lr apart; everything else must agree
+            a, b = sd[k].detach().double().cpu().reshape(-1), st1[k].double().reshape(-1)
+            err = (a - b).abs()
+            tol = noise_atol(info["grads"].get(k), gn, lr, 2e-6)
+            tol = (tol.double().reshape(-1) if torch.is_tensor(tol) else tol) + 1e-4 * b.abs()
+            bad = err > tol
+            assert int(bad.sum()) <= max(1, int(2e-3 * a.numel())) and float(err.max()) <= 2.1 * lr + 1e-4 * float(b.abs().max()), \
+                (f"{c['model']} seed {seed} {k}: {int(bad.sum())}/{a.numel()} off, max err {float(err.max()):.3e}")
         else:
             close(sd[k], st1[k], 1e-4, noise_atol(info["grads"].get(k), gn, lr, 2e-6), f"{c['model']} seed {seed} {k}")
 
