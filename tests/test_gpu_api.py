@@ -239,20 +239,23 @@ def test_early_stopping_and_run_trial():
     assert val2 == float("inf") and "error" in info2
 
 
+@pytest.mark.parametrize("widths,B", [((1300, 1100), 32),
+                                      ((2051, 1537), 100),       # odd widths: scalar gather path, no next-step fusion (k_in % 4 != 0); ragged batch
+                                      ((4100, 2052), 64)])
 @pytest.mark.parametrize("model_name", ["DirectPred", "MultiTripletNetwork"])
-def test_pipelined_step_equals_plain_step(model_name):
+def test_pipelined_step_equals_plain_step(model_name, widths, B):
     """Double-buffered batch assembly (PipelinedStep: the batch of step t+1 is gathered during step t, hipGraph
     replay) walks the same index tables as the plain one-plan step and must produce the identical trajectory."""
     from flexynesis_amd.arch import ArchSpec
     from flexynesis_amd.data import synthetic_cohort
     from flexynesis_amd.engine import ParamStore, PipelinedStep, StepPlan
     dev = torch.device("cuda:0")
-    layers = [("gex", 1300), ("cnv", 1100)]
+    layers = [("gex", widths[0]), ("cnv", widths[1])]
     trip = model_name == "MultiTripletNetwork"
     variables = [("c", "categorical", 4)] if trip else [("y", "numerical", 1)]
     spec = ArchSpec(model_name, layers, 32, 0.9, 16, variables, None, None, True)      # hidden >= 2^20/F: wide path
     cohort = synthetic_cohort(layers, 400, dev, seed=5)
-    B, nb, steps, lr = 32, 3, 8, 1e-3
+    nb, steps, lr = 3, 8, 1e-3
     rows = B * (3 if trip else 1)
     g = torch.Generator().manual_seed(0)
     tables = [torch.randint(0, 400, (nb * rows,), generator=g).to(dev) for _ in range(steps // nb + 2)]
@@ -276,7 +279,8 @@ def test_pipelined_step_equals_plain_step(model_name):
         store = ParamStore(spec, dev)
         store.load_state(init)
         pipe = PipelinedStep(store, B, cohort=cohort, n_batches=nb, seed=9, fuse_next_fwd=fuse)
-        assert bool(pipe.plans[0]._next_fwd) == (fuse and rows <= 128)   # (more than one M-tile: the separate forward is faster)
+        # (more than one M-tile: the separate forward is faster; a width that is no multiple of 4 cannot take the fused kernel)
+        assert bool(pipe.plans[0]._next_fwd) == (fuse and rows <= 128 and all(w % 4 == 0 for w in widths))
         pipe.idx.copy_(tables[0])
         pipe.prime()
         out, e = [], 0
