@@ -699,3 +699,34 @@ def test_fused_fxadam_under_a_lightning_style_closure():
             if not k.endswith(noise):
                 assert float((d > 1e-5 + 1e-3 * sb[k].double().abs()).double().mean()) <= 5e-3, k
     assert float((sa["encoders.0.layer_1.weight"] - m.state_dict()["encoders.0.layer_1.weight"]).abs().max()) > 1e-4
+
+
+def test_fit_and_predict_edge_cases():
+    """What the loop does at the edges the reference has too: no validation set, a batch larger than the training split
+    (drop_last leaves nothing), BatchNorm's batch-size-1 error (surfacing as a failed trial, +inf, in run_trial), batch size 2,
+    a head whose labels are all missing (zero-loss leaf, reference direct_pred.py:167-177), validation sets smaller than a
+    batch down to one row, predict on one sample."""
+    import flexynesis_amd.models as M
+    from flexynesis_amd._lib import FxError
+    from flexynesis_amd.fit import fit, run_trial, split_indices
+    ds = _synthetic_ds(n=300, F=(500, 300), seed=12)
+    cfg = {"latent_dim": 16, "hidden_dim_factor": 0.25, "lr": 1e-3, "supervisor_hidden_dim": 8, "epochs": 2, "batch_size": 32}
+    tr, va = split_indices(len(ds), 0.2, 0)
+    new = lambda cls=M.DirectPred, t=("y",): cls(cfg, ds, list(t), device_type="cuda")
+    assert np.isnan(fit(new(t=("y", "c")), ds, tr, None, batch_size=32, epochs=2, lr=1e-3).val_loss)
+    with pytest.raises(ValueError, match="exceeds the training split"):
+        fit(new(), ds, tr[:20], va, batch_size=32, epochs=2, lr=1e-3)
+    with pytest.raises(FxError, match="more than 1 value per channel"):
+        fit(new(), ds, tr, va, batch_size=1, epochs=1, lr=1e-3)
+    val, ep = run_trial(M.DirectPred, dict(cfg, batch_size=1), ds, ["y"], early_stop_patience=0, seed=0, device=torch.device(DEV))[:2]
+    assert val == float("inf") and ep == 0                                   # a failed trial does not abort the sweep
+    assert np.isfinite(fit(new(), ds, tr[:40], va, batch_size=2, epochs=1, lr=1e-3).val_loss)
+    import copy as _copy
+    dn = _copy.copy(ds)
+    dn.ann = dict(ds.ann, y=torch.full((len(ds),), float("nan")))
+    r = fit(M.DirectPred(cfg, dn, ["y", "c"], device_type="cuda"), dn, tr, va, batch_size=32, epochs=2, lr=1e-3)
+    assert np.isfinite(r.val_loss) and all(np.isfinite(h["train_loss"]) for h in r.history)
+    assert np.isfinite(fit(new(), ds, tr, va[:5], batch_size=32, epochs=1, lr=1e-3).val_loss)
+    assert np.isfinite(fit(new(M.supervised_vae, ("c",)), ds, tr, va[:1], batch_size=32, epochs=1, lr=1e-3).val_loss)
+    out = new(t=("y", "c")).predict(ds.subset([3]))
+    assert out["y"].shape == (1, 1) and out["c"].shape[0] == 1
