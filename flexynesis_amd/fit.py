@@ -274,13 +274,24 @@ def kfold_indices(n: int, n_splits: int, seed: int):
 FREEZE_PREFIXES = {"encoders": "encoders.", "supervisors": "MLPs."}       # apply_freeze_config, main.py:530-539
 
 
+def _fine_tune_units(model, lrs, cfgs, n_splits):
+    return [(lr, cfg, fi) for lr in lrs for cfg in cfgs for fi in range(n_splits)]
+
+
 def fine_tune(model, dataset, *, n_splits: int = 5, batch_size: int = 32, learning_rates=None, max_epoch: int = 50,
-              freeze_configs=None, seed: int = 0, device=None, use_graph: bool = True, verbose: bool = False):
+              freeze_configs=None, seed: int = 0, device=None, use_graph: bool = True, verbose: bool = False,
+              sharded: bool = False, schedule: str = "queue", comm_device=None):
     """The reference's ``FineTuner.run_experiments`` (main.py:575-659) on the engine: for every learning rate x
     freeze configuration, k-fold cross-validated short fits of a deep copy of ``model`` (fresh Adam, no gradient
     clipping, partial last batch kept, early stopping with patience 3), pick the configuration with the lowest mean
     validation loss, then continue training on all samples for the mean stopped epoch of that configuration.
     Frozen groups cost nothing: their backward, norm and Adam work is not launched.
+
+    ``sharded=True`` (inside an initialised torch.distributed job, one process per GPU): the lr x freeze x fold fits
+    -- 45 with the defaults, all starting from the same weights and independent of each other -- are the units of
+    ``trials.run_units`` (claimed longest-first from a shared counter); one all_gather collects (val_loss, stopped
+    epoch); the rank that ran the LAST fit, from which the reference continues (main.py:647), trains the final model
+    and broadcasts its weights.  Rank 0's starting weights are broadcast first, so every rank fine-tunes the same model.
 
     Returns (final_model, best, results) with ``results`` = the reference's ``val_loss_results`` records."""
     import copy
@@ -292,33 +303,89 @@ def fine_tune(model, dataset, *, n_splits: int = 5, batch_size: int = 32, learni
     if model.spec.model == "MultiTripletNetwork":          # the FineTuner wraps the dataset in TripletMultiOmicDataset
         n = int((~np.isnan(np.asarray(dataset.ann[model.main_var]))).sum())
     folds = kfold_indices(n, n_splits, seed)
-    results, last = [], model
 
     def frozen_of(cfg):
         return tuple(FREEZE_PREFIXES[k] for k in ("encoders", "supervisors") if cfg.get(k))
 
-    for lr in lrs:
-        for cfg in cfgs:
-            losses, eps = [], []
-            for fi, (tr, va) in enumerate(folds):
-                m = copy.deepcopy(model)
-                res = fit(m, dataset, tr, va, batch_size=batch_size, epochs=max_epoch, lr=float(lr), patience=3,
-                          seed=seed * 1000 + fi, use_graph=use_graph, device=device, clip=False, frozen=frozen_of(cfg),
-                          drop_last=False, fresh_optimizer=True)
-                losses.append(res.val_loss)
-                eps.append(res.stopped_epoch)
-                last = m
-            rec = {"learning_rate": lr, "average_val_loss": float(np.mean(losses)), "freeze": cfg, "epochs": int(np.mean(eps))}
-            results.append(rec)
-            if verbose:
-                print(f"[fine_tune] lr {lr} freeze {cfg}: val_loss {rec['average_val_loss']:.5f}, epochs {rec['epochs']}", flush=True)
-    best = min(results, key=lambda r: r["average_val_loss"])
-    # main.py:647-659: the final model continues from the LAST cross-validation model, on all samples
-    final = copy.deepcopy(last)
-    if best["epochs"] > 0:
-        fit(final, dataset, list(range(n)), None, batch_size=batch_size, epochs=best["epochs"], lr=float(best["learning_rate"]),
-            seed=seed * 1000 + 999, use_graph=use_graph, device=device, clip=False, frozen=frozen_of(best["freeze"]),
-            drop_last=False, fresh_optimizer=True)
+    def one_fit(lr, cfg, fi):
+        m = copy.deepcopy(model)
+        tr, va = folds[fi]
+        res = fit(m, dataset, tr, va, batch_size=batch_size, epochs=max_epoch, lr=float(lr), patience=3,
+                  seed=seed * 1000 + fi, use_graph=use_graph, device=device, clip=False, frozen=frozen_of(cfg),
+                  drop_last=False, fresh_optimizer=True)
+        return m, res
+
+    def final_fit(last, best):
+        # main.py:647-659: the final model continues from the LAST cross-validation model, on all samples
+        final = copy.deepcopy(last)
+        if best["epochs"] > 0:
+            fit(final, dataset, list(range(n)), None, batch_size=batch_size, epochs=best["epochs"], lr=float(best["learning_rate"]),
+                seed=seed * 1000 + 999, use_graph=use_graph, device=device, clip=False, frozen=frozen_of(best["freeze"]),
+                drop_last=False, fresh_optimizer=True)
+        return final
+
+    def summarise(vals, eps):
+        results, o = [], 0
+        for lr in lrs:
+            for cfg in cfgs:
+                v, e = vals[o:o + n_splits], eps[o:o + n_splits]
+                o += n_splits
+                rec = {"learning_rate": lr, "average_val_loss": float(np.mean(v)), "freeze": cfg, "epochs": int(np.mean(e))}
+                results.append(rec)
+                if verbose:
+                    print(f"[fine_tune] lr {lr} freeze {cfg}: val_loss {rec['average_val_loss']:.5f}, epochs {rec['epochs']}", flush=True)
+        return results, min(results, key=lambda r: r["average_val_loss"])
+
+    units = _fine_tune_units(model, lrs, cfgs, n_splits)
+    if not sharded:
+        vals, eps, last = [], [], model
+        for (lr, cfg, fi) in units:
+            last, res = one_fit(lr, cfg, fi)
+            vals.append(res.val_loss)
+            eps.append(res.stopped_epoch)
+        results, best = summarise(vals, eps)
+        return final_fit(last, best), best, results
+
+    import torch.distributed as dist
+    from . import trials
+    from .models.base import resolve_device
+    # buffers of the collectives live on the model's GPU (RCCL); ``comm_device`` overrides that for the gloo protocol tests
+    dev = torch.device(comm_device) if comm_device is not None else resolve_device(device)
+    shapes = model.spec.state_shapes()
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    # identical starting weights on every rank
+    model.load_state_dict(trials.broadcast_state(model.state_dict() if rank == 0 else None, shapes, 0, dev))
+    last_uid = len(units) - 1
+    n_tr, n_va = len(folds[0][0]), len(folds[0][1])
+    P = float(sum(int(np.prod(shp)) for k, shp in shapes.items() if len(shp) == 2 and int(np.prod(shp)) >= (1 << 20)
+                  and k.startswith("encoders.")))        # the encoders' wide weights: what a frozen-encoder fit does not stream
+
+    def unit_cost(u):
+        lr, cfg, fi = u
+        frozen_enc = bool(cfg.get("encoders"))
+        step = trials.COST_STEP_FIXED_S + (0.0 if frozen_enc else trials.COST_STEP_PER_PARAM_S * P) + trials.COST_VAL_PER_PARAM_S * P
+        return trials.COST_FIT_FIXED_S + max_epoch * (-(-n_tr // batch_size)) * step
+
+    def unit_fn(uid):
+        lr, cfg, fi = units[uid]
+        m, res = one_fit(lr, cfg, fi)
+        sd = {k: v.detach().clone() for k, v in m.state_dict().items()} if uid == last_uid else None
+        # the early-stopping epoch rides in the "epochs" column; a fit that never stopped early reports 0 (Lightning)
+        return res.val_loss, res.stopped_epoch, sd
+
+    table, held = trials.run_units(len(units), unit_fn, [unit_cost(u) for u in units], dev, keep=[last_uid], schedule=schedule)
+    results, best = summarise(table[:, 1].tolist(), table[:, 2].tolist())
+    owner = int(table[last_uid, 4]) if table[last_uid, 4] == table[last_uid, 4] else 0
+    final_sd = None
+    if rank == owner and last_uid in held:
+        last = copy.deepcopy(model)
+        last.load_state_dict(held[last_uid])
+        final_sd = final_fit(last, best).state_dict()
+    held_final = {last_uid: final_sd} if final_sd is not None else {}
+    state = trials.agree_and_broadcast_state(held_final, last_uid, table, shapes, dev)
+    final = copy.deepcopy(model)
+    if state is not None:
+        final.load_state_dict(state)
     return final, best, results
 
 
@@ -330,23 +397,37 @@ def split_indices(n: int, val_size: float, seed: int):
     return perm[: n - num_val], perm[n - num_val:]
 
 
-def run_trial(model_class, params: dict, dataset, target_variables, batch_variables=None, surv_event_var=None,
-              surv_time_var=None, use_loss_weighting=True, val_size: float = 0.2, early_stop_patience: int = 10,
-              seed: int = 0, device=None, use_graph: bool = True, **model_kwargs):
-    """One HPO trial = reference ``objective(params)`` (main.py:228-333): split -> new model -> fit ->
-    validate -> (val_loss, epochs, model).  A failed / non-finite trial reports +inf instead of raising so a
-    sharded sweep never hangs on a bad configuration."""
-    torch.manual_seed(int(seed))
+def _new_model(model_class, params, dataset, target_variables, batch_variables, surv_event_var, surv_time_var,
+               use_loss_weighting, device, model_kwargs):
     # keyword arguments, like the reference's model_args dict (main.py:230-261): CrossModalPred's positional order
     # differs (input_layers / output_layers come before use_loss_weighting) and it takes them through **model_kwargs
-    model = model_class(config=params, dataset=dataset, target_variables=target_variables, batch_variables=batch_variables,
-                        surv_event_var=surv_event_var, surv_time_var=surv_time_var, use_loss_weighting=use_loss_weighting,
-                        device_type=str(device) if device is not None else None, **model_kwargs)
-    n = len(dataset)
+    return model_class(config=params, dataset=dataset, target_variables=target_variables, batch_variables=batch_variables,
+                       surv_event_var=surv_event_var, surv_time_var=surv_time_var, use_loss_weighting=use_loss_weighting,
+                       device_type=str(device) if device is not None else None, **model_kwargs)
+
+
+def _n_loader_samples(model, dataset) -> int:
+    """len(loader_dataset): the triplet network trains on the valid anchors only (main.py:176-181, data.py:1102-1104)."""
     if model.spec.model == "MultiTripletNetwork":
-        lab = np.asarray(dataset.ann[model.main_var])
-        n = int((~np.isnan(lab)).sum())
-    train_idx, val_idx = split_indices(n, val_size, seed)
+        return int((~np.isnan(np.asarray(dataset.ann[model.main_var]))).sum())
+    return len(dataset)
+
+
+def trial_splits(n: int, val_size: float, seed: int, use_cv: bool = False, n_splits: int = 5):
+    """The split iterator of ``objective`` (main.py:266-281): KFold(n_splits, shuffle=True) folds, or the single
+    random_split in the same (train, val) format."""
+    return kfold_indices(n, n_splits, seed) if use_cv else [split_indices(n, val_size, seed)]
+
+
+def run_trial_fold(model_class, params: dict, dataset, target_variables, train_idx, val_idx, batch_variables=None,
+                   surv_event_var=None, surv_time_var=None, use_loss_weighting=True, early_stop_patience: int = 10,
+                   seed: int = 0, device=None, use_graph: bool = True, **model_kwargs):
+    """One pass of ``objective``'s loop body (main.py:283-326): new model -> fit with early stopping -> validate.
+    Returns (val_loss, epochs, model, info); a failed / non-finite fit reports +inf instead of raising so a sharded
+    sweep never hangs on a bad configuration.  This is the unit that cross-validated sweeps shard over the GPUs."""
+    torch.manual_seed(int(seed))
+    model = _new_model(model_class, params, dataset, target_variables, batch_variables, surv_event_var, surv_time_var,
+                       use_loss_weighting, device, model_kwargs)
     try:
         res = fit(model, dataset, train_idx, val_idx, batch_size=int(params["batch_size"]), epochs=int(params["epochs"]),
                   lr=float(params["lr"]), patience=early_stop_patience, seed=seed, use_graph=use_graph, device=device)
@@ -355,3 +436,50 @@ def run_trial(model_class, params: dict, dataset, target_variables, batch_variab
     val = res.val_loss if np.isfinite(res.val_loss) else float("inf")
     epochs = res.stopped_epoch if res.stopped_epoch else int(params["epochs"])      # main.py:319-322
     return val, epochs, model, {"history": res.history, "steps": res.steps}
+
+
+FOLD_SEED_STRIDE = 7919      # fold i of a trial seeds its model / shuffles with seed + i * stride (fold 0 = the single split's seed)
+
+
+def run_trial(model_class, params: dict, dataset, target_variables, batch_variables=None, surv_event_var=None,
+              surv_time_var=None, use_loss_weighting=True, val_size: float = 0.2, early_stop_patience: int = 10,
+              seed: int = 0, device=None, use_graph: bool = True, use_cv: bool = False, n_splits: int = 5, **model_kwargs):
+    """One HPO trial = reference ``objective(params)`` (main.py:228-333): split(s) -> per split a new model -> fit ->
+    validate -> (mean val_loss, int(mean epochs), the last model trained).  ``use_cv`` selects the k-fold branch
+    (main.py:267-269); the mean over folds is what the optimiser is told (:327-333).  With cross-validation the caller
+    rebuilds the final model on all samples (``full_train``, main.py:403-414)."""
+    # len(loader_dataset): the triplet network trains on the valid anchors only (main.py:176-181, data.py:1102-1104)
+    n = len(dataset)
+    if getattr(model_class, "__name__", "") == "MultiTripletNetwork":
+        n = int((~np.isnan(np.asarray(dataset.ann[target_variables[0]]))).sum())
+    vals, eps, infos, model = [], [], [], None
+    for fi, (tr, va) in enumerate(trial_splits(n, val_size, seed, use_cv, n_splits)):
+        val, ep, model, info = run_trial_fold(model_class, params, dataset, target_variables, tr, va, batch_variables,
+                                              surv_event_var, surv_time_var, use_loss_weighting, early_stop_patience,
+                                              int(seed) + fi * FOLD_SEED_STRIDE, device, use_graph, **model_kwargs)
+        if "error" in info:
+            return float("inf"), 0, model, info
+        vals.append(val)
+        eps.append(ep)
+        infos.append(info)
+    if not use_cv:
+        return vals[0], eps[0], model, infos[0]
+    mean_val = float(np.mean(vals))
+    info = {"fold_val_losses": vals, "fold_epochs": eps, "steps": sum(i.get("steps", 0) for i in infos),
+            "history": [i.get("history") for i in infos]}
+    return (mean_val if np.isfinite(mean_val) else float("inf")), int(np.mean(eps)), model, info
+
+
+def full_train(model_class, params: dict, dataset, target_variables, batch_variables=None, surv_event_var=None,
+               surv_time_var=None, use_loss_weighting=True, seed: int = 0, device=None, use_graph: bool = True,
+               **model_kwargs):
+    """``objective(params, full_train=True)`` (main.py:246-262): a new model trained on ALL samples for params["epochs"]
+    epochs -- shuffle, drop_last, clip 1.0, no validation, no early stopping -- the final model of a cross-validated
+    search (main.py:403-414, where ``epochs`` is the best trial's mean stopped epoch)."""
+    torch.manual_seed(int(seed))
+    model = _new_model(model_class, params, dataset, target_variables, batch_variables, surv_event_var, surv_time_var,
+                       use_loss_weighting, device, model_kwargs)
+    n = _n_loader_samples(model, dataset)
+    res = fit(model, dataset, list(range(n)), None, batch_size=int(params["batch_size"]), epochs=int(params["epochs"]),
+              lr=float(params["lr"]), patience=0, seed=seed, use_graph=use_graph, device=device)
+    return model, {"history": res.history, "steps": res.steps}

@@ -23,7 +23,7 @@ import torch.distributed as dist
 from . import trials
 from .arch import spec_from_dataset
 from .data import MultiOmicDataset
-from .fit import run_trial
+from .fit import FOLD_SEED_STRIDE, full_train, run_trial, run_trial_fold, trial_splits
 from .models import DirectPred
 
 
@@ -37,10 +37,15 @@ def _cohort(layers, n, device, seed):
 
 
 def run_cfg5(dev, n_trials: int = 64, epochs: int = 3, features: int = 20000, samples: int = 2048, seed: int = 0,
-             keep_winner: bool = True) -> dict:
+             keep_winner: bool = True, schedule: str = "queue", force_collectives: bool = False, use_cv: bool = False,
+             n_splits: int = 5) -> dict:
     """The cfg5 workload on the CURRENT process group (or a single process): rank 0 builds the synthetic cohort and
-    broadcasts it, trials are assigned longest-first, every rank runs its trials with the engine loop, one all_gather
-    collects the records and the winner's state_dict is broadcast.  Returns the summary dict (identical on every rank)."""
+    broadcasts it, the trials are claimed longest-first from a counter shared by the ranks (``schedule="static"``: the
+    LPT assignment computed up front), every rank runs its trials with the engine loop, one all_gather collects the
+    records and the winner's state_dict is broadcast.  ``use_cv``: the reference's cross-validated search
+    (main.py:267-269, :403-414) -- the unit of sharding is then one (trial, fold) fit, the optimiser's figure of merit the
+    mean over a trial's folds, and the final model is rebuilt on all samples by rank 0 and broadcast.
+    Returns the summary dict (identical on every rank)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     layers = [("gex", features), ("cnv", features)]
@@ -50,55 +55,100 @@ def run_cfg5(dev, n_trials: int = 64, epochs: int = 3, features: int = 20000, sa
     torch.cuda.synchronize(dev)
     t_gen = time.perf_counter() - t0
     t0 = time.perf_counter()
-    dat, ann = trials.broadcast_cohort(dat, ann, dev)
+    dat, ann = trials.broadcast_cohort(dat, ann, dev, force_collectives=force_collectives)
     torch.cuda.synchronize(dev)
     t_bcast = time.perf_counter() - t0
     feats = {k: [f"{k}_{i}" for i in range(v.shape[1])] for k, v in dat.items()}
     ds = MultiOmicDataset(dat, ann, {"y": "numerical"}, feats, [f"s{i}" for i in range(samples)], {})
     plist = trials.draw_search_space(n_trials, seed=seed, epochs=epochs)
-    n_train = samples - int(samples * 0.2)
-    costs = [trials.trial_cost(p, 2 * features, n_train) for p in plist]
     stats = {"samples": 0, "busy": 0.0}
-
-    def trial_fn(tid, params):
-        t = time.perf_counter()
-        val, ep, model, info = run_trial(DirectPred, params, ds, ["y"], early_stop_patience=0, seed=seed * 100003 + tid,
-                                         device=dev)
-        if "error" in info:
-            raise RuntimeError(info["error"])
-        stats["samples"] += info["steps"] * int(params["batch_size"])
-        sd = {k: v.detach().clone() for k, v in model.state_dict().items()} if keep_winner else None
-        del model
-        torch.cuda.synchronize(dev)
-        stats["busy"] += time.perf_counter() - t
-        return val, ep, sd
 
     def shapes_of(params):
         return spec_from_dataset("DirectPred", params, ds, ["y"]).state_shapes()
 
+    def account(t, info, params):
+        if "error" in info:
+            raise RuntimeError(info["error"])
+        stats["samples"] += info["steps"] * int(params["batch_size"])
+        torch.cuda.synchronize(dev)
+        stats["busy"] += time.perf_counter() - t
+
     t1 = time.perf_counter()
-    table, best, state = trials.run_sweep(plist, trial_fn, costs, dev, shapes_of if keep_winner else None)
+    if not use_cv:
+        n_val = int(samples * 0.2)
+        costs = [trials.trial_cost(p, [features, features], samples - n_val, n_val) for p in plist]
+
+        def trial_fn(tid, params):
+            t = time.perf_counter()
+            val, ep, model, info = run_trial(DirectPred, params, ds, ["y"], early_stop_patience=0, seed=seed * 100003 + tid,
+                                             device=dev)
+            # only a trial that beats this rank's best so far can be the winner: the others' weights are never cloned
+            sd = None
+            if keep_winner and "error" not in info and val < stats.get("best", float("inf")):
+                stats["best"] = val
+                sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+            del model
+            account(t, info, params)
+            return val, ep, sd
+
+        table, best, state = trials.run_sweep(plist, trial_fn, costs, dev, shapes_of if keep_winner else None,
+                                              schedule=schedule, force_collectives=force_collectives)
+        trial_vals = table[:, 1]
+        ok = table[:, 3] == trials.STATUS_OK
+    else:
+        splits = trial_splits(samples, 0.2, seed, True, n_splits)
+        units = [(tid, fi) for tid in range(n_trials) for fi in range(n_splits)]
+        costs = [trials.trial_cost(plist[tid], [features, features], len(splits[fi][0]), len(splits[fi][1])) for tid, fi in units]
+
+        def unit_fn(uid):
+            tid, fi = units[uid]
+            t = time.perf_counter()
+            val, ep, model, info = run_trial_fold(DirectPred, plist[tid], ds, ["y"], splits[fi][0], splits[fi][1],
+                                                  early_stop_patience=0, seed=seed * 100003 + tid + fi * FOLD_SEED_STRIDE, device=dev)
+            del model
+            account(t, info, plist[tid])
+            return val, ep, None
+
+        utable, _ = trials.run_units(len(units), unit_fn, costs, dev, keep=[], schedule=schedule)
+        per_trial = utable[:, 1].reshape(n_trials, n_splits)
+        trial_vals = per_trial.mean(axis=1)                       # main.py:327-333: the mean over the folds
+        trial_eps = utable[:, 2].reshape(n_trials, n_splits).mean(axis=1).astype(int)
+        ok = (utable[:, 3].reshape(n_trials, n_splits) == trials.STATUS_OK).all(axis=1)
+        best = int(np.argmin(np.where(ok, trial_vals, np.inf)))
+        state = None
+        if keep_winner and np.isfinite(trial_vals[best]):
+            # main.py:403-414: the final model is rebuilt on ALL samples with the best parameters and its mean epochs
+            held = {}
+            if rank == 0:
+                t = time.perf_counter()
+                final, info = full_train(DirectPred, dict(plist[best], epochs=max(int(trial_eps[best]), 1)), ds, ["y"],
+                                         seed=seed * 100003 + 99991, device=dev)
+                held[0] = {k: v.detach() for k, v in final.state_dict().items()}
+                account(t, info, plist[best])
+            owner_table = np.zeros((1, 5))
+            state = trials.agree_and_broadcast_state(held, 0, owner_table, shapes_of(plist[best]), dev, force_collectives)
     torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t1
     mine = torch.tensor([float(stats["samples"]), wall, stats["busy"]], dtype=torch.float64, device=dev)
-    if world > 1:
+    if world > 1 or (force_collectives and dist.is_initialized()):
         parts = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(parts, mine)
         allr = torch.stack(parts).cpu().numpy()
     else:
         allr = mine.cpu().numpy()[None]
-    ok = table[:, 3] == trials.STATUS_OK
     busy = allr[:, 2]
     return {
-        "workload": f"cfg5: {n_trials} DirectPred trials (2 x {features} features, N={samples}, {epochs} epochs), "
-                    f"{world} GPU(s), trial sharding (LPT)",
+        "workload": f"cfg5: {n_trials} DirectPred trials (2 x {features} features, N={samples}, {epochs} epochs"
+                    + (f", {n_splits}-fold CV + final model on all samples" if use_cv else "") + f"), "
+                    f"{world} GPU(s), trial sharding ({'work queue, longest first' if schedule == 'queue' and world > 1 else 'LPT'})",
         "n_gpus": world, "trials": int(n_trials), "trials_ok": int(ok.sum()), "best_trial": best,
-        "best_val_loss": float(table[best, 1]), "best_params": plist[best],
+        "best_val_loss": float(trial_vals[best]), "best_params": plist[best],
         "winner_state_tensors": len(state) if state is not None else 0,
         "cohort_generate_s": round(t_gen, 4), "cohort_broadcast_s": round(t_bcast, 4),
         "sweep_wall_s": round(float(allr[:, 1].max()), 3),
         "aggregate_samples_per_s": round(float(allr[:, 0].sum()) / float(allr[:, 1].max()), 1),
         "rank_busy_s": [round(float(b), 3) for b in busy],
+        "busy_over_wall": round(float(busy.sum()) / (world * max(float(allr[:, 1].max()), 1e-9)), 4),
         "tail_imbalance": round(1.0 - float(busy.mean()) / max(float(busy.max()), 1e-9), 4),
     }
 
@@ -110,6 +160,8 @@ def main(argv=None):
     ap.add_argument("--features", type=int, default=20000)
     ap.add_argument("--samples", type=int, default=2048)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--cv", type=int, default=0, help="k > 1: k-fold cross-validated trials (units = trial x fold)")
+    ap.add_argument("--schedule", default="queue", choices=["queue", "static"])
     a = ap.parse_args(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -119,7 +171,8 @@ def main(argv=None):
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
-    out = run_cfg5(dev, a.trials, a.epochs, a.features, a.samples, a.seed)
+    out = run_cfg5(dev, a.trials, a.epochs, a.features, a.samples, a.seed, schedule=a.schedule, use_cv=a.cv > 1,
+                   n_splits=max(a.cv, 2))
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

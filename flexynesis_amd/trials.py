@@ -38,19 +38,42 @@ def assign_trials(costs: Sequence[float], world: int) -> List[List[int]]:
     return [sorted(x) for x in out]
 
 
-def trial_cost(params: dict, sum_features: int, n_train: int) -> float:
-    """Predicted relative cost of one trial: HBM-bound step (~ parameter count) x optimisation steps."""
-    p = sum_features * sum_features * float(params["hidden_dim_factor"])
-    steps = max(n_train // int(params["batch_size"]), 1) * int(params.get("epochs", 1))
-    return p * steps
+# Cost model of one engine fit on one MI355X, fitted to measured step times (profiles/r03_trial_breakdown.md):
+# an optimisation step streams 24 B per wide-weight parameter at ~5 TB/s and has a latency-bound tail that does not
+# depend on the batch size; a validation batch reads the wide weights once (4 B/param); every fit pays a fixed cost
+# (model initialisation on the device, tape recording, two hipGraph captures).
+COST_STEP_FIXED_S = 0.28e-3
+COST_STEP_PER_PARAM_S = 24.0 / 5.0e12
+COST_VAL_FIXED_S = 0.20e-3
+COST_VAL_PER_PARAM_S = 4.0 / 3.5e12
+COST_FIT_FIXED_S = 0.06
+
+
+def trial_cost(params: dict, sum_features, n_train: int, n_val: int = 0) -> float:
+    """Predicted seconds of one trial.  ``sum_features``: the layers' feature counts (a sequence), or their sum for
+    equally wide layers (two, as in cfg2 / cfg5).  The step time barely depends on the batch size (1.24 -> 1.38 ms from
+    B = 32 to 128 at cfg2), so the number of steps -- n_train // batch_size per epoch -- is what separates trials."""
+    if isinstance(sum_features, (int, float)):
+        feats = [float(sum_features) / 2.0] * 2
+    else:
+        feats = [float(f) for f in sum_features]
+    p = sum(f * f * float(params["hidden_dim_factor"]) for f in feats)
+    B = int(params["batch_size"])
+    epochs = int(params.get("epochs", 1))
+    steps = max(int(n_train) // B, 1)
+    vals = -(-int(n_val) // B) if n_val else 0
+    per_epoch = steps * (COST_STEP_FIXED_S + COST_STEP_PER_PARAM_S * p) + vals * (COST_VAL_FIXED_S + COST_VAL_PER_PARAM_S * p)
+    return COST_FIT_FIXED_S + epochs * per_epoch + vals * (COST_VAL_FIXED_S + COST_VAL_PER_PARAM_S * p)
 
 
 def broadcast_cohort(dat: Optional[Dict[str, torch.Tensor]], ann: Optional[Dict[str, torch.Tensor]], device,
-                     src: int = 0):
+                     src: int = 0, force_collectives: bool = False):
     """Rank ``src`` holds the cohort; every rank returns (dat, ann) as fp32 tensors on ``device`` with the key
     ORDER of rank ``src`` (modality order is hash-order dependent in the reference, data.py:508-515, so ranks
     must never recompute it)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    # force_collectives: take the collective branch on a one-rank group too (the world-1 GPU test then runs the very RCCL
+    # calls an 8-GPU job makes, instead of the early-out)
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force_collectives):
         return ({k: v.to(device, torch.float32) for k, v in dat.items()},
                 {k: v.to(device, torch.float32) for k, v in ann.items()})
     rank = dist.get_rank()
@@ -70,18 +93,20 @@ def broadcast_cohort(dat: Optional[Dict[str, torch.Tensor]], ann: Optional[Dict[
     return out_d, out_a
 
 
-def gather_results(local: List[Tuple[int, float, int, float]], n_trials: int, device) -> np.ndarray:
-    """all_gather of (trial_id, val_loss, epochs, status) rows; returns an [n_trials, 4] array ordered by trial
+def gather_results(local: List[Tuple[int, float, int, float]], n_trials: int, device, rank: int = 0,
+                   force_collectives: bool = False) -> np.ndarray:
+    """all_gather of (trial_id, val_loss, epochs, status, rank) rows; returns an [n_trials, 5] array ordered by trial
     id.  A trial nobody reported is marked failed with val_loss=+inf (never a hang)."""
-    table = torch.full((n_trials, 4), float("nan"), dtype=torch.float64, device=device)
+    table = torch.full((n_trials, 5), float("nan"), dtype=torch.float64, device=device)
     table[:, 0] = torch.arange(n_trials, device=device)
     table[:, 1] = float("inf")
     table[:, 3] = STATUS_FAILED
-    mine = torch.full((n_trials, 4), float("nan"), dtype=torch.float64, device=device)
+    mine = torch.full((n_trials, 5), float("nan"), dtype=torch.float64, device=device)
     for (tid, val, ep, status) in local:
-        mine[tid] = torch.tensor([tid, val, ep, status], dtype=torch.float64, device=device)
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        parts = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+        mine[tid] = torch.tensor([tid, val, ep, status, rank], dtype=torch.float64, device=device)
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if dist.is_initialized() and (world > 1 or force_collectives):
+        parts = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(parts, mine)
     else:
         parts = [mine]
@@ -91,14 +116,16 @@ def gather_results(local: List[Tuple[int, float, int, float]], n_trials: int, de
     return table.cpu().numpy()
 
 
-def broadcast_state(state: Optional[Dict[str, torch.Tensor]], shapes: Dict[str, tuple], src: int, device):
+def broadcast_state(state: Optional[Dict[str, torch.Tensor]], shapes: Dict[str, tuple], src: int, device,
+                    force_collectives: bool = False):
     """Winner's state_dict -> every rank, as one flat fp32 buffer (num_batches_tracked rides along as floats)."""
     keys = list(shapes.keys())
     sizes = [int(np.prod(shapes[k])) if shapes[k] else 1 for k in keys]
     flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
-    if not dist.is_initialized() or dist.get_world_size() == 1 or dist.get_rank() == src:
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if not dist.is_initialized() or world == 1 or dist.get_rank() == src:
         flat = torch.cat([state[k].detach().to(device, torch.float32).reshape(-1) for k in keys])
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized() and (world > 1 or force_collectives):
         dist.broadcast(flat, src=src)
     out, o = {}, 0
     for k, n in zip(keys, sizes):
@@ -108,48 +135,120 @@ def broadcast_state(state: Optional[Dict[str, torch.Tensor]], shapes: Dict[str, 
     return out
 
 
+def _default_store():
+    """The process group's rendezvous store (TCP / file store on the host): ``store.add`` is an atomic fetch-and-add
+    across ranks, independent of the collective backend -- the shared counter of the work queue."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return None
+    try:
+        from torch.distributed.distributed_c10d import _get_default_store
+        return _get_default_store()
+    except Exception:
+        return None
+
+
+_QUEUE_SEQ = [0]
+
+
+class _Claims:
+    """Hands out unit indices to this rank: ``static`` = the deterministic LPT assignment computed on every rank,
+    ``queue`` = units in longest-first order claimed one by one from a counter shared by all ranks (no rank idles while
+    another still holds queued units: the tail imbalance is at most one unit).  Both modes visit every unit exactly
+    once across the ranks; which rank ran a unit is reported in the gathered table, never assumed."""
+
+    def __init__(self, costs: Sequence[float], world: int, rank: int, mode: str):
+        self.order = sorted(range(len(costs)), key=lambda i: (-float(costs[i]), i))
+        self.mode, self.store = mode, None
+        if mode == "queue" and world > 1:
+            self.store = _default_store()
+        if self.store is None:
+            self.mode = "static"
+            self.mine = list(assign_trials(costs, world)[rank])
+        else:
+            # every rank calls run_units the same number of times, so the sequence number names the same queue everywhere
+            _QUEUE_SEQ[0] += 1
+            self.key = f"fx_amd/queue/{_QUEUE_SEQ[0]}"
+
+    def __iter__(self):
+        if self.mode == "static":
+            yield from self.mine
+            return
+        while True:
+            k = int(self.store.add(self.key, 1)) - 1
+            if k >= len(self.order):
+                return
+            yield self.order[k]
+
+
+def run_units(n: int, unit_fn: Callable[[int], Tuple[float, int, Optional[dict]]], costs: Optional[Sequence[float]] = None,
+              device="cpu", keep: Optional[Sequence[int]] = None, schedule: str = "queue"):
+    """Run units 0..n-1 (HPO trials, cross-validation folds, fine-tuning fits) sharded over the ranks:
+    ``unit_fn(uid) -> (val_loss, epochs, state_dict | None)``.  Returns (table [n, 5]: uid, val_loss, epochs, status,
+    rank that ran it; local: {uid: state} of the units this rank must hold on to).  ``keep`` = unit ids whose state is
+    needed afterwards whatever their loss (the FineTuner continues from its LAST fit, main.py:647); None keeps only this
+    rank's best unit (0.8 GB of weights per cfg2 trial).  A failing / non-finite unit reports +inf and the sweep goes on."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    costs = list(costs) if costs is not None else [1.0] * n
+    if len(costs) != n:
+        raise ValueError(f"run_units: {len(costs)} costs for {n} units")
+    if schedule not in ("queue", "static"):
+        raise ValueError("schedule must be 'queue' or 'static'")
+    keep_set = None if keep is None else set(int(k) for k in keep)
+    local, held = [], {}
+    best_local = (float("inf"), -1)
+    for uid in _Claims(costs, world, rank, schedule):
+        try:
+            val, epochs, state = unit_fn(uid)
+            status = STATUS_OK if (val == val and math.isfinite(val)) else STATUS_FAILED
+            val = val if status == STATUS_OK else float("inf")
+        except Exception:                      # a broken unit reports +inf; the sweep goes on
+            val, epochs, state, status = float("inf"), 0, None, STATUS_FAILED
+        local.append((uid, float(val), int(epochs), status))
+        if state is not None and status == STATUS_OK:
+            if keep_set is not None:
+                if uid in keep_set:
+                    held[uid] = state
+            elif best_local[1] < 0 or (val, uid) < best_local:      # ties resolve to the lowest id, like np.argmin
+                held.clear()
+                held[uid] = state
+                best_local = (float(val), uid)
+        del state
+    table = gather_results(local, n, device, rank)
+    return table, held
+
+
+def agree_and_broadcast_state(held: Dict[int, dict], uid: int, table: np.ndarray, shapes: Dict[str, tuple], device,
+                              force_collectives: bool = False):
+    """Unit ``uid``'s state_dict on every rank, or None everywhere when its owner does not hold it.  Every rank must take
+    the same branch: the owner first announces whether it actually holds the weights (a unit_fn may return None), so a
+    missing state degrades to None on all ranks instead of the owner raising while the others wait in the broadcast."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    owner = int(table[uid, 4]) if table[uid, 4] == table[uid, 4] else 0
+    have = torch.tensor([1.0 if (rank == owner and uid in held) else 0.0], dtype=torch.float32, device=device)
+    if dist.is_initialized() and (world > 1 or force_collectives):
+        dist.all_reduce(have, op=dist.ReduceOp.SUM)
+    if float(have.item()) <= 0:
+        return None
+    return broadcast_state(held.get(uid) if rank == owner else None, shapes, owner, device, force_collectives)
+
+
 def run_sweep(param_list: List[dict], trial_fn: Callable[[int, dict], Tuple[float, int, Optional[dict]]],
-              costs: Optional[Sequence[float]] = None, device="cpu", state_shapes: Optional[Dict[str, tuple]] = None):
+              costs: Optional[Sequence[float]] = None, device="cpu", state_shapes: Optional[Dict[str, tuple]] = None,
+              schedule: str = "queue", force_collectives: bool = False):
     """Shard ``param_list`` over the ranks, run ``trial_fn(trial_id, params) -> (val_loss, epochs, state_dict)``
     locally, gather the result table, and (if ``state_shapes`` is given) broadcast the winner's weights.
     ``state_shapes`` may be a dict (all trials share one architecture) or a callable ``params -> {key: shape}``
     (HPO: latent size / hidden factor differ per trial, so the winner's layout is derived from its parameters on
-    every rank).  Returns (table [n,4], best_trial_id, best_state or None)."""
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    rank = dist.get_rank() if dist.is_initialized() else 0
+    every rank).  Returns (table [n, 5], best_trial_id, best_state or None)."""
     n = len(param_list)
-    costs = list(costs) if costs is not None else [1.0] * n
-    assignment = assign_trials(costs, world)
-    mine = assignment[rank]
-    local = []
-    best_local = (float("inf"), -1, None)          # only the best local trial's weights are kept (0.8 GB each at cfg2)
-    for tid in mine:
-        try:
-            val, epochs, state = trial_fn(tid, param_list[tid])
-            status = STATUS_OK if (val == val and math.isfinite(val)) else STATUS_FAILED
-            val = val if status == STATUS_OK else float("inf")
-        except Exception:                      # a broken trial reports +inf; the sweep goes on
-            val, epochs, state, status = float("inf"), 0, None, STATUS_FAILED
-        local.append((tid, float(val), int(epochs), status))
-        # ties resolve to the lowest trial id, like np.argmin over the gathered table
-        if state is not None and status == STATUS_OK and (best_local[2] is None or (val, tid) < best_local[:2]):
-            best_local = (float(val), tid, state)
-        del state
-    table = gather_results(local, n, device)
+    table, held = run_units(n, lambda uid: trial_fn(uid, param_list[uid]), costs, device, keep=None, schedule=schedule)
     best = int(np.argmin(table[:, 1]))
     best_state = None
     if state_shapes is not None and math.isfinite(table[best, 1]):
-        owner = next(r for r, lst in enumerate(assignment) if best in lst)
-        # Every rank must take the same branch: the owner announces whether it actually holds the winner's weights
-        # (a trial_fn may return None for them), so a missing state degrades to best_state=None everywhere instead of the
-        # owner raising while the others wait in the broadcast.
-        have = torch.tensor([1.0 if (rank == owner and best_local[1] == best and best_local[2] is not None) else 0.0],
-                            dtype=torch.float32, device=device)
-        if dist.is_initialized() and world > 1:
-            dist.all_reduce(have, op=dist.ReduceOp.SUM)
-        if float(have.item()) > 0:
-            shapes = state_shapes(param_list[best]) if callable(state_shapes) else state_shapes
-            best_state = broadcast_state(best_local[2] if rank == owner else None, shapes, owner, device)
+        shapes = state_shapes(param_list[best]) if callable(state_shapes) else state_shapes
+        best_state = agree_and_broadcast_state(held, best, table, shapes, device, force_collectives)
     return table, best, best_state
 
 

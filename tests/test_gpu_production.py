@@ -442,20 +442,43 @@ def test_sweep_collectives_on_rccl_world1():
         t = torch.ones(4, device=dev)
         dist.all_reduce(t)                                   # the communicator exists and works
         assert float(t.sum()) == 4.0
-        out = run_cfg5(dev, n_trials=5, epochs=2, features=1500, samples=320, seed=3)
-        assert out["trials_ok"] == 5 and out["n_gpus"] == 1
-        assert np.isfinite(out["best_val_loss"]) and out["winner_state_tensors"] > 10
-        assert out["aggregate_samples_per_s"] > 0 and len(out["rank_busy_s"]) == 1
-        # the pieces, with their results checked: cohort order, result table, winner weights
-        dat = {"zeta": torch.randn(64, 300), "alpha": torch.randn(64, 200)}
-        ann = {"y": torch.randn(64)}
-        d2, a2 = trials.broadcast_cohort(dat, ann, dev)
-        assert list(d2) == ["zeta", "alpha"] and d2["zeta"].is_cuda and torch.equal(d2["alpha"].cpu(), dat["alpha"])
-        table = trials.gather_results([(0, 0.5, 3, trials.STATUS_OK), (2, float("inf"), 0, trials.STATUS_FAILED)], 3, dev)
-        assert table[0, 1] == 0.5 and np.isinf(table[1, 1]) and table[1, 3] == trials.STATUS_FAILED
-        shapes = {"w": (3, 4), "bn.num_batches_tracked": ()}
-        st = trials.broadcast_state({"w": torch.arange(12.).reshape(3, 4), "bn.num_batches_tracked": torch.tensor(7)},
-                                    shapes, 0, dev)
+        # force_collectives: the one-rank group takes the very broadcast / all_gather / all_reduce calls an 8-GPU job makes
+        # (without it world_size == 1 returns early and the RCCL lines would run for the first time on the 8-GPU node)
+        calls = {"broadcast": 0, "all_gather": 0, "all_reduce": 0}
+        real = {k: getattr(dist, k) for k in calls}
+
+        def counted(name):
+            def f(*a, **k):
+                calls[name] += 1
+                return real[name](*a, **k)
+            return f
+        for k in calls:
+            setattr(dist, k, counted(k))
+        try:
+            out = run_cfg5(dev, n_trials=5, epochs=2, features=1500, samples=320, seed=3, force_collectives=True)
+            assert calls["broadcast"] >= 3 + 1 and calls["all_gather"] >= 2 and calls["all_reduce"] >= 1, calls
+            assert out["trials_ok"] == 5 and out["n_gpus"] == 1
+            assert np.isfinite(out["best_val_loss"]) and out["winner_state_tensors"] > 10
+            assert out["aggregate_samples_per_s"] > 0 and len(out["rank_busy_s"]) == 1
+            # the cross-validated search: units = trial x fold, mean over the folds, final model on all samples, broadcast
+            n0 = dict(calls)
+            cv = run_cfg5(dev, n_trials=3, epochs=2, features=1500, samples=320, seed=4, force_collectives=True, use_cv=True, n_splits=3)
+            assert cv["trials_ok"] == 3 and np.isfinite(cv["best_val_loss"]) and cv["winner_state_tensors"] > 10
+            assert calls["broadcast"] > n0["broadcast"] and calls["all_gather"] > n0["all_gather"]
+            # the pieces, with their results checked: cohort order, result table, winner weights
+            dat = {"zeta": torch.randn(64, 300), "alpha": torch.randn(64, 200)}
+            ann = {"y": torch.randn(64)}
+            d2, a2 = trials.broadcast_cohort(dat, ann, dev, force_collectives=True)
+            assert list(d2) == ["zeta", "alpha"] and d2["zeta"].is_cuda and torch.equal(d2["alpha"].cpu(), dat["alpha"])
+            table = trials.gather_results([(0, 0.5, 3, trials.STATUS_OK), (2, float("inf"), 0, trials.STATUS_FAILED)], 3, dev,
+                                          force_collectives=True)
+            assert table[0, 1] == 0.5 and np.isinf(table[1, 1]) and table[1, 3] == trials.STATUS_FAILED and table[0, 4] == 0
+            shapes = {"w": (3, 4), "bn.num_batches_tracked": ()}
+            st = trials.broadcast_state({"w": torch.arange(12.).reshape(3, 4), "bn.num_batches_tracked": torch.tensor(7)},
+                                        shapes, 0, dev, force_collectives=True)
+        finally:
+            for k in calls:
+                setattr(dist, k, real[k])
         assert st["w"].is_cuda and st["w"].cpu().tolist() == torch.arange(12.).reshape(3, 4).tolist()
         assert int(st["bn.num_batches_tracked"]) == 7
     finally:

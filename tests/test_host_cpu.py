@@ -465,3 +465,127 @@ def test_fused_level1_mode_is_chosen_only_under_a_suitable_trainer():
     p = types.SimpleNamespace(automatic_optimization=False)
     p.__dict__["_trainer"] = ok
     assert f(p) is False
+
+
+# ---- sharded cross-validation / fine-tuning protocol (gloo, world_size 2; the engine's fit() replaced by a stand-in) ----
+def _fake_fit_factory(log):
+    """Stand-in for flexynesis_amd.fit.fit: a deterministic 'training' whose outcome depends only on its arguments, so the
+    sharded and the sequential drivers must agree exactly whatever rank runs which unit."""
+    from flexynesis_amd.fit import FitResult
+
+    def fake_fit(model, dataset, train_idx, val_idx=None, *, batch_size, epochs, lr, patience=0, seed=0, frozen=(), **kw):
+        tag = (round(float(lr), 9), tuple(frozen), int(seed), len(train_idx), 0 if val_idx is None else len(val_idx))
+        log.append(tag)
+        import zlib
+        h = zlib.crc32(repr(tag).encode()) % 1000            # (hash() is salted per process)
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1e-3 * (1 + h % 7))          # "training" moves the weights in an argument-dependent way
+        val = 0.1 + (h % 97) / 100.0 + (0.0 if frozen else 0.001)
+        return FitResult(val_loss=val, epochs_run=int(epochs), stopped_epoch=(h % 4), history=[], steps=3)
+    return fake_fit
+
+
+def _toy_model():
+    from flexynesis_amd import models as M
+    cfg = {"latent_dim": 4, "hidden_dim_factor": 0.5, "lr": 1e-2, "supervisor_hidden_dim": 3, "batch_size": 8, "epochs": 2}
+    torch.manual_seed(5)
+    return M.DirectPred(cfg, _toy_dataset(), ["y"])
+
+
+def _ft_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import flexynesis_amd.fit as F
+    from flexynesis_amd import trials
+    log = []
+    F.fit = _fake_fit_factory(log)
+    model = _toy_model()
+    if rank == 1:                                   # rank 0's weights must win
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    res = {}
+    for schedule in ("queue", "static"):
+        final, best, results = F.fine_tune(model, _toy_dataset(), n_splits=3, batch_size=8, learning_rates=[1e-2, 1e-3],
+                                           max_epoch=3, seed=2, sharded=True, schedule=schedule, comm_device="cpu")
+        res[schedule] = (best, results, {k: v.double().sum().item() for k, v in final.state_dict().items()})
+    # queue mode: every unit claimed exactly once across the ranks
+    n_units, claimed = 11, []
+    t, held = trials.run_units(n_units, lambda u: (float(u), 1, {"w": torch.full((2,), float(u))}), [float(1 + u % 3) for u in range(n_units)],
+                               "cpu", keep=[4], schedule="queue")
+    out.put((rank, res, len(log), t.tolist(), sorted(held.keys())))
+    dist.destroy_process_group()
+
+
+def test_sharded_fine_tune_matches_sequential_gloo_world2():
+    """fine_tune(sharded=True) over two gloo ranks == the sequential driver: same per-configuration means, same best
+    configuration, same final weights on both ranks (reference FineTuner.run_experiments, main.py:575-659), with the
+    work-queue and with the static LPT schedule."""
+    import flexynesis_amd.fit as F
+    real_fit = F.fit
+    log = []
+    F.fit = _fake_fit_factory(log)
+    try:
+        final, best, results = F.fine_tune(_toy_model(), _toy_dataset(), n_splits=3, batch_size=8, learning_rates=[1e-2, 1e-3],
+                                           max_epoch=3, seed=2)
+    finally:
+        F.fit = real_fit
+    want = {k: v.double().sum().item() for k, v in final.state_dict().items()}
+    n_fits = 2 * 3 * 3
+    assert len(log) == n_fits + (1 if best["epochs"] > 0 else 0)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ft_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=240) for _ in range(2)), key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for schedule in ("queue", "static"):
+        for r in got:
+            b, res, sums = r[1][schedule]
+            assert b == best and res == results                         # identical records on every rank, equal to the sequential run
+            for k in want:
+                assert abs(sums[k] - want[k]) <= 1e-9 * max(1.0, abs(want[k])), (schedule, k)
+    # the 18 fits of each sharded run were split between the ranks (2 runs per worker; + the final fit on the owner of the last unit)
+    total = got[0][2] + got[1][2]
+    assert 2 * n_fits <= total <= 2 * (n_fits + 1) and min(got[0][2], got[1][2]) >= 4
+    t0, t1 = np.array(got[0][3]), np.array(got[1][3])
+    assert np.array_equal(t0, t1) and t0[:, 0].tolist() == list(range(11)) and (t0[:, 3] == 0).all()
+    assert set(t0[:, 4].tolist()) <= {0.0, 1.0}
+    owner = int(t0[4, 4])
+    assert got[owner][4] == [4] and got[1 - owner][4] == []           # only the requested unit's state is kept, on the rank that ran it
+
+
+def test_run_trial_cv_branch_and_full_train_follow_objective():
+    """run_trial(use_cv=True) = objective()'s KFold branch (main.py:267-269, :327-333): one fit per fold on a new model,
+    (mean of the folds' val losses, int(mean epochs), last model); full_train = objective(full_train=True)."""
+    import flexynesis_amd.fit as F
+    from flexynesis_amd import models as M
+    real_fit = F.fit
+    log = []
+    F.fit = _fake_fit_factory(log)
+    try:
+        cfg = {"latent_dim": 4, "hidden_dim_factor": 0.5, "lr": 1e-2, "supervisor_hidden_dim": 3, "batch_size": 8, "epochs": 5}
+        ds = _toy_dataset()
+        val, ep, model, info = F.run_trial(M.DirectPred, cfg, ds, ["y"], seed=3, use_cv=True, n_splits=4, early_stop_patience=2)
+        folds = F.kfold_indices(len(ds), 4, 3)
+        assert [(t[3], t[4]) for t in log] == [(len(tr), len(va)) for tr, va in folds]
+        assert len(info["fold_val_losses"]) == 4 and abs(val - float(np.mean(info["fold_val_losses"]))) < 1e-12
+        # epochs per fold = stopped_epoch or max_epochs (main.py:319-322); the trial reports int(mean)
+        assert ep == int(np.mean(info["fold_epochs"])) and all(e in (1, 2, 3, 5) for e in info["fold_epochs"])
+        assert isinstance(model, M.DirectPred)
+        seeds = [t[2] for t in log]
+        assert len(set(seeds)) == 4 and seeds[0] == 3                      # every fold: a new model and new shuffles
+        log.clear()
+        v1, e1, _, _ = F.run_trial(M.DirectPred, cfg, ds, ["y"], seed=3, use_cv=False)
+        assert len(log) == 1 and (log[0][3], log[0][4]) == tuple(len(x) for x in F.split_indices(len(ds), 0.2, 3))
+        log.clear()
+        m, info = F.full_train(M.DirectPred, dict(cfg, epochs=2), ds, ["y"], seed=4)
+        assert len(log) == 1 and log[0][3] == len(ds) and log[0][4] == 0    # all samples, no validation split
+    finally:
+        F.fit = real_fit
