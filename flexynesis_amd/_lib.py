@@ -43,8 +43,13 @@ PROTOTYPES = {
     "fx_gather_split": (I, [P, P, P, P, P, P, P, I, I, L, L, L, L, P, L, P]),
     "fx_block_bwd_blocks": (I, [I]),
     "fx_block_bwd": (I, [P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, P, P, P, L, P, P, I, I, L, L, I, I, F, I, P]),
+    "fx_enc_tail_blocks": (I, [I]),
+    "fx_enc_tail_fwd": (I, [P, I, I, I, I, I, F, P, P]),
+    "fx_fusion_fwd": (I, [P, L, P, L, P, P, P, P, I, P, P, I, I, P]),
+    "fx_block_bwd_group": (I, [P, I, I, I, I, F, P]),
     "fx_heads_fwd": (I, [P, I, P, L, I, I, I, F, P, P]),
     "fx_heads_bwd": (I, [P, I, P, L, P, L, I, I, I, F, P, P]),
+    "fx_heads_step": (I, [P, I, P, P, P, P, P, P, L, P, L, I, I, I, F, P, P, I, I, P, P, P, P, P, P]),
     "fx_split_bf16": (I, [P, P, P, I, I, L, L, P]),
     "fx_split_bf16_t": (I, [P, P, P, I, I, L, L, P]),
     "fx_linear_fwd_bf16x3_workspace_bytes": (L, [I, I, I]),
@@ -104,7 +109,7 @@ PROTOTYPES = {
 }
 
 # functions whose int return value is a size/count, not an error code
-_QUERIES = {"fx_version", "fx_gnn_row_blocks", "fx_rowlin_wgrad_workspace_bytes", "fx_bn_rows_workspace_bytes", "fx_col_moments_chunks", "fx_col_moments_workspace_bytes", "fx_block_bwd_blocks", "fx_gemm_splitk", "fx_linear_fwd_bf16x3_splitk", "fx_gram_hadamard_blocks", "fx_gemm_workspace_bytes", "fx_linear_fwd_bf16x3_workspace_bytes", "fx_mmd_workspace_floats", "fx_recon_blocks", "fx_sumsq_blocks",
+_QUERIES = {"fx_version", "fx_gnn_row_blocks", "fx_rowlin_wgrad_workspace_bytes", "fx_bn_rows_workspace_bytes", "fx_col_moments_chunks", "fx_col_moments_workspace_bytes", "fx_block_bwd_blocks", "fx_enc_tail_blocks", "fx_gemm_splitk", "fx_linear_fwd_bf16x3_splitk", "fx_gram_hadamard_blocks", "fx_gemm_workspace_bytes", "fx_linear_fwd_bf16x3_workspace_bytes", "fx_mmd_workspace_floats", "fx_recon_blocks", "fx_sumsq_blocks",
             "fx_last_error_string"}
 
 
@@ -113,6 +118,21 @@ class HeadDesc(C.Structure):
     _fields_ = [(n, P) for n in ("W1", "b1", "gamma", "beta", "running_mean", "running_var", "W2", "b2", "y1", "a1",
                                  "save_mean", "save_invstd", "out", "mask", "dout", "gW1", "gb1", "ggamma", "gbeta",
                                  "gW2", "gb2")] + [("seed", U64), ("offset", U64), ("hidden", I), ("n_out", I)]
+
+
+class BlockBwdDesc(C.Structure):
+    """include/fxhip.h: fx_block_bwd_desc."""
+    _fields_ = [("dE", P * 2), ("ldE", L * 2), ("W", P * 2), ("gW", P * 2), ("gb", P * 2), ("L", I * 2), ("n_up", I),
+                ("x", P), ("out", P), ("gamma", P), ("save_mean", P), ("save_invstd", P), ("dgamma", P), ("dbeta", P),
+                ("dbias", P), ("dy", P), ("dyT_hi", P), ("dyT_lo", P), ("ldt", L), ("gram_x", P), ("slots", P), ("C", I),
+                ("ldx", L), ("ldo", L), ("accumulate", I)]
+
+
+class EncTailDesc(C.Structure):
+    """include/fxhip.h: fx_enc_tail_desc."""
+    _fields_ = ([("slabs", P), ("slab_stride", L), ("lin_bias", P), ("x", P), ("out", P), ("gamma", P), ("beta", P),
+                 ("running_mean", P), ("running_var", P), ("save_mean", P), ("save_invstd", P), ("mask", P),
+                 ("W", P * 2), ("part", P * 2), ("seed", U64), ("offset", U64), ("n_slabs", I), ("H", I), ("n_up", I), ("L", I * 2)])
 
 
 class FxError(RuntimeError):

@@ -61,7 +61,7 @@ __device__ __forceinline__ float bb_colsum(float v, float (*red)[BB_COLS], int c
 __device__ __forceinline__ void bb_upstream(const float* __restrict__ dE, long ldE, const float* __restrict__ W,
                                             float* __restrict__ gW, float* __restrict__ gb, int L, int B, int C, int c0, int cc,
                                             int r0, float* dEs, float (*T)[132], float (*Ws)[BB_COLS], float da[BB_RPT],
-                                            int accumulate) {
+                                            int accumulate, int blk) {
   const int t = threadIdx.x;
   // the upstream width L (latent size: any integer) is processed in chunks of 64 rows of W / columns of dE
   for (int lc0 = 0; lc0 < L; lc0 += BB_MAXL) {
@@ -142,7 +142,7 @@ __device__ __forceinline__ void bb_upstream(const float* __restrict__ dE, long l
             *dst = accumulate ? *dst + g[j] : g[j];
           }
       }
-      if (gb && blockIdx.x == 0 && t < Lc) {   // bias gradient = column sums of dE_k
+      if (gb && blk == 0 && t < Lc) {   // bias gradient = column sums of dE_k
         float sg = 0.f;
 #pragma unroll 8
         for (int r = 0; r < 128; ++r) sg += dEs[r * BB_MAXL + t];
@@ -152,14 +152,14 @@ __device__ __forceinline__ void bb_upstream(const float* __restrict__ dE, long l
   }
 }
 
-__global__ __launch_bounds__(BB_T) void fx_block_bwd_kernel(BlockBwdArgs a) {
+__device__ __forceinline__ void bb_body(const BlockBwdArgs& a, int blk) {
   __shared__ __attribute__((aligned(16))) float dEs[128 * BB_MAXL];      // [r][L] upstream gradient (rows >= B zero)
   __shared__ __attribute__((aligned(16))) float T[BB_COLS][132];         // [c][r]: block output, later dy
   __shared__ float Ws[BB_MAXL][BB_COLS];                                  // one 64-row chunk of an upstream weight
   __shared__ float red[BB_RG][BB_COLS];
   __shared__ double dred[BB_T / 64];
   const int t = threadIdx.x, cx = t & 31, ry = t >> 5;
-  const int c0 = blockIdx.x * BB_COLS, c = c0 + cx, B = a.B;
+  const int c0 = blk * BB_COLS, c = c0 + cx, B = a.B;
   const int cc = min(c, a.C - 1);                    // clamped column: loads are unconditional, stores predicated
   const bool cok = c < a.C;
   const int r0 = ry * BB_RPT;
@@ -182,8 +182,8 @@ __global__ __launch_bounds__(BB_T) void fx_block_bwd_kernel(BlockBwdArgs a) {
   float da[BB_RPT];
 #pragma unroll
   for (int i = 0; i < BB_RPT; ++i) da[i] = 0.f;
-  bb_upstream(a.dE[0], a.ldE[0], a.W[0], a.gW[0], a.gb[0], a.L[0], B, a.C, c0, cc, r0, dEs, T, Ws, da, a.accumulate);
-  if (a.n_up > 1) bb_upstream(a.dE[1], a.ldE[1], a.W[1], a.gW[1], a.gb[1], a.L[1], B, a.C, c0, cc, r0, dEs, T, Ws, da, a.accumulate);
+  bb_upstream(a.dE[0], a.ldE[0], a.W[0], a.gW[0], a.gb[0], a.L[0], B, a.C, c0, cc, r0, dEs, T, Ws, da, a.accumulate, blk);
+  if (a.n_up > 1) bb_upstream(a.dE[1], a.ldE[1], a.W[1], a.gW[1], a.gb[1], a.L[1], B, a.C, c0, cc, r0, dEs, T, Ws, da, a.accumulate, blk);
   // ---- gate (ReLU + dropout in one test on the saved output) and BatchNorm backward (fx_bn_bwd_kernel's expressions)
   const float gate_scale = 1.0f / (1.0f - a.drop_p);
   float s1 = 0.f, s2 = 0.f;
@@ -276,8 +276,28 @@ __global__ __launch_bounds__(BB_T) void fx_block_bwd_kernel(BlockBwdArgs a) {
       double tot = 0.0;
 #pragma unroll
       for (int i = 0; i < BB_T / 64; ++i) tot += dred[i];
-      a.slots[blockIdx.x] = tot;
+      a.slots[blk] = tot;
     }
+  }
+}
+
+__global__ __launch_bounds__(BB_T) void fx_block_bwd_kernel(BlockBwdArgs a) { bb_body(a, blockIdx.x); }
+
+// Several encoder tails (one per modality) in one launch: grid (column blocks of the widest, modalities).  The modalities'
+// backward chains are independent until the optimiser; as two launches on two hipGraph branches they paid a fork and a join
+// (~10 us each on the critical chain: cross-queue dependencies) for running side by side.
+#define BB_MAX_GROUP 4
+struct BlockBwdGroup {
+  BlockBwdArgs a[BB_MAX_GROUP];
+};
+__global__ __launch_bounds__(BB_T) void fx_block_bwd_group_kernel(BlockBwdGroup g) {
+  const int blk = blockIdx.x;
+  // (a runtime index into the kernel-argument array would put the argument blocks in scratch: one call per constant index)
+  switch (blockIdx.y) {
+    case 0: if (blk * BB_COLS < g.a[0].C) bb_body(g.a[0], blk); break;
+    case 1: if (blk * BB_COLS < g.a[1].C) bb_body(g.a[1], blk); break;
+    case 2: if (blk * BB_COLS < g.a[2].C) bb_body(g.a[2], blk); break;
+    default: if (blk * BB_COLS < g.a[3].C) bb_body(g.a[3], blk); break;
   }
 }
 
@@ -286,18 +306,18 @@ extern "C" {
 int fx_block_bwd_blocks(int C) { return (C + BB_COLS - 1) / BB_COLS; }
 
 // see include/fxhip.h
-int fx_block_bwd(const float* const* dE, const long* ldE, const float* const* W, float* const* gW, float* const* gb,
-                 const int* L, int n_up, const float* x, const float* out, const float* gamma, const float* save_mean,
-                 const float* save_invstd, float* dgamma, float* dbeta, float* dbias, float* dy, void* dyT_hi, void* dyT_lo,
-                 long ldt, const float* gram_x, double* slots, int B, int C, long ldx, long ldo, int pre_act, int post_act,
-                 float drop_p, int accumulate, hipStream_t stream) {
+static int bb_fill(BlockBwdArgs& a, const float* const* dE, const long* ldE, const float* const* W, float* const* gW,
+                   float* const* gb, const int* L, int n_up, const float* x, const float* out, const float* gamma,
+                   const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* dbias, float* dy,
+                   void* dyT_hi, void* dyT_lo, long ldt, const float* gram_x, double* slots, int B, int C, long ldx, long ldo,
+                   int pre_act, int post_act, float drop_p, int accumulate) {
   FX_REQUIRE(dE && ldE && W && gW && gb && L && n_up >= 1 && n_up <= 2, "fx_block_bwd: 1 or 2 upstream Linears");
   FX_REQUIRE(x && out && gamma && save_mean && save_invstd && dgamma && dbeta, "fx_block_bwd: null pointer");
   FX_REQUIRE(B > 1 && B <= 128 && C > 0, "fx_block_bwd: B=%d must be in 2..128", B);
   FX_REQUIRE(!dyT_hi || (dyT_lo && ldt % 8 == 0 && ldt >= (B + 31) / 32 * 32),
              "fx_block_bwd: dyT needs hi and lo, ld %% 8 == 0, ld >= round32(B) (got %ld)", ldt);
   FX_REQUIRE(!gram_x || slots, "fx_block_bwd: gram_x needs the norm slots");
-  BlockBwdArgs a{};
+  a = BlockBwdArgs{};
   for (int k = 0; k < n_up; ++k) {
     FX_REQUIRE(dE[k] && W[k] && gW[k] && L[k] > 0 && ldE[k] >= L[k], "fx_block_bwd: upstream %d: bad L=%d / ld=%ld", k, L[k],
                ldE[k]);
@@ -310,8 +330,48 @@ int fx_block_bwd(const float* const* dE, const long* ldE, const float* const* W,
   a.gram_x = gram_x; a.slots = slots;
   a.B = B; a.C = C; a.ldx = ldx; a.ldo = ldo; a.pre_act = pre_act; a.post_act = post_act; a.drop_p = drop_p;
   a.accumulate = accumulate ? 1 : 0;
+  return 0;
+}
+
+int fx_block_bwd(const float* const* dE, const long* ldE, const float* const* W, float* const* gW, float* const* gb,
+                 const int* L, int n_up, const float* x, const float* out, const float* gamma, const float* save_mean,
+                 const float* save_invstd, float* dgamma, float* dbeta, float* dbias, float* dy, void* dyT_hi, void* dyT_lo,
+                 long ldt, const float* gram_x, double* slots, int B, int C, long ldx, long ldo, int pre_act, int post_act,
+                 float drop_p, int accumulate, hipStream_t stream) {
+  BlockBwdArgs a;
+  if (int rc = bb_fill(a, dE, ldE, W, gW, gb, L, n_up, x, out, gamma, save_mean, save_invstd, dgamma, dbeta, dbias, dy, dyT_hi,
+                       dyT_lo, ldt, gram_x, slots, B, C, ldx, ldo, pre_act, post_act, drop_p, accumulate))
+    return rc;
   hipLaunchKernelGGL(fx_block_bwd_kernel, dim3(fx_block_bwd_blocks(C)), dim3(BB_T), 0, stream, a);
   return fx_check_launch("fx_block_bwd");
+}
+
+struct fx_block_bwd_desc_ {   // include/fxhip.h: fx_block_bwd_desc
+  const float* dE[2]; long ldE[2]; const float* W[2]; float* gW[2]; float* gb[2]; int L[2]; int n_up;
+  const float* x; const float* out; const float* gamma; const float* save_mean; const float* save_invstd;
+  float* dgamma; float* dbeta; float* dbias; float* dy; void* dyT_hi; void* dyT_lo; long ldt;
+  const float* gram_x; double* slots; int C; long ldx, ldo; int accumulate;
+};
+
+// fx_block_bwd for n <= 4 independent encoder tails (one per modality) in one launch; every field as the argument of the
+// same name of fx_block_bwd.
+int fx_block_bwd_group(const void* descs_, int n, int B, int pre_act, int post_act, float drop_p, hipStream_t stream) {
+  const fx_block_bwd_desc_* d = (const fx_block_bwd_desc_*)descs_;
+  FX_REQUIRE(d && n > 0 && n <= BB_MAX_GROUP, "fx_block_bwd_group: 1..%d tails per launch", BB_MAX_GROUP);
+  BlockBwdGroup g{};
+  int max_blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    if (int rc = bb_fill(g.a[i], d[i].dE, d[i].ldE, d[i].W, d[i].gW, d[i].gb, d[i].L, d[i].n_up, d[i].x, d[i].out, d[i].gamma,
+                         d[i].save_mean, d[i].save_invstd, d[i].dgamma, d[i].dbeta, d[i].dbias, d[i].dy, d[i].dyT_hi, d[i].dyT_lo,
+                         d[i].ldt, d[i].gram_x, d[i].slots, B, d[i].C, d[i].ldx, d[i].ldo, pre_act, post_act, drop_p,
+                         d[i].accumulate))
+      return rc;
+    const int nb = fx_block_bwd_blocks(d[i].C);
+    max_blocks = nb > max_blocks ? nb : max_blocks;
+  }
+  for (int i = n; i < BB_MAX_GROUP; ++i) g.a[i] = g.a[0];
+  hipLaunchKernelGGL(fx_block_bwd_group_kernel, dim3(max_blocks, n), dim3(BB_T), 0, stream, g);
+  return fx_check_launch("fx_block_bwd_group");
 }
 
 }  // extern "C"

@@ -10,6 +10,7 @@
 // a fixed order: deterministic, no atomics).  Arithmetic is plain fp32 FMA with the same expressions as
 // fx_bn_act_fwd/bwd (same Philox stream for the dropout mask), so the fused and unfused paths agree to rounding.
 #include "fx_common.h"
+#include "fx_loss_dev.h"
 
 #define FX_MAX_HEADS 8
 constexpr int HB = 128;   // max rows
@@ -109,14 +110,22 @@ __device__ __forceinline__ void heads_mask4(unsigned long long seed, unsigned lo
 
 // All per-column loops run over the PADDED width HS = 32 with zero-padded parameters, so they have compile-time trip
 // counts and no predicates; only global stores are predicated on the true width.
-__global__ __launch_bounds__(256) void fx_heads_fwd_kernel(HeadsArgs a) {
-  const FxHeadDesc& h = a.h[blockIdx.x];
-  __shared__ Tile xs;                       // one 32-column chunk of the embedding
-  __shared__ Tile ys;                       // layer_1 output, then the block output (columns >= S stay zero)
-  __shared__ __attribute__((aligned(16))) float W1s[HS * HL];   // TRANSPOSED [L][32], columns >= S zero
-  __shared__ float W2s[HC * HS];            // [C][32], columns >= S zero
-  __shared__ float part[8][32];
-  __shared__ float stat[5][32];             // mean, invstd, gamma, beta, layer_1 bias (zero padded)
+struct HeadsFwdLds {
+  Tile xs;                       // one 32-column chunk of the embedding
+  Tile ys;                       // layer_1 output, then the block output (columns >= S stay zero)
+  __attribute__((aligned(16))) float W1s[HS * HL];   // TRANSPOSED [L][32], columns >= S zero
+  float W2s[HC * HS];            // [C][32], columns >= S zero
+  float part[8][32];
+  float stat[5][32];             // mean, invstd, gamma, beta, layer_1 bias (zero padded)
+};
+
+__device__ __forceinline__ void heads_fwd_body(const HeadsArgs& a, const FxHeadDesc& h, HeadsFwdLds& F) {
+  Tile& xs = F.xs;
+  Tile& ys = F.ys;
+  float* W1s = F.W1s;
+  float* W2s = F.W2s;
+  float (*part)[32] = F.part;
+  float (*stat)[32] = F.stat;
   const int t = threadIdx.x, r = t & 127, hf = t >> 7, col = t & 31, rg = t >> 5;
   const int S = h.S, C = h.C, B = a.B, L = a.L;
   const int s0 = hf * (HS / 2);
@@ -275,6 +284,11 @@ __global__ __launch_bounds__(256) void fx_heads_fwd_kernel(HeadsArgs a) {
     for (int s = 0; s < HS; ++s) o += ys[r][s] * W2s[c * HS + s];
     if (r < B) h.out[(long)r * C + c] = o;
   }
+}
+
+__global__ __launch_bounds__(256) void fx_heads_fwd_kernel(HeadsArgs a) {
+  __shared__ HeadsFwdLds F;
+  heads_fwd_body(a, a.h[blockIdx.x], F);
 }
 
 // Backward.  grid = n_heads + 1 workgroups:
@@ -514,6 +528,177 @@ __global__ __launch_bounds__(256) void fx_heads_bwd_kernel(HeadsArgs a) {
   if (t == 0) *a.dx_count = 0u;          // ready for the next launch / graph replay
 }
 
+// ---- one launch for the whole supervisor part of a training step ---------------------------------------------------------
+// forward -> loss (value + output gradient) -> backward of every head, the summed embedding gradient and the model's total
+// loss: what used to be fx_heads_fwd -> fx_mse_masked | fx_ce_masked | fx_cox_ph (one launch per head) -> fx_total_loss ->
+// fx_heads_bwd, i.e. 4 + n_heads dependent launches (17 + 6 + 5 + 38 us plus ~25 us of graph-edge gaps at cfg2,
+// profiles/r03_timeline_cfg2_a.txt).  One workgroup per head runs its head end to end: everything a phase needs from the
+// previous one is already in this workgroup's registers, LDS or L2.  The workgroups meet once, at the end: each publishes its
+// loss value and its share of the embedding gradient, and the last one to arrive adds the shares in head order
+// (deterministic) and evaluates the uncertainty-weighted total (direct_pred.py:192-223) over ALL named loss terms of the
+// model -- terms computed by earlier launches (triplet, MMD) are read from their slots.
+struct HeadsStepArgs {
+  HeadsArgs ha;
+  int kind[FX_MAX_HEADS];                  // 0 masked MSE, 1 masked softmax-CE, 2 Cox partial likelihood
+  const float* y[FX_MAX_HEADS];            // labels [B] (Cox: event indicators)
+  const float* dur[FX_MAX_HEADS];          // Cox: durations [B]
+  const float* logvar[FX_MAX_HEADS];       // uncertainty weight of the head's loss, or NULL
+  float* loss[FX_MAX_HEADS];               // raw loss value of the head
+  int n_terms, weighted;
+  const float* term_loss[16]; const float* term_logvar[16]; float* term_dlogvar[16];
+  float* total_out; float* epoch_acc;
+};
+
+union HeadsStepLds {
+  HeadsFwdLds f;
+  HeadsBwdLds b;
+};
+
+__global__ __launch_bounds__(256) void fx_heads_step_kernel(HeadsStepArgs sa) {
+  __shared__ HeadsStepLds U;
+  __shared__ float ckey[HB];
+  __shared__ int cidx[HB];
+  __shared__ double cscan[HB];
+  __shared__ double dred[16];
+  __shared__ float sm[16];
+  __shared__ int s_last;
+  const HeadsArgs& a = sa.ha;
+  const int hi = blockIdx.x;
+  const FxHeadDesc& h = a.h[hi];
+  const int t = threadIdx.x, r = t & 127, hf = t >> 7, col = t & 31, rg = t >> 5;
+  const int B = a.B, Ld = a.L, S = h.S, C = h.C;
+  // ================= forward (y1, a1, statistics and out also go to memory: predict / the drop-in path read them) ===
+  heads_fwd_body(a, h, U.f);
+  __syncthreads();                                   // out [B, C] is visible to the whole workgroup
+  // ================= loss value + gradient at the head output =================
+  float* dout = const_cast<float*>(h.dout);
+  if (sa.kind[hi] == 0) loss_mse_body(sa.loss[hi], dout, h.out, sa.y[hi], B, C, C, sa.logvar[hi], 1.0f, sm);
+  else if (sa.kind[hi] == 1) loss_ce_body(sa.loss[hi], dout, h.out, sa.y[hi], B, C, C, C, sa.logvar[hi], 1.0f, sm);
+  else loss_cox_body<HB, 1>(sa.loss[hi], dout, h.out, sa.dur[hi], sa.y[hi], B, C, C, sa.logvar[hi], 1.0f, ckey, cidx, cscan, dred);
+  __syncthreads();
+  // ================= backward: parameter gradients of this head and its share of the embedding gradient =================
+  HeadsBwdLds& L = U.b;
+  const float gate_scale = 1.0f / (1.0f - a.drop_p);
+  float vy[16], vw1[HS * HL / 256];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int idx = t + 256 * i;
+    vy[i] = h.y1[(long)min(idx >> 5, B - 1) * S + min(idx & 31, S - 1)];
+  }
+#pragma unroll
+  for (int i = 0; i < HS * HL / 256; ++i) vw1[i] = h.W1[min(t + 256 * i, S * Ld - 1)];
+  float sum_dy, sum_dy_xh, sum_dx;
+  heads_bwd_prefix(L, h, B, gate_scale);
+  // layer_out.weight / bias gradients (over the padded [C][32] grid; only true columns are stored)
+  for (int o = t; o < C * HS; o += 256) {
+    const int c = o >> 5, s = o & 31;
+    float g = 0.f;
+#pragma unroll 8
+    for (int rr = 0; rr < HB; ++rr) g = fmaf(L.R1[rr][c], L.R2[rr][s], g);      // rows >= B are zero
+    if (s < S) h.gW2[c * S + s] = g;
+  }
+  if (h.gb2 && t < C) {
+    float g = 0.f;
+#pragma unroll 8
+    for (int rr = 0; rr < HB; ++rr) g += L.R1[rr][t];
+    h.gb2[t] = g;
+  }
+  __syncthreads();
+  heads_bwd_bn(L, B, vy, sum_dy, sum_dy_xh, sum_dx);
+  if (col < S && rg == 0) {
+    h.ggamma[col] = sum_dy_xh;
+    h.gbeta[col] = sum_dy;
+    h.gb1[col] = sum_dx;
+  }
+  // ---- embedding gradient share: dy1 . W1 (layer_1.weight staged over the dead x-hat)
+  const bool want_dx = a.dx != nullptr;
+  const bool split = a.n_heads > 1;
+  const int Lh = (Ld + 1) >> 1, l0 = hf * Lh;
+  float accx[HL / 2];
+#pragma unroll
+  for (int j = 0; j < HL / 2; ++j) accx[j] = 0.f;
+  if (want_dx) {
+    float* W1s = &L.R2[0][0];
+    if (a.dx_accumulate && !split) {
+#pragma unroll
+      for (int j = 0; j < HL / 2; ++j) accx[j] = a.dx[(long)min(r, B - 1) * a.lddx + min(l0 + j, Ld - 1)];
+    }
+#pragma unroll
+    for (int i = 0; i < HS * HL / 256; ++i)
+      if (t + 256 * i < S * Ld) W1s[t + 256 * i] = vw1[i];
+    __syncthreads();
+    for (int s = 0; s < S; ++s) {
+      const float d = L.R3[r][s];
+      const float* w = W1s + s * Ld + l0;
+#pragma unroll
+      for (int j = 0; j < HL / 2; ++j) accx[j] = fmaf(d, w[j], accx[j]);
+    }
+    if (r < B) {
+      float* dst = split ? a.dx_part + ((long)hi * B + r) * Ld : a.dx + (long)r * a.lddx;
+#pragma unroll
+      for (int j = 0; j < HL / 2; ++j)
+        if (j < Lh && l0 + j < Ld) dst[l0 + j] = accx[j];
+    }
+  }
+  // ---- layer_1.weight gradient: gW1[s, l] = sum_r dy1[r, s] x[r, l], 32 columns of x at a time through R1
+  for (int c0 = 0; c0 < Ld; c0 += 32) {
+    __syncthreads();
+    heads_stage(L.R1, a.x, a.ldx, B, c0, Ld);
+    __syncthreads();
+    for (int o = t; o < S * 32; o += 256) {
+      const int s = o >> 5, l = o & 31;
+      float g = 0.f;
+#pragma unroll 8
+      for (int rr = 0; rr < HB; ++rr) g = fmaf(L.R3[rr][s], L.R1[rr][l], g);
+      if (c0 + l < Ld) h.gW1[(long)s * Ld + c0 + l] = g;
+    }
+  }
+  // ================= meet: the last workgroup adds the shares in head order and evaluates the total =================
+  bool last = true;
+  if (split) {
+    __threadfence();
+    __syncthreads();
+    if (t == 0) s_last = (atomicAdd(a.dx_count, 1u) == (unsigned)(a.n_heads - 1));
+    __syncthreads();
+    last = s_last != 0;
+    if (!last) return;
+    __threadfence();
+    if (want_dx && r < B) {
+#pragma unroll
+      for (int j = 0; j < HL / 2; ++j) {
+        if (j < Lh && l0 + j < Ld) {
+          float sacc = a.dx_accumulate ? a.dx[(long)r * a.lddx + l0 + j] : 0.f;
+          for (int k = 0; k < a.n_heads; ++k) sacc += __builtin_nontemporal_load(a.dx_part + ((long)k * B + r) * Ld + l0 + j);
+          a.dx[(long)r * a.lddx + l0 + j] = sacc;
+        }
+      }
+    }
+    if (t == 0) *a.dx_count = 0u;          // ready for the next launch / graph replay
+  } else {
+    __syncthreads();                       // thread 0's loss value (global) is ordered before the total below
+  }
+  if (t == 0 && sa.total_out) {
+    float tot = 0.f;
+    for (int i = 0; i < sa.n_terms; ++i) {
+      const float l = __builtin_nontemporal_load(sa.term_loss[i]);
+      if (sa.weighted) {
+        const float sv = sa.term_logvar[i][0];
+        const float w = expf(-sv);
+        tot += w * l + sv;
+        if (sa.term_dlogvar[i]) sa.term_dlogvar[i][0] = 1.0f - w * l;
+      } else {
+        tot += l;
+      }
+      if (sa.epoch_acc) sa.epoch_acc[i] += l;
+    }
+    if (sa.epoch_acc) {
+      sa.epoch_acc[sa.n_terms] += tot;
+      sa.epoch_acc[sa.n_terms + 1] += 1.0f;
+    }
+    sa.total_out[0] = tot;
+  }
+}
+
 extern "C" {
 
 struct fx_head_desc;   // include/fxhip.h; layout identical to FxHeadDesc
@@ -566,6 +751,52 @@ int fx_heads_bwd(const void* heads_, int n_heads, const float* x, long ldx, floa
   }
   hipLaunchKernelGGL(fx_heads_bwd_kernel, dim3(split ? 2 * n_heads : n_heads + 1), dim3(256), 0, stream, a);
   return fx_check_launch("fx_heads_bwd");
+}
+
+// All heads of a training step in one launch: forward, loss, backward, summed embedding gradient, total loss (see
+// fx_heads_step_kernel).  kinds[i]: 0 masked MSE, 1 masked softmax-CE, 2 Cox; labels[i] [B] (Cox: events), durations[i] (Cox
+// only), logvars[i] / losses[i] the head's uncertainty weight (NULL: unweighted) and loss slot; heads[i].dout receives the
+// output gradient.  terms: every named loss of the model in order (the heads' slots among them).
+int fx_heads_step(const void* heads_, int n_heads, const int* kinds, const float* const* labels, const float* const* durations,
+                  const float* const* logvars, float* const* losses, const float* x, long ldx, float* dx, long lddx,
+                  int dx_accumulate, int B, int L, float drop_p, const float* ctrl, void* dx_scratch, int n_terms, int weighted,
+                  const float* const* term_losses, const float* const* term_logvars, float* const* term_dlogvars, float* total_out,
+                  float* epoch_acc, hipStream_t stream) {
+  const FxHeadDesc* heads = (const FxHeadDesc*)heads_;
+  if (int rc = heads_check(heads, n_heads, x, B, L, "fx_heads_step")) return rc;
+  FX_REQUIRE(B > 1 && kinds && labels && losses, "fx_heads_step: train mode needs B > 1 and labels / loss slots");
+  FX_REQUIRE(n_terms >= 0 && n_terms <= 16 && (n_terms == 0 || (term_losses && total_out)), "fx_heads_step: bad loss terms (n=%d)", n_terms);
+  FX_REQUIRE(!weighted || n_terms == 0 || term_logvars, "fx_heads_step: weighted total needs log_vars");
+  FX_REQUIRE(n_heads == 1 || !dx || dx_scratch, "fx_heads_step: several heads need the dx scratch (shares + arrival counter)");
+  HeadsStepArgs s{};
+  HeadsArgs& a = s.ha;
+  for (int i = 0; i < n_heads; ++i) {
+    a.h[i] = heads[i];
+    FX_REQUIRE(a.h[i].b1 && a.h[i].gamma && a.h[i].beta && a.h[i].rmean && a.h[i].rvar && a.h[i].out && a.h[i].save_mean &&
+                   a.h[i].save_invstd && a.h[i].y1 && a.h[i].a1 && a.h[i].dout && a.h[i].gW1 && a.h[i].gb1 && a.h[i].ggamma &&
+                   a.h[i].gbeta && a.h[i].gW2,
+               "fx_heads_step: head %d has a null parameter / saved-tensor / gradient pointer", i);
+    FX_REQUIRE(kinds[i] >= 0 && kinds[i] <= 2 && labels[i] && losses[i] && (kinds[i] != 2 || (durations && durations[i])),
+               "fx_heads_step: head %d: bad loss kind / labels", i);
+    FX_REQUIRE(kinds[i] == 1 || a.h[i].C == 1, "fx_heads_step: head %d: MSE / Cox heads have one output", i);
+    s.kind[i] = kinds[i]; s.y[i] = labels[i]; s.dur[i] = durations ? durations[i] : nullptr;
+    s.logvar[i] = logvars ? logvars[i] : nullptr; s.loss[i] = losses[i];
+  }
+  a.n_heads = n_heads; a.x = x; a.ldx = ldx; a.dx = dx; a.lddx = lddx; a.dx_accumulate = dx_accumulate;
+  a.B = B; a.L = L; a.train = 1; a.drop_p = drop_p; a.ctrl = ctrl;
+  if (n_heads > 1) {
+    FX_REQUIRE((((uintptr_t)dx_scratch) & 3) == 0, "fx_heads_step: scratch must be 4-byte aligned");
+    a.dx_part = (float*)dx_scratch;
+    a.dx_count = (unsigned*)((float*)dx_scratch + (long)n_heads * B * L);    // zero on first use (caller zero-fills once)
+  }
+  s.n_terms = n_terms; s.weighted = weighted; s.total_out = total_out; s.epoch_acc = epoch_acc;
+  for (int i = 0; i < n_terms; ++i) {
+    s.term_loss[i] = term_losses[i];
+    s.term_logvar[i] = weighted ? term_logvars[i] : nullptr;
+    s.term_dlogvar[i] = (weighted && term_dlogvars) ? term_dlogvars[i] : nullptr;
+  }
+  hipLaunchKernelGGL(fx_heads_step_kernel, dim3(n_heads), dim3(256), 0, stream, s);
+  return fx_check_launch("fx_heads_step");
 }
 
 }  // extern "C"

@@ -262,6 +262,12 @@ class StepPlan:
         # all supervisor heads in one launch each way (fx_heads_fwd/bwd); FX_FUSE_HEADS=0 is an A/B switch for benchmarks
         self.fuse_heads = bool(fuse_heads) and os.environ.get("FX_FUSE_HEADS", "1") != "0"
         self.small_linear = os.environ.get("FX_SMALL_LINEAR", "1") != "0"
+        # encoder tails of all modalities in one launch + row-parallel reduce / fusion layer (fx_enc_tail.hip); FX_FUSE_TAIL=0: A/B
+        self.fuse_tail = os.environ.get("FX_FUSE_TAIL", "1") != "0"
+        self.group_bwd = os.environ.get("FX_GROUP_BWD", "1") != "0"       # encoder-tail backward of all modalities in one launch (A/B)
+        self._bb_group = None
+        # heads forward + losses + total + heads backward in one launch (fx_heads_step); FX_HEADS_STEP=0: A/B
+        self.fuse_heads_step = self.fuse_heads and os.environ.get("FX_HEADS_STEP", "1") != "0"
         self._gram_x: Dict[int, tuple] = {}
         self._jobs: Dict[str, tuple] = {}
         self._slot_o = 0
@@ -401,6 +407,55 @@ class StepPlan:
         self._weight_grad(rec, prefix + ".layer_1.weight", da1, x)
         if dx is not None:
             ops.linear_bwd_x(rec, dx, da1, st.p(prefix + ".layer_1.weight"), self.ws, accumulate=dx_accumulate)
+
+    def _tails_groupable(self, n, L) -> bool:
+        """fx_enc_tail_fwd + fx_fusion_fwd cover one BatchNorm pass of <= 128 rows, <= 4 modalities, block widths that are
+        multiples of 4, latent <= 128 (the reference's whole search space, config.py:7-15)."""
+        st = self.store
+        if not self.fuse_tail or self.passes != 1 or self.R > 128 or n > 4 or L > 128 or L % 4 != 0 or n * L > 512:
+            return False
+        return all(st.shapes[f"encoders.{i}.layer_1.weight"][0] % 4 == 0 for i in range(n))
+
+    def _mlp_tails_fwd(self, rec, n, L, ecat):
+        """All MLP encoders' tails in one launch -- slab sum + bias, BatchNorm, ReLU, Dropout and the column blocks' shares of
+        layer_out (modules.py:145-149) -- then ecat (ordered sum of the shares + layer_out bias) and the fusion Linear
+        (direct_pred.py:118-124) row-parallel in a second one: 2 launches on one stream instead of 4 per modality on parallel
+        graph branches + join + fusion."""
+        st, R = self.store, self.R
+        descs, parts, biases = [], [], []
+        for i in range(n):
+            prefix = f"encoders.{i}"
+            H = st.shapes[prefix + ".layer_1.weight"][0]
+            y1 = self._new(prefix + "/y1", R, H)
+            a1 = self._new(prefix + "/a1", R, H)
+            sm = self._new(prefix + "/save_mean", 1, H)
+            si = self._new(prefix + "/save_invstd", 1, H)
+            slabs = self._lin_fwd(rec, y1, self.X[i], prefix + ".layer_1.weight", prefix + ".layer_1.bias", want_slabs=True)
+            mask = self._draw(prefix, R, H) if (self.supplied and self.train) else None
+            seed, off = self._rng()
+            nb = ops.enc_tail_blocks(H)
+            part = self._new(prefix + "/layer_out_parts", nb, R, L)
+            descs.append(ops.enc_tail_desc(
+                slabs=slabs[0] if slabs is not None else None, n_slabs=slabs[1] if slabs is not None else 0, slab_stride=R * H,
+                lin_bias=st.p(prefix + ".layer_1.bias") if slabs is not None else None, x=y1, out=a1,
+                gamma=st.p(prefix + ".batchnorm.weight"), beta=st.p(prefix + ".batchnorm.bias"),
+                running_mean=st.b(prefix + ".batchnorm.running_mean"), running_var=st.b(prefix + ".batchnorm.running_var"),
+                save_mean=sm[0], save_invstd=si[0], mask=mask, ups=[(st.p(prefix + ".layer_out.weight"), part)], seed=seed, offset=off))
+            parts.append((part, nb))
+            bias_key = prefix + ".layer_out.bias"
+            biases.append(st.p(bias_key) if bias_key in st.shapes else None)
+        ops.enc_tail_fwd(rec, descs, R, ACT_NONE, ACT_RELU, self.train, DROPOUT_P if self.train else 0.0, ctrl=st.ctrl)
+        # From here to the encoder-tail backward the chain is a few workgroups wide (16 for the fusion layer, one per head):
+        # the next batch's assembly (PipelinedStep) forks HERE, under that part, instead of beside the wide backward kernels.
+        rec.mark("fork_assembly")
+        if n > 1:
+            emb = self._new("emb", R, L)
+            ops.fusion_fwd(rec, emb, ecat, parts, biases, st.p("fusion_block.weight"), st.p("fusion_block.bias"))
+            rec.mark("fork_issue_1")
+            return emb
+        ops.fusion_fwd(rec, None, ecat, parts, biases)
+        rec.mark("fork_issue_1")
+        return ecat
 
     def _hidden_fwd(self, rec, prefix, x, rows):
         """Linear -> LeakyReLU(0.2) -> BN   (reference modules.py:25-34 / :75-84)."""
@@ -613,9 +668,16 @@ class StepPlan:
             self._slot_o += nb
         sm, si = self.buf[bn_prefix[1] + "/save_mean"], self.buf[bn_prefix[1] + "/save_invstd"]
         bp = bn_prefix[0]
-        ops.block_bwd(rec, [(dE, st.p(wk), st.g(wk), st.g(bk) if bk else None) for (dE, wk, bk) in ups], y, out,
-                      st.p(bp + ".weight"), sm[0], si[0], st.g(bp + ".weight"), st.g(bp + ".bias"), st.g(bias_key),
-                      pre_act, post_act, drop_p, dy=dy, dyT=dyT, gram_x=gx, slots=slots)
+        ups_t = [(dE, st.p(wk), st.g(wk), st.g(bk) if bk else None) for (dE, wk, bk) in ups]
+        grp = getattr(self, "_bb_group", None)
+        if grp is not None:              # several modalities' tails in one launch: the caller emits fx_block_bwd_group
+            grp[0].append(ops.block_bwd_desc(ups_t, y, out, st.p(bp + ".weight"), sm[0], si[0], st.g(bp + ".weight"),
+                                             st.g(bp + ".bias"), st.g(bias_key), dy=dy, dyT=dyT, gram_x=gx, slots=slots))
+            if not big and not self._is_frozen(wkey):
+                grp[1].append(lambda: ops.linear_bwd_w(rec, st.g(wkey), dy, x_in, self.ws))
+        else:
+            ops.block_bwd(rec, ups_t, y, out, st.p(bp + ".weight"), sm[0], si[0], st.g(bp + ".weight"), st.g(bp + ".bias"),
+                          st.g(bias_key), pre_act, post_act, drop_p, dy=dy, dyT=dyT, gram_x=gx, slots=slots)
         if big:
             xt = None
             if want_t:
@@ -626,7 +688,7 @@ class StepPlan:
                     self._split_cache[("T", x_in.data_ptr())] = xt
                     ops.split_bf16_t(rec, xt[0], xt[1], x_in)
             self._jobs[wkey] = (dy, x_in, dyT, xt)
-        elif not self._is_frozen(wkey):
+        elif not self._is_frozen(wkey) and grp is None:
             ops.linear_bwd_w(rec, st.g(wkey), dy, x_in, self.ws)
 
     def _gram_x_for(self, rec, x):
@@ -674,6 +736,45 @@ class StepPlan:
             else:
                 ops.ce_masked(rec_f, li, do, o, self.y[v], lv)
 
+    def _heads_step(self, rec, emb, demb, first_accumulate=False, with_total=True) -> bool:
+        """Training plans: every supervisor head forward, its loss, its backward, the summed embedding gradient and (with
+        ``with_total``) the model's total loss in ONE launch (fx_heads_step) instead of heads_fwd -> one loss kernel per head
+        -> total_loss -> heads_bwd.  Returns False when the shapes are outside the kernel's range (the caller then records the
+        separate launches)."""
+        spec, st, B = self.spec, self.store, self.B
+        if not (self.train and self.fuse_heads_step and spec.variables and self._heads_fusable(emb)):
+            return False
+        names = spec.loss_names()
+        self._heads_fwd_fused(None, emb)                # descriptors (forward part); nothing is emitted
+        kinds, labels, durs, lvs, losses = [], [], [], [], []
+        for d, (v, kind, C) in zip(self._head_descs, spec.variables):
+            pre = "MLPs." + v
+            bias_key = pre + ".layer_out.bias"
+            do = self._new(f"MLPs.{v}/dout", B, C)
+            for field, t in (("dout", do), ("gW1", st.g(pre + ".layer_1.weight")), ("gb1", st.g(pre + ".layer_1.bias")),
+                             ("ggamma", st.g(pre + ".batchnorm.weight")), ("gbeta", st.g(pre + ".batchnorm.bias")),
+                             ("gW2", st.g(pre + ".layer_out.weight")), ("gb2", st.g(bias_key) if bias_key in st.shapes else None)):
+                setattr(d, field, t.data_ptr() if t is not None else None)
+            if v == spec.surv_event_var:
+                kinds.append(ops.LOSS_COX); durs.append(self.y[spec.surv_time_var])
+            else:
+                kinds.append(ops.LOSS_MSE if kind == "numerical" else ops.LOSS_CE); durs.append(None)
+            labels.append(self.y[v])
+            lvs.append(self._logvar(v))
+            losses.append(self.loss_vec[names.index(v):names.index(v) + 1])
+        scratch = None
+        if len(self._head_descs) > 1 and demb is not None:
+            scratch = self.buf["heads/dx_scratch"] = ops.heads_bwd_scratch(len(self._head_descs), B, emb.shape[1], self.dev)
+        weighted = self.train and spec.weighted
+        tl = [self.loss_vec[i:i + 1] for i in range(len(names))] if with_total else []
+        tv = [st.p("log_vars." + n).view(-1) for n in names] if (with_total and weighted) else []
+        td = [st.g("log_vars." + n).view(-1) for n in names] if (with_total and weighted) else []
+        ops.heads_step(rec, self._head_descs, kinds, labels, durs, lvs, losses, emb, demb, B, emb.shape[1], DROPOUT_P, st.ctrl,
+                       scratch, tl, tv, td, weighted, self.loss_vec[len(names):], self.epoch_acc if with_total else None,
+                       dx_accumulate=first_accumulate)
+        rec.mark("fork_issue_2")
+        return True
+
     def _heads_fusable(self, emb) -> bool:
         """fx_heads_fwd / fx_heads_bwd cover every search-space shape of the reference (config.py:7-15: latent <= 128,
         supervisor hidden <= 32, batch <= 128); anything larger goes through the per-layer kernels."""
@@ -701,7 +802,8 @@ class StepPlan:
                 save_invstd=self._new(pre + "/save_invstd", 1, S), out=self._new(f"MLPs.{v}/out", B, C), mask=mask,
                 seed=seed, offset=off, hidden=S, n_out=C))
         self._head_descs = descs
-        ops.heads_fwd(rec_f, descs, emb, B, emb.shape[1], self.train, DROPOUT_P if self.train else 0.0, ctrl=st.ctrl)
+        if rec_f is not None:
+            ops.heads_fwd(rec_f, descs, emb, B, emb.shape[1], self.train, DROPOUT_P if self.train else 0.0, ctrl=st.ctrl)
 
     def _head_bwd(self, rec_b, emb, demb, first_accumulate=False):
         if getattr(self, "_head_descs", None):
@@ -744,10 +846,13 @@ class StepPlan:
             cur = self.store.ctrl if self.n_batches > 0 else None
             first_w = "encoders.{}.hidden_layers.0.weight" if spec.is_vae else "encoders.{}.layer_1.weight"
             enc_pos = {li: j for j, li in enumerate(spec.enc_idx)} if spec.is_vae else {i: i for i in range(len(spec.layers))}
-            gpar = rg.parallel(len(spec.layers) if self.branches else 1)
+            # FX_ASSEMBLY_BRANCHES=0: the whole batch assembly on ONE side stream (with the main chain that is two hardware queues:
+            # more parallel branches alias onto the runtime's 4 queues and end up behind each other, profiles/r03_*)
+            gbr = self.branches and os.environ.get("FX_ASSEMBLY_BRANCHES", "0") != "0"
+            gpar = rg.parallel(len(spec.layers) if gbr else 1)
             gpar.__enter__()
             for i, (name, F) in enumerate(spec.layers):
-                gpar.branch(i if self.branches else 0)
+                gpar.branch(i if gbr else 0)
                 wk = first_w.format(enc_pos[i]) if i in enc_pos else None      # layers that are only reconstructed have no encoder
                 if spec.model == "GNN":
                     wk = None                                                    # node features feed a graph conv, not a wide Linear
@@ -761,7 +866,7 @@ class StepPlan:
                 else:
                     ops.gather_rows(rg, self.X[i], self.cohort.dat[name], self.idx, cur, self.R)
                 if wk is not None:
-                    self._branch = i if self.branches else 0
+                    self._branch = i if gbr else 0
                     while len(self._ws) <= self._branch:
                         self._ws.append(Workspace(self.dev))
                     self._want_gram(rg, self.X[i], wk, self.R, self.passes)   # batch-only half of the Gram norm: part of batch assembly
@@ -819,31 +924,37 @@ class StepPlan:
         trip = spec.model == "MultiTripletNetwork"
         tags = ["@a", "@p", "@n"] if trip else [""]
         ecat = self._new("ecat", R, n * L)
-        with rf.parallel(n if self.branches else 1) as par:      # one graph branch per modality
-            for i in range(n):
-                self._enter_branch(par, i)
-                self._mlp_fwd(rf, f"encoders.{i}", self.X[i], ecat[:, i * L:(i + 1) * L], R, self.passes,
-                              [f"encoders.{i}{t}" for t in tags])
-        self._branch = 0
-        if n > 1:
-            emb = self._new("emb", R, L)
-            self._small_fwd(rf, emb, ecat, "fusion_block.weight", "fusion_block.bias")
+        if self._tails_groupable(n, L):
+            emb = self._mlp_tails_fwd(rf, n, L, ecat)
         else:
-            emb = ecat
+            with rf.parallel(n if self.branches else 1) as par:      # one graph branch per modality
+                for i in range(n):
+                    self._enter_branch(par, i)
+                    self._mlp_fwd(rf, f"encoders.{i}", self.X[i], ecat[:, i * L:(i + 1) * L], R, self.passes,
+                                  [f"encoders.{i}{t}" for t in tags])
+            self._branch = 0
+            if n > 1:
+                emb = self._new("emb", R, L)
+                self._small_fwd(rf, emb, ecat, "fusion_block.weight", "fusion_block.bias")
+            else:
+                emb = ecat
         self.embeddings = emb[:B]
         demb = self._new("demb", R, L)
         if trip:
             names = spec.loss_names()
             ops.triplet(rf, self.loss_vec[0:1], demb[:B], demb[B:2 * B], demb[2 * B:], emb[:B], emb[B:2 * B],
                         emb[2 * B:], TRIPLET_MARGIN, self._logvar("triplet_loss"))
-        self._head_losses(rf, emb[:B])
-        self._total(rf)
+        stepped = self._heads_step(rf, emb[:B], demb[:B], first_accumulate=trip)
+        if not stepped:
+            self._head_losses(rf, emb[:B])
+            self._total(rf)
         if not self.train:
             if self.attribution:
                 self._build_mlp_attr(n, L)
             return
         # ---- backward
-        self._head_bwd(rb, emb[:B], demb[:B], first_accumulate=trip)
+        if not stepped:
+            self._head_bwd(rb, emb[:B], demb[:B], first_accumulate=trip)
         enc_frozen = self._is_frozen("encoders.0.layer_1.weight")
         if n > 1:
             decat = self._new("decat", R, n * L)
@@ -852,6 +963,18 @@ class StepPlan:
             decat = demb
         if enc_frozen:
             return          # FineTuner "encoders": True -- nothing upstream of the fusion layer needs a gradient
+        if (self.group_bwd and 1 < n <= 4 and self._block_ok(R, self.passes)
+                and not any(self._is_frozen(f"encoders.{i}.layer_out.weight") for i in range(n))):
+            # every modality's encoder-tail backward in ONE launch (fx_block_bwd_group): no graph fork / join on the chain
+            self._bb_group = ([], [])
+            for i in range(n):
+                self._mlp_bwd(rb, f"encoders.{i}", self.X[i], decat[:, i * L:(i + 1) * L], R, self.passes)
+            descs, post = self._bb_group
+            self._bb_group = None
+            ops.block_bwd_group(rb, descs, R, ACT_NONE, ACT_RELU, DROPOUT_P)
+            for f in post:
+                f()
+            return
         with rb.parallel(n if self.branches else 1) as par:
             for i in range(n):
                 self._enter_branch(par, i)
@@ -1021,15 +1144,18 @@ class StepPlan:
         emb = self._new("emb", B, L)
         self._lin_fwd(rf, emb, hflat, "encoders.0.fc.weight", "encoders.0.fc.bias")
         self.embeddings = emb
-        self._head_losses(rf, emb)
-        self._total(rf)
+        demb = self._new("demb", B, L) if self.train else None
+        stepped = self._heads_step(rf, emb, demb)
+        if not stepped:
+            self._head_losses(rf, emb)
+            self._total(rf)
         if not self.train:
             if self.attribution:
                 self._build_gnn_attr(layers, h, gop, g, L)
             return
         # ---- backward
-        demb = self._new("demb", B, L)
-        self._head_bwd(rb, emb, demb)
+        if not stepped:
+            self._head_bwd(rb, emb, demb)
         if self._is_frozen("encoders.0.fc.weight"):
             return              # FineTuner "encoders": True
         self._weight_grad(rb, "encoders.0.fc.weight", demb, hflat)
@@ -1147,9 +1273,13 @@ class StepPlan:
                 seed, off = self._rng()
                 ops.fill_normal(rf, pr, seed, off, ctrl=st.ctrl)
             priors.append(pr)
-        self._head_losses(rf, z)
+        stepped = self._heads_step(rf, z, dz, with_total=False)    # (the total needs the MMD term computed below)
+        if not stepped:
+            self._head_losses(rf, z)
         if self.train:
-            if spec.variables:
+            if stepped:
+                pass
+            elif spec.variables:
                 self._head_bwd(rf, z, dz, first_accumulate=False)  # emitted into the forward tape: see note above
             else:
                 # unsupervised run (reference __main__.py:997 accepts supervised_vae / CrossModalPred without target
@@ -1422,6 +1552,7 @@ class PipelinedStep:
         # FX_EARLY_GATHER=1 forks the batch assembly of step t+1 at the start of step t instead of after the losses.
         # Measured slower (1.313 vs 1.276 ms/step at cfg2): the gather / Gram kernels then compete with the forward chain.
         self.early_gather = bool(a._next_fwd) and os.environ.get("FX_EARLY_GATHER", "0") == "1"
+        self.fork_at_mark = int(os.environ.get("FX_FORK_AT_MARK", "2"))       # A/B (see _issue); 0 = after the forward tape (round 2)
         self.k = 0                       # plan holding the batch of the next step
         self.done = 0                    # steps issued since prime()
         self.graphs = [None, None]
@@ -1449,12 +1580,27 @@ class PipelinedStep:
         cur, nxt = self.plans[k], self.plans[1 - k]
         ops.step_begin(ops.IMMEDIATE, self.store.ctrl, lr, self.n_batches)
         main = torch.cuda.current_stream()
+        used, point = [], []
+        mode = self.fork_at_mark       # 0: after the forward tape; 1: at the plan's mark; 2 / 3: DEPEND on the mark, but issue after the
+                                       # next one / two main-chain launches (the chain's own launches are queued first)
+
+        def fork(name=None):
+            if used:
+                return
+            if name is None:
+                used.extend(nxt.t_gather.fork_from(main, after=point[0] if point else None))
+            elif name == "fork_assembly" and mode == 1:
+                used.extend(nxt.t_gather.fork_from(main))  # fork: batch assembly of step t+1 ...
+            elif name == "fork_assembly" and mode >= 2:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                point.append(ev)
+            elif name == "fork_issue_%d" % (mode - 1) and point:
+                used.extend(nxt.t_gather.fork_from(main, after=point[0]))
         if self.early_gather:
-            used = nxt.t_gather.fork_from(main)
-            cur.t_fwd.run()
-        else:
-            cur.t_fwd.run()
-            used = nxt.t_gather.fork_from(main)           # fork: batch assembly of step t+1 ...
+            fork()
+        cur.t_fwd.run(on_mark=fork)                       # (a plan may name its own fork point: StepPlan._mlp_tails_fwd)
+        fork()
         cur.t_bwd.run()                                   # ... overlaps the head / backward chain of step t
         for st in used:
             main.wait_stream(st)                          # join before the HBM-saturating dW+Adam launches

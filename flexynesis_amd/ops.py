@@ -203,11 +203,20 @@ class TapeRecorder:
     def keep(self, *objs):
         self.keepalive.extend(objs)
 
+    def mark(self, name: str):
+        """A named point in the tape: ``run(on_mark=f)`` calls ``f(name)`` when the launches before it have been issued
+        (PipelinedStep forks the next batch's assembly there).  No-op for plain ``run()``."""
+        self.segments[-1][self._cur].append((None, "__mark__", (name,)))
+
     @staticmethod
-    def _issue(branch, hook=None):
+    def _issue(branch, hook=None, on_mark=None):
         s = _stream()
         for fn, name, args in branch:
             if fn is None:      # cross-branch ordering inside a parallel segment (HIP events; graph edges under capture)
+                if name == "__mark__":
+                    if on_mark is not None:
+                        on_mark(args[0])
+                    continue
                 ev = args[0]
                 if name == "__record__":
                     ev.record(torch.cuda.current_stream())
@@ -225,13 +234,13 @@ class TapeRecorder:
             if rc != 0:
                 raise FxError(f"{name} failed (rc={rc}): {_lib.last_error()}")
 
-    def _run(self, hook=None):
+    def _run(self, hook=None, on_mark=None):
         for seg in self.segments:
             live = [br for br in seg if br]
             if not live:
                 continue
             if len(live) == 1:
-                self._issue(live[0], hook)
+                self._issue(live[0], hook, on_mark)
                 continue
             main = torch.cuda.current_stream()
             side = side_streams(len(live) - 1, group=0)
@@ -244,10 +253,10 @@ class TapeRecorder:
             for st in side:
                 main.wait_stream(st)          # join
 
-    def run(self):
-        self._run(None)
+    def run(self, on_mark=None):
+        self._run(None, on_mark)
 
-    def fork_from(self, main, pool=None):
+    def fork_from(self, main, pool=None, after=None):
         """Issue the whole tape off the critical path: every branch goes to its own stream (group 1 of the shared
         pool), each forked DIRECTLY from ``main``; returns the streams the caller must join (``main.wait_stream``).
         (A fork made from an already-forked stream -- i.e. ``run()`` under ``torch.cuda.stream(side)`` --
@@ -258,7 +267,10 @@ class TapeRecorder:
             raise FxError("fork_from: only tapes with a single (parallel) segment can run as a detached fork")
         used = side_streams(len(live[0]), group=1)
         for st in used:
-            st.wait_stream(main)
+            if after is not None:
+                st.wait_event(after)      # depend on an EARLIER point of ``main`` than the one the fork is issued at
+            else:
+                st.wait_stream(main)
         for br, st in zip(live[0], used):
             with torch.cuda.stream(st):
                 self._issue(br)
@@ -618,6 +630,38 @@ def block_bwd(rec, ups, x, out, gamma, save_mean, save_invstd, dgamma, dbeta, db
     return arrs
 
 
+def block_bwd_desc(ups, x, out, gamma, save_mean, save_invstd, dgamma, dbeta, dbias, dy=None, dyT=None, gram_x=None, slots=None,
+                   accumulate=False):
+    """One fx_block_bwd_desc (arguments as block_bwd)."""
+    _chk2d(x, "block_bwd.x")
+    _chk2d(out, "block_bwd.out")
+    B, Cc = x.shape
+    d = _lib.BlockBwdDesc()
+    if not 1 <= len(ups) <= 2:
+        raise FxError("block_bwd: 1 or 2 upstream Linears")
+    for k, (dE, W, gW, gb) in enumerate(ups):
+        _chk2d(dE, "block_bwd.dE")
+        _chk2d(W, "block_bwd.W")
+        if dE.shape[0] != B or W.shape != (dE.shape[1], Cc) or gW.shape != W.shape or not W.is_contiguous() or not gW.is_contiguous():
+            raise FxError("block_bwd: upstream shapes must be dE [B, L], W / gW [L, C] contiguous")
+        d.dE[k], d.ldE[k], d.W[k], d.gW[k], d.gb[k], d.L[k] = dE.data_ptr(), _ld(dE), W.data_ptr(), gW.data_ptr(), _ptr(gb), dE.shape[1]
+    d.n_up = len(ups)
+    d.x, d.out, d.gamma, d.save_mean, d.save_invstd = x.data_ptr(), out.data_ptr(), gamma.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr()
+    d.dgamma, d.dbeta, d.dbias, d.dy = dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dbias), _ptr(dy)
+    d.dyT_hi, d.dyT_lo, d.ldt = (_ptr(dyT[0]), _ptr(dyT[1]), _ld(dyT[0])) if dyT else (None, None, 0)
+    d.gram_x, d.slots, d.C, d.ldx, d.ldo, d.accumulate = _ptr(gram_x), _ptr(slots), Cc, _ld(x), _ld(out), int(bool(accumulate))
+    return d
+
+
+def block_bwd_group(rec, descs, B, pre_act, post_act, drop_p):
+    """fx_block_bwd of several independent encoder tails (one per modality) in one launch."""
+    arr = (_lib.BlockBwdDesc * len(descs))(*descs)
+    if hasattr(rec, "keep"):
+        rec.keep(arr)
+    rec.emit("fx_block_bwd_group", C.addressof(arr), len(descs), int(B), int(pre_act), int(post_act), float(drop_p))
+    return arr
+
+
 HEADS_MAX = dict(B=128, L=128, hidden=32, n_out=32, heads=8)     # limits of fx_heads_fwd / fx_heads_bwd
 
 
@@ -645,6 +689,60 @@ def heads_fwd(rec, descs, x, B, L, train, drop_p, ctrl=None):
     return arr
 
 
+def enc_tail_blocks(H: int) -> int:
+    return int(lib.fx_enc_tail_blocks(int(H)))
+
+
+def enc_tail_desc(*, slabs, n_slabs, slab_stride, lin_bias, x, out, gamma, beta, running_mean, running_var, save_mean, save_invstd,
+                  mask, ups, seed, offset):
+    """One fx_enc_tail_desc.  ups = [(W_k [L_k, H], part_k [blocks, B, L_k])] (one or two following Linears)."""
+    d = _lib.EncTailDesc()
+    H = x.shape[1]
+    for t, n in ((x, "x"), (out, "out")):
+        if not (t.is_contiguous() and t.dtype == torch.float32 and t.is_cuda):
+            raise FxError(f"enc_tail_desc.{n}: expected a contiguous fp32 GPU tensor")
+    d.slabs, d.slab_stride, d.lin_bias = _ptr(slabs), int(slab_stride), _ptr(lin_bias)
+    d.x, d.out, d.gamma, d.beta = x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+    d.running_mean, d.running_var = running_mean.data_ptr(), running_var.data_ptr()
+    d.save_mean, d.save_invstd, d.mask = _ptr(save_mean), _ptr(save_invstd), _ptr(mask)
+    if not 1 <= len(ups) <= 2:
+        raise FxError("enc_tail_desc: one or two following Linears")
+    for k, (W, part) in enumerate(ups):
+        if W.shape[1] != H or not W.is_contiguous() or part.numel() < enc_tail_blocks(H) * x.shape[0] * W.shape[0]:
+            raise FxError("enc_tail_desc: following Linear / partial-product buffer mismatch")
+        d.W[k], d.part[k], d.L[k] = W.data_ptr(), part.data_ptr(), int(W.shape[0])
+    d.seed, d.offset, d.n_slabs, d.H, d.n_up = int(seed), int(offset), int(n_slabs), int(H), len(ups)
+    return d
+
+
+def enc_tail_fwd(rec, descs, B, pre_act, post_act, train, drop_p, ctrl=None):
+    """Encoder tails of all modalities forward in one launch (slab sum + bias, BatchNorm block, partial products of the
+    following small Linears)."""
+    arr = (_lib.EncTailDesc * len(descs))(*descs)
+    if hasattr(rec, "keep"):
+        rec.keep(arr)
+    rec.emit("fx_enc_tail_fwd", C.addressof(arr), len(descs), int(B), int(pre_act), int(post_act), int(bool(train)), float(drop_p),
+             _ptr(ctrl))
+    return arr
+
+
+def fusion_fwd(rec, emb, ecat, parts, biases, W=None, b=None):
+    """ecat = concatenated ordered sums of ``parts`` [(part [blocks, B, width], blocks)] (+ biases), emb = ecat W^T + b."""
+    n = len(parts)
+    B = ecat.shape[0] if ecat is not None else emb.shape[0]
+    pp = (C.c_void_p * n)(*[p.data_ptr() for p, _ in parts])
+    nb = (C.c_int * n)(*[int(k) for _, k in parts])
+    bb = (C.c_void_p * n)(*[_ptr(x) for x in biases])
+    wd = (C.c_int * n)(*[int(p.shape[-1]) for p, _ in parts])
+    if hasattr(rec, "keep"):
+        rec.keep(pp, nb, bb, wd)
+    if W is not None and (not W.is_contiguous() or W.shape[1] != sum(int(p.shape[-1]) for p, _ in parts)):
+        raise FxError("fusion_fwd: fusion weight must be contiguous [L, sum of widths]")
+    rec.emit("fx_fusion_fwd", _ptr(emb), _ld(emb) if emb is not None else 0, _ptr(ecat), _ld(ecat) if ecat is not None else 0,
+             C.addressof(pp), C.addressof(nb), C.addressof(bb), C.addressof(wd), n, _ptr(W), _ptr(b), int(B),
+             int(W.shape[0]) if W is not None else 0)
+
+
 def heads_bwd_scratch(n_heads: int, B: int, L: int, device) -> torch.Tensor:
     """Zero-filled scratch for fx_heads_bwd's per-head dx workgroups (shares + arrival counter)."""
     return torch.zeros(n_heads * B * L + 4, dtype=torch.float32, device=device)
@@ -658,6 +756,32 @@ def heads_bwd(rec, descs, x, dx, B, L, drop_p, dx_accumulate=False, scratch=None
         raise FxError("heads_bwd: scratch too small")
     rec.emit("fx_heads_bwd", C.addressof(arr), len(descs), x.data_ptr(), _ld(x), _ptr(dx), _ld(dx) if dx is not None else 0,
              int(bool(dx_accumulate)), int(B), int(L), float(drop_p), _ptr(scratch))
+    return arr
+
+
+LOSS_MSE, LOSS_CE, LOSS_COX = 0, 1, 2
+
+
+def heads_step(rec, descs, kinds, labels, durations, logvars, losses, x, dx, B, L, drop_p, ctrl, scratch, term_losses, term_logvars,
+               term_dlogvars, weighted, total_out, epoch_acc, dx_accumulate=False):
+    """Forward + loss + backward of all supervisor heads, summed embedding gradient and the total loss in one launch."""
+    _chk2d(x, "heads_step.x")
+    arr = _head_array(rec, descs)
+    n = len(descs)
+    if scratch is not None and scratch.numel() < n * int(B) * int(L) + 1:
+        raise FxError("heads_step: scratch too small")
+
+    def parr(ts):
+        return (C.c_void_p * max(len(ts), 1))(*[_ptr(t) for t in ts])
+    k = (C.c_int * n)(*[int(v) for v in kinds])
+    lab, dur, lv, ls = parr(labels), parr(durations), parr(logvars), parr(losses)
+    tl, tv, td = parr(term_losses), parr(term_logvars if weighted else []), parr(term_dlogvars if weighted else [])
+    if hasattr(rec, "keep"):
+        rec.keep(k, lab, dur, lv, ls, tl, tv, td)
+    rec.emit("fx_heads_step", C.addressof(arr), n, C.addressof(k), C.addressof(lab), C.addressof(dur), C.addressof(lv), C.addressof(ls),
+             x.data_ptr(), _ld(x), _ptr(dx), _ld(dx) if dx is not None else 0, int(bool(dx_accumulate)), int(B), int(L), float(drop_p),
+             _ptr(ctrl), _ptr(scratch), len(term_losses), int(bool(weighted)), C.addressof(tl),
+             C.addressof(tv) if weighted else None, C.addressof(td) if weighted else None, total_out.data_ptr(), _ptr(epoch_acc))
     return arr
 
 

@@ -109,7 +109,7 @@ def run_cfg5(dev, n_trials: int = 64, epochs: int = 3, features: int = 20000, sa
             account(t, info, plist[tid])
             return val, ep, None
 
-        utable, _ = trials.run_units(len(units), unit_fn, costs, dev, keep=[], schedule=schedule)
+        utable, _ = trials.run_units(len(units), unit_fn, costs, dev, keep=[], schedule=schedule, force_collectives=force_collectives)
         per_trial = utable[:, 1].reshape(n_trials, n_splits)
         trial_vals = per_trial.mean(axis=1)                       # main.py:327-333: the mean over the folds
         trial_eps = utable[:, 2].reshape(n_trials, n_splits).mean(axis=1).astype(int)

@@ -181,7 +181,7 @@ class _Claims:
 
 
 def run_units(n: int, unit_fn: Callable[[int], Tuple[float, int, Optional[dict]]], costs: Optional[Sequence[float]] = None,
-              device="cpu", keep: Optional[Sequence[int]] = None, schedule: str = "queue"):
+              device="cpu", keep: Optional[Sequence[int]] = None, schedule: str = "queue", force_collectives: bool = False):
     """Run units 0..n-1 (HPO trials, cross-validation folds, fine-tuning fits) sharded over the ranks:
     ``unit_fn(uid) -> (val_loss, epochs, state_dict | None)``.  Returns (table [n, 5]: uid, val_loss, epochs, status,
     rank that ran it; local: {uid: state} of the units this rank must hold on to).  ``keep`` = unit ids whose state is
@@ -214,7 +214,7 @@ def run_units(n: int, unit_fn: Callable[[int], Tuple[float, int, Optional[dict]]
                 held[uid] = state
                 best_local = (float(val), uid)
         del state
-    table = gather_results(local, n, device, rank)
+    table = gather_results(local, n, device, rank, force_collectives)
     return table, held
 
 
@@ -243,7 +243,8 @@ def run_sweep(param_list: List[dict], trial_fn: Callable[[int, dict], Tuple[floa
     (HPO: latent size / hidden factor differ per trial, so the winner's layout is derived from its parameters on
     every rank).  Returns (table [n, 5], best_trial_id, best_state or None)."""
     n = len(param_list)
-    table, held = run_units(n, lambda uid: trial_fn(uid, param_list[uid]), costs, device, keep=None, schedule=schedule)
+    table, held = run_units(n, lambda uid: trial_fn(uid, param_list[uid]), costs, device, keep=None, schedule=schedule,
+                            force_collectives=force_collectives)
     best = int(np.argmin(table[:, 1]))
     best_state = None
     if state_shapes is not None and math.isfinite(table[best, 1]):

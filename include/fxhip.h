@@ -141,6 +141,33 @@ int fx_bn_act_fwd_slabs(float* out, float* x_out, const float* slabs, int nslabs
 int fx_gram_hadamard_blocks(long n);
 int fx_gram_hadamard(double* slots, const float* slabs_x, int nslabs_x, const float* slabs_d, int nslabs_d, long n,
                      fx_stream_t stream);
+/* Forward of an encoder TAIL for every modality in one launch (grid: column blocks x modalities), replacing per modality
+ * fx_reduce_slabs -> fx_bn_act_fwd -> fx_gemm_f32 (+ its split-K reduce): the tail is "wide Linear output -> BatchNorm block
+ * -> one or two small Linears" (MLP encoder, modules.py:145-149: BatchNorm1d -> ReLU -> Dropout -> layer_out; VAE encoder,
+ * modules.py:25-41,47-56: LeakyReLU -> BatchNorm1d -> FC_mean, FC_var).  Per modality: x = sum of the wide Linear's partial-sum
+ * slabs (+ lin_bias), in slab order (slabs NULL: x already holds the Linear's output); batch statistics (train) or running
+ * statistics; out = block output (saved for the backward); part[k][blk] = out[:, blk's 64 columns] . W_k[:, those columns]^T,
+ * k < n_up, one [B, L_k] partial product per column block (fx_enc_tail_blocks(H) of them), consumed by fx_fusion_fwd.
+ * B <= 128, H % 4 == 0, L_k <= 128, every array 16-byte aligned.  The dropout stream is fx_bn_act_fwd's (seed, offset, ctrl). */
+typedef struct fx_enc_tail_desc {
+  const float* slabs; long slab_stride; const float* lin_bias;   /* [n_slabs][B][H] (stride in floats), bias [H] or NULL */
+  float* x; float* out;                                            /* [B, H] contiguous */
+  const float* gamma; const float* beta; float* running_mean; float* running_var; float* save_mean; float* save_invstd;
+  const float* mask;                                               /* supplied dropout mask [B, H] or NULL */
+  const float* W[2]; float* part[2];                               /* following Linears [L_k, H]; partial products */
+  unsigned long long seed, offset;
+  int n_slabs, H, n_up, L[2];
+} fx_enc_tail_desc;
+int fx_enc_tail_blocks(int H);
+int fx_enc_tail_fwd(const fx_enc_tail_desc* descs, int n_modalities, int B, int pre_act, int post_act, int train, float drop_p,
+                    const float* ctrl, fx_stream_t stream);
+/* ecat[B, sum widths] = for every layer i the ordered sum of parts[i] [n_parts[i]][B][widths[i]] (+ part_bias[i]) -- the
+ * concatenated encoder outputs of direct_pred.py:118-121 from fx_enc_tail_fwd's partial products -- and, when Wf is given,
+ * emb = ecat Wf^T + bf (the fusion Linear, direct_pred.py:122-124; Wf [L, sum widths] contiguous, L <= 128).  One workgroup
+ * per 8 rows.  widths % 4 == 0, sum <= 512; ecat may be NULL when only emb is wanted. */
+int fx_fusion_fwd(float* emb, long ldemb, float* ecat, long ldecat, const float* const* parts, const int* n_parts,
+                  const float* const* part_bias, const int* widths, int n_layers, const float* Wf, const float* bf, int B, int L,
+                  fx_stream_t stream);
 /* x[r, :] = src[idx[r], :] (x optional) plus both splits in one pass (MultiOmicDataset.__getitem__ + default_collate,
  * data.py:1015-1027, and the operand preparation of the wide kernels).  hi / lo / hiT / loT 16-byte aligned, ldt % 8 == 0 and
  * >= n_rows rounded up to 32; 16-byte accesses when n_cols, ld_src and ldx are multiples of 4 (scalar otherwise). */
@@ -178,6 +205,18 @@ int fx_heads_fwd(const fx_head_desc* heads, int n_heads, const float* x, long ld
  * the shares in head order (deterministic); without it one workgroup walks the heads one after the other. */
 int fx_heads_bwd(const fx_head_desc* heads, int n_heads, const float* x, long ldx, float* dx, long lddx, int dx_accumulate,
                  int B, int L, float drop_p, void* dx_scratch, fx_stream_t stream);
+/* The whole supervisor part of a TRAINING step in one launch (one workgroup per head): forward of every head, its loss value
+ * and output gradient (kinds[i]: 0 masked MSE, 1 masked softmax-CE -- direct_pred.py:146-190 --, 2 Cox partial likelihood --
+ * modules.py:265-305, labels = events, durations[i] --, scaled by exp(-logvars[i][0]) when given), backward of every head
+ * (parameter gradients; dx (+)= the heads' embedding gradients added in head order) and the uncertainty-weighted total over
+ * ALL n_terms named losses of the model (direct_pred.py:192-223; terms written by earlier launches -- triplet, MMD -- are read
+ * from their slots; term_dlogvars / epoch_acc as fx_total_loss).  Replaces fx_heads_fwd -> per-head loss kernels ->
+ * fx_total_loss -> fx_heads_bwd.  heads[i].dout receives the output gradient; dx_scratch as fx_heads_bwd (needed for > 1 head). */
+int fx_heads_step(const fx_head_desc* heads, int n_heads, const int* kinds, const float* const* labels,
+                  const float* const* durations, const float* const* logvars, float* const* losses, const float* x, long ldx,
+                  float* dx, long lddx, int dx_accumulate, int B, int L, float drop_p, const float* ctrl, void* dx_scratch,
+                  int n_terms, int weighted, const float* const* term_losses, const float* const* term_logvars,
+                  float* const* term_dlogvars, float* total_out, float* epoch_acc, fx_stream_t stream);
 
 /* ---- the whole backward of an encoder tail "wide Linear -> BatchNorm block -> 1 or 2 small Linears" in one launch
  *      (MLP encoder, modules.py:145-149; VAE encoder, modules.py:25-41,47-56): autograd's mm for the small Linears'
@@ -196,6 +235,17 @@ int fx_block_bwd(const float* const* dE, const long* ldE, const float* const* W,
                  const float* save_invstd, float* dgamma, float* dbeta, float* dbias, float* dy, void* dyT_hi, void* dyT_lo,
                  long ldt, const float* gram_x, double* slots, int B, int C, long ldx, long ldo, int pre_act, int post_act,
                  float drop_p, int accumulate, fx_stream_t stream);
+
+/* fx_block_bwd for up to 4 independent encoder tails (one per modality) in ONE launch (grid: column blocks x tails); every
+ * field has the meaning of the fx_block_bwd argument of the same name.  B, the activations and drop_p are common. */
+typedef struct fx_block_bwd_desc {
+  const float* dE[2]; long ldE[2]; const float* W[2]; float* gW[2]; float* gb[2]; int L[2]; int n_up;
+  const float* x; const float* out; const float* gamma; const float* save_mean; const float* save_invstd;
+  float* dgamma; float* dbeta; float* dbias; float* dy; void* dyT_hi; void* dyT_lo; long ldt;
+  const float* gram_x; double* slots; int C; long ldx, ldo; int accumulate;
+} fx_block_bwd_desc;
+int fx_block_bwd_group(const fx_block_bwd_desc* descs, int n_tails, int B, int pre_act, int post_act, float drop_p,
+                       fx_stream_t stream);
 
 /* ---- small dense layers on the critical chain (fusion layer direct_pred.py:87-93,121-124; VAE FC_mean / FC_log_var
  *      supervised_vae.py:104-107,172-176): one forward launch, and ONE backward launch for the data, weight and bias
