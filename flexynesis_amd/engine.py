@@ -1553,6 +1553,7 @@ class PipelinedStep:
         # Measured slower (1.313 vs 1.276 ms/step at cfg2): the gather / Gram kernels then compete with the forward chain.
         self.early_gather = bool(a._next_fwd) and os.environ.get("FX_EARLY_GATHER", "0") == "1"
         self.fork_at_mark = int(os.environ.get("FX_FORK_AT_MARK", "2"))       # A/B (see _issue); 0 = after the forward tape (round 2)
+        self.fork_dep_begin = os.environ.get("FX_FORK_DEP_BEGIN", "0") == "1"
         self.k = 0                       # plan holding the batch of the next step
         self.done = 0                    # steps issued since prime()
         self.graphs = [None, None]
@@ -1583,6 +1584,10 @@ class PipelinedStep:
         used, point = [], []
         mode = self.fork_at_mark       # 0: after the forward tape; 1: at the plan's mark; 2 / 3: DEPEND on the mark, but issue after the
                                        # next one / two main-chain launches (the chain's own launches are queued first)
+        if self.fork_dep_begin and mode >= 2:      # depend on fx_step_begin only (the cursor); still issued behind the chain's launches
+            ev = torch.cuda.Event()
+            ev.record(main)
+            point.append(ev)
 
         def fork(name=None):
             if used:
@@ -1591,11 +1596,11 @@ class PipelinedStep:
                 used.extend(nxt.t_gather.fork_from(main, after=point[0] if point else None))
             elif name == "fork_assembly" and mode == 1:
                 used.extend(nxt.t_gather.fork_from(main))  # fork: batch assembly of step t+1 ...
-            elif name == "fork_assembly" and mode >= 2:
+            elif name == "fork_assembly" and mode >= 2 and not point:
                 ev = torch.cuda.Event()
                 ev.record(main)
                 point.append(ev)
-            elif name == "fork_issue_%d" % (mode - 1) and point:
+            elif (name == "fork_issue_%d" % (mode - 1) or (mode == 4 and name == "fork_assembly")) and point:
                 used.extend(nxt.t_gather.fork_from(main, after=point[0]))
         if self.early_gather:
             fork()

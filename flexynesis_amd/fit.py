@@ -112,7 +112,7 @@ def _eval_loss(model, store, cohort, idx_rows: torch.Tensor, batch_size: int, pa
 def fit(model, dataset, train_idx: Sequence[int], val_idx: Optional[Sequence[int]] = None, *, batch_size: int,
         epochs: int, lr: float, patience: int = 0, seed: int = 0, use_graph: bool = True, device=None,
         verbose: bool = False, clip: bool = True, frozen: Sequence[str] = (), drop_last: bool = True,
-        fresh_optimizer: bool = False, supplied: Optional[dict] = None) -> FitResult:
+        fresh_optimizer: bool = False, supplied: Optional[dict] = None, prof: Optional[dict] = None) -> FitResult:
     """Train ``model`` on ``dataset[train_idx]`` and validate on ``dataset[val_idx]`` once per epoch.
     For MultiTripletNetwork the indices address the valid (non-NaN main label) anchors, like the reference's
     ``TripletMultiOmicDataset`` (data.py:1102-1104).
@@ -129,12 +129,32 @@ def fit(model, dataset, train_idx: Sequence[int], val_idx: Optional[Sequence[int
     with torch.cuda.device(store.device):
         return _fit(model, store, dataset, train_idx, val_idx, batch_size=batch_size, epochs=epochs, lr=lr, patience=patience,
                     seed=seed, use_graph=use_graph, verbose=verbose, clip=clip, frozen=frozen, drop_last=drop_last,
-                    fresh_optimizer=fresh_optimizer, supplied=supplied)
+                    fresh_optimizer=fresh_optimizer, supplied=supplied, prof=prof)
+
+
+class _Phases:
+    """Wall-clock per phase of a fit (``prof`` dict of fit(): diagnostics only; every boundary synchronises the device)."""
+
+    def __init__(self, sink, dev):
+        import time
+        self.sink, self.dev, self.clock = sink, dev, time.perf_counter
+        if sink is not None:
+            torch.cuda.synchronize(dev)
+            self.t = self.clock()
+
+    def lap(self, name):
+        if self.sink is None:
+            return
+        torch.cuda.synchronize(self.dev)
+        now = self.clock()
+        self.sink[name] = self.sink.get(name, 0.0) + (now - self.t)
+        self.t = now
 
 
 def _fit(model, store, dataset, train_idx, val_idx, *, batch_size, epochs, lr, patience, seed, use_graph, verbose, clip, frozen,
-         drop_last, fresh_optimizer, supplied=None) -> FitResult:
+         drop_last, fresh_optimizer, supplied=None, prof=None) -> FitResult:
     dev = store.device
+    ph = _Phases(prof, dev)
     if fresh_optimizer:
         store.reset_optimizer()             # a new torch.optim.Adam per fit (main.py:562-566)
     cohort = _cohort_of(dataset, dev)
@@ -159,10 +179,12 @@ def _fit(model, store, dataset, train_idx, val_idx, *, batch_size, epochs, lr, p
     plan_kw = dict(clip=bool(clip), frozen=frozen)
     if supplied is not None and (trip or tail):
         raise ValueError("supplied permutations / draws cover full batches of the non-triplet models only")
+    ph.lap("setup")
     pipe = PipelinedStep(store, B, cohort=cohort, n_batches=n_batches, seed=int(seed) * 7919 + 13, epoch_acc=True,
                          supplied_draws=supplied is not None, **plan_kw) if n_batches >= 1 else None
     tail_plan = StepPlan(store, tail, train=True, fused=True, supplied_draws=False, seed=int(seed) * 7919 + 17, cohort=cohort,
                          n_batches=0, epoch_acc=True, **plan_kw) if tail else None
+    ph.lap("train plans")
     names = spec.loss_names()
     eval_cache: Dict[int, StepPlan] = {}
     history: List[Dict[str, float]] = []
@@ -193,6 +215,7 @@ def _fit(model, store, dataset, train_idx, val_idx, *, batch_size, epochs, lr, p
     write_table()
     if pipe is not None:
         pipe.prime()                  # batch 0 is assembled now; every step assembles the batch of the next one
+    ph.lap("prime")
     epochs_run = 0
     for epoch in range(int(epochs)):
         if pipe is not None:
@@ -208,8 +231,10 @@ def _fit(model, store, dataset, train_idx, val_idx, *, batch_size, epochs, lr, p
                 pipe.replay()
             else:
                 pipe.step(lr)
+                ph.lap("first step (eager)")
                 if use_graph:
                     pipe.capture(lr)
+                    ph.lap("graph capture")
             steps += 1
         if tail_plan is not None:
             if pipe is None:
@@ -220,6 +245,7 @@ def _fit(model, store, dataset, train_idx, val_idx, *, batch_size, epochs, lr, p
                 pipe.refresh()        # the pending batch's fused wide forward was computed before this step changed the weights
             steps += 1
         epochs_run = epoch + 1
+        ph.lap("steps")
         # epoch means weighted by batch size, like Lightning's on_epoch reduction of the logged losses
         acc = [0.0] * (len(names) + 1)
         wsum = 0.0
@@ -234,6 +260,7 @@ def _fit(model, store, dataset, train_idx, val_idx, *, batch_size, epochs, lr, p
         rec["train_loss"] = acc[len(names)] / max(wsum, 1.0)
         if va is not None:
             rec["val_loss"] = _eval_loss(model, store, cohort, va, B, passes, sampler, gen, eval_cache)
+        ph.lap("epoch readback + validation")
         history.append(rec)
         if verbose:
             print(f"[fit] epoch {epoch}: " + ", ".join(f"{k}={v:.5f}" for k, v in rec.items()), flush=True)
@@ -252,6 +279,7 @@ def _fit(model, store, dataset, train_idx, val_idx, *, batch_size, epochs, lr, p
         if not np.isfinite(rec["train_loss"]):
             break
     final_val = _eval_loss(model, store, cohort, va, B, passes, sampler, gen, eval_cache) if va is not None else float("nan")
+    ph.lap("final validation")
     model._sync_nbt()
     return FitResult(final_val, epochs_run, stopped_epoch, history, steps)
 
