@@ -83,22 +83,35 @@ class TripletSampler:
         return pos, neg
 
 
-def _eval_loss(model, store, cohort, idx_rows: torch.Tensor, batch_size: int, passes: int, sampler, gen, cache) -> float:
-    """Mean validation total (batch-size weighted, like Lightning's epoch reduction of validation_step)."""
+def _eval_loss(model, store, cohort, idx_rows: torch.Tensor, batch_size: int, passes: int, sampler, gen, cache,
+               supplied: Optional[dict] = None, epoch: int = 0) -> float:
+    """Mean validation total (batch-size weighted, like Lightning's epoch reduction of validation_step).
+    ``supplied`` (parity tests): "val_draws"(epoch, chunk) -> {name: tensor} replaces the in-kernel draws of the VAE family's
+    eval forward (z is sampled in eval mode too), "val_triplets"(epoch, chunk) -> (positive rows, negative rows) the device
+    triplet sampler."""
     n = idx_rows.numel()
     tot, cnt = 0.0, 0
     acc = []
-    for s in range(0, n, batch_size):
+    vdraws = supplied.get("val_draws") if supplied else None
+    vtrip = supplied.get("val_triplets") if supplied else None
+    for bi, s in enumerate(range(0, n, batch_size)):
         rows = idx_rows[s:s + batch_size]
         B = rows.numel()
-        if B not in cache:
-            cache[B] = StepPlan(store, B, train=False, cohort=cohort, n_batches=0, seed=model._seed + 7919 + B)
-        plan = cache[B]
+        key = (B, vdraws is not None)
+        if key not in cache:
+            cache[key] = StepPlan(store, B, train=False, cohort=cohort, n_batches=0, seed=model._seed + 7919 + B,
+                                  supplied_draws=vdraws is not None)
+        plan = cache[key]
         if passes == 3:
-            pos, neg = sampler.sample(rows, gen)
+            if vtrip is not None:
+                pos, neg = (torch.as_tensor(t, dtype=torch.int64).to(rows.device) for t in vtrip(epoch, bi))
+            else:
+                pos, neg = sampler.sample(rows, gen)
             plan.idx.copy_(torch.cat([rows, pos, neg]))
         else:
             plan.idx.copy_(rows)
+        if vdraws is not None:
+            plan.set_draws({k: torch.as_tensor(v).to(rows.device) for k, v in vdraws(epoch, bi).items()})
         plan.t_gather.run()
         plan.forward()
         k = len(plan.spec.loss_names())
@@ -122,8 +135,10 @@ def fit(model, dataset, train_idx: Sequence[int], val_idx: Optional[Sequence[int
     requires_grad=False are neither differentiated nor stepped, and the last partial batch of an epoch is used.
 
     ``supplied`` (parity tests): {"perms": [per-epoch permutation of range(len(train_idx))], "draws": fn(epoch, batch) ->
-    {name: tensor}} replaces the device shuffle and the in-kernel Philox draws by recorded ones; the schedule (pipelined
-    batch assembly, hipGraph replay, fused kernels) is the production one."""
+    {name: tensor}} replaces the device shuffle and the in-kernel Philox draws by recorded ones; optional "triplets":
+    fn(epoch, batch) -> (positive rows, negative rows) replaces the device triplet sampler, "val_draws" / "val_triplets":
+    fn(epoch, chunk) the same for the validation batches (epoch == number of epochs run addresses the final validation).
+    The schedule (pipelined batch assembly, hipGraph replay, fused kernels) is the production one."""
     store = model._bind(device)
     # streams, events and graph capture are keyed on torch's current device: make it the model's for the whole fit
     with torch.cuda.device(store.device):
@@ -177,8 +192,8 @@ def _fit(model, store, dataset, train_idx, val_idx, *, batch_size, epochs, lr, p
         raise ValueError(f"batch_size {B} exceeds the training split ({tr.numel()} samples) with drop_last=True")
     frozen = tuple(frozen)
     plan_kw = dict(clip=bool(clip), frozen=frozen)
-    if supplied is not None and (trip or tail):
-        raise ValueError("supplied permutations / draws cover full batches of the non-triplet models only")
+    if supplied is not None and (tail or (trip and "triplets" not in supplied)):
+        raise ValueError("supplied permutations / draws cover full batches only (and the triplet network needs its triplets)")
     ph.lap("setup")
     pipe = PipelinedStep(store, B, cohort=cohort, n_batches=n_batches, seed=int(seed) * 7919 + 13, epoch_acc=True,
                          supplied_draws=supplied is not None, **plan_kw) if n_batches >= 1 else None
@@ -191,10 +206,15 @@ def _fit(model, store, dataset, train_idx, val_idx, *, batch_size, epochs, lr, p
     best, wait, stopped_epoch, steps = float("inf"), 0, 0, 0
     tails: List[torch.Tensor] = []          # tail rows of the epochs whose table has been drawn, oldest first
 
-    def rows_of(perm, k):
+    def rows_of(perm, k, epoch=None):
         if not trip:
             return perm
-        pos, neg = sampler.sample(perm, gen)
+        if supplied is not None and epoch is not None:      # recorded positives / negatives, batch by batch
+            pn = [supplied["triplets"](epoch, b) for b in range(perm.numel() // k)]
+            pos = torch.cat([torch.as_tensor(p_, dtype=torch.int64) for p_, _ in pn]).to(dev)
+            neg = torch.cat([torch.as_tensor(n_, dtype=torch.int64) for _, n_ in pn]).to(dev)
+        else:
+            pos, neg = sampler.sample(perm, gen)
         return torch.cat([perm.view(-1, k), pos.view(-1, k), neg.view(-1, k)], dim=1).reshape(-1)
 
     tables_written = [0]
@@ -206,9 +226,10 @@ def _fit(model, store, dataset, train_idx, val_idx, *, batch_size, epochs, lr, p
             perm = tr[torch.as_tensor(supplied["perms"][e], dtype=torch.int64).to(dev)]
         else:
             perm = tr[torch.randperm(tr.numel(), generator=gen, device=dev)]
+        e_written = tables_written[0]
         tables_written[0] += 1
         if pipe is not None:
-            pipe.idx.copy_(rows_of(perm[: n_batches * B], B))
+            pipe.idx.copy_(rows_of(perm[: n_batches * B], B, e if supplied is not None and e_written < len(supplied["perms"]) else None))
         if tail:
             tails.append(rows_of(perm[n_batches * B:], tail))
 
@@ -259,7 +280,7 @@ def _fit(model, store, dataset, train_idx, val_idx, *, batch_size, epochs, lr, p
         rec = {n: acc[i] / max(wsum, 1.0) for i, n in enumerate(names)}
         rec["train_loss"] = acc[len(names)] / max(wsum, 1.0)
         if va is not None:
-            rec["val_loss"] = _eval_loss(model, store, cohort, va, B, passes, sampler, gen, eval_cache)
+            rec["val_loss"] = _eval_loss(model, store, cohort, va, B, passes, sampler, gen, eval_cache, supplied, epoch)
         ph.lap("epoch readback + validation")
         history.append(rec)
         if verbose:
@@ -278,7 +299,8 @@ def _fit(model, store, dataset, train_idx, val_idx, *, batch_size, epochs, lr, p
                     break
         if not np.isfinite(rec["train_loss"]):
             break
-    final_val = _eval_loss(model, store, cohort, va, B, passes, sampler, gen, eval_cache) if va is not None else float("nan")
+    final_val = (_eval_loss(model, store, cohort, va, B, passes, sampler, gen, eval_cache, supplied, epochs_run)
+                 if va is not None else float("nan"))
     ph.lap("final validation")
     model._sync_nbt()
     return FitResult(final_val, epochs_run, stopped_epoch, history, steps)

@@ -87,8 +87,9 @@ class _PlanLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         model, plan = ctx.model, ctx.plan
-        plan.backward()
         st = model._store
+        model._unalias_grads()             # (normally done by training_step, before the forward tape touched the arena)
+        plan.backward()
         scale = gout.reshape(-1)[:1].to(torch.float32).contiguous()
         ops.scale_by(ops.IMMEDIATE, st.G, scale)
         if plan.fused:
@@ -417,7 +418,23 @@ class FxModel(_Base):
         self._fused_scale_host.copy_(scale, non_blocking=True)
         self._fused_scale_event.record()
 
+    def _unalias_grads(self):
+        """Gradient accumulation (a second training_step + loss.backward() before zero_grad: Lightning's
+        accumulate_grad_batches, hand-written loops): a parameter whose .grad is still the zero-copy view of the gradient
+        arena from the previous backward would see the arena overwritten by this step's tapes (the supervisor heads'
+        gradients are produced by the forward tape already) and then be added to ITSELF by AccumulateGrad -- 2 g2 instead
+        of g1 + g2.  Such gradients are moved out of the arena before the arena is written; the first backward after
+        zero_grad(set_to_none) stays zero-copy."""
+        st = self._store
+        if st is None:
+            return
+        for key, p in self._param_items():
+            g = p.grad
+            if g is not None and key not in st.big and g.data_ptr() == st.g(key).data_ptr():
+                p.grad = g.clone()
+
     def training_step(self, train_batch, batch_idx, log=True):
+        self._unalias_grads()
         ref = self.__dict__.get("_fx_optimizer")
         opt = ref() if ref is not None else None
         fused = bool(self.fused_optimizer) and isinstance(opt, FxAdam) and opt.fused

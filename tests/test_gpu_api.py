@@ -730,3 +730,87 @@ def test_fit_and_predict_edge_cases():
     assert np.isfinite(fit(new(M.supervised_vae, ("c",)), ds, tr, va[:1], batch_size=32, epochs=1, lr=1e-3).val_loss)
     out = new(t=("y", "c")).predict(ds.subset([3]))
     assert out["y"].shape == (1, 1) and out["c"].shape[0] == 1
+
+
+def test_gradient_accumulation_two_backwards_before_zero_grad():
+    """Lightning's accumulate_grad_batches / a hand-written accumulation loop: two loss.backward() calls before zero_grad
+    must leave g1 + g2 in EVERY param.grad -- small parameters (whose .grad is a zero-copy view of the gradient arena after
+    the first backward) and wide weights alike.  (the arena view used to be overwritten by the second backward and
+    then added to itself: 2 g2.)"""
+    import flexynesis_amd.models as M
+    g = Golden("directpred_2omics_multitask")
+    m, ds = _model_from_golden(g, M.DirectPred)
+    m.load_state_dict(g.state0())
+    m.to(DEV)
+    m.fused_optimizer = False
+    m.train()
+    m._bind()
+    batches = []
+    for i in (0, 1):
+        b = g.batch(i)
+        batches.append(({n: x.to(DEV) for (n, _), x in zip(g.spec.layers, b["x"])}, {k: v.to(DEV) for k, v in b["y"].items()},
+                        tuple(f"s{j}" for j in range(8))))
+    params = dict(m.named_parameters())
+
+    def grads_of(bs, step0):
+        """gradients after backward over the batches ``bs`` without zero_grad in between (training_step index fixed per
+        batch so that the dropout masks of a batch are the same in both runs)"""
+        for p in params.values():
+            p.grad = None
+        for j, b in enumerate(bs):
+            m._store.ctrl[0] = float(step0 + j)           # the dropout stream is keyed on the step counter
+            loss = m.training_step(b, step0 + j)
+            loss.backward()
+        return {k: p.grad.detach().clone() for k, p in params.items() if p.grad is not None}
+
+    g1 = grads_of(batches[:1], 10)
+    g2 = grads_of(batches[1:], 11)
+    g12 = grads_of(batches, 10)
+    assert set(g12) == set(g1) == set(g2)
+    wide = "encoders.0.layer_1.weight"
+    assert wide in g12
+    for k in g12:
+        want = g1[k] + g2[k]
+        scale = float(want.abs().max()) + 1e-12
+        assert float((g12[k] - want).abs().max()) <= 1e-6 * scale + 1e-9, (k, float((g12[k] - want).abs().max()), scale)
+        # and it is NOT twice the second gradient (the failure mode) wherever the two batches' gradients differ
+        if float((g1[k] - g2[k]).abs().max()) > 1e-3 * scale:
+            assert float((g12[k] - 2 * g2[k]).abs().max()) > 1e-4 * scale, k
+    # the first backward after zero_grad(set_to_none) is still zero-copy
+    for p in params.values():
+        p.grad = None
+    m.training_step(batches[0], 20).backward()
+    pk = "encoders.0.layer_out.weight"
+    assert params[pk].grad.data_ptr() == m._store.g(pk).data_ptr()
+
+
+def test_run_trial_cv_and_sharded_fine_tune_on_the_engine():
+    """The cross-validated branch of objective() (main.py:267-269, :327-333) and the sharded FineTuner driver on real engine
+    fits.  With one process the sharded driver claims every unit itself, in longest-first order instead of loop order: the
+    fits are independent and deterministic, so its records, its best configuration and its final weights equal the
+    sequential driver's bit for bit."""
+    import flexynesis_amd.models as M
+    from flexynesis_amd.fit import fine_tune, full_train, kfold_indices, run_trial
+    ds = _synthetic_ds(n=90)
+    cfg = {"latent_dim": 16, "hidden_dim_factor": 0.5, "lr": 3e-3, "supervisor_hidden_dim": 8, "epochs": 3, "batch_size": 16}
+    val, ep, model, info = run_trial(M.DirectPred, cfg, ds, ["y", "c"], seed=4, device="cuda", use_cv=True, n_splits=3,
+                                     early_stop_patience=0)
+    assert len(info["fold_val_losses"]) == 3 and all(np.isfinite(v) for v in info["fold_val_losses"])
+    assert abs(val - float(np.mean(info["fold_val_losses"]))) < 1e-12 and ep == 3
+    folds = kfold_indices(90, 3, 4)
+    assert info["steps"] == sum(3 * (len(tr) // 16) for tr, _ in folds)
+    val2, _, _, info2 = run_trial(M.DirectPred, cfg, ds, ["y", "c"], seed=4, device="cuda", use_cv=True, n_splits=3,
+                                  early_stop_patience=0)
+    assert val2 == val and info2["fold_val_losses"] == info["fold_val_losses"]          # seeded: reproducible
+    final, finfo = full_train(M.DirectPred, dict(cfg, epochs=2), ds, ["y", "c"], seed=5, device="cuda")
+    assert finfo["steps"] == 2 * (90 // 16) and set(final.predict(ds)) == {"y", "c"}
+    torch.manual_seed(1)
+    m = M.DirectPred(cfg, ds, ["y", "c"], device_type="cuda")
+    kw = dict(n_splits=2, batch_size=16, learning_rates=[3e-3, 3e-4], max_epoch=3, seed=1, device="cuda",
+              freeze_configs=[{"encoders": True, "supervisors": False}, {"encoders": False, "supervisors": False}])
+    f_seq, b_seq, r_seq = fine_tune(copy.deepcopy(m), ds, **kw)
+    f_sh, b_sh, r_sh = fine_tune(copy.deepcopy(m), ds, sharded=True, **kw)
+    assert r_seq == r_sh and b_seq == b_sh
+    sa, sb = f_seq.state_dict(), f_sh.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k].cpu(), sb[k].cpu()), k

@@ -25,9 +25,9 @@ FULL = {
     "cfg2": dict(model="DirectPred", layers=[("gex", 20000), ("cnv", 20000)], variables=[("y", "numerical", 1)],
                  surv=(None, None), steps=2),
     "cfg3": dict(model="supervised_vae", layers=[("gex", 20000), ("cnv", 20000)],
-                 variables=[("c", "categorical", 4), ("event", "numerical", 1)], surv=("event", "time"), steps=1),
+                 variables=[("c", "categorical", 4), ("event", "numerical", 1)], surv=("event", "time"), steps=2),
     "cfg4": dict(model="MultiTripletNetwork", layers=[("gex", 30000), ("cnv", 30000), ("meth", 30000)],
-                 variables=[("c", "categorical", 4)], surv=(None, None), steps=1),
+                 variables=[("c", "categorical", 4)], surv=(None, None), steps=2),
 }
 
 
@@ -118,6 +118,73 @@ def test_fullsize_step_vs_oracle(name):
             del a, b_, bad, upd_ref
         for k in store.small_keys:      # every small parameter too
             _state_close(sd[k], st[k], info["grads"].get(k), exact, lr, f"{name} step{step} state {k}")
+
+
+def test_timed_schedule_vs_oracle_cfg2():
+    """EXACTLY what bench.py times, against the oracle: PipelinedStep with the next step's wide forward fused into the dW + Adam
+    launches, batch assembly one step ahead from the resident cohort, one eager step, then hipGraph replay -- five
+    consecutive optimisation steps at 2 x 20000 / B = 128 with supplied draws.  Every step is compared with the oracle's
+    step from the ENGINE's own previous state (weights, BatchNorm buffers, Adam moments and step count read back), so the
+    pipeline is never reloaded or refreshed: step t's wide forward really is the partial sums that step t-1's dW + Adam
+    launches left behind, and t > 1 exercises non-zero moments and bias corrections."""
+    from flexynesis_amd import ops
+    from flexynesis_amd.arch import ArchSpec
+    from flexynesis_amd.data import DeviceCohort
+    from flexynesis_amd.engine import ParamStore, PipelinedStep
+    from oracle import restate as O
+    cfg, dev, B, N, nb = FULL["cfg2"], _dev(), 128, 1024, 8
+    layers = cfg["layers"]
+    aspec = ArchSpec("DirectPred", layers, 64, 0.25, 16, cfg["variables"], None, None, True)
+    ospec = _oracle_spec(aspec)
+    dat, ann = O.synthetic_cohort(layers, N, seed=77)
+    cohort = DeviceCohort(dat, ann, dev)
+    store = ParamStore(aspec, dev, materialize_big_grads=False)
+    store.load_state(O.init_state(ospec, seed=9))
+    pipe = PipelinedStep(store, B, cohort=cohort, n_batches=nb, seed=3, supplied_draws=True)
+    assert sorted(pipe.plans[0]._next_fwd) == sorted(store.big_keys) and len(store.big_keys) == 2     # the fused schedule
+    gen = torch.Generator().manual_seed(99)
+    table = torch.randperm(N, generator=gen)[: nb * B]
+    pipe.idx.copy_(table.to(dev))
+    pipe.prime()
+    lr = 1e-3
+
+    def engine_state():
+        sd = store.state_dict()
+        t = int(store.ctrl[ops.CTRL_STEP]) + (int(store.ctrl[ops.CTRL_STEP_HI]) << 24)
+        opt = {"t": t, "m": {k: store.m(k).detach().cpu().clone() for k in store.param_keys},
+               "v": {k: store.v(k).detach().cpu().clone() for k in store.param_keys}} if t > 0 else {}
+        return sd, opt
+
+    for step in range(5):
+        st_prev, opt_prev = engine_state()
+        rows = table[step * B:(step + 1) * B]
+        xs = [dat[n][rows] for n, _ in layers]
+        y = {k: ann[k][rows] for k in pipe.pending.y}
+        draws = {dn: (torch.rand(t.shape, generator=gen) < 0.9).float() for dn, t in pipe.pending.draws.items()}
+        pipe.pending.set_draws({k: v.to(dev) for k, v in draws.items()})
+        if pipe.graphs[0] is not None:
+            pipe.replay()
+        else:
+            pipe.step(lr)                    # bench.py: one eager step, then capture, then replay
+            pipe.capture(lr)
+        got = pipe.losses()
+        gnorm = float(store.ctrl[ops.CTRL_GNORM])
+        st_ref, _, info = O.train_step(ospec, st_prev, opt_prev, {"x": xs, "y": y}, draws, lr)
+        for k, v in info["losses"].items():
+            close(got[k], v, 1e-4, 1e-6, f"step{step} loss {k}")
+        exact = sum(float((gv.double() ** 2).sum()) for gv in info["grads"].values()) ** 0.5
+        close(gnorm, exact, 1e-4, 1e-7, f"step{step} grad norm vs the fp64 norm of the oracle's gradients")
+        sd = store.state_dict()
+        for k in store.big_keys:
+            a, b_ = sd[k].double(), st_ref[k].double()
+            bad = (a - b_).abs() > 2e-5 + 1e-3 * b_.abs()
+            assert float(bad.double().mean()) <= 1e-3, f"{k} step{step}: {int(bad.sum())} of {bad.numel()} elements differ"
+            upd_ref = b_ - st_prev[k].double()
+            assert float((a - b_).norm() / upd_ref.norm()) <= 2e-2, f"{k} step{step}: update norm mismatch"
+            del a, b_, bad, upd_ref
+        for k in store.small_keys:
+            _state_close(sd[k], st_ref[k], info["grads"].get(k), exact, lr, f"step{step} state {k}")
+    assert pipe.graphs[0] is not None and pipe.done == 5
 
 
 @pytest.mark.parametrize("n_out,k_in,K", [(5000, 20000, 128), (7500, 30000, 384)])
