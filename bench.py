@@ -12,8 +12,9 @@ branch), forward, losses, backward, global-norm clip, Adam -- all hand-written H
 its own independent trial on its own cohort replica (trial sharding, SURVEY.md section 8e: no data-path
 collective); value = total samples of all ranks / max-over-ranks wall time ("weak" scaling).
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel fx_linear_dw_adam_bf16x3, HIP-event timed)
-and `cpu_baseline` (the oracle's CPU training loop timed on this box's host cores, N=1 only).
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel fx_linear_dw_adam_fwd_bf16x3 -- dW + clip + Adam of one wide
+weight and the next step's forward through it --, HIP-event timed on the launch stream) and `cpu_baseline` (the oracle's CPU
+training loop timed on this box's host cores, N=1 only).
 """
 import argparse
 import json
@@ -185,7 +186,8 @@ def main():
             # in separate rocprofv3 --pmc passes of this same command and committed under profiles/.
             traffic = None
             try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic_cfg2.json")))
+                # only a PMC file collected THIS round with this kernel counts (else null: the figure is not re-measured here)
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic_cfg2.json")))
                 if a.config == "cfg2" and B == 128 and a.precision == "bf16x3" and not a.features:
                     want = "fx_dw_adam_fwd_kernel" if dominant.endswith("_fwd_bf16x3") else "fx_gemm_bf16x3_kernel<false, 1"
                     for kname, d in pm["kernels"].items():
@@ -224,7 +226,10 @@ def main():
     n_launch = pipe.n_launches()
     sumF = sum(F for _, F in cfg["layers"])
     k_reads = 3 if cfg["model"] == "MultiTripletNetwork" else 1
-    bytes_step = 28.0 * P + 4.0 * k_reads * B * sumF
+    bytes_step = 28.0 * P + 4.0 * k_reads * B * sumF                  # the roofline the step is priced against
+    # what this schedule actually has to move: wide weights whose next forward rides on the dW + Adam launch cost 24 B/param
+    fused_elems = sum(store.big[k]["W"].numel() for k in pipe.plans[0]._next_fwd) if pipe.plans[0]._next_fwd else 0
+    bytes_moved = bytes_step - 4.0 * fused_elems
     ms_per_step = 1e3 * elapsed / a.steps
     value = world * a.steps * B / elapsed
 
@@ -271,6 +276,9 @@ def main():
                        "params": P, "global_batch": B * world, "parallelism": f"{world} independent trials (trial sharding)",
                        "launches_per_step": n_launch, "algorithmic_bytes_per_step": bytes_step,
                        "step_hbm_frac_of_8TBs": round(bytes_step / (ms_per_step * 1e-3) / 8e12, 4),
+                       # the bytes THIS schedule must move (24 instead of 28 B/param where the next forward is fused)
+                       "schedule_bytes_per_step": bytes_moved,
+                       "schedule_hbm_frac_of_8TBs": round(bytes_moved / (ms_per_step * 1e-3) / 8e12, 4),
                        "loss_finite": finite, "last_losses": {k: round(v, 6) for k, v in losses.items()}},
             "roofline": roof, "cpu_baseline": cpu, "sweep": sweep,
         }

@@ -1436,7 +1436,7 @@ class StepPlan:
         n = calls.get(name, 0)
         calls[name] = n + 1
         g = graphs.get(name)
-        if g is None and n >= 1:
+        if g is None and n >= 1 and not ops.capturing():
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with ops.graph_capture(g):
@@ -1512,6 +1512,45 @@ class StepPlan:
 
     def n_launches(self):
         return len(self.t_gather) + len(self.t_fwd) + len(self.t_bwd) + len(self.t_opt) + 1
+
+    def close(self):
+        """Release every hipGraph of this plan NOW (idempotent).  Owners call it at a point where no capture is in progress
+        and the plan's last replay has been waited for -- fit() when it returns, models when they drop a plan -- so that no
+        graph is left to die wherever the last reference happens to go (ops.retire_graph: a graph dying during another
+        capture terminates the process on ROCm)."""
+        g, self.graph = self.graph, None
+        ops.retire_graph(g)
+        for name in ("_tape_graph", "_eval_graph"):
+            d = self.__dict__.pop(name, None)
+            if isinstance(d, dict):
+                for v in d.values():
+                    ops.retire_graph(v)
+            else:
+                ops.retire_graph(d)
+        self.__dict__.pop("_tape_calls", None)
+        self.__dict__.pop("_eval_calls", None)
+
+    @ops.device_guard
+    def eval_step(self, use_graph: bool = True):
+        """Gather (from the index table the caller filled) + eval-mode forward of this plan.  The second call captures the
+        two tapes into one hipGraph, later calls replay it: per-epoch validation runs ~25 launches per chunk."""
+        if self.train:
+            raise RuntimeError("eval_step is for eval plans")
+        n = self.__dict__.get("_eval_calls", 0)
+        self.__dict__["_eval_calls"] = n + 1
+        g = self.__dict__.get("_eval_graph")
+        if use_graph and g is None and n >= 1 and not ops.capturing():
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with ops.graph_capture(g):
+                self.t_gather.run()
+                self.t_fwd.run()
+            self.__dict__["_eval_graph"] = g
+        if use_graph and g is not None:
+            g.replay()
+        else:
+            self.t_gather.run()
+            self.t_fwd.run()
 
     def losses(self) -> Dict[str, float]:
         vals = self.loss_vec.detach().cpu().tolist()
@@ -1634,6 +1673,15 @@ class PipelinedStep:
     def replay(self):
         self.graphs[self.k].replay()
         self._advance()
+
+    def close(self):
+        """Release the captured step graphs of both parities and the plans' own graphs (see StepPlan.close)."""
+        gs, self.graphs = self.graphs, [None, None]
+        for g in gs:
+            ops.retire_graph(g)
+        del gs
+        for p in self.plans:
+            p.close()
 
     def _advance(self):
         self.plans[self.k].bump_nbt()

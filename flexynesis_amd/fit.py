@@ -37,6 +37,10 @@ def _cohort_of(dataset, device) -> DeviceCohort:
     return c
 
 
+# per-epoch validation as a captured hipGraph per chunk size (second use on); FX_EVAL_GRAPHS=0: eager launches (A/B)
+EVAL_GRAPHS = __import__("os").environ.get("FX_EVAL_GRAPHS", "1") != "0"
+
+
 class TripletSampler:
     """On-device version of TripletMultiOmicDataset.__getitem__'s sampling (reference data.py:1106-1131):
     positive = uniformly random OTHER sample with the anchor's label; negative = uniformly random member of a
@@ -112,8 +116,7 @@ def _eval_loss(model, store, cohort, idx_rows: torch.Tensor, batch_size: int, pa
             plan.idx.copy_(rows)
         if vdraws is not None:
             plan.set_draws({k: torch.as_tensor(v).to(rows.device) for k, v in vdraws(epoch, bi).items()})
-        plan.t_gather.run()
-        plan.forward()
+        plan.eval_step(use_graph=EVAL_GRAPHS)
         k = len(plan.spec.loss_names())
         acc.append((plan.loss_vec[k].clone(), B))
     for v, B in acc:
@@ -147,6 +150,19 @@ def fit(model, dataset, train_idx: Sequence[int], val_idx: Optional[Sequence[int
                     fresh_optimizer=fresh_optimizer, supplied=supplied, prof=prof)
 
 
+class _OwnedPlans(dict):
+    """The eval-plan cache of one fit: every plan stored in it is registered for close() at the end of the fit."""
+
+    def __init__(self, owned):
+        super().__init__()
+        self._owned = owned
+
+    def __setitem__(self, k, v):
+        super().__setitem__(k, v)
+        if self._owned is not None:
+            self._owned.append(v)
+
+
 class _Phases:
     """Wall-clock per phase of a fit (``prof`` dict of fit(): diagnostics only; every boundary synchronises the device)."""
 
@@ -166,8 +182,19 @@ class _Phases:
         self.t = now
 
 
-def _fit(model, store, dataset, train_idx, val_idx, *, batch_size, epochs, lr, patience, seed, use_graph, verbose, clip, frozen,
-         drop_last, fresh_optimizer, supplied=None, prof=None) -> FitResult:
+def _fit(model, store, dataset, train_idx, val_idx, **kw) -> FitResult:
+    """fit() proper; every plan it builds is closed when it returns or raises (hipGraph lifetime: ops.retire_graph)."""
+    owned: list = []
+    try:
+        return _fit_impl(model, store, dataset, train_idx, val_idx, owned=owned, **kw)
+    finally:
+        torch.cuda.synchronize(store.device)      # the last replay has finished before its graphs are released
+        for o in owned:
+            o.close()
+
+
+def _fit_impl(model, store, dataset, train_idx, val_idx, *, batch_size, epochs, lr, patience, seed, use_graph, verbose, clip, frozen,
+              drop_last, fresh_optimizer, supplied=None, prof=None, owned=None) -> FitResult:
     dev = store.device
     ph = _Phases(prof, dev)
     if fresh_optimizer:
@@ -201,7 +228,10 @@ def _fit(model, store, dataset, train_idx, val_idx, *, batch_size, epochs, lr, p
                          n_batches=0, epoch_acc=True, **plan_kw) if tail else None
     ph.lap("train plans")
     names = spec.loss_names()
-    eval_cache: Dict[int, StepPlan] = {}
+    eval_cache: Dict[int, StepPlan] = _OwnedPlans(owned)
+    for o in (pipe, tail_plan):
+        if o is not None:
+            owned.append(o)
     history: List[Dict[str, float]] = []
     best, wait, stopped_epoch, steps = float("inf"), 0, 0, 0
     tails: List[torch.Tensor] = []          # tail rows of the epochs whose table has been drawn, oldest first

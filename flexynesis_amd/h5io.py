@@ -96,7 +96,6 @@ def lib():
         "H5Tget_class": (C.c_int, [hid_t]),
         "H5Tclose": (herr_t, [hid_t]),
         "H5Tis_variable_str": (C.c_int, [hid_t]),
-        "H5Dvlen_reclaim": (herr_t, [hid_t, hid_t, hid_t, C.c_void_p]),
         "H5Pcreate": (hid_t, [hid_t]),
         "H5Pset_chunk": (herr_t, [hid_t, C.c_int, C.POINTER(hsize_t)]),
         "H5Pget_layout": (C.c_int, [hid_t]),
@@ -107,6 +106,17 @@ def lib():
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
         fn.restype, fn.argtypes = res, args
+    # releasing variable-length strings: H5Treclaim (HDF5 >= 1.12) or the deprecated H5Dvlen_reclaim, which builds made with
+    # --disable-deprecated-symbols lack.  Bound if present; required only inside the variable-length path.
+    L._fx_reclaim = None
+    for name in ("H5Treclaim", "H5Dvlen_reclaim"):
+        try:
+            fn = getattr(L, name)
+        except AttributeError:
+            continue
+        fn.restype, fn.argtypes = herr_t, [hid_t, hid_t, hid_t, C.c_void_p]
+        L._fx_reclaim = fn
+        break
     if L.H5open() < 0:
         raise H5Error("H5open failed")
     L.H5Eset_auto2(0, None, None)          # errors are reported through return codes -> H5Error, not stderr dumps
@@ -224,7 +234,10 @@ class H5File:
                     try:
                         _chk(L.H5Dread(d, mt, H5S_ALL, H5S_ALL, H5P_DEFAULT, C.cast(ptrs, C.c_void_p)), f"H5Dread /{name}")
                         out = [(ptrs[i] or b"").decode() for i in range(n)]
-                        L.H5Dvlen_reclaim(mt, sp, H5P_DEFAULT, C.cast(ptrs, C.c_void_p))     # the library allocated the strings
+                        if L._fx_reclaim is None:
+                            raise H5Error("this libhdf5 exports neither H5Treclaim nor H5Dvlen_reclaim: variable-length strings "
+                                          "cannot be released")
+                        _chk(L._fx_reclaim(mt, sp, H5P_DEFAULT, C.cast(ptrs, C.c_void_p)), "vlen reclaim")   # the library allocated the strings
                     finally:
                         L.H5Sclose(sp)
                     return out

@@ -141,6 +141,48 @@ class FxAdam(torch.optim.Optimizer):
                                    # block counts training_step calls for the dropout streams; they differ under
                                    # gradient accumulation)
 
+    # -- checkpointing: the Adam moments and the step count live in the engine's arenas, not in torch's per-parameter
+    # ``state``; without these overrides ``optimizer.state_dict()`` (and a Lightning checkpoint) would hold no moments and a
+    # resumed run would silently restart Adam, unlike the reference's torch.optim.Adam.
+    def _step_count(self, st) -> int:
+        ctrl = st.ctrl if self.fused else self._ctrl
+        if ctrl is None:
+            return 0
+        return int(ctrl[ops.CTRL_STEP]) + (int(ctrl[ops.CTRL_STEP_HI]) << 24)
+
+    def state_dict(self):
+        m = self.model
+        st = m._bind()
+        sd = super().state_dict()
+        keys = [k for k, p in m._param_items()]
+        sd["fx"] = {"step": self._step_count(st), "fused": self.fused,
+                    "exp_avg": {k: st.m(k).detach().cpu().clone() for k in keys},
+                    "exp_avg_sq": {k: st.v(k).detach().cpu().clone() for k in keys}}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        fx = state_dict.get("fx")
+        super().load_state_dict({k: v for k, v in state_dict.items() if k != "fx"})
+        if fx is None:
+            return
+        m = self.model
+        st = m._bind()
+        with torch.no_grad():
+            for k, v in fx["exp_avg"].items():
+                st.m(k).copy_(torch.as_tensor(v).to(torch.float32))
+            for k, v in fx["exp_avg_sq"].items():
+                st.v(k).copy_(torch.as_tensor(v).to(torch.float32))
+            t = int(fx["step"])
+            if self.fused:
+                ctrl = st.ctrl
+            else:
+                if self._ctrl is None or self._ctrl.device != st.device:
+                    self._ctrl = torch.zeros(ops.CTRL_FLOATS, dtype=torch.float32, device=st.device)
+                ctrl = self._ctrl
+            ctrl[ops.CTRL_STEP] = float(t % (1 << 24))
+            ctrl[ops.CTRL_STEP_HI] = float(t >> 24)
+        self._mask_sig = self._mask = None
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -171,7 +213,7 @@ class FxAdam(torch.optim.Optimizer):
                 live.append(has)
                 if has and p.grad.data_ptr() != st.g(key).data_ptr():
                     st.g(key).copy_(p.grad)
-            sig = tuple(live)
+            sig = (id(st), str(st.device)) + tuple(live)      # (the mask lives in THIS store's arena layout and device)
             if sig != self._mask_sig:
                 mask = torch.zeros_like(st.P)
                 for (key, p), has in zip(items, live):
@@ -198,8 +240,20 @@ class FxModel(_Base):
 
     def _reset_runtime(self, target=None):
         d = self.__dict__ if target is None else target
+        if target is None:                                 # (a pickled / copied state dict only loses its references)
+            for plan in (d.get("_plans") or {}).values():  # release their hipGraphs at a known point (StepPlan.close)
+                plan.close()
         for k, v in self._RUNTIME.items():
             d[k] = v() if callable(v) else v
+
+    def close(self):
+        """Release the engine state of this model (plans, their hipGraphs, the arena binding) now instead of whenever the
+        object is collected.  The parameters keep their current values (they become ordinary tensors again on the next
+        ``state_dict`` / ``to``); the model can be used again and re-binds lazily."""
+        store = self.__dict__.get("_store")
+        if store is not None:
+            torch.cuda.synchronize(store.device)
+        self._reset_runtime()
 
     def __init__(self, config, dataset, target_variables, batch_variables=None, surv_event_var=None,
                  surv_time_var=None, use_loss_weighting=True, device_type=None, **spec_kw):
@@ -323,14 +377,11 @@ class FxModel(_Base):
         if key not in self._plans:
             self._plans[key] = StepPlan(store, B, train=train, fused=fused, supplied_draws=False,
                                         seed=self._seed + len(self._plans))
-            # FX_LEVEL1_GRAPHS=1: training plans of the level-1 path (driven tape by tape from an external loop) replay their
-            # tapes as hipGraphs from the third use on (fused drop-in 70.9 -> 77.6 k samples/s at cfg2).  Opt-in: with it
-            # on, three of eight runs of the whole GPU test suite (hundreds of short-lived models and graphs in one process)
-            # died inside a later hipGraphLaunch of an unrelated training graph.  The suspected cause -- models kept alive
-            # by a model <-> optimiser cycle, so that their graphs were destroyed by the cyclic GC, possibly in the middle
-            # of another capture -- is removed (weak reference; ops.graph_capture switches the GC off): five of five runs
-            # pass with the switch on since, ten of ten with it off.  It stays off by default until that has aged.
-            self._plans[key].tape_graphs = bool(train) and os.environ.get("FX_LEVEL1_GRAPHS", "0") == "1"
+            # Training plans of the level-1 path (driven tape by tape from an external loop) replay their tapes as hipGraphs
+            # from the third use on (fused drop-in 70.9 -> 77.6 k samples/s at cfg2); FX_LEVEL1_GRAPHS=0 launches eagerly.
+            # (Opt-in in round 2, when the test suite crashed intermittently with it: the cause was graph objects dying during
+            # another graph's capture -- ops.retire_graph -- not the tape graphs themselves; tests/test_gpu_soak.py.)
+            self._plans[key].tape_graphs = bool(train) and os.environ.get("FX_LEVEL1_GRAPHS", "1") != "0"
         return self._plans[key]
 
     # -- batch plumbing -------------------------------------------------------------------------------------

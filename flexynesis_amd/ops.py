@@ -116,10 +116,32 @@ def capture_stream() -> "torch.cuda.Stream":
     return side_streams(1, group=2)[0]
 
 
+# ---- hipGraph lifetime ------------------------------------------------------------------------------------------
+# On ROCm torch's ~CUDAGraph calls hipDeviceSynchronize (ATen/hip/HIPGraph.cpp: hipGraphExecDestroy defers its frees to the
+# next sync point, so torch forces one).  A device synchronisation is "operation not permitted when stream is capturing":
+# a graph object that dies while ANOTHER graph is being captured terminates the process (scripts/graph_lifetime_probe.py
+# case a: rc -6; the intermittent crashes of round 2 were graphs of dead models released by the cyclic collector in the
+# middle of a later capture).  Three rules follow: (1) the collector is off while capturing; (2) owners release their
+# graphs explicitly at a known point (StepPlan.close / PipelinedStep.close, called by fit()) instead of whenever the last
+# reference happens to go; (3) a release requested DURING a capture is parked and executed when the capture has ended.
+_CAPTURING = [0]
+_GRAVEYARD: List[object] = []
+
+
+def capturing() -> bool:
+    return _CAPTURING[0] > 0
+
+
+def retire_graph(g):
+    """Give up a CUDAGraph (or any object owning one).  Outside a capture the caller's reference was the last one and the
+    object dies on return; during a capture it is parked until the capture is over."""
+    if g is not None and _CAPTURING[0] > 0:
+        _GRAVEYARD.append(g)
+
+
 class graph_capture:
     """``with ops.graph_capture(g): ...`` = ``torch.cuda.graph(g, stream=capture_stream())`` with Python's cyclic garbage
-    collector switched off for the duration: a collection in the middle of a capture can destroy an older CUDAGraph (its
-    private memory pool goes back to the driver), which is not a legal call while a stream is capturing."""
+    collector switched off for the duration and graph releases deferred to its end (see above)."""
 
     def __init__(self, g):
         self._ctx = torch.cuda.graph(g, stream=capture_stream())
@@ -130,6 +152,7 @@ class graph_capture:
         self._ctx.__enter__()              # (torch collects garbage and empties the cache before capture_begin)
         self._gc = gc.isenabled()
         gc.disable()
+        _CAPTURING[0] += 1
         return self
 
     def __exit__(self, *exc):
@@ -137,6 +160,9 @@ class graph_capture:
         try:
             return self._ctx.__exit__(*exc)
         finally:
+            _CAPTURING[0] -= 1
+            if _CAPTURING[0] == 0:
+                _GRAVEYARD.clear()         # parked graphs die now: the device synchronisation of their destructor is legal again
             if self._gc:
                 gc.enable()
 

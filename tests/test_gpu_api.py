@@ -814,3 +814,51 @@ def test_run_trial_cv_and_sharded_fine_tune_on_the_engine():
     sa, sb = f_seq.state_dict(), f_sh.state_dict()
     for k in sa:
         assert torch.equal(sa[k].cpu(), sb[k].cpu()), k
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_fx_adam_state_dict_round_trip_resumes_adam(fused):
+    """optimizer.state_dict() carries the Adam moments and the step count out of the engine's arenas: a model +
+    optimiser restored from checkpoints continue exactly like the uninterrupted pair (torch.optim.Adam's contract, which a
+    Lightning checkpoint relies on)."""
+    import flexynesis_amd.models as M
+    g = Golden("directpred_2omics_multitask")
+    m, ds = _model_from_golden(g, M.DirectPred)
+    m.load_state_dict(g.state0())
+    m.to(DEV)
+    m.fused_optimizer = fused
+    batches = []
+    for i in (0, 1):
+        b = g.batch(i)
+        batches.append(({n: x.to(DEV) for (n, _), x in zip(g.spec.layers, b["x"])}, {k: v.to(DEV) for k, v in b["y"].items()},
+                        tuple(f"s{j}" for j in range(8))))
+
+    def steps(model, opt, first, n):
+        for it in range(first, first + n):
+            model.train()
+            opt.zero_grad()
+            model._bind().ctrl[0] = float(it)                     # same dropout stream position in both runs
+            loss = model.training_step(batches[it % 2], it)
+            loss.backward()
+            model.configure_gradient_clipping(opt, 1.0, "norm")
+            opt.step()
+
+    ma = copy.deepcopy(m)
+    ma.fused_optimizer = fused
+    oa = ma.configure_optimizers()
+    steps(ma, oa, 0, 3)
+    ck_model = {k: v.detach().cpu().clone() for k, v in ma.state_dict().items()}
+    ck_opt = oa.state_dict()
+    assert ck_opt["fx"]["step"] == 3 and float(ck_opt["fx"]["exp_avg_sq"]["encoders.0.layer_1.weight"].abs().sum()) > 0
+    steps(ma, oa, 3, 2)                                           # the uninterrupted run
+    mb = copy.deepcopy(m)
+    mb.fused_optimizer = fused
+    mb.load_state_dict(ck_model)
+    ob = mb.configure_optimizers()
+    ob.load_state_dict(ck_opt)
+    steps(mb, ob, 3, 2)                                           # the resumed run
+    sa, sb = ma.state_dict(), mb.state_dict()
+    for k in sa:
+        if sa[k].dtype.is_floating_point:
+            assert float((sa[k] - sb[k]).abs().max()) <= 1e-7 + 1e-6 * float(sa[k].abs().max()), k
+    assert ob.state_dict()["fx"]["step"] == 5

@@ -1,0 +1,129 @@
+"""hipGraph lifetime.  Root cause of round 2's intermittent crashes inside hipGraphLaunch, reproduced in
+isolation by scripts/graph_lifetime_probe.py: on ROCm torch's ~CUDAGraph synchronises the device, which is not permitted while
+any stream is capturing -- a graph object that dies during ANOTHER graph's capture terminates the process.  The engine therefore
+(1) keeps the cyclic collector off while capturing, (2) releases graphs explicitly (StepPlan.close / PipelinedStep.close at the
+end of fit(), FxModel.close), (3) parks a release requested during a capture until the capture has ended (ops.retire_graph).
+These tests exercise (2) and (3) directly and then soak the process the way an HPO sweep / FineTuner run does, with per-epoch
+validation graphs and level-1 tape graphs ON (their defaults)."""
+import gc
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _ds(n, F, seed):
+    from flexynesis_amd.data import MultiOmicDataset
+    g = torch.Generator().manual_seed(seed)
+    dat = {"gex": torch.randn(n, F[0], generator=g), "cnv": torch.randn(n, F[1], generator=g)}
+    ann = {"y": dat["gex"][:, :8].sum(1) / 3, "c": (dat["cnv"][:, 0] > 0).float()}
+    feats = {k: [f"{k}{i}" for i in range(v.shape[1])] for k, v in dat.items()}
+    return MultiOmicDataset(dat, ann, {"y": "numerical", "c": "categorical"}, feats, [f"s{i}" for i in range(n)], {})
+
+
+def _pipe(B=32, seed=0):
+    from flexynesis_amd.arch import ArchSpec
+    from flexynesis_amd.data import synthetic_cohort
+    from flexynesis_amd.engine import ParamStore, PipelinedStep
+    layers = [("gex", 1100), ("cnv", 900)]
+    spec = ArchSpec("DirectPred", layers, 16, 0.25, 8, [("y", "numerical", 1)], None, None, True)
+    cohort = synthetic_cohort(layers, 256, DEV, seed=seed)
+    store = ParamStore(spec, DEV, materialize_big_grads=False, big_threshold=1 << 16)
+    pipe = PipelinedStep(store, B, cohort=cohort, n_batches=4, seed=seed)
+    pipe.idx.copy_(torch.randperm(256, device=DEV)[: 4 * B])
+    pipe.prime()
+    pipe.step(1e-3)
+    pipe.capture(1e-3)
+    return pipe
+
+
+def test_graph_released_during_a_capture_is_parked_until_it_ends():
+    """The crash, made deterministic and defused: closing a plan (= giving up its hipGraphs) while another graph is being
+    captured.  Without ops.retire_graph the CUDAGraph destructor would run inside the capture and abort the process."""
+    from flexynesis_amd import ops
+    a, b = _pipe(seed=1), _pipe(seed=2)
+    for _ in range(3):
+        a.replay(); b.replay()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    x = torch.ones(1024, device=DEV)
+    with ops.graph_capture(g):
+        x.mul_(2.0)
+        assert ops.capturing()
+        a.close()                                   # two step graphs given up in the middle of a capture
+        assert len(ops._GRAVEYARD) == 2 and a.graphs == [None, None]
+        x.add_(1.0)
+    assert not ops.capturing() and not ops._GRAVEYARD          # released when the capture ended
+    g.replay()
+    for _ in range(3):
+        b.replay()                                   # unrelated graphs keep working
+    torch.cuda.synchronize()
+    assert float(x[0]) == 3.0 and all(v == v for v in b.losses().values())
+    a.close(); b.close()                             # idempotent
+    del g
+
+
+def test_fit_releases_its_graphs_when_it_returns():
+    import flexynesis_amd.models as M
+    from flexynesis_amd import engine, fit as F
+    made = []
+    orig = engine.PipelinedStep.capture
+
+    def spy(self, lr):
+        made.append(self)
+        return orig(self, lr)
+    engine.PipelinedStep.capture = spy
+    try:
+        ds = _ds(300, (300, 200), 3)
+        cfg = {"latent_dim": 16, "hidden_dim_factor": 0.5, "lr": 1e-3, "supervisor_hidden_dim": 8, "epochs": 3, "batch_size": 32}
+        m = M.DirectPred(cfg, ds, ["y", "c"], device_type="cuda")
+        tr, va = F.split_indices(300, 0.2, 0)
+        res = F.fit(m, ds, tr, va, batch_size=32, epochs=3, lr=1e-3, seed=1)
+    finally:
+        engine.PipelinedStep.capture = orig
+    assert res.steps == 3 * (len(tr) // 32) and len(made) == 1
+    assert made[0].graphs == [None, None] and all(p.graph is None and "_eval_graph" not in p.__dict__ for p in made[0].plans)
+
+
+def test_soak_fits_and_level1_models_with_every_graph_feature_on(monkeypatch):
+    """~60 engine fits (training graphs, per-epoch validation graphs captured in the middle of a fit) interleaved with
+    short-lived level-1 models whose tapes run as hipGraphs, models dying by reference count, by the cyclic collector and
+    by close(): the lifetime pattern of an HPO sweep followed by the FineTuner, in one process."""
+    import flexynesis_amd.models as M
+    from flexynesis_amd import fit as F
+    monkeypatch.setenv("FX_LEVEL1_GRAPHS", "1")
+    assert F.EVAL_GRAPHS
+    wide, small = _ds(256, (4100, 2052), 1), _ds(400, (300, 200), 2)
+    cfg = {"latent_dim": 32, "hidden_dim_factor": 0.25, "lr": 1e-3, "supervisor_hidden_dim": 8, "epochs": 2, "batch_size": 64}
+    tr, va = F.split_indices(len(small), 0.2, 1)
+    keep, tape_graphs = [], 0
+    for it in range(60):
+        m = M.DirectPred(cfg, wide, ["y", "c"], device_type="cuda")
+        m.fused_optimizer = bool(it & 1)
+        opt = m.configure_optimizers()
+        for s in range(4):
+            idx = torch.arange(s * 32, s * 32 + 64) % 256
+            batch = ({k: v[idx].to(DEV) for k, v in wide.dat.items()}, {k: torch.as_tensor(v)[idx].to(DEV) for k, v in wide.ann.items()}, None)
+            m.train()
+            opt.zero_grad()
+            loss = m.training_step(batch, s, log=False)
+            loss.backward()
+            m.configure_gradient_clipping(opt, 1.0, "norm")
+            opt.step()
+        tape_graphs += sum(len(p.__dict__.get("_tape_graph", {})) for p in m._plans.values())
+        assert torch.isfinite(loss.detach()).all()
+        if it % 3 == 0:
+            m.close()                                   # explicit release
+        elif it % 3 == 1:
+            keep.append((m, opt))                       # stays alive for a while, dies in a batch below
+        del m, opt
+        m2 = M.DirectPred(cfg, small, ["y", "c"], device_type="cuda")
+        res = F.fit(m2, small, tr, va, batch_size=64, epochs=3, lr=3e-3, seed=it)
+        assert res.steps == 3 * (len(tr) // 64) and res.val_loss == res.val_loss
+        if it % 8 == 7:
+            keep.clear()
+            gc.collect()
+    torch.cuda.synchronize()
+    assert tape_graphs >= 60                            # the level-1 models really ran from captured tapes

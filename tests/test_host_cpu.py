@@ -589,3 +589,15 @@ def test_run_trial_cv_branch_and_full_train_follow_objective():
         assert len(log) == 1 and log[0][3] == len(ds) and log[0][4] == 0    # all samples, no validation split
     finally:
         F.fit = real_fit
+
+
+def test_dropout_seed_stream_restarts_with_the_global_seed():
+    """modules._next_seed: calling torch.manual_seed(s) again in the same process reproduces the dropout seeds."""
+    from flexynesis_amd import modules
+    torch.manual_seed(123)
+    a = [modules._next_seed() for _ in range(4)]
+    torch.manual_seed(123)
+    b = [modules._next_seed() for _ in range(4)]
+    torch.manual_seed(124)
+    c = [modules._next_seed() for _ in range(4)]
+    assert a == b and a != c and len(set(a)) == 4
