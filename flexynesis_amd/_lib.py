@@ -47,6 +47,10 @@ PROTOTYPES = {
     "fx_enc_tail_fwd": (I, [P, I, I, I, I, I, F, P, P]),
     "fx_fusion_fwd": (I, [P, L, P, L, P, P, P, P, I, P, P, I, I, P]),
     "fx_block_bwd_group": (I, [P, I, I, I, I, F, P]),
+    "fx_gather_split_group": (I, [P, I, P, I, P, L, P]),
+    "fx_gram_kb_slices": (I, [I]),
+    "fx_gram_kb_group": (I, [P, P, P, P, I, I, P]),
+    "fx_reduce_group": (I, [P, P, P, P, P, P, I, P]),
     "fx_heads_fwd": (I, [P, I, P, L, I, I, I, F, P, P]),
     "fx_heads_bwd": (I, [P, I, P, L, P, L, I, I, I, F, P, P]),
     "fx_heads_step": (I, [P, I, P, P, P, P, P, P, L, P, L, I, I, I, F, P, P, I, I, P, P, P, P, P, P]),
@@ -109,7 +113,7 @@ PROTOTYPES = {
 }
 
 # functions whose int return value is a size/count, not an error code
-_QUERIES = {"fx_version", "fx_gnn_row_blocks", "fx_rowlin_wgrad_workspace_bytes", "fx_bn_rows_workspace_bytes", "fx_col_moments_chunks", "fx_col_moments_workspace_bytes", "fx_block_bwd_blocks", "fx_enc_tail_blocks", "fx_gemm_splitk", "fx_linear_fwd_bf16x3_splitk", "fx_gram_hadamard_blocks", "fx_gemm_workspace_bytes", "fx_linear_fwd_bf16x3_workspace_bytes", "fx_mmd_workspace_floats", "fx_recon_blocks", "fx_sumsq_blocks",
+_QUERIES = {"fx_version", "fx_gnn_row_blocks", "fx_rowlin_wgrad_workspace_bytes", "fx_bn_rows_workspace_bytes", "fx_col_moments_chunks", "fx_col_moments_workspace_bytes", "fx_block_bwd_blocks", "fx_enc_tail_blocks", "fx_gram_kb_slices", "fx_gemm_splitk", "fx_linear_fwd_bf16x3_splitk", "fx_gram_hadamard_blocks", "fx_gemm_workspace_bytes", "fx_linear_fwd_bf16x3_workspace_bytes", "fx_mmd_workspace_floats", "fx_recon_blocks", "fx_sumsq_blocks",
             "fx_last_error_string"}
 
 
@@ -126,6 +130,12 @@ class BlockBwdDesc(C.Structure):
                 ("x", P), ("out", P), ("gamma", P), ("save_mean", P), ("save_invstd", P), ("dgamma", P), ("dbeta", P),
                 ("dbias", P), ("dy", P), ("dyT_hi", P), ("dyT_lo", P), ("ldt", L), ("gram_x", P), ("slots", P), ("C", I),
                 ("ldx", L), ("ldo", L), ("accumulate", I)]
+
+
+class GatherSplitDesc(C.Structure):
+    """include/fxhip.h: fx_gather_split_desc."""
+    _fields_ = [("x", P), ("hi", P), ("lo", P), ("hiT", P), ("loT", P), ("src", P), ("n_cols", I), ("ld_src", L), ("ldx", L),
+                ("ldo", L), ("ldt", L)]
 
 
 class EncTailDesc(C.Structure):

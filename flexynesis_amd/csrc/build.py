@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["fx_gemm.hip", "fx_gemm_bf16x3.hip", "fx_dw_adam_fwd.hip", "fx_norm_act.hip", "fx_fused_small.hip", "fx_heads.hip", "fx_small_linear.hip", "fx_enc_tail.hip",
+SOURCES = ["fx_gemm.hip", "fx_gemm_bf16x3.hip", "fx_dw_adam_fwd.hip", "fx_norm_act.hip", "fx_fused_small.hip", "fx_heads.hip", "fx_small_linear.hip", "fx_enc_tail.hip", "fx_assembly.hip",
            "fx_block_bwd.hip", "fx_losses.hip", "fx_optim.hip", "fx_ingest.hip", "fx_gnn.hip"]
 HEADERS = ["fx_common.h", "fx_reduce.h", "fx_small.h", "fx_loss_dev.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]

@@ -301,6 +301,16 @@ __global__ __launch_bounds__(BB_T) void fx_block_bwd_group_kernel(BlockBwdGroup 
   }
 }
 
+// two tails (the common case: two omics layers): half the inlined copies, no register spills
+struct BlockBwdGroup2 {
+  BlockBwdArgs a[2];
+};
+__global__ __launch_bounds__(BB_T) void fx_block_bwd_group2_kernel(BlockBwdGroup2 g) {
+  const int blk = blockIdx.x;
+  if (blockIdx.y == 0) { if (blk * BB_COLS < g.a[0].C) bb_body(g.a[0], blk); }
+  else { if (blk * BB_COLS < g.a[1].C) bb_body(g.a[1], blk); }
+}
+
 extern "C" {
 
 int fx_block_bwd_blocks(int C) { return (C + BB_COLS - 1) / BB_COLS; }
@@ -370,6 +380,13 @@ int fx_block_bwd_group(const void* descs_, int n, int B, int pre_act, int post_a
     max_blocks = nb > max_blocks ? nb : max_blocks;
   }
   for (int i = n; i < BB_MAX_GROUP; ++i) g.a[i] = g.a[0];
+  if (n <= 2) {
+    BlockBwdGroup2 g2{};
+    g2.a[0] = g.a[0];
+    g2.a[1] = g.a[n - 1];
+    hipLaunchKernelGGL(fx_block_bwd_group2_kernel, dim3(max_blocks, n), dim3(BB_T), 0, stream, g2);
+    return fx_check_launch("fx_block_bwd_group");
+  }
   hipLaunchKernelGGL(fx_block_bwd_group_kernel, dim3(max_blocks, n), dim3(BB_T), 0, stream, g);
   return fx_check_launch("fx_block_bwd_group");
 }

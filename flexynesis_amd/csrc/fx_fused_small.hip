@@ -238,7 +238,7 @@ struct GatherSplit {
 typedef float gs_f4 __attribute__((ext_vector_type(4)));
 typedef __bf16 gs_bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 gs_bf16x8 __attribute__((ext_vector_type(8)));
-__global__ __launch_bounds__(256) void fx_gather_split_kernel(GatherSplit a) {
+__device__ __forceinline__ void gs_body(const GatherSplit& a) {
   __shared__ float tile[32][GS_COLS + 1];
   const long* idx = a.idx;
   if (a.ctrl) idx += (long)a.ctrl[FXC_BATCH_CURSOR] * a.cursor_stride;
@@ -299,6 +299,23 @@ __global__ __launch_bounds__(256) void fx_gather_split_kernel(GatherSplit a) {
   }
 }
 
+__global__ __launch_bounds__(256) void fx_gather_split_kernel(GatherSplit a) { gs_body(a); }
+
+// every modality of a batch in one launch: grid (column tiles of the widest, row blocks, modalities)
+#define GS_MAX_GROUP 4
+struct GatherSplitGroup {
+  GatherSplit a[GS_MAX_GROUP];
+};
+__global__ __launch_bounds__(256) void fx_gather_split_group_kernel(GatherSplitGroup g) {
+  // (a runtime index into the kernel-argument array would put the argument blocks in scratch: one call per constant index)
+  switch (blockIdx.z) {
+    case 0: if ((int)blockIdx.x * GS_COLS < ((g.a[0].F + 31) / 32) * 32) gs_body(g.a[0]); break;
+    case 1: if ((int)blockIdx.x * GS_COLS < ((g.a[1].F + 31) / 32) * 32) gs_body(g.a[1]); break;
+    case 2: if ((int)blockIdx.x * GS_COLS < ((g.a[2].F + 31) / 32) * 32) gs_body(g.a[2]); break;
+    default: if ((int)blockIdx.x * GS_COLS < ((g.a[3].F + 31) / 32) * 32) gs_body(g.a[3]); break;
+  }
+}
+
 // ---- host launchers used by the extern "C" entry points in fx_norm_act.hip ---------------------------
 int fx_launch_bn_fwd_r16(const BnFwd16& a, hipStream_t stream) {
   hipLaunchKernelGGL(fx_bn_fwd_r16_kernel, dim3((a.C + COLS - 1) / COLS), dim3(256), 0, stream, a);
@@ -337,20 +354,52 @@ int fx_gram_hadamard(double* slots, const float* slabs_x, int nslabs_x, const fl
   return fx_check_launch("fx_gram_hadamard");
 }
 
-int fx_gather_split(float* x, void* hi, void* lo, void* hiT, void* loT, const float* src, const long* idx, int n_rows,
-                    int n_cols, long ld_src, long ldx, long ldo, long ldt, const float* ctrl_cursor, long cursor_stride,
-                    hipStream_t stream) {
+static int gs_fill(GatherSplit& a, float* x, void* hi, void* lo, void* hiT, void* loT, const float* src, const long* idx,
+                   int n_rows, int n_cols, long ld_src, long ldx, long ldo, long ldt, const float* ctrl_cursor, long cursor_stride) {
   FX_REQUIRE(hi && lo && hiT && loT && src && idx && n_rows > 0 && n_cols > 0, "fx_gather_split: bad args");
-  const int Rp = (n_rows + 31) / 32 * 32, Fp = (n_cols + 31) / 32 * 32;
+  const int Rp = (n_rows + 31) / 32 * 32;
   FX_REQUIRE(ldo >= n_rows && ldo % 128 == 0 && ldt >= Rp,
              "fx_gather_split: hi/lo are K-blocked with rows padded to 128 (got %ld), hiT/loT need ld >= %d (got %ld)", ldo, Rp, ldt);
   FX_REQUIRE(ldt % 8 == 0 && (((uintptr_t)hiT | (uintptr_t)loT | (uintptr_t)hi | (uintptr_t)lo) & 15) == 0,
              "fx_gather_split: split outputs must be 16-byte aligned with ldt %% 8 == 0 (got %ld)", ldt);
   const int vec = (n_cols % 4 == 0) && (ld_src % 4 == 0) && (!x || ldx % 4 == 0) && ((((uintptr_t)src) | ((uintptr_t)x)) & 15) == 0;
-  GatherSplit a{x, (__bf16*)hi, (__bf16*)lo, (__bf16*)hiT, (__bf16*)loT, src, idx, ctrl_cursor, cursor_stride,
-                n_rows, n_cols, ld_src, ldx, ldo, ldt, vec};
+  a = GatherSplit{x, (__bf16*)hi, (__bf16*)lo, (__bf16*)hiT, (__bf16*)loT, src, idx, ctrl_cursor, cursor_stride,
+                  n_rows, n_cols, ld_src, ldx, ldo, ldt, vec};
+  return 0;
+}
+
+int fx_gather_split(float* x, void* hi, void* lo, void* hiT, void* loT, const float* src, const long* idx, int n_rows,
+                    int n_cols, long ld_src, long ldx, long ldo, long ldt, const float* ctrl_cursor, long cursor_stride,
+                    hipStream_t stream) {
+  GatherSplit a;
+  if (int rc = gs_fill(a, x, hi, lo, hiT, loT, src, idx, n_rows, n_cols, ld_src, ldx, ldo, ldt, ctrl_cursor, cursor_stride)) return rc;
+  const int Rp = (n_rows + 31) / 32 * 32, Fp = (n_cols + 31) / 32 * 32;
   hipLaunchKernelGGL(fx_gather_split_kernel, dim3((Fp + GS_COLS - 1) / GS_COLS, Rp / 32), dim3(256), 0, stream, a);
   return fx_check_launch("fx_gather_split");
+}
+
+struct fx_gather_split_desc_ {   // include/fxhip.h: fx_gather_split_desc
+  float* x; void* hi; void* lo; void* hiT; void* loT; const float* src; int n_cols; long ld_src, ldx, ldo, ldt;
+};
+
+// fx_gather_split for up to 4 cohort layers in one launch: the same index table, cursor and row count for all of them.
+int fx_gather_split_group(const void* descs_, int n, const long* idx, int n_rows, const float* ctrl_cursor, long cursor_stride,
+                          hipStream_t stream) {
+  const fx_gather_split_desc_* d = (const fx_gather_split_desc_*)descs_;
+  FX_REQUIRE(d && n > 0 && n <= GS_MAX_GROUP, "fx_gather_split_group: 1..%d layers per launch", GS_MAX_GROUP);
+  GatherSplitGroup g{};
+  int max_tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    if (int rc = gs_fill(g.a[i], d[i].x, d[i].hi, d[i].lo, d[i].hiT, d[i].loT, d[i].src, idx, n_rows, d[i].n_cols, d[i].ld_src,
+                         d[i].ldx, d[i].ldo, d[i].ldt, ctrl_cursor, cursor_stride))
+      return rc;
+    const int tiles = ((d[i].n_cols + 31) / 32 * 32 + GS_COLS - 1) / GS_COLS;
+    max_tiles = tiles > max_tiles ? tiles : max_tiles;
+  }
+  for (int i = n; i < GS_MAX_GROUP; ++i) g.a[i] = g.a[0];
+  const int Rp = (n_rows + 31) / 32 * 32;
+  hipLaunchKernelGGL(fx_gather_split_group_kernel, dim3(max_tiles, Rp / 32, n), dim3(256), 0, stream, g);
+  return fx_check_launch("fx_gather_split_group");
 }
 
 }  // extern "C"

@@ -96,6 +96,11 @@ __device__ __forceinline__ void heads_mask4(unsigned long long seed, unsigned lo
                                             float mk[4]) {
   uint32_t b[8];
   fx_philox4(seed, off + (i0 >> 2), b);
+  if ((i0 & 3) == 0) {                       // aligned (hidden width a multiple of 4): the four elements are one counter block
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mk[k] = fx_u01(b[k]) <= keep ? 1.f : 0.f;
+    return;
+  }
   fx_philox4(seed, off + (i0 >> 2) + 1, b + 4);
   const int sh = (int)(i0 & 3);
 #pragma unroll
@@ -119,7 +124,7 @@ struct HeadsFwdLds {
   float stat[5][32];             // mean, invstd, gamma, beta, layer_1 bias (zero padded)
 };
 
-__device__ __forceinline__ void heads_fwd_body(const HeadsArgs& a, const FxHeadDesc& h, HeadsFwdLds& F) {
+__device__ __forceinline__ void heads_fwd_body(const HeadsArgs& a, const FxHeadDesc& h, HeadsFwdLds& F, bool update_running = true) {
   Tile& xs = F.xs;
   Tile& ys = F.ys;
   float* W1s = F.W1s;
@@ -233,8 +238,10 @@ __device__ __forceinline__ void heads_fwd_body(const HeadsArgs& a, const FxHeadD
       h.save_mean[col] = mean;
       h.save_invstd[col] = invstd;
       const float var_u = B > 1 ? var_b * ((float)B / (float)(B - 1)) : var_b;
-      h.rmean[col] = (1.0f - FX_BN_MOMENTUM) * h.rmean[col] + FX_BN_MOMENTUM * mean;
-      h.rvar[col] = (1.0f - FX_BN_MOMENTUM) * h.rvar[col] + FX_BN_MOMENTUM * var_u;
+      if (update_running) {
+        h.rmean[col] = (1.0f - FX_BN_MOMENTUM) * h.rmean[col] + FX_BN_MOMENTUM * mean;
+        h.rvar[col] = (1.0f - FX_BN_MOMENTUM) * h.rvar[col] + FX_BN_MOMENTUM * var_u;
+      }
     }
   } else {
     const int sc = min(col, S - 1);
@@ -253,8 +260,14 @@ __device__ __forceinline__ void heads_fwd_body(const HeadsArgs& a, const FxHeadD
   } else if (drop) {
     const unsigned long long rng_off = heads_step_offset(a.ctrl, h.offset);
 #pragma unroll
-    for (int jb = 0; jb < HS / 8; ++jb)
-      heads_mask4(h.seed, rng_off, (unsigned long long)r * S + s0 + 4 * jb, 1.0f - a.drop_p, mk + 4 * jb);
+    for (int jb = 0; jb < HS / 8; ++jb) {
+      if (s0 + 4 * jb < S) {                 // (padded columns hold zeros whatever the mask: no draw)
+        heads_mask4(h.seed, rng_off, (unsigned long long)r * S + s0 + 4 * jb, 1.0f - a.drop_p, mk + 4 * jb);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mk[4 * jb + k] = 1.f;
+      }
+    }
   } else {
 #pragma unroll
     for (int j = 0; j < HS / 2; ++j) mk[j] = 1.f;
@@ -537,6 +550,10 @@ __global__ __launch_bounds__(256) void fx_heads_bwd_kernel(HeadsArgs a) {
 // loss value and its share of the embedding gradient, and the last one to arrive adds the shares in head order
 // (deterministic) and evaluates the uncertainty-weighted total (direct_pred.py:192-223) over ALL named loss terms of the
 // model -- terms computed by earlier launches (triplet, MMD) are read from their slots.
+// Two workgroups per head: workgroup 2 h runs the chain the NEXT launch waits for (forward, loss, BatchNorm backward, the
+// embedding-gradient share, the meeting), workgroup 2 h + 1 the weight gradients of the head (layer_out, layer_1); it
+// recomputes forward and loss for itself -- the same instructions on the same inputs, so what both write (saved
+// activations, loss value, output gradient) is bit-identical -- and takes ~8 us of matrix products off the critical chain.
 struct HeadsStepArgs {
   HeadsArgs ha;
   int kind[FX_MAX_HEADS];                  // 0 masked MSE, 1 masked softmax-CE, 2 Cox partial likelihood
@@ -549,7 +566,7 @@ struct HeadsStepArgs {
   float* total_out; float* epoch_acc;
 };
 
-union HeadsStepLds {
+union __attribute__((aligned(16))) HeadsStepLds {
   HeadsFwdLds f;
   HeadsBwdLds b;
 };
@@ -563,12 +580,13 @@ __global__ __launch_bounds__(256) void fx_heads_step_kernel(HeadsStepArgs sa) {
   __shared__ float sm[16];
   __shared__ int s_last;
   const HeadsArgs& a = sa.ha;
-  const int hi = blockIdx.x;
+  const int hi = blockIdx.x >> 1;
+  const bool chain_role = (blockIdx.x & 1) == 0;       // 0: the critical chain; 1: the head's weight gradients
   const FxHeadDesc& h = a.h[hi];
   const int t = threadIdx.x, r = t & 127, hf = t >> 7, col = t & 31, rg = t >> 5;
   const int B = a.B, Ld = a.L, S = h.S, C = h.C;
   // ================= forward (y1, a1, statistics and out also go to memory: predict / the drop-in path read them) ===
-  heads_fwd_body(a, h, U.f);
+  heads_fwd_body(a, h, U.f, chain_role);
   __syncthreads();                                   // out [B, C] is visible to the whole workgroup
   // ================= loss value + gradient at the head output =================
   float* dout = const_cast<float*>(h.dout);
@@ -589,22 +607,40 @@ __global__ __launch_bounds__(256) void fx_heads_step_kernel(HeadsStepArgs sa) {
   for (int i = 0; i < HS * HL / 256; ++i) vw1[i] = h.W1[min(t + 256 * i, S * Ld - 1)];
   float sum_dy, sum_dy_xh, sum_dx;
   heads_bwd_prefix(L, h, B, gate_scale);
-  // layer_out.weight / bias gradients (over the padded [C][32] grid; only true columns are stored)
-  for (int o = t; o < C * HS; o += 256) {
-    const int c = o >> 5, s = o & 31;
-    float g = 0.f;
+  if (!chain_role) {
+    // layer_out.weight / bias gradients (over the padded [C][32] grid; only true columns are stored)
+    for (int o = t; o < C * HS; o += 256) {
+      const int c = o >> 5, s = o & 31;
+      float g = 0.f;
 #pragma unroll 8
-    for (int rr = 0; rr < HB; ++rr) g = fmaf(L.R1[rr][c], L.R2[rr][s], g);      // rows >= B are zero
-    if (s < S) h.gW2[c * S + s] = g;
-  }
-  if (h.gb2 && t < C) {
-    float g = 0.f;
+      for (int rr = 0; rr < HB; ++rr) g = fmaf(L.R1[rr][c], L.R2[rr][s], g);      // rows >= B are zero
+      if (s < S) h.gW2[c * S + s] = g;
+    }
+    if (h.gb2 && t < C) {
+      float g = 0.f;
 #pragma unroll 8
-    for (int rr = 0; rr < HB; ++rr) g += L.R1[rr][t];
-    h.gb2[t] = g;
+      for (int rr = 0; rr < HB; ++rr) g += L.R1[rr][t];
+      h.gb2[t] = g;
+    }
   }
   __syncthreads();
   heads_bwd_bn(L, B, vy, sum_dy, sum_dy_xh, sum_dx);
+  if (!chain_role) {
+    // ---- layer_1.weight gradient: gW1[s, l] = sum_r dy1[r, s] x[r, l], 32 columns of x at a time through R1
+    for (int c0 = 0; c0 < Ld; c0 += 32) {
+      __syncthreads();
+      heads_stage(L.R1, a.x, a.ldx, B, c0, Ld);
+      __syncthreads();
+      for (int o = t; o < S * 32; o += 256) {
+        const int s = o >> 5, l = o & 31;
+        float g = 0.f;
+#pragma unroll 8
+        for (int rr = 0; rr < HB; ++rr) g = fmaf(L.R3[rr][s], L.R1[rr][l], g);
+        if (c0 + l < Ld) h.gW1[(long)s * Ld + c0 + l] = g;
+      }
+    }
+    return;
+  }
   if (col < S && rg == 0) {
     h.ggamma[col] = sum_dy_xh;
     h.gbeta[col] = sum_dy;
@@ -627,30 +663,35 @@ __global__ __launch_bounds__(256) void fx_heads_step_kernel(HeadsStepArgs sa) {
     for (int i = 0; i < HS * HL / 256; ++i)
       if (t + 256 * i < S * Ld) W1s[t + 256 * i] = vw1[i];
     __syncthreads();
-    for (int s = 0; s < S; ++s) {
-      const float d = L.R3[r][s];
-      const float* w = W1s + s * Ld + l0;
+    if ((Ld & 7) == 0) {                     // 16-byte LDS reads of the (broadcast) weight rows: 4x fewer LDS instructions
+      typedef float hf4 __attribute__((ext_vector_type(4)));
+#define HEADS_DX_LOOP(NV)                                                                    \
+  for (int s = 0; s < S; ++s) {                                                              \
+    const float d = L.R3[r][s];                                                              \
+    const hf4* w4 = reinterpret_cast<const hf4*>(W1s + s * Ld + l0);                         \
+    _Pragma("unroll") for (int j = 0; j < (NV); ++j) {                                       \
+      const hf4 wv = w4[j];                                                                  \
+      accx[4 * j + 0] = fmaf(d, wv[0], accx[4 * j + 0]);                                     \
+      accx[4 * j + 1] = fmaf(d, wv[1], accx[4 * j + 1]);                                     \
+      accx[4 * j + 2] = fmaf(d, wv[2], accx[4 * j + 2]);                                     \
+      accx[4 * j + 3] = fmaf(d, wv[3], accx[4 * j + 3]);                                     \
+    }                                                                                        \
+  }
+      if (Lh <= 32) { HEADS_DX_LOOP(8) } else { HEADS_DX_LOOP(HL / 8) }      // (a thread owns Lh <= 64 columns)
+#undef HEADS_DX_LOOP
+    } else {
+      for (int s = 0; s < S; ++s) {
+        const float d = L.R3[r][s];
+        const float* w = W1s + s * Ld + l0;
 #pragma unroll
-      for (int j = 0; j < HL / 2; ++j) accx[j] = fmaf(d, w[j], accx[j]);
+        for (int j = 0; j < HL / 2; ++j) accx[j] = fmaf(d, w[j], accx[j]);
+      }
     }
     if (r < B) {
       float* dst = split ? a.dx_part + ((long)hi * B + r) * Ld : a.dx + (long)r * a.lddx;
 #pragma unroll
       for (int j = 0; j < HL / 2; ++j)
         if (j < Lh && l0 + j < Ld) dst[l0 + j] = accx[j];
-    }
-  }
-  // ---- layer_1.weight gradient: gW1[s, l] = sum_r dy1[r, s] x[r, l], 32 columns of x at a time through R1
-  for (int c0 = 0; c0 < Ld; c0 += 32) {
-    __syncthreads();
-    heads_stage(L.R1, a.x, a.ldx, B, c0, Ld);
-    __syncthreads();
-    for (int o = t; o < S * 32; o += 256) {
-      const int s = o >> 5, l = o & 31;
-      float g = 0.f;
-#pragma unroll 8
-      for (int rr = 0; rr < HB; ++rr) g = fmaf(L.R3[rr][s], L.R1[rr][l], g);
-      if (c0 + l < Ld) h.gW1[(long)s * Ld + c0 + l] = g;
     }
   }
   // ================= meet: the last workgroup adds the shares in head order and evaluates the total =================
@@ -795,7 +836,7 @@ int fx_heads_step(const void* heads_, int n_heads, const int* kinds, const float
     s.term_logvar[i] = weighted ? term_logvars[i] : nullptr;
     s.term_dlogvar[i] = (weighted && term_dlogvars) ? term_dlogvars[i] : nullptr;
   }
-  hipLaunchKernelGGL(fx_heads_step_kernel, dim3(n_heads), dim3(256), 0, stream, s);
+  hipLaunchKernelGGL(fx_heads_step_kernel, dim3(2 * n_heads), dim3(256), 0, stream, s);
   return fx_check_launch("fx_heads_step");
 }
 

@@ -849,9 +849,13 @@ class StepPlan:
             # FX_ASSEMBLY_BRANCHES=0: the whole batch assembly on ONE side stream (with the main chain that is two hardware queues:
             # more parallel branches alias onto the runtime's 4 queues and end up behind each other, profiles/r03_*)
             gbr = self.branches and os.environ.get("FX_ASSEMBLY_BRANCHES", "0") != "0"
-            gpar = rg.parallel(len(spec.layers) if gbr else 1)
+            grouped = self._assembly_groupable(first_w, enc_pos)
+            gpar = rg.parallel(len(spec.layers) if (gbr and not grouped) else 1)
             gpar.__enter__()
-            for i, (name, F) in enumerate(spec.layers):
+            if grouped:                      # (inside the tape's single segment: PipelinedStep issues it as one detached fork)
+                gpar.branch(0)
+                self._build_assembly_grouped(rg, cur, first_w, enc_pos)
+            for i, (name, F) in enumerate(spec.layers if not grouped else []):
                 gpar.branch(i if gbr else 0)
                 wk = first_w.format(enc_pos[i]) if i in enc_pos else None      # layers that are only reconstructed have no encoder
                 if spec.model == "GNN":
@@ -885,6 +889,49 @@ class StepPlan:
             self._build_mlp_family()
         if self.train and not self._next_fwd:
             self._build_optimizer()          # (with fused next-step forwards: built by link_next, once the partner exists)
+
+    def _assembly_groupable(self, first_w, enc_pos) -> bool:
+        """Every cohort layer feeds a wide, trained first Linear on the split-bf16 path with one BatchNorm pass of <= 128 rows:
+        the whole assembly is then 3 launches (fx_gather_split_group, fx_gram_kb_group, fx_reduce_group) + the label gather."""
+        spec, st = self.spec, self.store
+        if (os.environ.get("FX_GROUP_ASSEMBLY", "1") == "0" or spec.model == "GNN" or self.precision != "bf16x3"
+                or not (1 <= len(spec.layers) <= 4) or self.R > 128 or self.passes != 1):
+            return False
+        for i in range(len(spec.layers)):
+            wk = first_w.format(enc_pos[i]) if i in enc_pos else None
+            if wk not in st.big:
+                return False
+        # the Gram factor is produced in the reduced [R, R] form that fx_block_bwd consumes
+        return self._block_ok(self.R, self.passes) or not (self.fused and self.train and self.clip)
+
+    def _build_assembly_grouped(self, rg, cur, first_w, enc_pos):
+        spec, st, R = self.spec, self.store, self.R
+        items, splits, want = [], [], []
+        for i, (name, F) in enumerate(spec.layers):
+            wk = first_w.format(enc_pos[i])
+            sp, spt = ops.new_split_kb(R, F, self.dev), ops.new_split(F, R, self.dev)
+            self._split_cache[("fwd", self.X[i].data_ptr())] = sp
+            self._split_cache[("T", self.X[i].data_ptr())] = spt
+            items.append((self.X[i], sp[0], sp[1], spt[0], spt[1], self.cohort.dat[name]))
+            splits.append(sp)
+            want.append(self.fused and self.train and self.clip and not self._is_frozen(wk))
+        ops.gather_split_group(rg, items, self.idx, cur, R, R)
+        if any(want):
+            # X X^T [R, R] per modality (the batch-only factor of the Gram norm that fx_block_bwd consumes): partial sums on the
+            # bf16 MFMA from the K-blocked splits just written, then one ordered reduce for all modalities
+            sel = [i for i, w_ in enumerate(want) if w_]
+            slabs = [self._new(f"gram_x_slabs/{i}", ops.gram_kb_slices(spec.layers[i][1]), R * R) for i in sel]
+            ops.gram_kb_group(rg, [splits[i] for i in sel], slabs, [spec.layers[i][1] for i in sel], R)
+            jobs = []
+            for i, sl in zip(sel, slabs):
+                gx = self._new(f"gram_x_full/{self.X[i].data_ptr()}", R, R)
+                self._gram_x[("full", self.X[i].data_ptr())] = gx
+                jobs.append((gx, sl, ops.gram_kb_slices(spec.layers[i][1]), None))
+            if (R * R) % 4 == 0:
+                ops.reduce_group(rg, jobs)
+            else:
+                for (gx, sl, k, _) in jobs:
+                    ops.reduce_slabs(rg, gx, sl.view(k, R, R), None, k)
 
     def link_next(self, nxt: "StepPlan"):
         """Record the optimiser tape against the plan that holds the NEXT batch (PipelinedStep's other half): the fused
@@ -1635,11 +1682,17 @@ class PipelinedStep:
                 used.extend(nxt.t_gather.fork_from(main, after=point[0] if point else None))
             elif name == "fork_assembly" and mode == 1:
                 used.extend(nxt.t_gather.fork_from(main))  # fork: batch assembly of step t+1 ...
-            elif name == "fork_assembly" and mode >= 2 and not point:
+            elif name == "fork_assembly" and 2 <= mode <= 4 and not point:
                 ev = torch.cuda.Event()
                 ev.record(main)
                 point.append(ev)
             elif (name == "fork_issue_%d" % (mode - 1) or (mode == 4 and name == "fork_assembly")) and point:
+                used.extend(nxt.t_gather.fork_from(main, after=point[0]))
+            elif mode == 5 and name == "fork_issue_1":       # depend on the fusion layer's launch: the assembly starts under the
+                ev = torch.cuda.Event()                      # one-workgroup-per-head kernel, not beside the 16-workgroup fusion launch
+                ev.record(main)
+                point.append(ev)
+            elif mode == 5 and name == "fork_issue_2" and point:
                 used.extend(nxt.t_gather.fork_from(main, after=point[0]))
         if self.early_gather:
             fork()

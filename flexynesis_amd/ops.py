@@ -715,6 +715,58 @@ def heads_fwd(rec, descs, x, B, L, train, drop_p, ctrl=None):
     return arr
 
 
+def gather_split_group(rec, items, idx, ctrl_cursor, cursor_stride, n_rows):
+    """gather_split of several cohort layers in one launch.  items = [(x, hi, lo, hiT, loT, src)]."""
+    R = int(n_rows)
+    arr = (_lib.GatherSplitDesc * len(items))()
+    for d, (x, hi, lo, hiT, loT, src) in zip(arr, items):
+        Fc = src.shape[1]
+        _chk_kb(hi, lo, R, Fc, "gather_split_group")
+        if hiT.shape != (Fc, pad32(R)) or idx.dtype != torch.int64:
+            raise FxError("gather_split_group: bad buffer shapes")
+        d.x, d.hi, d.lo, d.hiT, d.loT, d.src = _ptr(x), hi.data_ptr(), lo.data_ptr(), hiT.data_ptr(), loT.data_ptr(), src.data_ptr()
+        d.n_cols, d.ld_src, d.ldx, d.ldo, d.ldt = Fc, _ld(src), _ld(x) if x is not None else Fc, hi.shape[1], _ld(hiT)
+    if hasattr(rec, "keep"):
+        rec.keep(arr)
+    rec.emit("fx_gather_split_group", C.addressof(arr), len(items), idx.data_ptr(), R, _ptr(ctrl_cursor), int(cursor_stride))
+
+
+def gram_kb_slices(k_in: int) -> int:
+    return int(lib.fx_gram_kb_slices(int(k_in)))
+
+
+def gram_kb_group(rec, splits, slabs, k_ins, R):
+    """X X^T partial sums (one slab per K slice) of several modalities in one launch; splits = [(hi, lo)] K-blocked."""
+    n = len(splits)
+    hi = (C.c_void_p * n)(*[s_[0].data_ptr() for s_ in splits])
+    lo = (C.c_void_p * n)(*[s_[1].data_ptr() for s_ in splits])
+    sl = (C.c_void_p * n)(*[t.data_ptr() for t in slabs])
+    ks = (C.c_int * n)(*[int(k) for k in k_ins])
+    for t, k in zip(slabs, k_ins):
+        if t.numel() < gram_kb_slices(k) * R * R:
+            raise FxError("gram_kb_group: slab buffer too small")
+    if hasattr(rec, "keep"):
+        rec.keep(hi, lo, sl, ks)
+    rec.emit("fx_gram_kb_group", C.addressof(hi), C.addressof(lo), C.addressof(sl), C.addressof(ks), n, int(R))
+
+
+def reduce_group(rec, jobs):
+    """Ordered slab sums of several jobs in one launch.  jobs = [(y, slabs, n_slabs, bias | None)]; y.numel() % 4 == 0."""
+    n = len(jobs)
+    ys = (C.c_void_p * n)(*[j[0].data_ptr() for j in jobs])
+    sl = (C.c_void_p * n)(*[j[1].data_ptr() for j in jobs])
+    bs = (C.c_void_p * n)(*[_ptr(j[3]) for j in jobs])
+    ln = (C.c_long * n)(*[int(j[0].numel()) for j in jobs])
+    ns = (C.c_int * n)(*[int(j[2]) for j in jobs])
+    bn = (C.c_int * n)(*[int(j[3].numel()) if j[3] is not None else 4 for j in jobs])
+    for (y, slabs, k, b) in jobs:
+        if not y.is_contiguous() or slabs.numel() < k * y.numel():
+            raise FxError("reduce_group: y must be contiguous and the slab buffer hold n_slabs copies of it")
+    if hasattr(rec, "keep"):
+        rec.keep(ys, sl, bs, ln, ns, bn)
+    rec.emit("fx_reduce_group", C.addressof(ys), C.addressof(sl), C.addressof(bs), C.addressof(ln), C.addressof(ns), C.addressof(bn), n)
+
+
 def enc_tail_blocks(H: int) -> int:
     return int(lib.fx_enc_tail_blocks(int(H)))
 

@@ -141,6 +141,24 @@ int fx_bn_act_fwd_slabs(float* out, float* x_out, const float* slabs, int nslabs
 int fx_gram_hadamard_blocks(long n);
 int fx_gram_hadamard(double* slots, const float* slabs_x, int nslabs_x, const float* slabs_d, int nslabs_d, long n,
                      fx_stream_t stream);
+/* fx_gather_split for up to 4 cohort layers (modalities) in ONE launch: the same index table, cursor and row count for all of
+ * them (MultiOmicDataset.__getitem__ + default_collate over every layer, data.py:1015-1027). */
+typedef struct fx_gather_split_desc {
+  float* x; void* hi; void* lo; void* hiT; void* loT; const float* src; int n_cols; long ld_src, ldx, ldo, ldt;
+} fx_gather_split_desc;
+int fx_gather_split_group(const fx_gather_split_desc* descs, int n_layers, const long* idx, int n_rows, const float* ctrl_cursor,
+                          long cursor_stride, fx_stream_t stream);
+/* The batch-only factor X X^T of the Gram-identity gradient norm (clip_grad_norm_, main.py:216) for up to 4 modalities in
+ * one launch: slabs[i][z] [R, R] = partial sum over K slice z < fx_gram_kb_slices(k_in[i]) of X_i X_i^T, from the K-blocked
+ * split (hi, lo) of X_i [R <= 128 rows, k_in[i] columns] (fx_gather_split / fx_split_bf16 layout); three bf16 MFMA
+ * products per term, fp32 accumulation.  fx_reduce_group adds the slabs in order. */
+int fx_gram_kb_slices(int k_in);
+int fx_gram_kb_group(const void* const* hi, const void* const* lo, float* const* slabs, const int* k_in, int n_modalities, int R,
+                     fx_stream_t stream);
+/* y[i][k] = sum_z slabs[i][z][k] (+ bias[i][k % bias_n[i]]) for k < len[i], slabs in order (deterministic), up to 4 jobs in
+ * one launch.  len and bias_n multiples of 4, arrays 16-byte aligned; bias / bias_n may be NULL. */
+int fx_reduce_group(float* const* y, const float* const* slabs, const float* const* bias, const long* len, const int* n_slabs,
+                    const int* bias_n, int n_jobs, fx_stream_t stream);
 /* Forward of an encoder TAIL for every modality in one launch (grid: column blocks x modalities), replacing per modality
  * fx_reduce_slabs -> fx_bn_act_fwd -> fx_gemm_f32 (+ its split-K reduce): the tail is "wide Linear output -> BatchNorm block
  * -> one or two small Linears" (MLP encoder, modules.py:145-149: BatchNorm1d -> ReLU -> Dropout -> layer_out; VAE encoder,

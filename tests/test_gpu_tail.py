@@ -132,3 +132,49 @@ def test_fusion_fwd_vs_fp64(B, widths, blocks, L):
     _close(ecat, ref, 2e-6, 2e-5, "ecat")
     if L:
         _close(emb, ref @ W.double().t() + b.double(), 1e-5, 1e-5, "emb")
+
+
+@pytest.mark.parametrize("R,Fs", [(128, [20000, 20000]), (100, [1500, 644, 2052]), (37, [260]), (128, [4100, 33, 96, 5000])])
+def test_grouped_assembly_kernels(R, Fs):
+    """fx_gather_split_group == fx_gather_split per layer (bit for bit), fx_gram_kb_group + fx_reduce_group == X X^T (fp64)
+    to the split-bf16 accuracy."""
+    from flexynesis_amd import ops
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(R + len(Fs))
+    N = 300
+    srcs = [torch.randn(N, F, device=dev, generator=g) for F in Fs]
+    idx = torch.randint(0, N, (R,), device=dev, generator=g)
+    single, items = [], []
+    for src in srcs:
+        F = src.shape[1]
+        bufs = []
+        for _ in range(2):
+            x = torch.full((R, F), float("nan"), device=dev)
+            sp, spt = ops.new_split_kb(R, F, dev), ops.new_split(F, R, dev)
+            bufs.append((x, sp[0], sp[1], spt[0], spt[1]))
+        ops.gather_split(ops.IMMEDIATE, *bufs[0], src, idx, n_rows=R)
+        single.append(bufs[0])
+        items.append((*bufs[1], src))
+    ops.gather_split_group(ops.IMMEDIATE, items, idx, None, 0, R)
+    torch.cuda.synchronize()
+    for a, b in zip(single, items):
+        for ta, tb in zip(a, b[:5]):
+            assert torch.equal(ta.view(torch.int16) if ta.dtype == torch.bfloat16 else ta, tb.view(torch.int16) if tb.dtype == torch.bfloat16 else tb)
+        assert torch.equal(a[0], b[5][idx])
+    slabs = [torch.full((ops.gram_kb_slices(F), R * R), float("nan"), device=dev) for F in Fs]
+    ops.gram_kb_group(ops.IMMEDIATE, [(it[1], it[2]) for it in items], slabs, Fs, R)
+    torch.cuda.synchronize()
+    for sl, it in zip(slabs, items):
+        assert not torch.isnan(sl).any()
+        ref = it[0].double() @ it[0].double().t()
+        got = sl.double().sum(0).view(R, R)
+        _close(got, ref, 1e-4, 2e-5 * float(ref.abs().max()), "X X^T")
+    if (R * R) % 4 == 0:
+        outs = [torch.empty(R, R, device=dev) for _ in Fs]
+        ops.reduce_group(ops.IMMEDIATE, [(o, sl, sl.shape[0], None) for o, sl in zip(outs, slabs)])
+        torch.cuda.synchronize()
+        for o, sl in zip(outs, slabs):
+            ref = torch.zeros(R * R, device=dev)
+            for z in range(sl.shape[0]):
+                ref += sl[z]
+            assert torch.equal(o.view(-1), ref)                     # ordered sum: bit-identical to the sequential one
