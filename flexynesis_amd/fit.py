@@ -88,7 +88,7 @@ class TripletSampler:
 
 
 def _eval_loss(model, store, cohort, idx_rows: torch.Tensor, batch_size: int, passes: int, sampler, gen, cache,
-               supplied: Optional[dict] = None, epoch: int = 0) -> float:
+               supplied: Optional[dict] = None, epoch: int = 0, use_graph: bool = True) -> float:
     """Mean validation total (batch-size weighted, like Lightning's epoch reduction of validation_step).
     ``supplied`` (parity tests): "val_draws"(epoch, chunk) -> {name: tensor} replaces the in-kernel draws of the VAE family's
     eval forward (z is sampled in eval mode too), "val_triplets"(epoch, chunk) -> (positive rows, negative rows) the device
@@ -116,7 +116,7 @@ def _eval_loss(model, store, cohort, idx_rows: torch.Tensor, batch_size: int, pa
             plan.idx.copy_(rows)
         if vdraws is not None:
             plan.set_draws({k: torch.as_tensor(v).to(rows.device) for k, v in vdraws(epoch, bi).items()})
-        plan.eval_step(use_graph=EVAL_GRAPHS)
+        plan.eval_step(use_graph=EVAL_GRAPHS and use_graph)      # (fit(use_graph=False) captures nothing at all)
         k = len(plan.spec.loss_names())
         acc.append((plan.loss_vec[k].clone(), B))
     for v, B in acc:
@@ -310,7 +310,7 @@ def _fit_impl(model, store, dataset, train_idx, val_idx, *, batch_size, epochs, 
         rec = {n: acc[i] / max(wsum, 1.0) for i, n in enumerate(names)}
         rec["train_loss"] = acc[len(names)] / max(wsum, 1.0)
         if va is not None:
-            rec["val_loss"] = _eval_loss(model, store, cohort, va, B, passes, sampler, gen, eval_cache, supplied, epoch)
+            rec["val_loss"] = _eval_loss(model, store, cohort, va, B, passes, sampler, gen, eval_cache, supplied, epoch, use_graph)
         ph.lap("epoch readback + validation")
         history.append(rec)
         if verbose:
@@ -329,7 +329,7 @@ def _fit_impl(model, store, dataset, train_idx, val_idx, *, batch_size, epochs, 
                     break
         if not np.isfinite(rec["train_loss"]):
             break
-    final_val = (_eval_loss(model, store, cohort, va, B, passes, sampler, gen, eval_cache, supplied, epochs_run)
+    final_val = (_eval_loss(model, store, cohort, va, B, passes, sampler, gen, eval_cache, supplied, epochs_run, use_graph)
                  if va is not None else float("nan"))
     ph.lap("final validation")
     model._sync_nbt()
@@ -505,9 +505,10 @@ def run_trial_fold(model_class, params: dict, dataset, target_variables, train_i
     """One pass of ``objective``'s loop body (main.py:283-326): new model -> fit with early stopping -> validate.
     Returns (val_loss, epochs, model, info); a failed / non-finite fit reports +inf instead of raising so a sharded
     sweep never hangs on a bad configuration.  This is the unit that cross-validated sweeps shard over the GPUs."""
-    torch.manual_seed(int(seed))
-    model = _new_model(model_class, params, dataset, target_variables, batch_variables, surv_event_var, surv_time_var,
-                       use_loss_weighting, device, model_kwargs)
+    with _CTOR_LOCK:          # seed + constructor draw from the process-wide generators: one at a time when trials run on threads
+        torch.manual_seed(int(seed))
+        model = _new_model(model_class, params, dataset, target_variables, batch_variables, surv_event_var, surv_time_var,
+                           use_loss_weighting, device, model_kwargs)
     try:
         res = fit(model, dataset, train_idx, val_idx, batch_size=int(params["batch_size"]), epochs=int(params["epochs"]),
                   lr=float(params["lr"]), patience=early_stop_patience, seed=seed, use_graph=use_graph, device=device)
@@ -518,6 +519,7 @@ def run_trial_fold(model_class, params: dict, dataset, target_variables, train_i
     return val, epochs, model, {"history": res.history, "steps": res.steps}
 
 
+_CTOR_LOCK = __import__("threading").Lock()
 FOLD_SEED_STRIDE = 7919      # fold i of a trial seeds its model / shuffles with seed + i * stride (fold 0 = the single split's seed)
 
 

@@ -94,7 +94,10 @@ _GROUP = 8
 
 
 def side_streams(n: int, group: int = 0) -> List["torch.cuda.Stream"]:
-    dev = torch.cuda.current_device()
+    import threading
+    # one pool per (device, host thread): trials in flight on several threads (trials.run_units(in_flight=...)) must not share
+    # side streams -- a shared stream would order one trial's batch assembly behind the other's
+    dev = (torch.cuda.current_device(), threading.get_ident())
     pool = _POOLS.setdefault(dev, [])
     need = group * _GROUP + n
     if n > _GROUP:

@@ -11,6 +11,8 @@ state_dict is broadcast.  Rank 0 prints one JSON line with the result table summ
 """
 from __future__ import annotations
 
+from typing import Optional
+
 import argparse
 import json
 import os
@@ -38,14 +40,21 @@ def _cohort(layers, n, device, seed):
 
 def run_cfg5(dev, n_trials: int = 64, epochs: int = 3, features: int = 20000, samples: int = 2048, seed: int = 0,
              keep_winner: bool = True, schedule: str = "queue", force_collectives: bool = False, use_cv: bool = False,
-             n_splits: int = 5) -> dict:
+             n_splits: int = 5, in_flight: int = 2, use_graph: Optional[bool] = None) -> dict:
     """The cfg5 workload on the CURRENT process group (or a single process): rank 0 builds the synthetic cohort and
     broadcasts it, the trials are claimed longest-first from a counter shared by the ranks (``schedule="static"``: the
     LPT assignment computed up front), every rank runs its trials with the engine loop, one all_gather collects the
     records and the winner's state_dict is broadcast.  ``use_cv``: the reference's cross-validated search
     (main.py:267-269, :403-414) -- the unit of sharding is then one (trial, fold) fit, the optimiser's figure of merit the
     mean over a trial's folds, and the final model is rebuilt on all samples by rank 0 and broadcast.
+    ``in_flight`` trials run concurrently on every GPU (host threads with their own streams, eager launches:
+    trials.run_units); ``use_graph`` (default: only with one trial in flight) replays hipGraphs inside a trial.
     Returns the summary dict (identical on every rank)."""
+    import threading
+    use_graph = (int(in_flight) <= 1) if use_graph is None else bool(use_graph)
+    if int(in_flight) > 1 and use_graph:
+        raise ValueError("trials in flight on several threads must not capture hipGraphs: use_graph=False")
+    slock = threading.Lock()
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     layers = [("gex", features), ("cnv", features)]
@@ -69,9 +78,10 @@ def run_cfg5(dev, n_trials: int = 64, epochs: int = 3, features: int = 20000, sa
     def account(t, info, params):
         if "error" in info:
             raise RuntimeError(info["error"])
-        stats["samples"] += info["steps"] * int(params["batch_size"])
-        torch.cuda.synchronize(dev)
-        stats["busy"] += time.perf_counter() - t
+        torch.cuda.current_stream(dev).synchronize()
+        with slock:
+            stats["samples"] += info["steps"] * int(params["batch_size"])
+            stats["busy"] += time.perf_counter() - t
 
     t1 = time.perf_counter()
     if not use_cv:
@@ -81,18 +91,21 @@ def run_cfg5(dev, n_trials: int = 64, epochs: int = 3, features: int = 20000, sa
         def trial_fn(tid, params):
             t = time.perf_counter()
             val, ep, model, info = run_trial(DirectPred, params, ds, ["y"], early_stop_patience=0, seed=seed * 100003 + tid,
-                                             device=dev)
+                                             device=dev, use_graph=use_graph)
             # only a trial that beats this rank's best so far can be the winner: the others' weights are never cloned
             sd = None
-            if keep_winner and "error" not in info and val < stats.get("best", float("inf")):
-                stats["best"] = val
+            with slock:
+                better = keep_winner and "error" not in info and val <= stats.get("best", float("inf"))
+                if better:
+                    stats["best"] = val
+            if better:
                 sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
             del model
             account(t, info, params)
             return val, ep, sd
 
         table, best, state = trials.run_sweep(plist, trial_fn, costs, dev, shapes_of if keep_winner else None,
-                                              schedule=schedule, force_collectives=force_collectives)
+                                              schedule=schedule, force_collectives=force_collectives, in_flight=in_flight)
         trial_vals = table[:, 1]
         ok = table[:, 3] == trials.STATUS_OK
     else:
@@ -104,12 +117,14 @@ def run_cfg5(dev, n_trials: int = 64, epochs: int = 3, features: int = 20000, sa
             tid, fi = units[uid]
             t = time.perf_counter()
             val, ep, model, info = run_trial_fold(DirectPred, plist[tid], ds, ["y"], splits[fi][0], splits[fi][1],
-                                                  early_stop_patience=0, seed=seed * 100003 + tid + fi * FOLD_SEED_STRIDE, device=dev)
+                                                  early_stop_patience=0, seed=seed * 100003 + tid + fi * FOLD_SEED_STRIDE, device=dev,
+                                                  use_graph=use_graph)
             del model
             account(t, info, plist[tid])
             return val, ep, None
 
-        utable, _ = trials.run_units(len(units), unit_fn, costs, dev, keep=[], schedule=schedule, force_collectives=force_collectives)
+        utable, _ = trials.run_units(len(units), unit_fn, costs, dev, keep=[], schedule=schedule, force_collectives=force_collectives,
+                                     in_flight=in_flight)
         per_trial = utable[:, 1].reshape(n_trials, n_splits)
         trial_vals = per_trial.mean(axis=1)                       # main.py:327-333: the mean over the folds
         trial_eps = utable[:, 2].reshape(n_trials, n_splits).mean(axis=1).astype(int)
@@ -122,7 +137,7 @@ def run_cfg5(dev, n_trials: int = 64, epochs: int = 3, features: int = 20000, sa
             if rank == 0:
                 t = time.perf_counter()
                 final, info = full_train(DirectPred, dict(plist[best], epochs=max(int(trial_eps[best]), 1)), ds, ["y"],
-                                         seed=seed * 100003 + 99991, device=dev)
+                                         seed=seed * 100003 + 99991, device=dev, use_graph=use_graph)
                 held[0] = {k: v.detach() for k, v in final.state_dict().items()}
                 account(t, info, plist[best])
             owner_table = np.zeros((1, 5))
@@ -141,14 +156,15 @@ def run_cfg5(dev, n_trials: int = 64, epochs: int = 3, features: int = 20000, sa
         "workload": f"cfg5: {n_trials} DirectPred trials (2 x {features} features, N={samples}, {epochs} epochs"
                     + (f", {n_splits}-fold CV + final model on all samples" if use_cv else "") + f"), "
                     f"{world} GPU(s), trial sharding ({'work queue, longest first' if schedule == 'queue' and world > 1 else 'LPT'})",
-        "n_gpus": world, "trials": int(n_trials), "trials_ok": int(ok.sum()), "best_trial": best,
+        "n_gpus": world, "trials_in_flight_per_gpu": int(in_flight), "hipgraph_replay": bool(use_graph), "trials": int(n_trials), "trials_ok": int(ok.sum()), "best_trial": best,
         "best_val_loss": float(trial_vals[best]), "best_params": plist[best],
+        "trial_val_losses": [float(v) for v in trial_vals],
         "winner_state_tensors": len(state) if state is not None else 0,
         "cohort_generate_s": round(t_gen, 4), "cohort_broadcast_s": round(t_bcast, 4),
         "sweep_wall_s": round(float(allr[:, 1].max()), 3),
         "aggregate_samples_per_s": round(float(allr[:, 0].sum()) / float(allr[:, 1].max()), 1),
         "rank_busy_s": [round(float(b), 3) for b in busy],
-        "busy_over_wall": round(float(busy.sum()) / (world * max(float(allr[:, 1].max()), 1e-9)), 4),
+        "busy_over_wall": round(float(busy.sum()) / (world * max(int(in_flight), 1) * max(float(allr[:, 1].max()), 1e-9)), 4),
         "tail_imbalance": round(1.0 - float(busy.mean()) / max(float(busy.max()), 1e-9), 4),
     }
 
@@ -162,6 +178,7 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cv", type=int, default=0, help="k > 1: k-fold cross-validated trials (units = trial x fold)")
     ap.add_argument("--schedule", default="queue", choices=["queue", "static"])
+    ap.add_argument("--in-flight", type=int, default=2, help="trials running concurrently per GPU (host threads, eager launches)")
     a = ap.parse_args(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -172,7 +189,7 @@ def main(argv=None):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
     out = run_cfg5(dev, a.trials, a.epochs, a.features, a.samples, a.seed, schedule=a.schedule, use_cv=a.cv > 1,
-                   n_splits=max(a.cv, 2))
+                   n_splits=max(a.cv, 2), in_flight=a.in_flight)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

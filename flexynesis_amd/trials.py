@@ -181,12 +181,21 @@ class _Claims:
 
 
 def run_units(n: int, unit_fn: Callable[[int], Tuple[float, int, Optional[dict]]], costs: Optional[Sequence[float]] = None,
-              device="cpu", keep: Optional[Sequence[int]] = None, schedule: str = "queue", force_collectives: bool = False):
+              device="cpu", keep: Optional[Sequence[int]] = None, schedule: str = "queue", force_collectives: bool = False,
+              in_flight: int = 1):
     """Run units 0..n-1 (HPO trials, cross-validation folds, fine-tuning fits) sharded over the ranks:
     ``unit_fn(uid) -> (val_loss, epochs, state_dict | None)``.  Returns (table [n, 5]: uid, val_loss, epochs, status,
     rank that ran it; local: {uid: state} of the units this rank must hold on to).  ``keep`` = unit ids whose state is
     needed afterwards whatever their loss (the FineTuner continues from its LAST fit, main.py:647); None keeps only this
-    rank's best unit (0.8 GB of weights per cfg2 trial).  A failing / non-finite unit reports +inf and the sweep goes on."""
+    rank's best unit (0.8 GB of weights per cfg2 trial).  A failing / non-finite unit reports +inf and the sweep goes on.
+
+    ``in_flight`` > 1: that many units run CONCURRENTLY on this rank's GPU, each on a host thread with its own HIP stream
+    (eager launches: the units must not capture hipGraphs -- ``fit(use_graph=False)``).  One unit's latency-bound launches
+    then run while the other's HBM-bound dW + Adam launches hold the memory system: +10 % aggregate samples/s at two units
+    in flight on cfg5-style trials (scripts/bench_two_trials.py); the units' results are unchanged (every unit is seeded
+    on its own and deterministic)."""
+    import contextlib
+    import threading
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     costs = list(costs) if costs is not None else [1.0] * n
@@ -196,24 +205,47 @@ def run_units(n: int, unit_fn: Callable[[int], Tuple[float, int, Optional[dict]]
         raise ValueError("schedule must be 'queue' or 'static'")
     keep_set = None if keep is None else set(int(k) for k in keep)
     local, held = [], {}
-    best_local = (float("inf"), -1)
-    for uid in _Claims(costs, world, rank, schedule):
-        try:
-            val, epochs, state = unit_fn(uid)
-            status = STATUS_OK if (val == val and math.isfinite(val)) else STATUS_FAILED
-            val = val if status == STATUS_OK else float("inf")
-        except Exception:                      # a broken unit reports +inf; the sweep goes on
-            val, epochs, state, status = float("inf"), 0, None, STATUS_FAILED
-        local.append((uid, float(val), int(epochs), status))
-        if state is not None and status == STATUS_OK:
-            if keep_set is not None:
-                if uid in keep_set:
-                    held[uid] = state
-            elif best_local[1] < 0 or (val, uid) < best_local:      # ties resolve to the lowest id, like np.argmin
-                held.clear()
-                held[uid] = state
-                best_local = (float(val), uid)
-        del state
+    best_local = [float("inf"), -1]
+    claims = iter(_Claims(costs, world, rank, schedule))
+    lock = threading.Lock()
+    dev = torch.device(device)
+
+    def worker(own_stream: bool):
+        if dev.type == "cuda":
+            torch.cuda.set_device(dev)                      # (the current device is per host thread)
+        ctx = torch.cuda.stream(torch.cuda.Stream(dev)) if (own_stream and dev.type == "cuda") else contextlib.nullcontext()
+        with ctx:
+            while True:
+                with lock:
+                    uid = next(claims, None)
+                if uid is None:
+                    return
+                try:
+                    val, epochs, state = unit_fn(uid)
+                    status = STATUS_OK if (val == val and math.isfinite(val)) else STATUS_FAILED
+                    val = val if status == STATUS_OK else float("inf")
+                except Exception:                      # a broken unit reports +inf; the sweep goes on
+                    val, epochs, state, status = float("inf"), 0, None, STATUS_FAILED
+                with lock:
+                    local.append((uid, float(val), int(epochs), status))
+                    if state is not None and status == STATUS_OK:
+                        if keep_set is not None:
+                            if uid in keep_set:
+                                held[uid] = state
+                        elif best_local[1] < 0 or (val, uid) < tuple(best_local):   # ties resolve to the lowest id, like np.argmin
+                            held.clear()
+                            held[uid] = state
+                            best_local[0], best_local[1] = float(val), uid
+                del state
+
+    if int(in_flight) <= 1:
+        worker(False)
+    else:
+        threads = [threading.Thread(target=worker, args=(True,), name=f"fx-unit-{i}") for i in range(int(in_flight))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
     table = gather_results(local, n, device, rank, force_collectives)
     return table, held
 
@@ -236,7 +268,7 @@ def agree_and_broadcast_state(held: Dict[int, dict], uid: int, table: np.ndarray
 
 def run_sweep(param_list: List[dict], trial_fn: Callable[[int, dict], Tuple[float, int, Optional[dict]]],
               costs: Optional[Sequence[float]] = None, device="cpu", state_shapes: Optional[Dict[str, tuple]] = None,
-              schedule: str = "queue", force_collectives: bool = False):
+              schedule: str = "queue", force_collectives: bool = False, in_flight: int = 1):
     """Shard ``param_list`` over the ranks, run ``trial_fn(trial_id, params) -> (val_loss, epochs, state_dict)``
     locally, gather the result table, and (if ``state_shapes`` is given) broadcast the winner's weights.
     ``state_shapes`` may be a dict (all trials share one architecture) or a callable ``params -> {key: shape}``
@@ -244,7 +276,7 @@ def run_sweep(param_list: List[dict], trial_fn: Callable[[int, dict], Tuple[floa
     every rank).  Returns (table [n, 5], best_trial_id, best_state or None)."""
     n = len(param_list)
     table, held = run_units(n, lambda uid: trial_fn(uid, param_list[uid]), costs, device, keep=None, schedule=schedule,
-                            force_collectives=force_collectives)
+                            force_collectives=force_collectives, in_flight=in_flight)
     best = int(np.argmin(table[:, 1]))
     best_state = None
     if state_shapes is not None and math.isfinite(table[best, 1]):

@@ -127,3 +127,97 @@ def test_soak_fits_and_level1_models_with_every_graph_feature_on(monkeypatch):
             gc.collect()
     torch.cuda.synchronize()
     assert tape_graphs >= 60                            # the level-1 models really ran from captured tapes
+
+
+def test_small_fp32_kernels_beside_an_mfma_kernel_are_exact():
+    """Regression for the packed-fp32 hazard (scripts/pkfma_hazard_probe.hip): with v_pk_fma_f32 in its inner loop
+    fx_small_linear_fwd dropped single terms in lanes 48..63 (40 launches in 60000) whenever waves of an MFMA kernel
+    (ds_read_b128 -> MFMA chains: fx_gram_kb_group, the dW + Adam kernel) shared its SIMDs -- which the step's own side branch
+    and trials in flight make routine.  The library is built without packed fp32 ops; the small kernels must now be bit-stable
+    beside that noise."""
+    import threading, time
+    from flexynesis_amd import ops
+    from flexynesis_amd.arch import ArchSpec
+    from flexynesis_amd.data import synthetic_cohort
+    from flexynesis_amd.engine import ParamStore, PipelinedStep
+    g = torch.Generator(device=DEV); g.manual_seed(0)
+    B, L, n = 128, 85, 2
+    ecat = torch.randn(B, n * L, device=DEV, generator=g)
+    W = torch.randn(L, n * L, device=DEV, generator=g) * 0.1
+    b = torch.randn(L, device=DEV, generator=g)
+    dy = torch.randn(B, L, device=DEV, generator=g)
+    layers = [("gex", 4000), ("cnv", 4000)]
+    spec = ArchSpec("DirectPred", layers, 64, 0.25, 16, [("y", "numerical", 1)], None, None, True)
+    cohort = synthetic_cohort(layers, 2048, DEV, seed=1)
+    stop, started, err = [False], threading.Event(), []
+
+    def hammer():
+        try:
+            torch.cuda.set_device(DEV)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                st2 = ParamStore(spec, DEV, materialize_big_grads=False)
+                p2 = PipelinedStep(st2, 64, cohort=cohort, n_batches=12, seed=9)
+                p2.idx.copy_(torch.randperm(2048, device=DEV)[: 12 * 64]); p2.prime()
+                p2.step(1e-3); p2.step(1e-3)
+                calls = [c for nm in ("gather", "fwd", "bwd", "opt") for seg in getattr(p2.plans[0], "t_" + nm).segments for br in seg
+                         for c in br if c[0] is not None and c[1] in ("fx_gram_kb_group", "fx_linear_dw_adam_fwd_bf16x3")]
+                assert {c[1] for c in calls} == {"fx_gram_kb_group", "fx_linear_dw_adam_fwd_bf16x3"}
+                s_ = torch.cuda.current_stream().cuda_stream
+                k = 0
+                started.set()
+                while not stop[0]:
+                    for fn, name, args in calls:
+                        fn(*args, s_)
+                    k += 1
+                    if k % 16 == 0:
+                        torch.cuda.current_stream().synchronize()
+                torch.cuda.current_stream().synchronize()
+                p2.close()
+        except Exception as e:          # pragma: no cover
+            err.append(e); started.set()
+
+    th = threading.Thread(target=hammer)
+    th.start()
+    try:
+        assert started.wait(120) and not err, err
+        time.sleep(0.2)
+        with torch.cuda.stream(torch.cuda.Stream()):
+            ref_y = torch.empty(B, L, device=DEV)
+            ops.small_linear_fwd(ops.IMMEDIATE, ref_y, ecat, W, b)
+            ref_dx, ref_gW, ref_gb = torch.empty(B, n * L, device=DEV), torch.empty_like(W), torch.empty_like(b)
+            ops.small_linear_bwd(ops.IMMEDIATE, ref_dx, ref_gW, ref_gb, dy, ecat, W)
+            torch.cuda.current_stream().synchronize()
+            bad = 0
+            for chunk in range(100):
+                outs = []
+                for it in range(200):
+                    y = torch.empty(B, L, device=DEV)
+                    ops.small_linear_fwd(ops.IMMEDIATE, y, ecat, W, b)
+                    outs.append((y, ref_y))
+                    if it % 4 == 0:
+                        dx, gW = torch.empty(B, n * L, device=DEV), torch.empty_like(W)
+                        ops.small_linear_bwd(ops.IMMEDIATE, dx, gW, torch.empty_like(b), dy, ecat, W)
+                        outs += [(dx, ref_dx), (gW, ref_gW)]
+                bad += sum(0 if torch.equal(o, r) else 1 for o, r in outs)
+            assert bad == 0, f"{bad} launches differ from the quiet result"
+    finally:
+        stop[0] = True
+        th.join(120)
+    assert not err, err
+
+
+def test_trials_in_flight_match_one_at_a_time():
+    """run_cfg5(in_flight=2): two trials at a time on host threads with their own streams -- every trial's validation loss,
+    the winner and its weights equal the one-at-a-time sweep's (hipGraph replay or eager)."""
+    from flexynesis_amd.sweep import run_cfg5
+    kw = dict(n_trials=6, epochs=2, features=3000, samples=512, seed=3)
+    a = run_cfg5(DEV, in_flight=1, use_graph=True, **kw)
+    b = run_cfg5(DEV, in_flight=1, use_graph=False, **kw)
+    c = run_cfg5(DEV, in_flight=2, **kw)
+    d = run_cfg5(DEV, in_flight=3, **kw)
+    for o in (b, c, d):
+        assert o["trial_val_losses"] == a["trial_val_losses"]
+        assert o["best_trial"] == a["best_trial"] and o["winner_state_tensors"] == a["winner_state_tensors"]
+    assert c["trials_in_flight_per_gpu"] == 2 and not c["hipgraph_replay"]
+    with pytest.raises(ValueError):
+        run_cfg5(DEV, in_flight=2, use_graph=True, **kw)
