@@ -414,7 +414,41 @@ class StepPlan:
         st = self.store
         if not self.fuse_tail or self.passes != 1 or self.R > 128 or n > 4 or L > 128 or L % 4 != 0 or n * L > 512:
             return False
-        return all(st.shapes[f"encoders.{i}.layer_1.weight"][0] % 4 == 0 for i in range(n))
+        wide = "layer_1" if "encoders.0.layer_1.weight" in st.shapes else "hidden_layers.0"      # MLP / VAE encoder
+        return all(st.shapes[f"encoders.{i}.{wide}.weight"][0] % 4 == 0 for i in range(n))
+
+    def _vae_tails_fwd(self, rec, enc, L, mcat, vcat, mean, logv):
+        """All VAE encoders' tails in one launch -- slab sum + bias, LeakyReLU, BatchNorm and the column blocks' shares of
+        FC_mean and FC_var (modules.py:25-41) -- then mcat / vcat (ordered sums of the shares + biases) with the top-level
+        FC_mean / FC_log_var (supervised_vae.py:104-107,172-176) row-parallel: 3 launches on one stream instead of 6 per
+        modality on parallel graph branches + join + 2.  Returns the encoders' block outputs."""
+        st, R = self.store, self.R
+        descs, parts_m, parts_v, hs = [], [], [], []
+        for i, xi in enumerate(enc):
+            p = f"encoders.{i}"
+            H = st.shapes[p + ".hidden_layers.0.weight"][0]
+            y, h = self._new(p + "/y", R, H), self._new(p + "/h", R, H)
+            sm, si = self._new(p + "/save_mean", 1, H), self._new(p + "/save_invstd", 1, H)
+            slabs = self._lin_fwd(rec, y, self.X[xi], p + ".hidden_layers.0.weight", p + ".hidden_layers.0.bias", want_slabs=True)
+            nb = ops.enc_tail_blocks(H)
+            pm, pv = self._new(p + "/mean_parts", nb, R, L), self._new(p + "/var_parts", nb, R, L)
+            descs.append(ops.enc_tail_desc(
+                slabs=slabs[0] if slabs is not None else None, n_slabs=slabs[1] if slabs is not None else 0, slab_stride=R * H,
+                lin_bias=st.p(p + ".hidden_layers.0.bias") if slabs is not None else None, x=y, out=h,
+                gamma=st.p(p + ".hidden_layers.2.weight"), beta=st.p(p + ".hidden_layers.2.bias"),
+                running_mean=st.b(p + ".hidden_layers.2.running_mean"), running_var=st.b(p + ".hidden_layers.2.running_var"),
+                save_mean=sm[0], save_invstd=si[0], mask=None,
+                ups=[(st.p(p + ".FC_mean.weight"), pm), (st.p(p + ".FC_var.weight"), pv)], seed=0, offset=0))
+            parts_m.append((pm, nb))
+            parts_v.append((pv, nb))
+            hs.append(h)
+        ops.enc_tail_fwd(rec, descs, R, ACT_LEAKY, ACT_NONE, self.train, 0.0, ctrl=st.ctrl)
+        n = len(enc)
+        ops.fusion_fwd(rec, mean, mcat, parts_m, [st.p(f"encoders.{i}.FC_mean.bias") for i in range(n)], st.p("FC_mean.weight"),
+                       st.p("FC_mean.bias"))
+        ops.fusion_fwd(rec, logv, vcat, parts_v, [st.p(f"encoders.{i}.FC_var.bias") for i in range(n)], st.p("FC_log_var.weight"),
+                       st.p("FC_log_var.bias"))
+        return hs
 
     def _mlp_tails_fwd(self, rec, n, L, ecat):
         """All MLP encoders' tails in one launch -- slab sum + bias, BatchNorm, ReLU, Dropout and the column blocks' shares of
@@ -1271,19 +1305,23 @@ class StepPlan:
         mcat, vcat = self._new("mcat", B, n * L), self._new("vcat", B, n * L)
         hs = []
         vae_par = self.branches and os.environ.get("FX_VAE_BRANCHES", "1") != "0"
-        with rf.parallel(n if vae_par else 1) as par:       # one graph branch per encoder (wide kernels staggered)
-            for i in range(n):
-                if vae_par:
-                    self._enter_branch(par, i)
-                p = f"encoders.{i}"
-                h = self._hidden_fwd(rf, p, self.X[enc[i]], B)
-                hs.append(h)
-                ops.linear_fwd(rf, mcat[:, i * L:(i + 1) * L], h, st.p(p + ".FC_mean.weight"), st.p(p + ".FC_mean.bias"), self.ws)
-                ops.linear_fwd(rf, vcat[:, i * L:(i + 1) * L], h, st.p(p + ".FC_var.weight"), st.p(p + ".FC_var.bias"), self.ws)
-        self._branch = 0
         mean, logv, z = self._new("mean", B, L), self._new("log_var", B, L), self._new("z", B, L)
-        self._small_fwd(rf, mean, mcat, "FC_mean.weight", "FC_mean.bias")
-        self._small_fwd(rf, logv, vcat, "FC_log_var.weight", "FC_log_var.bias")
+        vae_group = self._tails_groupable(n, L) and os.environ.get("FX_VAE_GROUP", "1") != "0"
+        if vae_group:
+            hs = self._vae_tails_fwd(rf, enc, L, mcat, vcat, mean, logv)
+        else:
+            with rf.parallel(n if vae_par else 1) as par:       # one graph branch per encoder (wide kernels staggered)
+                for i in range(n):
+                    if vae_par:
+                        self._enter_branch(par, i)
+                    p = f"encoders.{i}"
+                    h = self._hidden_fwd(rf, p, self.X[enc[i]], B)
+                    hs.append(h)
+                    ops.linear_fwd(rf, mcat[:, i * L:(i + 1) * L], h, st.p(p + ".FC_mean.weight"), st.p(p + ".FC_mean.bias"), self.ws)
+                    ops.linear_fwd(rf, vcat[:, i * L:(i + 1) * L], h, st.p(p + ".FC_var.weight"), st.p(p + ".FC_var.bias"), self.ws)
+            self._branch = 0
+            self._small_fwd(rf, mean, mcat, "FC_mean.weight", "FC_mean.bias")
+            self._small_fwd(rf, logv, vcat, "FC_log_var.weight", "FC_log_var.bias")
         eps = self._draw("eps", B, L) if self.supplied else None
         eps_used = self._new("eps_used", B, L)
         seed, off = self._rng()
@@ -1294,32 +1332,37 @@ class StepPlan:
         lv_mmd = self._logvar("mmd_loss")
         hd, logits = [], []
         row_sums = self._new("mmd_rows", 2 * (MMD_PRIOR + B))
-        rec_part = self._new("recon_part", 1024)
         # dz must start from zero each step: the first head's data-grad GEMM overwrites it (accumulate=False),
         # so heads go FIRST in the backward tape and the MMD rows kernel (+=) is emitted after them; without heads an
         # explicit zero-fill takes their place.
+        self.xhat = [self._new(f"xhat.{i}", B, spec.layers[dec[i]][1]) for i in range(nd)] if not self.train else None
+        priors, rec_parts = [], []
         with rf.parallel(nd if vae_par else 1) as par:      # one graph branch per decoder
             for i in range(nd):
                 if vae_par:
                     self._enter_branch(par, i)
                 p = f"decoders.{i}"
                 F = spec.layers[dec[i]][1]
+                # The decoder's MMD prior sample (supervised_vae.py:420-426) and, behind FC_output, its reconstruction term
+                # with dlogits overwriting the logits (:301-313) ride in the decoder's own branch; the main chain after the join
+                # is heads -> MMD rows / finalize per decoder -> total.
+                if self.supplied:
+                    pr = self._draw(f"prior.{i}", MMD_PRIOR, L)
+                else:
+                    pr = self._new(f"prior.{i}", MMD_PRIOR, L)
+                    seed, off = self._rng()
+                    ops.fill_normal(rf, pr, seed, off, ctrl=st.ctrl)
+                priors.append(pr)
                 h = self._hidden_fwd(rf, p, z, B)
                 hd.append(h)
                 lg = self._new(p + "/logits", B, F)
                 logits.append(lg)
                 self._lin_fwd(rf, lg, h, p + ".FC_output.weight", p + ".FC_output.bias")
+                rp = self._new(f"recon_part.{i}", 1024)
+                rec_parts.append(rp)
+                ops.recon_sigmoid(rf, rp, lg if self.train else None, self.xhat[i] if self.xhat else None, lg, self.X[dec[i]], lv_mmd,
+                                  1.0 / nd)
         self._branch = 0
-        self.xhat = [self._new(f"xhat.{i}", B, spec.layers[dec[i]][1]) for i in range(nd)] if not self.train else None
-        priors = []
-        for i in range(nd):
-            if self.supplied:
-                pr = self._draw(f"prior.{i}", MMD_PRIOR, L)
-            else:
-                pr = self._new(f"prior.{i}", MMD_PRIOR, L)
-                seed, off = self._rng()
-                ops.fill_normal(rf, pr, seed, off, ctrl=st.ctrl)
-            priors.append(pr)
         stepped = self._heads_step(rf, z, dz, with_total=False)    # (the total needs the MMD term computed below)
         if not stepped:
             self._head_losses(rf, z)
@@ -1334,24 +1377,32 @@ class StepPlan:
                 ops.fill(rf, dz, 0.0)
         for i in range(nd):       # mmd_loss = mean over the reconstructed layers (supervised_vae.py:309-313)
             F = spec.layers[dec[i]][1]
-            dlg = logits[i] if self.train else None                  # dlogits overwrite logits in place
             nblk = int(ops.lib.fx_recon_blocks(B * F))
             ops.mmd_rows(rf, row_sums, dz if self.train else None, priors[i], z, lv_mmd, 1.0 / nd)
-            ops.recon_sigmoid(rf, rec_part, dlg, self.xhat[i] if self.xhat else None, logits[i], self.X[dec[i]], lv_mmd, 1.0 / nd)
-            ops.mmd_finalize(rf, self.loss_vec[0:1], row_sums, MMD_PRIOR, B, rec_part, nblk, float(B * F), 1.0 / nd, i > 0)
+            ops.mmd_finalize(rf, self.loss_vec[0:1], row_sums, MMD_PRIOR, B, rec_parts[i], nblk, float(B * F), 1.0 / nd, i > 0)
         self._total(rf)
         if not self.train:
             if self.attribution:
                 self._build_svae_attr(enc, hs, mcat, vcat, eps_used, L)
             return
-        # ---- backward through decoders (dlogits live in logits[i]) -> dz, then latent, then encoders
+        # ---- backward through decoders (dlogits live in logits[i]) -> dz, then latent, then encoders.  One graph branch per
+        # decoder (the narrow launches around one decoder's FC_output products run beside the other's); their shares of dz
+        # are added on the main chain afterwards, in decoder order.
+        dhs = []
+        with rb.parallel(nd if vae_par else 1) as par:
+            for i in range(nd):
+                if vae_par:
+                    self._enter_branch(par, i)
+                p = f"decoders.{i}"
+                dh = self._new(p + "/dh", B, st.shapes[p + ".hidden_layers.0.weight"][0])
+                dhs.append(dh)
+                self._weight_grad(rb, p + ".FC_output.weight", logits[i], hd[i])
+                ops.colsum(rb, st.g(p + ".FC_output.bias"), logits[i])
+                self._lin_bwd_x(rb, dh, logits[i], p + ".FC_output.weight")
+                self._hidden_bwd(rb, p, z, dh)
+        self._branch = 0
         for i in range(nd):
-            p = f"decoders.{i}"
-            dh = self._new(p + "/dh", B, st.shapes[p + ".hidden_layers.0.weight"][0])
-            self._weight_grad(rb, p + ".FC_output.weight", logits[i], hd[i])
-            ops.colsum(rb, st.g(p + ".FC_output.bias"), logits[i])
-            self._lin_bwd_x(rb, dh, logits[i], p + ".FC_output.weight")
-            self._hidden_bwd(rb, p, z, dh, dx=dz, dx_accumulate=True)
+            ops.linear_bwd_x(rb, dz, dhs[i], st.p(f"decoders.{i}.hidden_layers.0.weight"), self.ws, accumulate=True)
         # z = mean + log_var * eps
         dlv = self._new("dlog_var", B, L)
         ops.mul(rb, dlv, dz, eps_used)
