@@ -14,7 +14,7 @@
 //                     activation, dropout (Philox: one counter block per 4 consecutive columns, the stream of
 //                     fx_bn_act_fwd) -> out (saved), and the block's share of every following small Linear:
 //                     part_k[blk][r, l] = sum_{c in block} out[r, c] W_k[l, c]  (plain fp32 FMA from LDS tiles).
-//   fx_fusion_fwd     grid (row blocks).  One workgroup owns 8 rows: ecat[r, :] = for every modality the ordered sum of
+//   fx_fusion_fwd     grid (row blocks).  One workgroup owns 4 rows: ecat[r, :] = for every modality the ordered sum of
 //                     its column blocks' partial products + layer_out bias (four threads share the slab range of an
 //                     output and combine in a fixed order), then emb[r, :] = ecat[r, :] W_f^T + b_f from an LDS copy of
 //                     W_f.  Without a fusion layer (one modality) it only reduces.
@@ -310,7 +310,8 @@ __global__ __launch_bounds__(ET_T) void fx_enc_tail_fwd_kernel(EncTailArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-#define FU_ROWS 8
+#define FU_ROWS 4
+#define FU_SUB 8            // threads (neighbouring lanes) that split one unit's slab range
 #define FU_T 1024
 #define FU_MAXK 512
 #define FU_MAX_LAYERS 8
@@ -340,17 +341,18 @@ __global__ __launch_bounds__(FU_T) void fx_fusion_fwd_kernel(FusionArgs a) {
       wreg[i] = a.Wf[(long)min(l, L - 1) * Kf + min(k, Kf - 1)];
     }
   }
-  // ---- ecat rows: unit = (row, 4 consecutive columns of one modality); its 4 threads (neighbouring lanes) split the slab range
-  const int sub = t & 3, unit0 = t >> 2;
+  // ---- ecat rows: unit = (row, 4 consecutive columns of one modality); its FU_SUB threads (neighbouring lanes) split the slab
+  // range (4 rows x 8 sub-ranges: 32 workgroups at B = 128, ~10 slabs of 16 bytes per thread in 2-3 dependent rounds)
+  const int sub = t & (FU_SUB - 1), unit0 = t / FU_SUB;
   const int units = FU_ROWS * (Kf >> 2);
-  for (int u = unit0; u < units; u += FU_T / 4) {
+  for (int u = unit0; u < units; u += FU_T / FU_SUB) {
     const int rr = u / (Kf >> 2), c = (u - rr * (Kf >> 2)) << 2;
     const int r = r0 + rr;
     const float* part = a.part[0]; const float* bias = a.bias[0]; int np = a.n_part[0], wd = a.width[0], c0 = a.col0[0];
 #pragma unroll
     for (int i = 1; i < FU_MAX_LAYERS; ++i)
       if (i < a.n_layers && c >= a.col0[i]) { part = a.part[i]; bias = a.bias[i]; np = a.n_part[i]; wd = a.width[i]; c0 = a.col0[i]; }
-    const int per = (np + 3) >> 2, z0 = sub * per, z1 = min(np, z0 + per);
+    const int per = (np + FU_SUB - 1) / FU_SUB, z0 = min(np, sub * per), z1 = min(np, z0 + per);
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (r < B) {
       const float* src = part + (long)r * wd + (c - c0);
@@ -365,17 +367,17 @@ __global__ __launch_bounds__(FU_T) void fx_fusion_fwd_kernel(FusionArgs a) {
       }
       for (; z < z1; ++z) s += *reinterpret_cast<const f32x4*>(src + (long)z * stride);
     }
-    // combine the four slab ranges in range order (fixed: deterministic)
-    const int base = (t & 63) & ~3;
-    f32x4 s1, s2, s3;
+    // combine the sub-ranges in range order (fixed: deterministic)
+    const int base = (t & 63) & ~(FU_SUB - 1);
+    f32x4 tot = s;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      s1[j] = __shfl(s[j], base + 1, 64);
-      s2[j] = __shfl(s[j], base + 2, 64);
-      s3[j] = __shfl(s[j], base + 3, 64);
+    for (int q = 1; q < FU_SUB; ++q) {
+      f32x4 sq;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sq[j] = __shfl(s[j], base + q, 64);
+      tot += sq;
     }
     if (sub == 0) {
-      f32x4 tot = ((s + s1) + s2) + s3;
       if (bias) tot += *reinterpret_cast<const f32x4*>(bias + (c - c0));
       *reinterpret_cast<f32x4*>(&es[rr][c]) = tot;
       if (r < B && a.ecat) *reinterpret_cast<f32x4*>(a.ecat + (long)r * a.ldecat + c) = tot;
