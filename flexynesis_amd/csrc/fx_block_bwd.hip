@@ -14,7 +14,10 @@
 // fx_clip_finalize in a fixed order).  Thread (cx = column, ry = row group) keeps its 8 rows of x, the block output
 // and the gradient in registers; the small operands (dE [B, L], 32-column tiles) go through LDS.  512 threads: the
 // phases are LDS-latency bound, and with 157 workgroups on 256 CUs the only latency hiding is inside the workgroup
-// (256 threads: 42 us, phase ablation in scripts/bench_block_bwd.py).
+// (256 threads: 42 us, phase ablation in scripts/bench_block_bwd.py).  Round 3: the three products (da = dE . W,
+// gW = dE^T . out, dY dY^T) moved from FMA loops over LDS operands to the exact-fp32 matrix pipe
+// (v_mfma_f32_16x16x4_f32, one 16 x 16 block family per wave): 50 -> 27 us at cfg2 for two modalities, same arithmetic
+// error against fp64 (1.6e-7 rms, scripts/block_bwd_error.py).
 #include "fx_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -29,6 +32,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define BB_ACT_LEAKY 1
 #define BB_ACT_RELU 2
 #define BB_LEAKY 0.2f
+#define BB_DLD 68            // LDS row stride of the staged dE chunk [128][64 + 4]
+#define BB_WLD 68            // ... of the staged W chunk, transposed [32 columns][64 + 4]
+// The three products of a workgroup -- da = dE . W, gW = dE^T . out, dY dY^T -- run on the exact-fp32 matrix pipe
+// (v_mfma_f32_16x16x4_f32: fp32 operands, fp32 accumulate).  Operand A: lane (m = lane & 15, kq = lane >> 4) holds A[m][k]
+// for one k per instruction, B: lane (n = lane & 15, kq) holds B[k][n]; result: lane holds D[4 (lane >> 4) + i][lane & 15],
+// i = 0..3.  A lane reads four consecutive k (16 q + 4 kq + e) at once and instruction e uses element e on both sides: the
+// contraction index is a dummy, any pairing of k between A and B that is the same on both sides gives the same sum.
+#define BB_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
 
 struct BlockBwdArgs {
   // up to two small Linears fed by the block output: dE_k [B, L_k] (upstream gradient), W_k [L_k, C]
@@ -56,26 +67,26 @@ __device__ __forceinline__ float bb_colsum(float v, float (*red)[BB_COLS], int c
   return s;
 }
 
-// One upstream Linear (dE [B, L], W [L, C]): da[16] += dE . W for this thread's rows/column, gW = dE^T . out, gb = colsum(dE).
+// One upstream Linear (dE [B, L], W [L, C]): dacc += dE . W for wave w's 16 rows x 32 columns (two 16 x 16 blocks in MFMA
+// result layout), gW = dE^T . out, gb = colsum(dE).
 // Plain pointer arguments: indexing the kernel-argument arrays with a runtime k put the whole struct in scratch.
 __device__ __forceinline__ void bb_upstream(const float* __restrict__ dE, long ldE, const float* __restrict__ W,
                                             float* __restrict__ gW, float* __restrict__ gb, int L, int B, int C, int c0, int cc,
-                                            int r0, float* dEs, float (*T)[132], float (*Ws)[BB_COLS], float da[BB_RPT],
-                                            int accumulate, int blk) {
-  const int t = threadIdx.x;
+                                            float* dEs, float (*T)[132], float (*Wt)[BB_WLD], f32x4 dacc[2], int accumulate,
+                                            int blk) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int l15 = lane & 15, kq = lane >> 4;
   // the upstream width L (latent size: any integer) is processed in chunks of 64 rows of W / columns of dE
   for (int lc0 = 0; lc0 < L; lc0 += BB_MAXL) {
     const int Lc = min(BB_MAXL, L - lc0);
-    // W chunk [64][32 columns] -> LDS (a register array indexed by l would need the l loop fully unrolled: 1024 FMAs
-    // with 256 live LDS vectors -> 3.4 KB of scratch per thread in the first version)
     float wv[4];
     {
       const int wl = t >> 5;                       // 16 rows per pass, 4 passes
 #pragma unroll
       for (int j = 0; j < 4; ++j) wv[j] = W[(long)(lc0 + min(wl + 16 * j, Lc - 1)) * C + cc];
     }
-    __syncthreads();                               // previous users of dEs / first use of T
-    {   // stage dE_k[:, lc0 : lc0+64] row-major [128][64], zero padded: thread = (row t>>4 + 32 j, 4 columns)
+    __syncthreads();                               // previous users of dEs / Wt; T holds the block output
+    {   // stage dE_k[:, lc0 : lc0+64] row-major [128][BB_DLD], zero padded: thread = (row t>>4 + 32 j, 4 columns)
       const int lq = 4 * (t & 15), rb = t >> 4;
       float v[4][4];
 #pragma unroll
@@ -90,62 +101,56 @@ __device__ __forceinline__ void bb_upstream(const float* __restrict__ dE, long l
         f32x4 o;
 #pragma unroll
         for (int q = 0; q < 4; ++q) o[q] = (r < B && lq + q < Lc) ? v[j][q] : 0.f;
-        *reinterpret_cast<f32x4*>(&dEs[r * BB_MAXL + lq]) = o;
+        *reinterpret_cast<f32x4*>(&dEs[r * BB_DLD + lq]) = o;
       }
     }
-    {
+    {   // W chunk transposed: Wt[column][l]
       const int wl = t >> 5, cxx = t & 31;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) Ws[wl + 16 * j][cxx] = (wl + 16 * j < Lc) ? wv[j] : 0.f;
+      for (int j = 0; j < 4; ++j) Wt[cxx][wl + 16 * j] = (wl + 16 * j < Lc) ? wv[j] : 0.f;
     }
     __syncthreads();
-    // da[i] += sum_l dE[r0+i][l] * W[l][c]
-    {
-      const int cxx = t & 31;
-#pragma unroll 4
-      for (int l4 = 0; l4 < BB_MAXL; l4 += 4) {
-        const float w0 = Ws[l4][cxx], w1 = Ws[l4 + 1][cxx], w2 = Ws[l4 + 2][cxx], w3 = Ws[l4 + 3][cxx];
+    // ---- da[16 w + ., 0..31] += dE[16 w + ., :] . W[:, c0 ..]: A = dEs rows, B = Wt columns, 4 x 4 k-steps
 #pragma unroll
-        for (int i = 0; i < BB_RPT; ++i) {
-          const f32x4 d = *reinterpret_cast<const f32x4*>(&dEs[(r0 + i) * BB_MAXL + l4]);
-          da[i] = fmaf(d[0], w0, da[i]);
-          da[i] = fmaf(d[1], w1, da[i]);
-          da[i] = fmaf(d[2], w2, da[i]);
-          da[i] = fmaf(d[3], w3, da[i]);
-        }
+    for (int q = 0; q < BB_MAXL / 16; ++q) {
+      const f32x4 av = *reinterpret_cast<const f32x4*>(&dEs[(16 * w + l15) * BB_DLD + 16 * q + 4 * kq]);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(&Wt[l15][16 * q + 4 * kq]);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(&Wt[16 + l15][16 * q + 4 * kq]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        dacc[0] = BB_MFMA(av[e], b0[e], dacc[0]);
+        dacc[1] = BB_MFMA(av[e], b1[e], dacc[1]);
       }
     }
-    // gW_k[lc0 + l][c0 + c'] = sum_r dE[r][l] * out[r][c']: thread (l = t & 63, columns cg*4 .. cg*4+3)
+    // ---- gW_k[lc0 + l][c0 + c'] = sum_r dE[r][l] out[r][c']: wave w owns the 16 x 16 block (l block w >> 1, column block w & 1)
     {
-      const int l = t & 63, cg = t >> 6;
-      float g[4];
+      const int lb = w >> 1, cb = w & 1;
+      f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+      for (int q = 0; q < 128 / 16; ++q) {
+        const int rk = 16 * q + 4 * kq;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(&T[16 * cb + l15][rk]);
+        f32x4 av;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) g[j] = 0.f;
-#pragma unroll 4
-      for (int r = 0; r < 128; r += 4) {
-        const float d0 = dEs[r * BB_MAXL + l], d1 = dEs[(r + 1) * BB_MAXL + l], d2 = dEs[(r + 2) * BB_MAXL + l],
-                    d3 = dEs[(r + 3) * BB_MAXL + l];
+        for (int e = 0; e < 4; ++e) av[e] = dEs[(rk + e) * BB_DLD + 16 * lb + l15];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const f32x4 av = *reinterpret_cast<const f32x4*>(&T[cg * 4 + j][r]);
-          g[j] = fmaf(d0, av[0], g[j]);
-          g[j] = fmaf(d1, av[1], g[j]);
-          g[j] = fmaf(d2, av[2], g[j]);
-          g[j] = fmaf(d3, av[3], g[j]);
-        }
+        for (int e = 0; e < 4; ++e) g = BB_MFMA(av[e], bv[e], g);
       }
-      if (l < Lc) {
+      const int col = c0 + 16 * cb + l15;
+      if (col < C) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (c0 + cg * 4 + j < C) {
-            float* dst = gW + (long)(lc0 + l) * C + c0 + cg * 4 + j;      // every element has exactly one owner thread
-            *dst = accumulate ? *dst + g[j] : g[j];
+        for (int i = 0; i < 4; ++i) {
+          const int l = 16 * lb + 4 * kq + i;
+          if (l < Lc) {
+            float* dst = gW + (long)(lc0 + l) * C + col;                 // every element has exactly one owner lane
+            *dst = accumulate ? *dst + g[i] : g[i];
           }
+        }
       }
       if (gb && blk == 0 && t < Lc) {   // bias gradient = column sums of dE_k
         float sg = 0.f;
 #pragma unroll 8
-        for (int r = 0; r < 128; ++r) sg += dEs[r * BB_MAXL + t];
+        for (int r = 0; r < 128; ++r) sg += dEs[r * BB_DLD + t];
         gb[lc0 + t] = accumulate ? gb[lc0 + t] + sg : sg;
       }
     }
@@ -153,9 +158,9 @@ __device__ __forceinline__ void bb_upstream(const float* __restrict__ dE, long l
 }
 
 __device__ __forceinline__ void bb_body(const BlockBwdArgs& a, int blk) {
-  __shared__ __attribute__((aligned(16))) float dEs[128 * BB_MAXL];      // [r][L] upstream gradient (rows >= B zero)
+  __shared__ __attribute__((aligned(16))) float dEs[128 * BB_DLD];       // [r][L] upstream gradient (rows >= B zero); later da [r][33]
   __shared__ __attribute__((aligned(16))) float T[BB_COLS][132];         // [c][r]: block output, later dy
-  __shared__ float Ws[BB_MAXL][BB_COLS];                                  // one 64-row chunk of an upstream weight
+  __shared__ __attribute__((aligned(16))) float Wt[BB_COLS][BB_WLD];     // one 64-row chunk of an upstream weight, transposed
   __shared__ float red[BB_RG][BB_COLS];
   __shared__ double dred[BB_T / 64];
   const int t = threadIdx.x, cx = t & 31, ry = t >> 5;
@@ -179,11 +184,22 @@ __device__ __forceinline__ void bb_body(const BlockBwdArgs& a, int blk) {
     T[cx][r0 + i] = ov[i];
   }
   // ---- da = sum_k dE_k . W_k (this thread: 16 rows x its column), and the small Linears' weight/bias gradients
+  f32x4 dacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  bb_upstream(a.dE[0], a.ldE[0], a.W[0], a.gW[0], a.gb[0], a.L[0], B, a.C, c0, cc, dEs, T, Wt, dacc, a.accumulate, blk);
+  if (a.n_up > 1) bb_upstream(a.dE[1], a.ldE[1], a.W[1], a.gW[1], a.gb[1], a.L[1], B, a.C, c0, cc, dEs, T, Wt, dacc, a.accumulate, blk);
+  // da from the MFMA result layout to this thread's (column cx, rows r0 ..) through the dE stage (dead now)
   float da[BB_RPT];
+  {
+    const int lane = t & 63, w = t >> 6;
+    __syncthreads();                                 // every wave is done reading dEs
 #pragma unroll
-  for (int i = 0; i < BB_RPT; ++i) da[i] = 0.f;
-  bb_upstream(a.dE[0], a.ldE[0], a.W[0], a.gW[0], a.gb[0], a.L[0], B, a.C, c0, cc, r0, dEs, T, Ws, da, a.accumulate, blk);
-  if (a.n_up > 1) bb_upstream(a.dE[1], a.ldE[1], a.W[1], a.gW[1], a.gb[1], a.L[1], B, a.C, c0, cc, r0, dEs, T, Ws, da, a.accumulate, blk);
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dEs[(16 * w + 4 * (lane >> 4) + i) * 33 + 16 * nb + (lane & 15)] = dacc[nb][i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < BB_RPT; ++i) da[i] = dEs[(r0 + i) * 33 + cx];
+  }
   // ---- gate (ReLU + dropout in one test on the saved output) and BatchNorm backward (fx_bn_bwd_kernel's expressions)
   const float gate_scale = 1.0f / (1.0f - a.drop_p);
   float s1 = 0.f, s2 = 0.f;
@@ -243,30 +259,32 @@ __device__ __forceinline__ void bb_body(const BlockBwdArgs& a, int blk) {
       *reinterpret_cast<bf16x8*>(a.dyT_lo + (long)(c0 + col) * a.ldt + rb) = lo;
     }
   }
-  if (a.gram_x) {      // <dY_blk dY_blk^T, X X^T>: thread owns the 4 x 8 block (i0.., j0..) of the B x B product
-    const int i0 = (t >> 4) * 4, j0 = (t & 15) * 8;
-    float p[4][8];
+  if (a.gram_x) {      // <dY_blk dY_blk^T, X X^T>: wave w owns rows 16 w .. 16 w + 15 of the B x B product (8 blocks of 16 x 16)
+    const int lane = t & 63, w = t >> 6, l15 = lane & 15, kq = lane >> 4;
+    f32x4 av[BB_COLS / 16];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int q = 0; q < BB_COLS / 16; ++q)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) p[i][j] = 0.f;
-#pragma unroll 4
-    for (int col = 0; col < BB_COLS; ++col) {
-      const f32x4 vi = *reinterpret_cast<const f32x4*>(&T[col][i0]);
-      const f32x4 vj0 = *reinterpret_cast<const f32x4*>(&T[col][j0]), vj1 = *reinterpret_cast<const f32x4*>(&T[col][j0 + 4]);
-      const float vj[8] = {vj0[0], vj0[1], vj0[2], vj0[3], vj1[0], vj1[1], vj1[2], vj1[3]};
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) p[i][j] = fmaf(vi[i], vj[j], p[i][j]);
-    }
+      for (int e = 0; e < 4; ++e) av[q][e] = T[16 * q + 4 * kq + e][16 * w + l15];
     double acc = 0.0;
+#pragma unroll 2
+    for (int bj = 0; bj < 8; ++bj) {
+      f32x4 p = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (i0 + i < B) {
+      for (int q = 0; q < BB_COLS / 16; ++q) {
+        f32x4 bv;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (j0 + j < B) acc += (double)p[i][j] * (double)a.gram_x[(long)(i0 + i) * B + j0 + j];
+        for (int e = 0; e < 4; ++e) bv[e] = T[16 * q + 4 * kq + e][16 * bj + l15];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p = BB_MFMA(av[q][e], bv[e], p);
+      }
+      const int j = 16 * bj + l15;
+      if (j < B) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int ii = 16 * w + 4 * kq + i;
+          if (ii < B) acc += (double)p[i] * (double)a.gram_x[(long)ii * B + j];
+        }
       }
     }
     acc = fx_wave_sum_d(acc);

