@@ -1412,6 +1412,21 @@ class StepPlan:
         self._small_bwd(rb, dvcat, dlv, vcat, "FC_log_var.weight", "FC_log_var.bias", need_dx=not enc_frozen)
         if enc_frozen:
             return
+        if self.group_bwd and 1 < n <= 4 and self._block_ok(B, 1):
+            # every encoder's tail backward in ONE launch (fx_block_bwd_group, two upstream Linears each): no fork / join on the chain
+            self._bb_group = ([], [])
+            for i in range(n):
+                p = f"encoders.{i}"
+                dm, dv = dmcat[:, i * L:(i + 1) * L], dvcat[:, i * L:(i + 1) * L]
+                self._tail_bwd(rb, [(dm, p + ".FC_mean.weight", p + ".FC_mean.bias"), (dv, p + ".FC_var.weight", p + ".FC_var.bias")],
+                               self.X[enc[i]], self.buf[p + "/y"], hs[i], (p + ".hidden_layers.2", p), p + ".hidden_layers.0.bias",
+                               p + ".hidden_layers.0.weight", ACT_LEAKY, ACT_NONE, 0.0)
+            descs, post = self._bb_group
+            self._bb_group = None
+            ops.block_bwd_group(rb, descs, B, ACT_LEAKY, ACT_NONE, 0.0)
+            for f in post:
+                f()
+            return
         enc_par = vae_par and self._block_ok(B, 1)
         if enc_par:
             _par_ctx = rb.parallel(n)
