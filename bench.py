@@ -242,8 +242,14 @@ def main():
             torch.cuda.empty_cache()
             from flexynesis_amd.sweep import run_cfg5
             with _stdout_to_stderr():
+                # one untimed single-epoch trial per rank first: a process's first model pays torch's RNG / elementwise kernel
+                # loads and the host-loop's first-call costs (~0.25 s, profiles/r03_trial_breakdown.md "trial 0"), which a real
+                # sweep of tens of trials per GPU amortises and an 8-trial leg would report as 10-15 % of its wall time
+                run_cfg5(dev, n_trials=world, epochs=1, features=cfg["layers"][0][1] if a.features else 20000, samples=2048,
+                         seed=1, keep_winner=False)
                 sweep = run_cfg5(dev, n_trials=a.sweep_trials_per_gpu * world, epochs=3,
                                  features=cfg["layers"][0][1] if a.features else 20000, samples=2048, seed=0)
+                sweep["untimed_warmup_trials_per_gpu"] = 1
         except Exception as e:     # reported, never fatal for the headline number
             sweep = {"error": repr(e)}
 
