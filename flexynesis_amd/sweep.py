@@ -11,12 +11,12 @@ state_dict is broadcast.  Rank 0 prints one JSON line with the result table summ
 """
 from __future__ import annotations
 
-from typing import Optional
-
 import argparse
 import json
 import os
+import threading
 import time
+from typing import Optional
 
 import numpy as np
 import torch
@@ -50,7 +50,6 @@ def run_cfg5(dev, n_trials: int = 64, epochs: int = 3, features: int = 20000, sa
     ``in_flight`` trials run concurrently on every GPU (host threads with their own streams, eager launches:
     trials.run_units); ``use_graph`` (default: only with one trial in flight) replays hipGraphs inside a trial.
     Returns the summary dict (identical on every rank)."""
-    import threading
     use_graph = (int(in_flight) <= 1) if use_graph is None else bool(use_graph)
     if int(in_flight) > 1 and use_graph:
         raise ValueError("trials in flight on several threads must not capture hipGraphs: use_graph=False")

@@ -15,7 +15,9 @@ BatchNorm batch statistics, i.e. break parity with the reference.
 """
 from __future__ import annotations
 
+import contextlib
 import math
+import threading
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -194,8 +196,6 @@ def run_units(n: int, unit_fn: Callable[[int], Tuple[float, int, Optional[dict]]
     then run while the other's HBM-bound dW + Adam launches hold the memory system: +10 % aggregate samples/s at two units
     in flight on cfg5-style trials (scripts/bench_two_trials.py); the units' results are unchanged (every unit is seeded
     on its own and deterministic)."""
-    import contextlib
-    import threading
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     costs = list(costs) if costs is not None else [1.0] * n
