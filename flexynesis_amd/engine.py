@@ -1328,15 +1328,17 @@ class StepPlan:
         ops.reparam(rf, z, mean, logv, eps=eps, eps_out=eps_used, seed=seed, offset=off, ctrl=st.ctrl)
         self.embeddings = z
         self.mean = mean
-        dz = self._new("dz", B, L)
+        # dz arrives in 1 + nd shares added in this order at the start of the backward tape: the heads' (written by the heads
+        # launch, or zero-filled), then each decoder's MMD term (supervised_vae.py:309-313) computed inside that decoder's branch
+        dzs = self._new("dz_shares", 1 + nd, B * L)
+        dz = dzs[0].view(B, L)
         lv_mmd = self._logvar("mmd_loss")
         hd, logits = [], []
-        row_sums = self._new("mmd_rows", 2 * (MMD_PRIOR + B))
         # dz must start from zero each step: the first head's data-grad GEMM overwrites it (accumulate=False),
         # so heads go FIRST in the backward tape and the MMD rows kernel (+=) is emitted after them; without heads an
         # explicit zero-fill takes their place.
         self.xhat = [self._new(f"xhat.{i}", B, spec.layers[dec[i]][1]) for i in range(nd)] if not self.train else None
-        priors, rec_parts = [], []
+        priors, rec_parts, row_sums = [], [], []
         with rf.parallel(nd if vae_par else 1) as par:      # one graph branch per decoder
             for i in range(nd):
                 if vae_par:
@@ -1353,6 +1355,12 @@ class StepPlan:
                     seed, off = self._rng()
                     ops.fill_normal(rf, pr, seed, off, ctrl=st.ctrl)
                 priors.append(pr)
+                rs = self._new(f"mmd_rows.{i}", 2 * (MMD_PRIOR + B))
+                row_sums.append(rs)
+                dzm = dzs[1 + i].view(B, L)
+                if self.train:
+                    ops.fill(rf, dzm, 0.0)
+                ops.mmd_rows(rf, rs, dzm if self.train else None, pr, z, lv_mmd, 1.0 / nd)
                 h = self._hidden_fwd(rf, p, z, B)
                 hd.append(h)
                 lg = self._new(p + "/logits", B, F)
@@ -1378,8 +1386,7 @@ class StepPlan:
         for i in range(nd):       # mmd_loss = mean over the reconstructed layers (supervised_vae.py:309-313)
             F = spec.layers[dec[i]][1]
             nblk = int(ops.lib.fx_recon_blocks(B * F))
-            ops.mmd_rows(rf, row_sums, dz if self.train else None, priors[i], z, lv_mmd, 1.0 / nd)
-            ops.mmd_finalize(rf, self.loss_vec[0:1], row_sums, MMD_PRIOR, B, rec_parts[i], nblk, float(B * F), 1.0 / nd, i > 0)
+            ops.mmd_finalize(rf, self.loss_vec[0:1], row_sums[i], MMD_PRIOR, B, rec_parts[i], nblk, float(B * F), 1.0 / nd, i > 0)
         self._total(rf)
         if not self.train:
             if self.attribution:
@@ -1388,19 +1395,40 @@ class StepPlan:
         # ---- backward through decoders (dlogits live in logits[i]) -> dz, then latent, then encoders.  One graph branch per
         # decoder (the narrow launches around one decoder's FC_output products run beside the other's); their shares of dz
         # are added on the main chain afterwards, in decoder order.
+        dz_sum = self._new("dz", B, L)
+        ops.reduce_slabs(rb, dz_sum, dzs, None, 1 + nd)          # heads + MMD terms, in share order
+        dz = dz_sum
         dhs = []
+        # One graph branch per decoder.  Each holds the data-gradient product through FC_output (a full read of the weight:
+        # HBM-bound, two of them side by side take as long as one after the other) with the hidden layer's backward behind it, and
+        # ~90 us of narrow launches that only the optimiser tape needs of this weight (Gram norm share = two B x B products +
+        # their Hadamard sum, transposed operand splits, bias gradient).  Decoder 0 reads its weight FIRST and prepares afterwards,
+        # the others prepare first: every branch's narrow work then runs under another branch's weight read.  (As extra branches
+        # the preparation cost more in fork / join edges than it hid: 2.93 vs 2.89 ms; behind an event with the rest of the
+        # backward as a further branch the runtime's four hardware queues serialised it again.)
         with rb.parallel(nd if vae_par else 1) as par:
             for i in range(nd):
-                if vae_par:
-                    self._enter_branch(par, i)
                 p = f"decoders.{i}"
                 dh = self._new(p + "/dh", B, st.shapes[p + ".hidden_layers.0.weight"][0])
                 dhs.append(dh)
-                self._weight_grad(rb, p + ".FC_output.weight", logits[i], hd[i])
-                ops.colsum(rb, st.g(p + ".FC_output.bias"), logits[i])
+                if vae_par:
+                    self._enter_branch(par, i)
+                prep_first = vae_par and i > 0
+                if prep_first:
+                    self._weight_grad(rb, p + ".FC_output.weight", logits[i], hd[i])
+                    ops.colsum(rb, st.g(p + ".FC_output.bias"), logits[i])
                 self._lin_bwd_x(rb, dh, logits[i], p + ".FC_output.weight")
                 self._hidden_bwd(rb, p, z, dh)
+                if not prep_first:
+                    self._weight_grad(rb, p + ".FC_output.weight", logits[i], hd[i])
+                    ops.colsum(rb, st.g(p + ".FC_output.bias"), logits[i])
         self._branch = 0
+        self._svae_bwd_latent(rb, enc, hs, mcat, vcat, dz, dhs, eps_used, n, nd, L, B)
+
+    def _svae_bwd_latent(self, rb, enc, hs, mcat, vcat, dz, dhs, eps_used, n, nd, L, B):
+        """dz shares of the decoders (in decoder order), the reparameterisation, the top-level FC_mean / FC_log_var and the
+        encoder tails (supervised_vae.py:172-200 backwards)."""
+        st = self.store
         for i in range(nd):
             ops.linear_bwd_x(rb, dz, dhs[i], st.p(f"decoders.{i}.hidden_layers.0.weight"), self.ws, accumulate=True)
         # z = mean + log_var * eps
@@ -1412,46 +1440,35 @@ class StepPlan:
         self._small_bwd(rb, dvcat, dlv, vcat, "FC_log_var.weight", "FC_log_var.bias", need_dx=not enc_frozen)
         if enc_frozen:
             return
-        if self.group_bwd and 1 < n <= 4 and self._block_ok(B, 1):
-            # every encoder's tail backward in ONE launch (fx_block_bwd_group, two upstream Linears each): no fork / join on the chain
-            self._bb_group = ([], [])
+        if not self._block_ok(B, 1):
             for i in range(n):
                 p = f"encoders.{i}"
                 dm, dv = dmcat[:, i * L:(i + 1) * L], dvcat[:, i * L:(i + 1) * L]
-                self._tail_bwd(rb, [(dm, p + ".FC_mean.weight", p + ".FC_mean.bias"), (dv, p + ".FC_var.weight", p + ".FC_var.bias")],
-                               self.X[enc[i]], self.buf[p + "/y"], hs[i], (p + ".hidden_layers.2", p), p + ".hidden_layers.0.bias",
-                               p + ".hidden_layers.0.weight", ACT_LEAKY, ACT_NONE, 0.0)
+                dh = self._new(p + "/dh", B, st.shapes[p + ".hidden_layers.0.weight"][0])
+                self._weight_grad(rb, p + ".FC_mean.weight", dm, hs[i])
+                ops.colsum(rb, st.g(p + ".FC_mean.bias"), dm)
+                self._weight_grad(rb, p + ".FC_var.weight", dv, hs[i])
+                ops.colsum(rb, st.g(p + ".FC_var.bias"), dv)
+                ops.linear_bwd_x(rb, dh, dm, st.p(p + ".FC_mean.weight"), self.ws)
+                ops.linear_bwd_x(rb, dh, dv, st.p(p + ".FC_var.weight"), self.ws, accumulate=True)
+                self._hidden_bwd(rb, p, self.X[enc[i]], dh)
+            return
+        # every encoder's tail backward in ONE launch (fx_block_bwd_group, two upstream Linears each); a single encoder: fx_block_bwd
+        group = self.group_bwd and 1 < n <= 4
+        if group:
+            self._bb_group = ([], [])
+        for i in range(n):
+            p = f"encoders.{i}"
+            dm, dv = dmcat[:, i * L:(i + 1) * L], dvcat[:, i * L:(i + 1) * L]
+            self._tail_bwd(rb, [(dm, p + ".FC_mean.weight", p + ".FC_mean.bias"), (dv, p + ".FC_var.weight", p + ".FC_var.bias")],
+                           self.X[enc[i]], self.buf[p + "/y"], hs[i], (p + ".hidden_layers.2", p), p + ".hidden_layers.0.bias",
+                           p + ".hidden_layers.0.weight", ACT_LEAKY, ACT_NONE, 0.0)
+        if group:
             descs, post = self._bb_group
             self._bb_group = None
             ops.block_bwd_group(rb, descs, B, ACT_LEAKY, ACT_NONE, 0.0)
             for f in post:
                 f()
-            return
-        enc_par = vae_par and self._block_ok(B, 1)
-        if enc_par:
-            _par_ctx = rb.parallel(n)
-            par = _par_ctx.__enter__()
-        for i in range(n):
-            if enc_par:
-                self._enter_branch(par, i)
-            p = f"encoders.{i}"
-            dm, dv = dmcat[:, i * L:(i + 1) * L], dvcat[:, i * L:(i + 1) * L]
-            if self._block_ok(B, 1):
-                self._tail_bwd(rb, [(dm, p + ".FC_mean.weight", p + ".FC_mean.bias"), (dv, p + ".FC_var.weight", p + ".FC_var.bias")],
-                               self.X[enc[i]], self.buf[p + "/y"], hs[i], (p + ".hidden_layers.2", p), p + ".hidden_layers.0.bias",
-                               p + ".hidden_layers.0.weight", ACT_LEAKY, ACT_NONE, 0.0)
-                continue
-            dh = self._new(p + "/dh", B, st.shapes[p + ".hidden_layers.0.weight"][0])
-            self._weight_grad(rb, p + ".FC_mean.weight", dm, hs[i])
-            ops.colsum(rb, st.g(p + ".FC_mean.bias"), dm)
-            self._weight_grad(rb, p + ".FC_var.weight", dv, hs[i])
-            ops.colsum(rb, st.g(p + ".FC_var.bias"), dv)
-            ops.linear_bwd_x(rb, dh, dm, st.p(p + ".FC_mean.weight"), self.ws)
-            ops.linear_bwd_x(rb, dh, dv, st.p(p + ".FC_var.weight"), self.ws, accumulate=True)
-            self._hidden_bwd(rb, p, self.X[enc[i]], dh)
-        if enc_par:
-            _par_ctx.__exit__(None, None, None)
-            self._branch = 0
 
     def _build_optimizer(self, nxt: Optional["StepPlan"] = None):
         """clip_grad_norm_(1.0) + Adam over every parameter (main.py:216-217, direct_pred.py:143)."""
