@@ -7,8 +7,10 @@
 // pure launch latency: 3 forward + 5 backward dependent launches per head at ~5-8 us each on the critical path
 // between the wide forward and the dW+Adam kernels.  Here one workgroup per head does the whole forward through
 // LDS, and one workgroup does the whole backward of all heads (sequentially, so the embedding gradient is summed in
-// a fixed order: deterministic, no atomics).  Arithmetic is plain fp32 FMA with the same expressions as
-// fx_bn_act_fwd/bwd (same Philox stream for the dropout mask), so the fused and unfused paths agree to rounding.
+// a fixed order: deterministic, no atomics).  Arithmetic is fp32 with the same expressions as fx_bn_act_fwd/bwd (same
+// Philox stream for the dropout mask), so the fused and unfused paths agree to rounding; since round 3 the two
+// [B, L]-sized products (layer_1 forward, the embedding gradient of fx_heads_step) run on the exact-fp32 matrix pipe
+// (v_mfma_f32_16x16x4_f32) with their operands fetched straight from memory / the LDS tiles.
 #include "fx_common.h"
 #include "fx_loss_dev.h"
 
@@ -116,33 +118,78 @@ __device__ __forceinline__ void heads_mask4(unsigned long long seed, unsigned lo
 // All per-column loops run over the PADDED width HS = 32 with zero-padded parameters, so they have compile-time trip
 // counts and no predicates; only global stores are predicated on the true width.
 struct HeadsFwdLds {
-  Tile xs;                       // one 32-column chunk of the embedding
   Tile ys;                       // layer_1 output, then the block output (columns >= S stay zero)
-  __attribute__((aligned(16))) float W1s[HS * HL];   // TRANSPOSED [L][32], columns >= S zero
   float W2s[HC * HS];            // [C][32], columns >= S zero
   float part[8][32];
   float stat[5][32];             // mean, invstd, gamma, beta, layer_1 bias (zero padded)
 };
 
 __device__ __forceinline__ void heads_fwd_body(const HeadsArgs& a, const FxHeadDesc& h, HeadsFwdLds& F, bool update_running = true) {
-  Tile& xs = F.xs;
   Tile& ys = F.ys;
-  float* W1s = F.W1s;
   float* W2s = F.W2s;
   float (*part)[32] = F.part;
   float (*stat)[32] = F.stat;
   const int t = threadIdx.x, r = t & 127, hf = t >> 7, col = t & 31, rg = t >> 5;
   const int S = h.S, C = h.C, B = a.B, L = a.L;
   const int s0 = hf * (HS / 2);
-  // W1s[l][s] = W1[s][l] (zero for s >= S): the 16 weights one thread needs per l are 4 x ds_read_b128.
-  // Thread (l = t & 127, row pair t >> 7): 16 passes cover the 32 padded rows, coalesced over l, no integer division.
-  float vw1[HS / 2];
-  {
-    const int l_ = t & 127;
+  // ---- layer_1 on the exact-fp32 matrix pipe (v_mfma_f32_16x16x4_f32): y1[r, s] = b1[s] + sum_l x[r, l] W1[s, l].
+  // Operand A: lane (m = lane & 15, kq = lane >> 4) supplies x[row m][k], operand B: lane (n = lane & 15, kq) supplies
+  // W1[s = n][k]; a lane fetches four consecutive k = 16 q + 4 kq + e straight from memory (x rows and W1 rows are both
+  // contiguous in k) and instruction e uses element e on both sides.  Wave w owns rows 32 w .. 32 w + 31 (two row blocks)
+  // x the 32 padded hidden columns (two column blocks); the result lands in the LDS tile ys for the BatchNorm phases.
+  typedef float hf4 __attribute__((ext_vector_type(4)));
+  const int lane = t & 63, wv_ = t >> 6, l15 = lane & 15, kq = lane >> 4;
+  hf4 xa[2][HL / 16], wb[2][HL / 16];
+  const int nq = (L + 15) >> 4;
+  // one 16-byte load per operand fragment when the rows allow it (L % 16 == 0, 16-byte aligned rows: the engine's embeddings),
+  // else four clamped scalar loads
+  const bool vec = (L & 15) == 0 && (a.ldx & 3) == 0 && ((((uintptr_t)a.x) | ((uintptr_t)h.W1)) & 15) == 0;
+  if (vec) {
 #pragma unroll
-    for (int i = 0; i < HS / 2; ++i) {
-      const int s_ = (t >> 7) + 2 * i;
-      vw1[i] = h.W1[(long)min(s_, S - 1) * L + min(l_, L - 1)];
+    for (int q = 0; q < HL / 16; ++q) {
+      if (q < nq) {
+        const int k = 16 * q + 4 * kq;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          const int rr = 32 * wv_ + 16 * rb + l15;
+          xa[rb][q] = *reinterpret_cast<const hf4*>(a.x + (long)min(rr, B - 1) * a.ldx + k);
+        }
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) wb[cb][q] = *reinterpret_cast<const hf4*>(h.W1 + (long)min(16 * cb + l15, S - 1) * L + k);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < HL / 16; ++q) {
+      if (q < nq) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+          if (32 * wv_ + 16 * rb + l15 >= B) xa[rb][q] = hf4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+          if (16 * cb + l15 >= S) wb[cb][q] = hf4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < HL / 16; ++q) {
+      if (q < nq) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = 16 * q + 4 * kq + e, kc = min(k, L - 1);
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb) {
+            const int rr = 32 * wv_ + 16 * rb + l15;
+            const float v = a.x[(long)min(rr, B - 1) * a.ldx + kc];
+            xa[rb][q][e] = (rr < B && k < L) ? v : 0.f;
+          }
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            const int sc = 16 * cb + l15;
+            const float v = h.W1[(long)min(sc, S - 1) * L + kc];
+            wb[cb][q][e] = (sc < S && k < L) ? v : 0.f;
+          }
+        }
+      }
     }
   }
   {
@@ -165,60 +212,39 @@ __device__ __forceinline__ void heads_fwd_body(const HeadsArgs& a, const FxHeadD
     stat[3][t] = t < S ? b_ : 0.f;
     stat[4][t] = t < S ? b1_ : 0.f;
   }
-  {
-    const int l_ = t & 127;
-#pragma unroll
-    for (int i = 0; i < HS / 2; ++i) {
-      const int s_ = (t >> 7) + 2 * i;
-      if (l_ < L) W1s[l_ * HS + s_] = s_ < S ? vw1[i] : 0.f;
-    }
-  }
   __syncthreads();
-  // ---- layer_1: y1[r, s] = b1[s] + sum_l x[r, l] W1[s, l]; each thread owns one row and 16 of the 32 padded columns
-  float acc[HS / 2];
+  {
+    hf4 acc[2][2];
 #pragma unroll
-  for (int j = 0; j < HS / 2; ++j) acc[j] = stat[4][s0 + j];
-  // all chunks of the embedding are requested up front (one memory round trip instead of one per chunk)
-  float vx[HL / 32][16];
+    for (int cb = 0; cb < 2; ++cb) {
+      const float b1v = stat[4][16 * cb + l15];
 #pragma unroll
-  for (int ch = 0; ch < HL / 32; ++ch) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int idx = t + 256 * i, rr = min(idx >> 5, B - 1), cc = min(32 * ch + (idx & 31), L - 1);
-      vx[ch][i] = a.x[(long)rr * a.ldx + cc];
+      for (int rb = 0; rb < 2; ++rb) acc[rb][cb] = hf4{b1v, b1v, b1v, b1v};
     }
-  }
 #pragma unroll
-  for (int ch = 0; ch < HL / 32; ++ch) {
-    const int c0 = 32 * ch;
-    if (c0 >= L) break;
-    __syncthreads();
+    for (int q = 0; q < HL / 16; ++q) {
+      if (q < nq) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int idx = t + 256 * i, rr = idx >> 5, cc = idx & 31;
-      xs[rr][cc] = (rr < B && c0 + cc < L) ? vx[ch][i] : 0.f;
-    }
-    __syncthreads();
-    const int lmax = min(32, L - c0);
-    const float4* w4 = reinterpret_cast<const float4*>(W1s + c0 * HS + s0);
-    for (int l = 0; l < lmax; ++l) {
-      const float xv = xs[r][l];
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int q = 0; q < HS / 8; ++q) {
-        const float4 wv = w4[l * (HS / 4) + q];
-        acc[4 * q + 0] = fmaf(xv, wv.x, acc[4 * q + 0]);
-        acc[4 * q + 1] = fmaf(xv, wv.y, acc[4 * q + 1]);
-        acc[4 * q + 2] = fmaf(xv, wv.z, acc[4 * q + 2]);
-        acc[4 * q + 3] = fmaf(xv, wv.w, acc[4 * q + 3]);
+          for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+              acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[rb][q][e], wb[cb][q][e], acc[rb][cb], 0, 0, 0);
       }
     }
-  }
+    // result layout: lane holds rows 4 kq + i (i = 0..3) of the 16 x 16 block, column l15
 #pragma unroll
-  for (int j = 0; j < HS / 2; ++j) ys[r][s0 + j] = (r < B) ? acc[j] : 0.f;
-  if (r < B && h.y1) {
+    for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-    for (int j = 0; j < HS / 2; ++j)
-      if (s0 + j < S) h.y1[(long)r * S + s0 + j] = acc[j];
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int rr = 32 * wv_ + 16 * rb + 4 * kq + i, sc = 16 * cb + l15;
+          const float v = (rr < B && sc < S) ? acc[rb][cb][i] : 0.f;
+          ys[rr][sc] = v;
+          if (rr < B && sc < S && h.y1) h.y1[(long)rr * S + sc] = v;
+        }
   }
   // ---- BatchNorm statistics (two-pass, biased variance for normalisation, unbiased for running_var)
   float mean = 0.f, invstd = 0.f;
@@ -585,7 +611,6 @@ __global__ __launch_bounds__(256) void fx_heads_step_kernel(HeadsStepArgs sa) {
   const FxHeadDesc& h = a.h[hi];
   const int t = threadIdx.x, r = t & 127, hf = t >> 7, col = t & 31, rg = t >> 5;
   const int B = a.B, Ld = a.L, S = h.S, C = h.C;
-  // ================= forward (y1, a1, statistics and out also go to memory: predict / the drop-in path read them) ===
   heads_fwd_body(a, h, U.f, chain_role);
   __syncthreads();                                   // out [B, C] is visible to the whole workgroup
   // ================= loss value + gradient at the head output =================
@@ -649,51 +674,60 @@ __global__ __launch_bounds__(256) void fx_heads_step_kernel(HeadsStepArgs sa) {
   // ---- embedding gradient share: dy1 . W1 (layer_1.weight staged over the dead x-hat)
   const bool want_dx = a.dx != nullptr;
   const bool split = a.n_heads > 1;
-  const int Lh = (Ld + 1) >> 1, l0 = hf * Lh;
-  float accx[HL / 2];
-#pragma unroll
-  for (int j = 0; j < HL / 2; ++j) accx[j] = 0.f;
   if (want_dx) {
+    // dx[r, l] = sum_s dy1[r, s] W1[s, l] on the exact-fp32 matrix pipe: A = dy1 (LDS tile R3, padded hidden columns are
+    // zero), B = layer_1.weight staged as [S][Ld] over the dead x-hat; wave w owns rows 32 w .. 32 w + 31, all column blocks
+    typedef float hf4 __attribute__((ext_vector_type(4)));
     float* W1s = &L.R2[0][0];
-    if (a.dx_accumulate && !split) {
-#pragma unroll
-      for (int j = 0; j < HL / 2; ++j) accx[j] = a.dx[(long)min(r, B - 1) * a.lddx + min(l0 + j, Ld - 1)];
-    }
 #pragma unroll
     for (int i = 0; i < HS * HL / 256; ++i)
       if (t + 256 * i < S * Ld) W1s[t + 256 * i] = vw1[i];
     __syncthreads();
-    if ((Ld & 7) == 0) {                     // 16-byte LDS reads of the (broadcast) weight rows: 4x fewer LDS instructions
-      typedef float hf4 __attribute__((ext_vector_type(4)));
-#define HEADS_DX_LOOP(NV)                                                                    \
-  for (int s = 0; s < S; ++s) {                                                              \
-    const float d = L.R3[r][s];                                                              \
-    const hf4* w4 = reinterpret_cast<const hf4*>(W1s + s * Ld + l0);                         \
-    _Pragma("unroll") for (int j = 0; j < (NV); ++j) {                                       \
-      const hf4 wv = w4[j];                                                                  \
-      accx[4 * j + 0] = fmaf(d, wv[0], accx[4 * j + 0]);                                     \
-      accx[4 * j + 1] = fmaf(d, wv[1], accx[4 * j + 1]);                                     \
-      accx[4 * j + 2] = fmaf(d, wv[2], accx[4 * j + 2]);                                     \
-      accx[4 * j + 3] = fmaf(d, wv[3], accx[4 * j + 3]);                                     \
-    }                                                                                        \
-  }
-      if (Lh <= 32) { HEADS_DX_LOOP(8) } else { HEADS_DX_LOOP(HL / 8) }      // (a thread owns Lh <= 64 columns)
-#undef HEADS_DX_LOOP
-    } else {
-      for (int s = 0; s < S; ++s) {
-        const float d = L.R3[r][s];
-        const float* w = W1s + s * Ld + l0;
+    const int lane = t & 63, wv_ = t >> 6, l15 = lane & 15, kq = lane >> 4;
+    hf4 av[2][HS / 16];
 #pragma unroll
-        for (int j = 0; j < HL / 2; ++j) accx[j] = fmaf(d, w[j], accx[j]);
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int q = 0; q < HS / 16; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) av[rb][q][e] = L.R3[32 * wv_ + 16 * rb + l15][16 * q + 4 * kq + e];
+    float* dst = split ? a.dx_part + (long)hi * B * Ld : a.dx;
+    const long ldd = split ? (long)Ld : a.lddx;
+    const bool add_old = a.dx_accumulate && !split;
+    const int ncb = (Ld + 15) >> 4;
+#pragma unroll
+    for (int cb = 0; cb < HL / 16; ++cb) {
+      if (cb < ncb) {
+        const int cl = 16 * cb + l15, clc = min(cl, Ld - 1);
+        hf4 bv[HS / 16];
+#pragma unroll
+        for (int q = 0; q < HS / 16; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int sr = 16 * q + 4 * kq + e;
+            const float v = W1s[min(sr, S - 1) * Ld + clc];
+            bv[q][e] = (sr < S && cl < Ld) ? v : 0.f;
+          }
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          hf4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int q = 0; q < HS / 16; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rb][q][e], bv[q][e], acc, 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int rr = 32 * wv_ + 16 * rb + 4 * kq + i;
+            if (rr < B && cl < Ld) {
+              float* d = dst + (long)rr * ldd + cl;
+              *d = add_old ? *d + acc[i] : acc[i];
+            }
+          }
+        }
       }
     }
-    if (r < B) {
-      float* dst = split ? a.dx_part + ((long)hi * B + r) * Ld : a.dx + (long)r * a.lddx;
-#pragma unroll
-      for (int j = 0; j < HL / 2; ++j)
-        if (j < Lh && l0 + j < Ld) dst[l0 + j] = accx[j];
-    }
   }
+  const int Lh = (Ld + 1) >> 1, l0 = hf * Lh;      // (the meet below: a thread's rows / columns of the per-head shares)
   // ================= meet: the last workgroup adds the shares in head order and evaluates the total =================
   bool last = true;
   if (split) {
