@@ -630,6 +630,27 @@ __global__ __launch_bounds__(256) void fx_heads_step_kernel(HeadsStepArgs sa) {
   }
 #pragma unroll
   for (int i = 0; i < HS * HL / 256; ++i) vw1[i] = h.W1[min(t + 256 * i, S * Ld - 1)];
+  // weight-gradient role: the B operand of gW1 = dy1^T . x (lane (l = lane & 15, kq): x[16 q + 4 kq + e][column block + l]) is
+  // requested here, two dependent phases before its use; wave w owns column blocks w and w + 4 of the embedding
+  typedef float hf4 __attribute__((ext_vector_type(4)));
+  const int glane = t & 63, gw = t >> 6, gl15 = glane & 15, gkq = glane >> 4;
+  hf4 gx[2][HB / 16];
+  if (!chain_role) {
+#pragma unroll
+    for (int cbi = 0; cbi < 2; ++cbi) {
+      const int cl = 16 * (gw + 4 * cbi) + gl15;
+      if (16 * (gw + 4 * cbi) < Ld) {
+#pragma unroll
+        for (int q = 0; q < HB / 16; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int rr = 16 * q + 4 * gkq + e;
+            const float v = a.x[(long)min(rr, B - 1) * a.ldx + min(cl, Ld - 1)];
+            gx[cbi][q][e] = (rr < B && cl < Ld) ? v : 0.f;
+          }
+      }
+    }
+  }
   float sum_dy, sum_dy_xh, sum_dx;
   heads_bwd_prefix(L, h, B, gate_scale);
   if (!chain_role) {
@@ -651,17 +672,29 @@ __global__ __launch_bounds__(256) void fx_heads_step_kernel(HeadsStepArgs sa) {
   __syncthreads();
   heads_bwd_bn(L, B, vy, sum_dy, sum_dy_xh, sum_dx);
   if (!chain_role) {
-    // ---- layer_1.weight gradient: gW1[s, l] = sum_r dy1[r, s] x[r, l], 32 columns of x at a time through R1
-    for (int c0 = 0; c0 < Ld; c0 += 32) {
-      __syncthreads();
-      heads_stage(L.R1, a.x, a.ldx, B, c0, Ld);
-      __syncthreads();
-      for (int o = t; o < S * 32; o += 256) {
-        const int s = o >> 5, l = o & 31;
-        float g = 0.f;
-#pragma unroll 8
-        for (int rr = 0; rr < HB; ++rr) g = fmaf(L.R3[rr][s], L.R1[rr][l], g);
-        if (c0 + l < Ld) h.gW1[(long)s * Ld + c0 + l] = g;
+    // ---- layer_1.weight gradient on the exact-fp32 matrix pipe: gW1[s, l] = sum_r dy1[r, s] x[r, l]
+    // (A = dy1^T: lane (s = lane & 15, kq) reads R3[16 q + 4 kq + e][s block + s]; B = the x fragments requested above)
+#pragma unroll
+    for (int cbi = 0; cbi < 2; ++cbi) {
+      const int cl = 16 * (gw + 4 * cbi) + gl15;
+      if (16 * (gw + 4 * cbi) < Ld) {
+#pragma unroll
+        for (int sb = 0; sb < HS / 16; ++sb) {
+          hf4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int q = 0; q < HB / 16; ++q) {
+            hf4 av;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) av[e] = L.R3[16 * q + 4 * gkq + e][16 * sb + gl15];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], gx[cbi][q][e], g, 0, 0, 0);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int sr = 16 * sb + 4 * gkq + i;
+            if (sr < S && cl < Ld) h.gW1[(long)sr * Ld + cl] = g[i];
+          }
+        }
       }
     }
     return;
