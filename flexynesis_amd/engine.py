@@ -1722,7 +1722,12 @@ class PipelinedStep:
         # Measured slower (1.313 vs 1.276 ms/step at cfg2): the gather / Gram kernels then compete with the forward chain.
         self.early_gather = bool(a._next_fwd) and os.environ.get("FX_EARLY_GATHER", "0") == "1"
         self.fork_at_mark = int(os.environ.get("FX_FORK_AT_MARK", "2"))       # A/B (see _issue); 0 = after the forward tape (round 2)
-        self.fork_dep_begin = os.environ.get("FX_FORK_DEP_BEGIN", "0") == "1"
+        # The assembly of the next batch depends on fx_step_begin only (the cursor), i.e. it starts beside the first chain
+        # launch -- many workgroups, throughput-bound -- and is over before the one-workgroup-per-head launch, which its memory
+        # traffic slowed from 32 to 43 us: cfg2 -5..9 us per step, cfg3 -60..90, cfg1 -10.  Not for the stacked-rows plans
+        # (triplet): their assembly is 0.4 ms of X X^T products that would run against the wide forwards (5.78 vs 5.75 ms).
+        dep_default = "1" if a.passes == 1 else "0"
+        self.fork_dep_begin = os.environ.get("FX_FORK_DEP_BEGIN", dep_default) == "1"
         self.k = 0                       # plan holding the batch of the next step
         self.done = 0                    # steps issued since prime()
         self.graphs = [None, None]
