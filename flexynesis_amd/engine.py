@@ -662,6 +662,19 @@ class StepPlan:
         else:
             ops.linear_bwd_w(rec, self.store.g(key), dy, x, self.ws)
 
+    def _weight_grad_prep_x(self, rec, key, x):
+        """The pieces of _weight_grad that depend on the layer's INPUT only (X X^T slabs for the Gram norm, the transposed operand
+        split): a caller that has the input long before the output gradient emits them early, where they cost nothing -- the
+        later _weight_grad finds them in the caches."""
+        if self._is_frozen(key) or not (self.fused and key in self.store.big):
+            return
+        if self.clip:
+            self._gram_x_for(rec, x)
+        if self.precision == "bf16x3" and ("T", x.data_ptr()) not in self._split_cache:
+            xt = ops.new_split(x.shape[1], x.shape[0], self.dev)
+            self._split_cache[("T", x.data_ptr())] = xt
+            ops.split_bf16_t(rec, xt[0], xt[1], x)
+
     def _block_ok(self, rows, passes) -> bool:
         """fx_block_bwd covers one BatchNorm pass of at most 128 rows (everything but the triplet network's stacked passes)."""
         return self.block_bwd and self.train and passes == 1 and rows <= 128
@@ -1363,6 +1376,9 @@ class StepPlan:
                 ops.mmd_rows(rf, rs, dzm if self.train else None, pr, z, lv_mmd, 1.0 / nd)
                 h = self._hidden_fwd(rf, p, z, B)
                 hd.append(h)
+                if self.train and vae_par and i > 0 and os.environ.get("FX_VAE_PREP_X", "1") != "0":
+                    # (beside decoder 0's FC_output product; decoder 0 itself heads the critical chain and prepares in the backward)
+                    self._weight_grad_prep_x(rf, p + ".FC_output.weight", h)
                 lg = self._new(p + "/logits", B, F)
                 logits.append(lg)
                 self._lin_fwd(rf, lg, h, p + ".FC_output.weight", p + ".FC_output.bias")
