@@ -1027,11 +1027,6 @@ class StepPlan:
                     self._mlp_fwd(rf, f"encoders.{i}", self.X[i], ecat[:, i * L:(i + 1) * L], R, self.passes,
                                   [f"encoders.{i}{t}" for t in tags])
             self._branch = 0
-            # Stacked-rows plans (triplet): the next batch's assembly is 0.4 ms of work (X X^T of 3 B rows per modality) and was
-            # the LAST thing to finish before the optimiser tape when it forked after the whole forward tape.  It may start as soon
-            # as the last wide forward has been launched (the event the staggering records behind it): beside the narrow forward
-            # tails and the heads, not beside the wide forwards (PipelinedStep._issue).
-            self.assembly_after_ev = self._last_wide_ev if (self.passes > 1 and self.train) else None
             if n > 1:
                 emb = self._new("emb", R, L)
                 self._small_fwd(rf, emb, ecat, "fusion_block.weight", "fusion_block.bias")
@@ -1747,7 +1742,6 @@ class PipelinedStep:
         # launch -- many workgroups, throughput-bound -- and is over before the one-workgroup-per-head launch, which its memory
         # traffic slowed from 32 to 43 us: cfg2 -5..9 us per step, cfg3 -60..90, cfg1 -10.  Not for the stacked-rows plans
         # (triplet): their assembly is 0.4 ms of X X^T products that would run against the wide forwards (5.78 vs 5.75 ms).
-        self.fork_after_wide = os.environ.get("FX_FORK_AFTER_WIDE", "1") != "0"      # stacked-rows plans: see assembly_after_ev
         dep_default = "1" if a.passes == 1 else "0"
         self.fork_dep_begin = os.environ.get("FX_FORK_DEP_BEGIN", dep_default) == "1"
         self.k = 0                       # plan holding the batch of the next step
@@ -1789,8 +1783,7 @@ class PipelinedStep:
             if used:
                 return
             if name is None:
-                after = point[0] if point else (getattr(cur, "assembly_after_ev", None) if self.fork_after_wide else None)
-                used.extend(nxt.t_gather.fork_from(main, after=after))
+                used.extend(nxt.t_gather.fork_from(main, after=point[0] if point else None))
             elif name == "fork_assembly" and mode == 1:
                 used.extend(nxt.t_gather.fork_from(main))  # fork: batch assembly of step t+1 ...
             elif name == "fork_assembly" and 2 <= mode <= 4 and not point:
