@@ -897,6 +897,7 @@ class StepPlan:
             # more parallel branches alias onto the runtime's 4 queues and end up behind each other, profiles/r03_*)
             gbr = self.branches and os.environ.get("FX_ASSEMBLY_BRANCHES", "0") != "0"
             grouped = self._assembly_groupable(first_w, enc_pos)
+            self.assembly_grouped = grouped
             gpar = rg.parallel(len(spec.layers) if (gbr and not grouped) else 1)
             gpar.__enter__()
             if grouped:                      # (inside the tape's single segment: PipelinedStep issues it as one detached fork)
@@ -1742,7 +1743,9 @@ class PipelinedStep:
         # launch -- many workgroups, throughput-bound -- and is over before the one-workgroup-per-head launch, which its memory
         # traffic slowed from 32 to 43 us: cfg2 -5..9 us per step, cfg3 -60..90, cfg1 -10.  Not for the stacked-rows plans
         # (triplet): their assembly is 0.4 ms of X X^T products that would run against the wide forwards (5.78 vs 5.75 ms).
-        dep_default = "1" if a.passes == 1 else "0"
+        # (only for plans whose assembly is the grouped one -- four launches without split-K scratch, the configurations the
+        # full-size parity tests and the bench run; every other plan keeps the long-tested fork behind the forward tape)
+        dep_default = "1" if (a.passes == 1 and getattr(a, "assembly_grouped", False)) else "0"
         self.fork_dep_begin = os.environ.get("FX_FORK_DEP_BEGIN", dep_default) == "1"
         self.k = 0                       # plan holding the batch of the next step
         self.done = 0                    # steps issued since prime()
