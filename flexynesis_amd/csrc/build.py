@@ -15,8 +15,10 @@ SOURCES = ["fx_gemm.hip", "fx_gemm_bf16x3.hip", "fx_dw_adam_fwd.hip", "fx_norm_a
 HEADERS = ["fx_common.h", "fx_reduce.h", "fx_small.h", "fx_loss_dev.h"]
 # packed fp32 VALU ops are off: a v_pk_fma_f32 whose low source register was written by the preceding VALU instructions drops
 # that term in lanes 48..63 when another wave on the SIMD streams ds_read_b128 results into back-to-back MFMAs (measured:
-# scripts/ldsdma_probe.hip, DESIGN.md "packed fp32 hazard") -- i.e. whenever a small fp32 kernel shares a CU with one of the
-# MFMA kernels, which the step's side branches and trials in flight make routine
+# scripts/pkfma_hazard_probe.hip) -- i.e. whenever a small fp32 kernel shares a CU with one of the
+# MFMA kernels, which the step's side branches and trials in flight make routine.  (hipcc hands -Xclang options to the host
+# pass too, which prints "'-packed-fp32-ops' is not a recognized feature for this target (ignoring feature)" once per file:
+# harmless; -Xarch_device does not accept -Xclang.)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 OUT = os.path.join(HERE, "libfxhip.so")
