@@ -42,6 +42,7 @@ CONFIGS = {
     "cfg4": dict(model="MultiTripletNetwork", layers=[("gex", 30000), ("cnv", 30000), ("meth", 30000)],
                  variables=[("c", "categorical", 4)], surv=(None, None), n_samples=2048),
 }
+PMC_FILE = "r04_pmc_traffic_cfg2.json"      # rocprofv3 --pmc passes of this command, this round, this kernel (scripts/profile_round.sh)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
@@ -81,9 +82,116 @@ def parse():
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--features", type=int, default=0, help="override the per-layer feature count (shape experiments; "
                     "the headline metric is quoted on the default)")
+    ap.add_argument("--repeats", type=int, default=25, help="after the timed region: this many more windows of --steps steps, "
+                    "reported as median / min / max (0 = skip)")
+    ap.add_argument("--no-other", action="store_true", help="skip the short legs of the other BASELINE configs / modes")
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "f32"],
                     help="wide-layer contraction: split-bf16 MFMA with fp32 accumulate (default) or exact fp32 MFMA")
     return ap.parse_args()
+
+
+def _engine_leg(config, B, dev, precision, steps, warmup, lr, rank=0, features=0):
+    """One engine configuration timed like the headline: hipGraph replay of PipelinedStep, per-epoch device reshuffle inside the
+    timed region, `steps` steps after `warmup`.  Returns (record, pipe, store, reshuffle) -- the caller deletes what it does
+    not keep."""
+    from flexynesis_amd.arch import ArchSpec
+    from flexynesis_amd.data import synthetic_cohort
+    from flexynesis_amd.engine import ParamStore, PipelinedStep
+    cfg = dict(CONFIGS[config])
+    if features:
+        cfg["layers"] = [(n, features) for n, _ in cfg["layers"]]
+    spec = ArchSpec(cfg["model"], cfg["layers"], 64, 0.25, 16, cfg["variables"], cfg["surv"][0], cfg["surv"][1], True)
+    cohort = synthetic_cohort(cfg["layers"], cfg["n_samples"], dev, seed=1234 + rank)
+    n_train = cfg["n_samples"] - int(cfg["n_samples"] * 0.2)
+    rows_per_batch = B * (3 if cfg["model"] == "MultiTripletNetwork" else 1)
+    n_batches = max(n_train // rows_per_batch, 1)
+    torch.manual_seed(1000 + rank)
+    store = ParamStore(spec, dev, materialize_big_grads=False)
+    pipe = PipelinedStep(store, B, cohort=cohort, n_batches=n_batches, seed=17 + rank, precision=precision)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(4321 + rank)
+
+    def reshuffle():
+        perm = torch.randperm(n_train, generator=gen, device=dev)
+        pipe.idx.copy_(perm[:n_batches * rows_per_batch])
+
+    reshuffle()
+    pipe.prime()
+    pipe.step(lr)
+    pipe.capture(lr)
+
+    def run(k):
+        for _ in range(k):
+            if pipe.epoch_end_next():
+                reshuffle()
+            pipe.replay()
+
+    run(warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    P = store.n_params()
+    sumF = sum(F for _, F in cfg["layers"])
+    k_reads = 3 if cfg["model"] == "MultiTripletNetwork" else 1
+    bytes_step = 28.0 * P + 4.0 * k_reads * B * sumF
+    ms = 1e3 * dt / steps
+    losses = pipe.losses()
+    rec = {"workload": f"{config}: {cfg['model']} {len(cfg['layers'])} x {cfg['layers'][0][1]} features, B={B}, {precision}, hipGraph replay",
+           "samples_per_s": round(steps * B / dt, 1), "ms_per_step": round(ms, 4), "steps": steps,
+           "step_hbm_frac_of_8TBs": round(bytes_step / (ms * 1e-3) / 8e12, 4), "params": P, "launches_per_step": pipe.n_launches(),
+           "loss_finite": all(v == v and abs(v) != float("inf") for v in losses.values())}
+    return rec, pipe, store, run
+
+
+def _dropin_leg(dev, kind, steps, warmup, B=128):
+    """The unmodified-caller path (INTEGRATION.md level 1): the model class under the Lightning protocol -- zero_grad, training_step,
+    loss.backward(), configure_gradient_clipping, optimizer.step() -- at the cfg2 shape.  kind: 'fused' = FxAdam running the
+    engine's clip + dW + Adam launches (what a Lightning Trainer gets automatically), 'fx' = FxAdam on materialised gradients,
+    'torch' = torch.optim.Adam + torch's clip_grad_norm_."""
+    from flexynesis_amd import models as M
+    from flexynesis_amd.data import MultiOmicDataset
+    n, F = 2048, 20000
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234)
+    dat = {k: torch.randn(n, F, generator=g, device=dev) for k in ("gex", "cnv")}
+    ann = {"y": dat["gex"][:, :16].sum(1) / 4 + 0.1 * torch.randn(n, generator=g, device=dev)}
+    feats = {k: [f"{k}_{j}" for j in range(F)] for k in dat}
+    ds = MultiOmicDataset(dat, ann, {"y": "numerical"}, feats, [f"s{i}" for i in range(n)], {})
+    cfg = {"latent_dim": 64, "hidden_dim_factor": 0.25, "lr": 1e-3, "supervisor_hidden_dim": 16, "epochs": 1, "batch_size": B}
+    m = M.DirectPred(cfg, ds, ["y"], device_type="cuda")
+    m.to(dev)
+    m.train()
+    m.fused_optimizer = kind == "fused"
+    opt = m.configure_optimizers() if kind in ("fx", "fused") else torch.optim.Adam(m.parameters(), lr=1e-3)
+    perm = torch.randperm(n, generator=g, device=dev)
+
+    def step(i):
+        o = (i * B) % (n - B)
+        idx = perm[o:o + B]
+        batch = ({k: v[idx] for k, v in dat.items()}, {"y": ann["y"][idx]}, None)
+        opt.zero_grad()
+        loss = m.training_step(batch, i, log=False)
+        loss.backward()
+        m.configure_gradient_clipping(opt, 1.0, "norm")
+        opt.step()
+        return loss
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = step(warmup + i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    rec = {"workload": f"cfg2 under the Lightning protocol (level-1 drop-in), optimizer {type(opt).__name__}" + (" fused" if kind == "fused" else ""),
+           "samples_per_s": round(steps * B / dt, 1), "ms_per_step": round(1e3 * dt / steps, 4), "steps": steps,
+           "loss_finite": bool(torch.isfinite(loss).all())}
+    if hasattr(m, "close"):
+        m.close()
+    return rec
 
 
 def main():
@@ -167,6 +275,21 @@ def main():
     losses = pipe.losses()
     finite = all(v == v and abs(v) != float("inf") for v in losses.values())
 
+    # ---- the same window R more times (rank 0's own clock; the headline `value` stays the first window, timed as the contract says)
+    repeat_stats = None
+    if a.repeats > 0:
+        win = []
+        for _ in range(a.repeats):
+            torch.cuda.synchronize()
+            r0 = time.perf_counter()
+            run(a.steps)
+            torch.cuda.synchronize()
+            win.append(1e3 * (time.perf_counter() - r0) / a.steps)
+        win.sort()
+        repeat_stats = {"repeats": a.repeats, "steps_per_window": a.steps, "ms_per_step_median": round(win[len(win) // 2], 4),
+                        "ms_per_step_min": round(win[0], 4), "ms_per_step_max": round(win[-1], 4),
+                        "samples_per_s_median": round(B / (win[len(win) // 2] * 1e-3), 1)}
+
     # ---- dominant-kernel timing with HIP events on the launch stream (eager re-issue of the same tapes)
     roof = None
     if rank == 0:
@@ -187,7 +310,7 @@ def main():
             traffic = None
             try:
                 # only a PMC file collected THIS round with this kernel counts (else null: the figure is not re-measured here)
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic_cfg2.json")))
+                pm = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
                 if a.config == "cfg2" and B == 128 and a.precision == "bf16x3" and not a.features:
                     want = "fx_dw_adam_fwd_kernel" if dominant.endswith("_fwd_bf16x3") else "fx_gemm_bf16x3_kernel<false, 1"
                     for kname, d in pm["kernels"].items():
@@ -219,6 +342,8 @@ def main():
                 pass
             roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "traffic_source": (f"profiles/{PMC_FILE} (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                                       "on another box of the pool; not re-measured in this run)") if traffic else None,
                     "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(ms),
                     "algorithmic_bytes_per_launch": bytes_per_launch, "device_copy_GBps_this_box": copy_gbs,
                     "torch_copy_GBps_this_box": copy_torch}
@@ -235,11 +360,13 @@ def main():
 
     # ---- cfg5 leg (outside the timed region): the sharded HPO sweep with its real collectives -- cohort broadcast from
     # rank 0, LPT assignment, engine trials, all_gather of the records, winner state_dict broadcast (flexynesis_amd/sweep.py)
+    # everything the legs below need from the headline objects has been read: release them (graphs first, at a known point)
+    pipe.close()
+    del pipe, store, cohort
+    torch.cuda.empty_cache()
     sweep = None
     if a.sweep_trials_per_gpu > 0:
         try:
-            del pipe, store, cohort
-            torch.cuda.empty_cache()
             from flexynesis_amd.sweep import run_cfg5
             with _stdout_to_stderr():
                 # one untimed single-epoch trial per rank first: a process's first model pays torch's RNG / elementwise kernel
@@ -252,6 +379,29 @@ def main():
                 sweep["untimed_warmup_trials_per_gpu"] = 1
         except Exception as e:     # reported, never fatal for the headline number
             sweep = {"error": repr(e)}
+
+    # ---- the other BASELINE configs and modes, 20 steps each (rank 0, N = 1 only; after the headline so that nothing of them is
+    # resident while it is timed): driver-visible counterparts of what profiles/ and DESIGN.md quote
+    other = None
+    if rank == 0 and world == 1 and not a.no_other and a.config == "cfg2" and not a.features:
+        other = {}
+        with _stdout_to_stderr():
+            for name, (cfgname, prec) in (("cfg1", ("cfg1", "bf16x3")), ("cfg3", ("cfg3", "bf16x3")), ("cfg4", ("cfg4", "bf16x3")),
+                                          ("cfg2_f32", ("cfg2", "f32"))):
+                try:
+                    rec, p_, s_, _ = _engine_leg(cfgname, B, dev, prec, 20, 5, a.lr)
+                    p_.close()
+                    del p_, s_
+                    other[name] = rec
+                except Exception as e:
+                    other[name] = {"error": repr(e)}
+                torch.cuda.empty_cache()
+            for kind in ("fused", "fx", "torch"):
+                try:
+                    other["dropin_" + kind] = _dropin_leg(dev, kind, 20, 5, B)
+                except Exception as e:
+                    other["dropin_" + kind] = {"error": repr(e)}
+                torch.cuda.empty_cache()
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -286,7 +436,7 @@ def main():
                        "schedule_bytes_per_step": bytes_moved,
                        "schedule_hbm_frac_of_8TBs": round(bytes_moved / (ms_per_step * 1e-3) / 8e12, 4),
                        "loss_finite": finite, "last_losses": {k: round(v, 6) for k, v in losses.items()}},
-            "roofline": roof, "cpu_baseline": cpu, "sweep": sweep,
+            "roofline": roof, "cpu_baseline": cpu, "repeat_stats": repeat_stats, "other": other, "sweep": sweep,
         }
         print(json.dumps(out), flush=True)
     if use_pg:

@@ -62,6 +62,7 @@ PROTOTYPES = {
     "fx_linear_dw_adam_bf16x3_ex": (I, [P, P, P, P, P, P, P, I, I, I, L, L, L, P, I, I, I, P]),
     "fx_linear_fwd_bf16x3_ex": (I, [P, P, P, P, P, I, I, I, L, L, L, P, L, I, I, I, I, P]),
     "fx_linear_dw_adam_fwd_bf16x3_slabs": (I, [I, I]),
+    "fx_linear_dw_adam_fwd_bf16x3_slabs_ex": (I, [I, I, I, I]),
     "fx_linear_dw_adam_fwd_bf16x3": (I, [P, P, P, P, P, P, P, I, I, I, L, L, L, P, P, P, L, I, P, L, I, P]),
     "fx_reduce_slabs": (I, [P, P, P, I, I, L, I, L, P]),
     "fx_linear_bwd_x_bf16x3": (I, [P, P, P, P, I, I, I, L, L, L, P, L, P]),

@@ -43,6 +43,56 @@ enum FxCtrl {
 #define FX_BN_EPS 1e-5f
 #define FX_BN_MOMENTUM 0.1f
 
+// ---- Adam update (torch.optim.Adam, single-tensor form: lerp / addcmul / sqrt / div / add eps / addcdiv) -----------------------
+// One definition for every optimiser kernel (fx_adam_flat*, the dW + Adam epilogues, the fused dW + Adam + next-forward kernel),
+// so that they stay bit-identical to each other.  The IEEE sqrt and the two IEEE divisions of the textbook form are 32 of its 54
+// VALU instructions per element, and the wide kernels are VALU-bound in their Adam phase.  Here:
+// hardware approximations (v_sqrt_f32 / v_rcp_f32, 1 ulp) plus ONE fused-multiply-add residual correction each, which yields the
+// correctly rounded result unless the exact value lies within ~1e-7 ulp of a rounding boundary (Markstein: q' = q + (a - q b) r
+// with r within 1 ulp of 1 / b) -- about one element in 10^7 differs from the IEEE result, by one ulp.  16 instructions.
+struct FxAdamK {
+  float coef, step_size, bc2s, rbc2s;
+};
+__device__ __forceinline__ FxAdamK fx_adam_consts(float lr, float bc1, float bc2s, float coef) {
+  FxAdamK k;
+  k.coef = coef;
+  k.step_size = lr / bc1;
+  k.bc2s = bc2s;
+  k.rbc2s = 1.0f / bc2s;          // IEEE: the correctly rounded reciprocal the constant division below needs
+  return k;
+}
+__device__ __forceinline__ float fx_sqrt_rn(float x) {
+  const float s0 = __builtin_amdgcn_sqrtf(x);
+  const float r = __builtin_amdgcn_rcpf(s0);
+  const float e = __builtin_fmaf(-s0, s0, x);
+  const float s1 = __builtin_fmaf(e, 0.5f * r, s0);
+  return __builtin_amdgcn_class(s0, 0x267) ? s0 : s1;      // 0, inf, NaN: as the hardware returned them
+}
+__device__ __forceinline__ float fx_div_rn(float a, float b) {       // b finite, normal, > 0
+  const float r = __builtin_amdgcn_rcpf(b);
+  const float q0 = a * r;
+  const float e = __builtin_fmaf(-q0, b, a);
+  return __builtin_fmaf(e, r, q0);
+}
+__device__ __forceinline__ void fx_adam_update(float& p, float& m, float& v, float g_raw, const FxAdamK& k) {
+  const float gr = g_raw * k.coef;
+  const float m2 = m + (gr - m) * (1.0f - FX_BETA1);
+  const float v2 = v * FX_BETA2 + (1.0f - FX_BETA2) * gr * gr;
+#ifdef FX_ADAM_IEEE       /* A/B timing only (scripts/build_variant.py): the compiler's IEEE sqrt / division expansions */
+  p = p - k.step_size * (m2 / (sqrtf(v2) / k.bc2s + FX_ADAM_EPS));
+  m = m2;
+  v = v2;
+  return;
+#endif
+  const float s = fx_sqrt_rn(v2);
+  const float q0 = s * k.rbc2s;                                      // s / bc2s, divisor constant over the launch
+  const float d0 = __builtin_fmaf(__builtin_fmaf(-q0, k.bc2s, s), k.rbc2s, q0) + FX_ADAM_EPS;
+  const float d = fminf(d0, 3.0e38f);                                // v = inf (overflowed gradients): the step is 0, as m / inf
+  p = p - k.step_size * fx_div_rn(m2, d);
+  m = m2;
+  v = v2;
+}
+
 // ---- wavefront reductions (64 lanes) -------------------------------------------------------------
 __device__ __forceinline__ float fx_wave_sum(float v) {
 #pragma unroll

@@ -38,6 +38,24 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define FT_T 512
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
+// -DFT_PROFILE (scripts/build_variant.py, never the shipped library): wave 0 of every workgroup accumulates the 100 MHz wall-clock
+// ticks it spends in each phase of a tile; fx_debug_dw_adam_fwd_profile() reads / resets the sums.
+#ifdef FT_PROFILE
+__device__ unsigned long long ft_prof[16];
+__device__ unsigned long long ft_stamp[1024 * 8];      // [workgroup][k]: wall clock at the start of phase 3 of the workgroup's tile 3 k + 2
+#define FT_STAMP(it) if (tid == 0 && ((it) % 3) == 2 && (it) / 3 < 8 && blockIdx.x < 1024) ft_stamp[blockIdx.x * 8 + (it) / 3] = wall_clock64();
+#define FT_PROF_DECL unsigned long long pt_[16] = {0}, pl_ = wall_clock64()
+#define FT_TICK(i) { const unsigned long long n_ = wall_clock64(); pt_[i] += n_ - pl_; pl_ = n_; }
+#define FT_PROF_FLUSH if (tid == 0) { for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&ft_prof[i_], pt_[i_]); }
+#define FT_PROF_WAITVM __builtin_amdgcn_s_waitcnt(0x0f70)   /* vmcnt(0) only (gfx9 encoding: vmcnt lo [3:0], hi [15:14]) */
+#else
+#define FT_PROF_DECL
+#define FT_TICK(i)
+#define FT_PROF_FLUSH
+#define FT_PROF_WAITVM
+#define FT_STAMP(it)
+#endif
+
 struct DwAdamFwdArgs {
   float* W; float* m; float* v;
   const __bf16* Ah; const __bf16* Al;       // dY^T [M, lda]
@@ -48,10 +66,44 @@ struct DwAdamFwdArgs {
   int M, N, K;
   long lda, ldb, ldw;
   int Mn, kblocks;
-  int tiles_m, tiles_n, S;
+  int tiles_m, tiles_n, S;                  // S = runs per row block of the "low" class (see ft_plan)
   long slab_stride;
-  int xcd_group;                            // 1: the S runs of a row block share an XCD (block id -> (XCD, row block, run))
+  int xcd_group;                            // 0 plain, 1: the S runs of a row block share an XCD (block id -> (XCD, row block, run)), 2: XCD-contiguous row blocks
+  int n_hi;                                 // plain mapping: the LAST n_hi row blocks are split into S + 1 runs (all 512 slots filled)
+  int slots;                                // XCD-contiguous mapping: workgroup slots per XCD
+  int S_total;                              // slabs the consumer adds up; a row block with fewer runs zero-fills the rest
+  int prio;                                 // 0: the two workgroups of a CU take turns at issue priority (per tile); 1 off; 2, 3 variants
 };
+
+// ---- work decomposition -----------------------------------------------------------------------------
+// A run = (64-row block, every S-th 128-column tile); one workgroup per run, one partial-sum slab per run index.  The chip holds
+// G = 512 workgroups (2 per CU).  Round 2 used S = floor(G / row blocks) for every row block: 79 x 6 = 474 workgroups at the cfg2
+// shape, i.e. 38 CUs ran ONE workgroup (12.4 us per tile against 8.8 us per tile for a CU that holds two) and sat idle for the
+// last third of the launch.  Now the last n_hi = G - row blocks x S row blocks get S + 1 (shorter) runs, so that every slot is
+// taken; because the hardware places workgroup b and b + 256 on the same CU and issues the OLDER workgroup's waves first (measured:
+// 16.2 vs 19.3 us per tile), it is right that the higher-numbered workgroups are the ones with the shorter runs.
+#define FT_G 512
+struct FtPlan { int S_lo, n_hi, S_total; };
+static FtPlan ft_plan(int tiles_m, int tiles_n, int slots) {
+  FtPlan p;
+  p.S_lo = slots / tiles_m;
+  if (p.S_lo < 1) p.S_lo = 1;
+  if (p.S_lo > tiles_n) p.S_lo = tiles_n;
+  p.n_hi = 0;
+  if (p.S_lo < tiles_n && tiles_m * p.S_lo < slots) {
+    p.n_hi = slots - tiles_m * p.S_lo;
+    if (p.n_hi > tiles_m) p.n_hi = tiles_m;
+  }
+  p.S_total = p.S_lo + (p.n_hi > 0 ? 1 : 0);
+  return p;
+}
+__device__ __forceinline__ void ft_plan_dev(int tiles_m, int tiles_n, int slots, int& S_lo, int& n_hi) {
+  S_lo = slots / tiles_m;
+  S_lo = S_lo < 1 ? 1 : S_lo;
+  S_lo = S_lo > tiles_n ? tiles_n : S_lo;
+  n_hi = 0;
+  if (S_lo < tiles_n && tiles_m * S_lo < slots) n_hi = min(slots - tiles_m * S_lo, tiles_m);
+}
 
 __device__ __forceinline__ int ft_swz(int row, int chunk) { return row * FT_K + ((chunk ^ ((row >> 2) & 3)) << 3); }
 
@@ -79,8 +131,23 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
   __shared__ __attribute__((aligned(16))) __bf16 smem[32768];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave id, scalar
-  int tm, c;
-  if (g.xcd_group) {
+  int tm, c, S = g.S;                                              // S = this row block's number of runs
+  if (g.xcd_group == 2) {
+    // XCD-CONTIGUOUS row blocks: XCD x owns the row blocks [x * rpx, (x + 1) * rpx) with all their runs (the rows an XCD
+    // touches -- and translates -- are 1/8 of the weight), and splits them over its own `slots` workgroups as ft_plan does
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, rpx = (g.tiles_m + 7) >> 3;
+    const int r0 = xcd * rpx, nb = min(rpx, g.tiles_m - r0);
+    if (nb <= 0) return;
+    int S_lo, n_hi;
+    ft_plan_dev(nb, g.tiles_n, g.slots, S_lo, n_hi);
+    const int n_lo = nb - n_hi, low = n_lo * S_lo;
+    if (j < low) { tm = r0 + j % n_lo; c = j / n_lo; S = S_lo; }
+    else {
+      const int j2 = j - low;
+      if (j2 >= n_hi * (S_lo + 1)) return;
+      tm = r0 + n_lo + j2 % n_hi; c = j2 / n_hi; S = S_lo + 1;
+    }
+  } else if (g.xcd_group) {
     // Workgroup ids go round-robin over the 8 XCDs.  Here every row block lives on ONE XCD with all its S runs, so its
     // dY^T tile (64 rows x K, re-read for every column tile) is shared in that XCD's L2: with K = 3 B = 384 the tiles of
     // the ~59 workgroups of an XCD would otherwise outgrow the 4 MB L2 (5.8 MB) and be re-fetched for every tile.
@@ -89,8 +156,9 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
     c = j % g.S;
     if (tm >= g.tiles_m) return;                       // padding of the index space (before any barrier)
   } else {
-    tm = blockIdx.x % g.tiles_m;
-    c = blockIdx.x / g.tiles_m;
+    const int n_lo = g.tiles_m - g.n_hi, low = n_lo * g.S;
+    if ((int)blockIdx.x < low) { tm = blockIdx.x % n_lo; c = blockIdx.x / n_lo; }
+    else { const int b2 = blockIdx.x - low; tm = n_lo + b2 % g.n_hi; c = b2 / g.n_hi; S = g.S + 1; }
   }
   const int m0 = tm * FT_M;
   const int rows_valid = min(FT_M, g.M - m0);
@@ -122,8 +190,7 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
   const int fa_d = 32 * rb + l31, fb_d = 32 * cb + l31;
   const int fa_f = 32 * bq + l31, fb_f = 32 * hq + l31;
 
-  const float lr = g.ctrl[FXC_LR], bc1 = g.ctrl[FXC_BC1], bc2s = g.ctrl[FXC_BC2_SQRT], coef = g.ctrl[FXC_CLIP_COEF];
-  const float step_size = lr / bc1;
+  const FxAdamK ak = fx_adam_consts(g.ctrl[FXC_LR], g.ctrl[FXC_BC1], g.ctrl[FXC_BC2_SQRT], g.ctrl[FXC_CLIP_COEF]);
 
   f32x16 yacc[MT];
 #pragma unroll
@@ -131,13 +198,30 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
 #pragma unroll
     for (int i = 0; i < 16; ++i) yacc[m][i] = 0.f;
 
+  FT_PROF_DECL;
   // Run c takes the column tiles c, c + S, c + 2 S, ...: the S workgroups of a row block sit on ADJACENT tiles at any
   // moment (a contiguous S x 512-byte window of every row of W / m / v moves along the rows), and all row blocks work on
   // the same few X tiles at the same time (L2 hits).  Contiguous chunks per run measured like the "slices" copy pattern
   // (scripts/copybench.hip: 5.3-5.5 TB/s against 6.5 for a moving contiguous window).
-  for (int tn = c; tn < g.tiles_n; tn += g.S) {
+  for (int tn = c; tn < g.tiles_n; tn += S) {
     const int n0 = tn * FT_N;
     const unsigned b_src = (unsigned)(((long)(n0 + b_r) * g.ldb + 8 * b_ch) * 2);
+    FT_STAMP((tn - c) / S);
+    // Oldest-first issue arbitration favours the workgroup that arrived first on its CU (block b over block b + grid / 2): 14.5 vs
+    // 20.7 us per tile, and the two halves of the grid drift apart by several column tiles, which costs L2 hits on the operands.
+    // prio 0 (default): both halves alternate 1 / 0 per tile (in anti-phase at the start): 457 -> 446 us per launch, drift 1.9 -> 0.85
+    // tiles; prio 1: off; prio 2: the first half alternates 2 / 0, the second half stays at 1 (each side wins half of the time whatever
+    // their relative phase: drift 0.47 tiles, same time); prio 3: static, second half above first (mirrors the problem)
+    if (g.prio == 0) {
+      if ((((tn - c) / S) + (blockIdx.x >= (gridDim.x >> 1) ? 1 : 0)) & 1) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    } else if (g.prio == 2) {
+      if (blockIdx.x >= (gridDim.x >> 1)) __builtin_amdgcn_s_setprio(1);
+      else if (((tn - c) / S) & 1) __builtin_amdgcn_s_setprio(2);
+      else __builtin_amdgcn_s_setprio(0);
+    } else if (g.prio == 3) {
+      if (blockIdx.x >= (gridDim.x >> 1)) __builtin_amdgcn_s_setprio(1);
+    }
     // ================= phase 1: dW tile [64 x 128] = dY^T[m0.., :] . X^T[n0.., :]^T over the batch =================
     f32x16 acc;
 #pragma unroll
@@ -151,9 +235,12 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rBh, LDS_PTR(sb + 4096 + w * 512), 16, b_src + ko, 0, 0, 0);                  \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rBl, LDS_PTR(sb + 8192 + w * 512), 16, b_src + ko, 0, 0, 0);                  \
   }
+    FT_TICK(0);
     FT_GLDS_K(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
+      FT_PROF_WAITVM; FT_TICK(13);
       __syncthreads();                       // stage kt & 1 has landed (the barrier drains the DMA); the other one is free
+      FT_TICK(1);
       if (kt + 1 < nk) FT_GLDS_K((kt + 1) & 1, kt + 1);
       const __bf16* sb = smem + (kt & 1) * 12288;
 #pragma unroll
@@ -166,13 +253,16 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
         acc = FT_MFMA(ah, bl, acc);
         acc = FT_MFMA(ah, bh, acc);
       }
+      FT_TICK(2);
     }
     __syncthreads();                         // every wave is done with the operand stages
+    FT_TICK(3);
     // ================= phase 2: transpose through LDS (C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
     float* ct = reinterpret_cast<float*>(smem);                        // [64][128] fp32
 #pragma unroll
     for (int r = 0; r < 16; ++r) ct[(32 * rb + (r & 3) + 8 * (r >> 2) + 4 * kh) * FT_N + 32 * cb + l31] = acc[r];
     __syncthreads();
+    FT_TICK(4);
     // ================= phase 3: Adam on 512-byte row segments; W_new -> bf16 (hi, lo) in LDS =================
     __bf16* wn_hi = smem + 16384;
     __bf16* wn_lo = smem + 24576;
@@ -190,6 +280,9 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
         m4[i] = __builtin_amdgcn_raw_buffer_load_b128(rM, off[i], 0, NT);
         v4[i] = __builtin_amdgcn_raw_buffer_load_b128(rV, off[i], 0, NT);
       }
+      FT_TICK(5);
+      FT_PROF_WAITVM;
+      FT_TICK(6);
 #pragma unroll
       for (int i = 0; i < UNITS; ++i) {
         const int u = tid + FT_T * (pass * UNITS + i), row = u >> 5, c4 = u & 31;
@@ -200,13 +293,11 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
         bf16x4 h, l;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float gr = g4[j] * coef;
-          const float m2 = mf[j] + (gr - mf[j]) * (1.0f - FX_BETA1);
-          const float v2 = vf[j] * FX_BETA2 + (1.0f - FX_BETA2) * gr * gr;
-          const float denom = sqrtf(v2) / bc2s + FX_ADAM_EPS;
-          po[j] = pf[j] - step_size * (m2 / denom);
-          mo[j] = m2;
-          vo[j] = v2;
+          float pj = pf[j], mj = mf[j], vj = vf[j];
+          fx_adam_update(pj, mj, vj, g4[j], ak);
+          po[j] = pj;
+          mo[j] = mj;
+          vo[j] = vj;
           h[j] = (__bf16)po[j];
           l[j] = (__bf16)(po[j] - (float)h[j]);
         }
@@ -218,8 +309,11 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
         *reinterpret_cast<bf16x4*>(wn_hi + wo) = h;
         *reinterpret_cast<bf16x4*>(wn_lo + wo) = l;
       }
+      FT_TICK(7);
     }
+    FT_PROF_WAITVM; FT_TICK(14);
     __syncthreads();                         // W_new (hi, lo) visible; ct is dead -> its space stages the next batch
+    FT_TICK(8);
     // ================= phase 4: Y[b, m0 + h] += Xn[b, n0 .. n0 + 127] . W_new[h, :]^T =================
     // sub-step q = m * 4 + kb: M-tile m of the next batch against K-step block kb of the tile
 #define FT_GLDS_X(stage, q)                                                                               \
@@ -232,7 +326,9 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
     FT_GLDS_X(0, 0);
 #pragma unroll
     for (int q = 0; q < 4 * MT; ++q) {
+      FT_PROF_WAITVM; FT_TICK(15);
       __syncthreads();
+      FT_TICK(9);
       if (q + 1 < 4 * MT) FT_GLDS_X((q + 1) & 1, q + 1);
       const int kb = q & 3, m = q >> 2;
       const __bf16* xb = smem + (q & 1) * 8192;
@@ -248,8 +344,10 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
         yacc[m] = FT_MFMA(ah, bl, yacc[m]);
         yacc[m] = FT_MFMA(ah, bh, yacc[m]);
       }
+      FT_TICK(10);
     }
     __syncthreads();                         // the next tile's first DMA overwrites the X stages / W_new
+    FT_TICK(11);
   }
 
   // ---- the run's partial sums: rows = batch (dropped beyond Mn by the range check), columns = rows of W
@@ -263,25 +361,74 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
       const int b = 128 * m + 32 * bq + (r & 3) + 8 * (r >> 2) + 4 * kh;
       ft_store32(yacc[m][r], rY, (unsigned)(((long)b * g.M + hcol) * 4) | oob);
     }
+  if (c == 0)                                      // slabs this row block has no run for: zeros (the consumer adds S_total slabs)
+    for (int z = S; z < g.S_total; ++z) {
+      const __amdgpu_buffer_rsrc_t rZ = ft_rsrc(g.Y + (long)z * g.slab_stride, (long)g.Mn * g.M * 4);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int b = 128 * m + 32 * bq + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          ft_store32(0.f, rZ, (unsigned)(((long)b * g.M + hcol) * 4) | oob);
+        }
+    }
+  FT_TICK(12);
+  FT_PROF_FLUSH;
 }
+
 
 static inline bool ft_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-static int ft_runs(int n_out, int k_in) {
-  const int tiles_m = (n_out + FT_M - 1) / FT_M, tiles_n = (k_in + FT_N - 1) / FT_N;
-  int S = 512 / tiles_m;                                   // ~ one workgroup per resident slot (256 CUs x 2)
-  if (S < 1) S = 1;
-  if (S > tiles_n) S = tiles_n;
-  return S;
+// mapping actually used for a launch: 1 = XCD-grouped interleaved row blocks (K = 3 B: the dY^T tiles of an XCD's workgroups would
+// outgrow its L2), 2 = XCD-contiguous (large weights), 0 = plain
+static int ft_mapping(int map_flag, int tiles_m, int batch_padded) {
+  if (map_flag == 1) return 0;
+  if (map_flag == 2) return 1;
+  if (map_flag == 3) return tiles_m >= 16 ? 2 : 0;
+  if ((long)FT_M * batch_padded * 4 * 60 > (3L << 20)) return 1;
+  return tiles_m >= 16 ? 2 : 0;
+}
+static int ft_slabs_for(int mapping, int tiles_m, int tiles_n) {
+  if (mapping == 1) return ft_plan(tiles_m, tiles_n, FT_G).S_lo;
+  if (mapping == 0) return ft_plan(tiles_m, tiles_n, FT_G).S_total;
+  int mx = 1;
+  const int rpx = (tiles_m + 7) / 8;
+  for (int x = 0; x < 8; ++x) {
+    const int nb = tiles_m - x * rpx < rpx ? tiles_m - x * rpx : rpx;
+    if (nb <= 0) break;
+    const int st = ft_plan(nb, tiles_n, FT_G / 8).S_total;
+    mx = st > mx ? st : mx;
+  }
+  return mx;
 }
 
 extern "C" {
 
-// Number of partial-sum slabs fx_linear_dw_adam_fwd_bf16x3 writes for a weight [n_out, k_in].
-int fx_linear_dw_adam_fwd_bf16x3_slabs(int n_out, int k_in) {
-  if (n_out <= 0 || k_in <= 0) return 0;
-  return ft_runs(n_out, k_in);
+#ifdef FT_PROFILE
+// out[16] = tick sums (100 MHz) per phase over all workgroups since the last reset; reset != 0 clears them afterwards
+int fx_debug_dw_adam_fwd_profile(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ft_prof), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(ft_prof), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
 }
+// out[1024 * 8]: the wall-clock stamps (100 MHz) of the last launch
+int fx_debug_dw_adam_fwd_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(ft_stamp), sizeof(unsigned long long) * 1024 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
+
+// Number of partial-sum slabs fx_linear_dw_adam_fwd_bf16x3 writes for a weight [n_out, k_in].
+// Partial-sum slabs a launch with these flags / this padded batch writes (the consumer adds that many; a slab buffer may be larger:
+// the launch zero-fills every slab it is given).
+int fx_linear_dw_adam_fwd_bf16x3_slabs_ex(int n_out, int k_in, int batch_padded, int flags) {
+  if (n_out <= 0 || k_in <= 0) return 0;
+  const int tiles_m = (n_out + FT_M - 1) / FT_M, tiles_n = (k_in + FT_N - 1) / FT_N;
+  const int forced = (flags >> 8) & 0xFF;
+  if (forced) return forced > tiles_n ? tiles_n : forced;
+  return ft_slabs_for(ft_mapping((flags >> 1) & 3, tiles_m, batch_padded), tiles_m, tiles_n);
+}
+// ... with the default flags and a batch of <= 128 rows
+int fx_linear_dw_adam_fwd_bf16x3_slabs(int n_out, int k_in) { return fx_linear_dw_adam_fwd_bf16x3_slabs_ex(n_out, k_in, 128, 0); }
 
 int fx_linear_dw_adam_fwd_bf16x3(float* W, float* adam_m, float* adam_v, const void* dyT_hi, const void* dyT_lo,
                                  const void* xT_hi, const void* xT_lo, int batch_padded, int n_out, int k_in, long lddy,
@@ -314,19 +461,33 @@ int fx_linear_dw_adam_fwd_bf16x3(float* W, float* adam_m, float* adam_v, const v
   g.lda = lddy; g.ldb = ldx; g.ldw = ldw;
   g.Mn = next_rows; g.kblocks = (k_in + FT_K - 1) / FT_K;
   g.tiles_m = (n_out + FT_M - 1) / FT_M; g.tiles_n = (k_in + FT_N - 1) / FT_N;
-  g.S = ft_runs(n_out, k_in);
-  if ((flags >> 8) & 0xFF) {                       // bits 8-15: explicit number of runs per row block (experiments)
-    g.S = (flags >> 8) & 0xFF;
-    if (g.S > g.tiles_n) g.S = g.tiles_n;
+  // flags: bit 0 = non-temporal W / m / v accesses; bits 1-2 = block mapping: 0 auto (XCD-grouped row blocks when the
+  // dY^T tiles of an XCD's workgroups would outgrow its L2), 1 = plain, 2 = XCD-grouped, 3 = XCD-contiguous row blocks;
+  // bits 8-15: explicit number of runs per row block, uniform (experiments)
+  const int nt = flags & 1;
+  const int mapping = ft_mapping((flags >> 1) & 3, g.tiles_m, batch_padded);
+  g.xcd_group = mapping;
+  g.slots = FT_G / 8;
+  const FtPlan pl = ft_plan(g.tiles_m, g.tiles_n, FT_G);
+  g.S = pl.S_lo;
+  g.n_hi = mapping == 0 ? pl.n_hi : 0;
+  g.prio = (flags >> 17) & 3;
+  const int forced = (flags >> 8) & 0xFF;
+  if (forced) {
+    g.S = forced > g.tiles_n ? g.tiles_n : forced;
+    g.n_hi = 0;
+    if (g.xcd_group == 2) g.xcd_group = 0;
   }
   g.slab_stride = (long)next_rows * n_out;
-  // flags: bit 0 = non-temporal W / m / v accesses; bits 1-2 = block mapping: 0 auto (XCD-grouped row blocks when the
-  // dY^T tiles of an XCD's workgroups would outgrow its L2), 1 = plain, 2 = XCD-grouped
-  const int nt = flags & 1, map = (flags >> 1) & 3;
-  g.xcd_group = map == 2 || (map == 0 && (long)FT_M * batch_padded * 4 * 60 > (3L << 20));
-  FX_REQUIRE(y_slabs_bytes >= (long)g.S * g.slab_stride * 4, "fx_linear_dw_adam_fwd_bf16x3: slab buffer too small (%ld bytes for %d slabs)",
-             y_slabs_bytes, g.S);
-  const long nblk = g.xcd_group ? 8L * ((g.tiles_m + 7) / 8) * g.S : (long)g.tiles_m * g.S;
+  const int need = fx_linear_dw_adam_fwd_bf16x3_slabs_ex(n_out, k_in, batch_padded, flags);
+  FX_REQUIRE(y_slabs_bytes >= (long)need * g.slab_stride * 4, "fx_linear_dw_adam_fwd_bf16x3: slab buffer too small (%ld bytes for %d slabs)",
+             y_slabs_bytes, need);
+  const long given = y_slabs_bytes / (g.slab_stride * 4);          // every slab of the buffer is written (zeros where a row block has no run)
+  g.S_total = given > 255 ? 255 : (int)given;
+  long nblk;
+  if (g.xcd_group == 2) nblk = 8L * g.slots;
+  else if (g.xcd_group == 1) nblk = 8L * ((g.tiles_m + 7) / 8) * g.S;
+  else nblk = (long)(g.tiles_m - g.n_hi) * g.S + (long)g.n_hi * (g.S + 1);
   FX_REQUIRE(nblk < (1L << 31), "fx_linear_dw_adam_fwd_bf16x3: grid too large");
   const dim3 grid((unsigned)nblk), blk(FT_T);
   const int mt = (int)(xn_rows_padded / 128);

@@ -219,9 +219,7 @@ __global__ __launch_bounds__(256) void fx_gemm_f32_kernel(GemmArgs g) {
     }
   } else {  // EPI_ADAM: fused clip + Adam on the parameter tile (torch.optim.Adam defaults)
     const __amdgpu_buffer_rsrc_t rP = g_rsrc(g.C, cbytes), rM = g_rsrc(g.adam_m, cbytes), rV = g_rsrc(g.adam_v, cbytes);
-    const float lr = g.ctrl[FXC_LR], bc1 = g.ctrl[FXC_BC1], bc2s = g.ctrl[FXC_BC2_SQRT];
-    const float coef = g.ctrl[FXC_CLIP_COEF];
-    const float step_size = lr / bc1;
+    const FxAdamK ak = fx_adam_consts(g.ctrl[FXC_LR], g.ctrl[FXC_BC1], g.ctrl[FXC_BC2_SQRT], g.ctrl[FXC_CLIP_COEF]);
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
       const int mbase = m0 + wr * 64 + blk * 32 + 4 * (lane >> 5);
@@ -236,13 +234,11 @@ __global__ __launch_bounds__(256) void fx_gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const unsigned off = (unsigned)(((long)(mbase + (r & 3) + 8 * (r >> 2)) * g.ldc + n) * 4) | oob;
-        const float gr = (blk == 0 ? acc0[r] : acc1[r]) * coef;
-        const float m2 = mv[r] + (gr - mv[r]) * (1.0f - FX_BETA1);
-        const float v2 = vv[r] * FX_BETA2 + (1.0f - FX_BETA2) * gr * gr;
-        const float denom = sqrtf(v2) / bc2s + FX_ADAM_EPS;
-        g_st1(pv[r] - step_size * (m2 / denom), rP, off);
-        g_st1(m2, rM, off);
-        g_st1(v2, rV, off);
+        float pj = pv[r], mj = mv[r], vj = vv[r];
+        fx_adam_update(pj, mj, vj, blk == 0 ? acc0[r] : acc1[r], ak);
+        g_st1(pj, rP, off);
+        g_st1(mj, rM, off);
+        g_st1(vj, rV, off);
       }
     }
   }

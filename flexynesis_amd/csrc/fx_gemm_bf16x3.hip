@@ -334,9 +334,7 @@ __global__ __launch_bounds__(128 * WN) void fx_gemm_bf16x3_kernel(XGemmArgs g) {
     const long bytes = (long)max(min(TM, g.M - m0), 0) * g.ldc * 4;
     const long rbase = (long)m0 * g.ldc;
     const __amdgpu_buffer_rsrc_t rP = fx_rsrc(g.C + rbase, bytes), rM = fx_rsrc(g.adam_m + rbase, bytes), rV = fx_rsrc(g.adam_v + rbase, bytes);
-    const float lr = g.ctrl[FXC_LR], bc1 = g.ctrl[FXC_BC1], bc2s = g.ctrl[FXC_BC2_SQRT];
-    const float coef = g.ctrl[FXC_CLIP_COEF];
-    const float step_size = lr / bc1;
+    const FxAdamK ak = fx_adam_consts(g.ctrl[FXC_LR], g.ctrl[FXC_BC1], g.ctrl[FXC_BC2_SQRT], g.ctrl[FXC_CLIP_COEF]);
     if ((g.N & 3) == 0 && (g.ldc & 3) == 0) {
       // Row-contiguous 16-byte streaming of W/m/v: the dW tile is transposed through LDS (the operand
       // buffers are free after the K loop) so that consecutive lanes own consecutive float4 of a weight row --
@@ -375,13 +373,11 @@ __global__ __launch_bounds__(128 * WN) void fx_gemm_bf16x3_kernel(XGemmArgs g) {
           f32x4 po, mo, vo;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float gr = g4[j] * coef;
-            const float m2 = mf[j] + (gr - mf[j]) * (1.0f - FX_BETA1);
-            const float v2 = vf[j] * FX_BETA2 + (1.0f - FX_BETA2) * gr * gr;
-            const float denom = sqrtf(v2) / bc2s + FX_ADAM_EPS;
-            po[j] = pf[j] - step_size * (m2 / denom);
-            mo[j] = m2;
-            vo[j] = v2;
+            float pj = pf[j], mj = mf[j], vj = vf[j];
+            fx_adam_update(pj, mj, vj, g4[j], ak);
+            po[j] = pj;
+            mo[j] = mj;
+            vo[j] = vj;
           }
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, po), rP, off[i], 0, NT);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mo), rM, off[i], 0, NT);
@@ -406,13 +402,11 @@ __global__ __launch_bounds__(128 * WN) void fx_gemm_bf16x3_kernel(XGemmArgs g) {
         for (int r = 0; r < 16; ++r) {
           const int m = mbase + (r & 3) + 8 * (r >> 2);
           const unsigned off = (unsigned)(((long)m * g.ldc + n) * 4) | oob;
-          const float gr = (blk == 0 ? acc0[r] : acc1[r]) * coef;
-          const float m2 = mv[r] + (gr - mv[r]) * (1.0f - FX_BETA1);
-          const float v2 = vv[r] * FX_BETA2 + (1.0f - FX_BETA2) * gr * gr;
-          const float denom = sqrtf(v2) / bc2s + FX_ADAM_EPS;
-          bst32f<NT>(pv[r] - step_size * (m2 / denom), rP, off);
-          bst32f<NT>(m2, rM, off);
-          bst32f<NT>(v2, rV, off);
+          float pj = pv[r], mj = mv[r], vj = vv[r];
+          fx_adam_update(pj, mj, vj, blk == 0 ? acc0[r] : acc1[r], ak);
+          bst32f<NT>(pj, rP, off);
+          bst32f<NT>(mj, rM, off);
+          bst32f<NT>(vj, rV, off);
         }
       }
     }

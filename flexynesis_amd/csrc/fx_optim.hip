@@ -125,17 +125,14 @@ __global__ __launch_bounds__(256) void fx_adam_flat_kernel(float* __restrict__ p
                                                            float* __restrict__ m, float* __restrict__ v, long n,
                                                            const float* __restrict__ ctrl,
                                                            const float* __restrict__ trainable) {
-  const float lr = ctrl[FXC_LR], bc1 = ctrl[FXC_BC1], bc2s = ctrl[FXC_BC2_SQRT], coef = ctrl[FXC_CLIP_COEF];
-  const float step_size = lr / bc1;
+  const FxAdamK ak = fx_adam_consts(ctrl[FXC_LR], ctrl[FXC_BC1], ctrl[FXC_BC2_SQRT], ctrl[FXC_CLIP_COEF]);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     if (trainable && trainable[i] == 0.f) continue;      // requires_grad=False: not in the optimiser (FineTuner, main.py:562-566)
-    const float gr = g[i] * coef;
-    const float m2 = m[i] + (gr - m[i]) * (1.0f - FX_BETA1);
-    const float v2 = v[i] * FX_BETA2 + (1.0f - FX_BETA2) * gr * gr;
-    const float denom = sqrtf(v2) / bc2s + FX_ADAM_EPS;
-    p[i] = p[i] - step_size * (m2 / denom);
-    m[i] = m2;
-    v[i] = v2;
+    float pi = p[i], mi = m[i], vi = v[i];
+    fx_adam_update(pi, mi, vi, g[i], ak);
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
   }
 }
 
@@ -161,17 +158,14 @@ __global__ __launch_bounds__(256) void fx_adam_flat_clip_kernel(float* __restric
     ctrl[FXC_GNORM] = total;
     ctrl[FXC_CLIP_COEF] = coef;
   }
-  const float lr = ctrl[FXC_LR], bc1 = ctrl[FXC_BC1], bc2s = ctrl[FXC_BC2_SQRT];
-  const float step_size = lr / bc1;
+  const FxAdamK ak = fx_adam_consts(ctrl[FXC_LR], ctrl[FXC_BC1], ctrl[FXC_BC2_SQRT], coef);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     if (trainable && trainable[i] == 0.f) continue;
-    const float gr = g[i] * coef;
-    const float m2 = m[i] + (gr - m[i]) * (1.0f - FX_BETA1);
-    const float v2 = v[i] * FX_BETA2 + (1.0f - FX_BETA2) * gr * gr;
-    const float denom = sqrtf(v2) / bc2s + FX_ADAM_EPS;
-    p[i] = p[i] - step_size * (m2 / denom);
-    m[i] = m2;
-    v[i] = v2;
+    float pi = p[i], mi = m[i], vi = v[i];
+    fx_adam_update(pi, mi, vi, g[i], ak);
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
   }
 }
 

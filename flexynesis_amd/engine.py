@@ -535,7 +535,7 @@ class StepPlan:
             self._want_gram(rec, x, wkey, x.shape[0], self.passes if x.shape[0] == self.R else 1)
             if self._can_fuse_next(wkey, x):
                 M, N = y.shape
-                S = ops.dw_adam_fwd_slabs(N, x.shape[1])
+                S = ops.dw_adam_fwd_slabs(N, x.shape[1], ops.pad32(x.shape[0]))
                 slabs = self._new(f"yslabs/{wkey}", S, M, N)
                 self._next_fwd[wkey] = (slabs, S, sp)
                 if not want_slabs:

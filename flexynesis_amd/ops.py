@@ -37,7 +37,8 @@ TUNE = {
     "fwd_nt": _env_int("FX_NT_FWD", 0), "adam_order": {0: 1, 1: 0, 2: 2}.get(_env_int("FX_ADAM_XCD", 1), 0),
     "adam_wn": _env_int("FX_ADAM_WN", 0), "adam_plain": int(_env_int("FX_NT_ADAM", 1) == 0),
     "fused_runs": _env_int("FX_FUSED_RUNS", 0),   # runs (= partial-sum slabs) per row block; 0 = the library's choice
-    "fused_map": _env_int("FX_FUSED_MAP", 0),     # fx_linear_dw_adam_fwd_bf16x3 workgroup mapping: 0 auto, 1 plain, 2 XCD-grouped
+    "fused_map": _env_int("FX_FUSED_MAP", 0),     # fx_linear_dw_adam_fwd_bf16x3 workgroup mapping: 0 auto, 1 plain, 2 XCD-grouped, 3 XCD-contiguous row blocks
+    "fused_prio": _env_int("FX_FUSED_PRIO", 0),   # 1 = the two workgroups of a CU alternate s_setprio per tile (experiment)
 }
 
 
@@ -533,11 +534,14 @@ def linear_dw_adam_bf16x3(rec, W, m, v, dyT_hi, dyT_lo, xT_hi, xT_lo, ctrl, tile
              xT_hi.data_ptr(), xT_lo.data_ptr(), Bp, N, K, _ld(dyT_hi), _ld(xT_hi), _ld(W), ctrl.data_ptr())
 
 
-def dw_adam_fwd_slabs(n_out: int, k_in: int) -> int:
-    s = TUNE["fused_runs"]
-    if s > 0:
-        return min(s, (int(k_in) + 127) // 128)
-    return int(lib.fx_linear_dw_adam_fwd_bf16x3_slabs(int(n_out), int(k_in)))
+def _fused_flags(nt=True, mapping=0) -> int:
+    return int(bool(nt)) | ((int(mapping) & 3) << 1) | ((TUNE["fused_runs"] & 0xFF) << 8) | ((TUNE["fused_prio"] & 3) << 17)
+
+
+def dw_adam_fwd_slabs(n_out: int, k_in: int, batch_padded: int = 128, mapping: Optional[int] = None) -> int:
+    """Partial-sum slabs linear_dw_adam_fwd_bf16x3 writes for a weight [n_out, k_in] (mapping None = the configured default)."""
+    m = TUNE["fused_map"] if mapping is None else mapping
+    return int(lib.fx_linear_dw_adam_fwd_bf16x3_slabs_ex(int(n_out), int(k_in), int(batch_padded), _fused_flags(True, m)))
 
 
 def linear_dw_adam_fwd_bf16x3(rec, W, m, v, dyT_hi, dyT_lo, xT_hi, xT_lo, ctrl, xn_hi, xn_lo, next_rows, y_slabs, nt=True,
@@ -553,13 +557,13 @@ def linear_dw_adam_fwd_bf16x3(rec, W, m, v, dyT_hi, dyT_lo, xT_hi, xT_lo, ctrl, 
     if not (_ld(m) == _ld(W) == _ld(v)):
         raise FxError("linear_dw_adam_fwd_bf16x3: W/m/v must share a leading dimension")
     _chk_kb(xn_hi, xn_lo, next_rows, K, "linear_dw_adam_fwd_bf16x3")
-    S = dw_adam_fwd_slabs(N, K)
+    S = dw_adam_fwd_slabs(N, K, Bp, mapping)
     if y_slabs.dtype != torch.float32 or not y_slabs.is_contiguous() or y_slabs.numel() < S * next_rows * N:
         raise FxError(f"linear_dw_adam_fwd_bf16x3: y_slabs must hold {S} x {next_rows} x {N} fp32")
     rec.emit("fx_linear_dw_adam_fwd_bf16x3", W.data_ptr(), m.data_ptr(), v.data_ptr(), dyT_hi.data_ptr(), dyT_lo.data_ptr(),
              xT_hi.data_ptr(), xT_lo.data_ptr(), Bp, N, K, _ld(dyT_hi), _ld(xT_hi), _ld(W), ctrl.data_ptr(), xn_hi.data_ptr(),
              xn_lo.data_ptr(), xn_hi.shape[1], int(next_rows), y_slabs.data_ptr(), y_slabs.numel() * 4,
-             int(bool(nt)) | ((int(mapping) & 3) << 1) | ((TUNE["fused_runs"] & 0xFF) << 8))
+             _fused_flags(nt, mapping))
 
 
 def reduce_slabs(rec, y, slabs, bias, n_slabs):

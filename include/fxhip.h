@@ -111,10 +111,16 @@ int fx_linear_dw_adam_bf16x3_ex(float* W, float* adam_m, float* adam_v, const vo
  * instead of 28 bytes per parameter and step).  The partial sums land in
  * y_slabs [fx_linear_dw_adam_fwd_bf16x3_slabs(n_out, k_in)][next_rows][n_out]; fx_reduce_slabs adds them (+ bias) in a
  * fixed order.  W, m, v results are bit-identical to fx_linear_dw_adam_bf16x3.
- * flags: bit 0 = non-temporal W / m / v accesses; bits 1-2 = workgroup mapping (0 auto, 1 plain, 2 row blocks grouped per
- * XCD); bits 8-15 = runs per row block (0 = fx_linear_dw_adam_fwd_bf16x3_slabs(); the slab buffer must hold that many).
+ * flags: bit 0 = non-temporal W / m / v accesses; bits 1-2 = workgroup mapping (0 auto = 3 for large weights / 2 for stacked
+ * batches, 1 plain, 2 row blocks interleaved over the XCDs with all their runs, 3 contiguous row-block ranges per XCD); bits 8-15 = runs per row block (0 = the library's plan,
+ * fx_linear_dw_adam_fwd_bf16x3_slabs_ex(); the slab buffer must hold at least that many); bits 17-18 = issue-priority scheme of the two
+ * workgroups a CU holds (0 = they take turns per tile, 1 = none, 2 / 3 = variants).
  * k_in % 4 == 0; descriptors are rebased per row block, so the weight itself may exceed 4 GiB. */
 int fx_linear_dw_adam_fwd_bf16x3_slabs(int n_out, int k_in);
+/* ... for explicit flags and padded batch: the row blocks are cut into runs so that all 512 workgroup slots of the chip are
+ * taken (the last row blocks get one run more), per XCD with flag mapping 3; every slab of the buffer passed to the launch is
+ * written (zeros where a row block has fewer runs), so a consumer may add up all of them */
+int fx_linear_dw_adam_fwd_bf16x3_slabs_ex(int n_out, int k_in, int batch_padded, int flags);
 int fx_linear_dw_adam_fwd_bf16x3(float* W, float* adam_m, float* adam_v, const void* dyT_hi, const void* dyT_lo,
                                  const void* xT_hi, const void* xT_lo, int batch_padded, int n_out, int k_in, long lddy,
                                  long ldx, long ldw, const float* ctrl, const void* xn_hi, const void* xn_lo,

@@ -55,9 +55,14 @@ __global__ __launch_bounds__(512) void adam_runs(float* __restrict__ W, float* _
   if (threadIdx.x == 9999) pad[threadIdx.x % LDSB] = 1;
   constexpr int R = 64, C = 128, UPR = 32, PER = 4;
   const int tiles_m = (H + R - 1) / R, tiles_n = (F + C - 1) / C;
-  const int tm = blockIdx.x % tiles_m, c = blockIdx.x / tiles_m;
+  int tm = blockIdx.x % tiles_m, c = blockIdx.x / tiles_m;
+  if (contiguous == 2) {   // XCD-contiguous row blocks: XCD x (= blockIdx & 7) owns row blocks [x * rpx, (x + 1) * rpx), interleaved tiles
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, rpx = (tiles_m + 7) >> 3;
+    tm = xcd * rpx + j % rpx; c = j / rpx;
+    if (tm >= tiles_m || c >= S) return;
+  }
   int t0 = c, t1 = tiles_n, ts = S;
-  if (contiguous) { t0 = (int)((long)c * tiles_n / S); t1 = (int)((long)(c + 1) * tiles_n / S); ts = 1; }
+  if (contiguous == 1) { t0 = (int)((long)c * tiles_n / S); t1 = (int)((long)(c + 1) * tiles_n / S); ts = 1; }
   for (int tn = t0; tn < t1; tn += ts) {
     f4 p[PER], m[PER], v[PER];
     long off[PER];
@@ -229,6 +234,11 @@ int main(int argc, char** argv) {
     char nm[128];
     snprintf(nm, 128, "persistent runs 64x128, S=%d, %s, 2 WG/CU", S, contiguous ? "contiguous chunks" : "interleaved tiles");
     run(nm, [&] { hipLaunchKernelGGL((adam_runs<65536>), dim3(79 * S), dim3(512), 0, 0, W, M, V, H, F, ld, S, contiguous); });
+  }
+  for (int S : {6, 12}) {
+    char nm[128];
+    snprintf(nm, 128, "persistent runs 64x128, S=%d, interleaved, XCD-contiguous row blocks, 2 WG/CU", S);
+    run(nm, [&] { hipLaunchKernelGGL((adam_runs<65536>), dim3(8 * 10 * S), dim3(512), 0, 0, W, M, V, H, F, ld, S, 2); });
   }
   for (int S : {12, 24}) {
     char nm[128];

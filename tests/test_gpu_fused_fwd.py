@@ -49,18 +49,27 @@ def test_dw_adam_fwd_matches_the_kernels_it_replaces(n_out, k_in, B, Bn):
     ops.linear_fwd_bf16x3(ops.IMMEDIATE, y1, xnh, xnl, W1[:, :k_in], bias, ops.Workspace(dev))
     # fused
     W2, m2, v2 = W0.clone(), m0.clone(), v0.clone()
-    S = ops.dw_adam_fwd_slabs(n_out, k_in)
+    Bp = ops.pad32(B)
+    S = ops.dw_adam_fwd_slabs(n_out, k_in, Bp)
     assert 1 <= S <= (k_in + 127) // 128
     slabs = torch.full((S, Bn, n_out), float("nan"), device=dev)
     ops.linear_dw_adam_fwd_bf16x3(ops.IMMEDIATE, W2[:, :k_in], m2[:, :k_in], v2[:, :k_in], dyt[0], dyt[1], xt[0], xt[1], ctrl,
                                   xnh, xnl, Bn, slabs)
-    if n_out == 1875:             # both workgroup mappings give the same bits
+    # every workgroup mapping (1 plain: the last row blocks get one run more so that all 512 slots are taken; 2 row blocks
+    # interleaved over the XCDs; 3 contiguous row-block ranges per XCD) gives the same W / m / v bits and the same forward up to
+    # the order in which a row block's column tiles are summed; a slab buffer larger than needed is zero-filled
+    for mapping in (1, 2, 3):
         W3, m3, v3 = W0.clone(), m0.clone(), v0.clone()
-        slabs3 = torch.full((S, Bn, n_out), float("nan"), device=dev)
+        S3 = ops.dw_adam_fwd_slabs(n_out, k_in, Bp, mapping)
+        slabs3 = torch.full((S3 + 1, Bn, n_out), float("nan"), device=dev)
         ops.linear_dw_adam_fwd_bf16x3(ops.IMMEDIATE, W3[:, :k_in], m3[:, :k_in], v3[:, :k_in], dyt[0], dyt[1], xt[0], xt[1], ctrl,
-                                      xnh, xnl, Bn, slabs3, mapping=1)
+                                      xnh, xnl, Bn, slabs3, mapping=mapping)
         torch.cuda.synchronize()
-        assert torch.equal(W3, W2) and torch.equal(slabs3, slabs)
+        assert torch.equal(W3, W2) and torch.equal(m3, m2) and torch.equal(v3, v2), mapping
+        assert not bool(torch.isnan(slabs3).any()), f"mapping {mapping}: a slab element was never written"
+        assert not bool(slabs3[S3].any()), "the surplus slab must be zero"
+        y3, y2s = slabs3.sum(0), slabs.sum(0)
+        assert float((y3.double() - y2s.double()).norm() / y2s.double().norm()) <= 2e-6, mapping
     y2 = torch.empty(Bn, n_out, device=dev)
     ops.reduce_slabs(ops.IMMEDIATE, y2, slabs, bias, S)
     torch.cuda.synchronize()
