@@ -41,6 +41,9 @@ CONFIGS = {
                  n_samples=2048),
     "cfg4": dict(model="MultiTripletNetwork", layers=[("gex", 30000), ("cnv", 30000), ("meth", 30000)],
                  variables=[("c", "categorical", 4)], surv=(None, None), n_samples=2048),
+    # cfg2 with --fusion_type early (reference data.py:234-257): ONE layer of 40000 features, a single [10000, 40000] weight
+    "cfg2_early": dict(model="DirectPred", layers=[("all", 40000)], variables=[("y", "numerical", 1)], surv=(None, None),
+                       n_samples=2048),
 }
 PMC_FILE = "r04_pmc_traffic_cfg2.json"      # rocprofv3 --pmc passes of this command, this round, this kernel (scripts/profile_round.sh)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
@@ -199,6 +202,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("FX_BENCH_SHARE_GPU"):      # multi-process readiness on ONE GPU (tests): every rank uses device 0; implies gloo
+        local = 0
+        os.environ.setdefault("FX_BENCH_BACKEND", "gloo")
+    backend = os.environ.get("FX_BENCH_BACKEND", "nccl")
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             sys.exit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
@@ -208,7 +215,10 @@ def main():
     if use_pg:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         with _stdout_to_stderr():
-            dist.init_process_group("nccl", device_id=dev)
+            if backend == "gloo":     # collectives through host memory: same code path above the transport (ranks may share a GPU)
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=dev)
             dist.barrier()            # creates the communicator now (and its banner goes to stderr)
             torch.cuda.synchronize()
 
@@ -269,7 +279,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if use_pg:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if backend == "gloo" else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     losses = pipe.losses()
@@ -387,7 +397,7 @@ def main():
         other = {}
         with _stdout_to_stderr():
             for name, (cfgname, prec) in (("cfg1", ("cfg1", "bf16x3")), ("cfg3", ("cfg3", "bf16x3")), ("cfg4", ("cfg4", "bf16x3")),
-                                          ("cfg2_f32", ("cfg2", "f32"))):
+                                          ("cfg2_f32", ("cfg2", "f32")), ("cfg2_early_fusion", ("cfg2_early", "bf16x3"))):
                 try:
                     rec, p_, s_, _ = _engine_leg(cfgname, B, dev, prec, 20, 5, a.lr)
                     p_.close()

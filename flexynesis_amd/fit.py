@@ -455,7 +455,7 @@ def fine_tune(model, dataset, *, n_splits: int = 5, batch_size: int = 32, learni
 
     table, held = trials.run_units(len(units), unit_fn, [unit_cost(u) for u in units], dev, keep=[last_uid], schedule=schedule)
     results, best = summarise(table[:, 1].tolist(), table[:, 2].tolist())
-    owner = int(table[last_uid, 4]) if table[last_uid, 4] == table[last_uid, 4] else 0
+    owner = int(table[last_uid, 4]) if (table[last_uid, 4] == table[last_uid, 4] and table[last_uid, 4] >= 0) else 0
     final_sd = None
     if rank == owner and last_uid in held:
         last = copy.deepcopy(model)

@@ -143,7 +143,7 @@ def run_cfg5(dev, n_trials: int = 64, epochs: int = 3, features: int = 20000, sa
             state = trials.agree_and_broadcast_state(held, 0, owner_table, shapes_of(plist[best]), dev, force_collectives)
     torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t1
-    mine = torch.tensor([float(stats["samples"]), wall, stats["busy"]], dtype=torch.float64, device=dev)
+    mine = torch.tensor([float(stats["samples"]), wall, stats["busy"]], dtype=torch.float64, device=trials.collective_device(dev))
     if world > 1 or (force_collectives and dist.is_initialized()):
         parts = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(parts, mine)
@@ -181,12 +181,15 @@ def main(argv=None):
     a = ap.parse_args(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if os.environ.get("FX_BENCH_SHARE_GPU") else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if os.environ.get("FX_BENCH_BACKEND", "nccl") == "gloo":       # collectives through host memory (ranks may share a GPU)
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     out = run_cfg5(dev, a.trials, a.epochs, a.features, a.samples, a.seed, schedule=a.schedule, use_cv=a.cv > 1,
                    n_splits=max(a.cv, 2), in_flight=a.in_flight)
     if rank == 0:

@@ -27,6 +27,14 @@ import torch.distributed as dist
 STATUS_OK, STATUS_FAILED = 0.0, 1.0
 
 
+def collective_device(device):
+    """Where the tensors of a collective live: the GPU for RCCL ("nccl"); the host for gloo, which moves host memory (device tensors
+    are staged through it around the call) -- the CPU tests, two ranks sharing one GPU in the gpu suite, FX_BENCH_BACKEND=gloo."""
+    if dist.is_initialized() and dist.get_backend() == "gloo":
+        return torch.device("cpu")
+    return torch.device(device)
+
+
 def assign_trials(costs: Sequence[float], world: int) -> List[List[int]]:
     """Longest-processing-time-first assignment of trials to ranks (trial cost ~ params/batch varies ~6x over
     the reference's search space, reference config.py:7-15).  Deterministic on every rank."""
@@ -84,14 +92,15 @@ def broadcast_cohort(dat: Optional[Dict[str, torch.Tensor]], ann: Optional[Dict[
         meta = [{"dat": [(k, tuple(v.shape)) for k, v in dat.items()], "ann": [(k, tuple(v.shape)) for k, v in ann.items()]}]
     dist.broadcast_object_list(meta, src=src)
     out_d, out_a = {}, {}
+    cdev = collective_device(device)
     for group, src_dict, out in (("dat", dat, out_d), ("ann", ann, out_a)):
         for k, shp in meta[0][group]:
             if rank == src:
-                t = src_dict[k].to(device, torch.float32).contiguous()
+                t = src_dict[k].to(cdev, torch.float32).contiguous()
             else:
-                t = torch.empty(shp, dtype=torch.float32, device=device)
+                t = torch.empty(shp, dtype=torch.float32, device=cdev)
             dist.broadcast(t, src=src)
-            out[k] = t
+            out[k] = t.to(device)
     return out_d, out_a
 
 
@@ -99,10 +108,13 @@ def gather_results(local: List[Tuple[int, float, int, float]], n_trials: int, de
                    force_collectives: bool = False) -> np.ndarray:
     """all_gather of (trial_id, val_loss, epochs, status, rank) rows; returns an [n_trials, 5] array ordered by trial
     id.  A trial nobody reported is marked failed with val_loss=+inf (never a hang)."""
+    device = collective_device(device)
     table = torch.full((n_trials, 5), float("nan"), dtype=torch.float64, device=device)
     table[:, 0] = torch.arange(n_trials, device=device)
     table[:, 1] = float("inf")
+    table[:, 2] = 0.0                 # a unit nobody reported: failed, +inf, 0 epochs, no owner (consumers take means of this column)
     table[:, 3] = STATUS_FAILED
+    table[:, 4] = -1.0
     mine = torch.full((n_trials, 5), float("nan"), dtype=torch.float64, device=device)
     for (tid, val, ep, status) in local:
         mine[tid] = torch.tensor([tid, val, ep, status, rank], dtype=torch.float64, device=device)
@@ -123,12 +135,14 @@ def broadcast_state(state: Optional[Dict[str, torch.Tensor]], shapes: Dict[str, 
     """Winner's state_dict -> every rank, as one flat fp32 buffer (num_batches_tracked rides along as floats)."""
     keys = list(shapes.keys())
     sizes = [int(np.prod(shapes[k])) if shapes[k] else 1 for k in keys]
-    flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+    cdev = collective_device(device)
+    flat = torch.empty(sum(sizes), dtype=torch.float32, device=cdev)
     world = dist.get_world_size() if dist.is_initialized() else 1
     if not dist.is_initialized() or world == 1 or dist.get_rank() == src:
-        flat = torch.cat([state[k].detach().to(device, torch.float32).reshape(-1) for k in keys])
+        flat = torch.cat([state[k].detach().to(cdev, torch.float32).reshape(-1) for k in keys])
     if dist.is_initialized() and (world > 1 or force_collectives):
         dist.broadcast(flat, src=src)
+    flat = flat.to(device)
     out, o = {}, 0
     for k, n in zip(keys, sizes):
         t = flat[o:o + n].reshape(shapes[k])
@@ -149,7 +163,24 @@ def _default_store():
         return None
 
 
-_QUEUE_SEQ = [0]
+def _agree_on_queue(store, order, costs) -> str:
+    """The name of this run_units call's shared counter: rank 0 draws a fresh id from the store and BROADCASTS it, together with
+    the number of units and a digest of the claim order, and every rank checks that it was about to run the same sweep.  (Round 3
+    named the queue by a per-process call counter: a rank that had called run_units once more or once less -- an exception path,
+    a rank-0-only warm-up -- silently split the queue.  Now such a rank fails the check, on every rank, before any unit runs.)"""
+    import hashlib
+    digest = hashlib.sha1(repr((len(order), list(order), [round(float(c), 9) for c in costs])).encode()).hexdigest()
+    msg = [None]
+    if dist.get_rank() == 0:
+        msg = [{"sid": int(store.add("fx_amd/sweep_seq", 1)), "digest": digest}]
+    dist.broadcast_object_list(msg, src=0)
+    same = torch.tensor([1.0 if msg[0]["digest"] == digest else 0.0],
+                        device=torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(same, op=dist.ReduceOp.MIN)
+    if float(same.item()) < 1.0:
+        raise RuntimeError("run_units: the ranks do not agree on the units of this sweep (number, costs or order differ): "
+                           "every rank must call run_units with the same arguments, the same number of times")
+    return f"fx_amd/queue/{msg[0]['sid']}"
 
 
 class _Claims:
@@ -167,9 +198,7 @@ class _Claims:
             self.mode = "static"
             self.mine = list(assign_trials(costs, world)[rank])
         else:
-            # every rank calls run_units the same number of times, so the sequence number names the same queue everywhere
-            _QUEUE_SEQ[0] += 1
-            self.key = f"fx_amd/queue/{_QUEUE_SEQ[0]}"
+            self.key = _agree_on_queue(self.store, self.order, costs)
 
     def __iter__(self):
         if self.mode == "static":
@@ -257,8 +286,8 @@ def agree_and_broadcast_state(held: Dict[int, dict], uid: int, table: np.ndarray
     missing state degrades to None on all ranks instead of the owner raising while the others wait in the broadcast."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
-    owner = int(table[uid, 4]) if table[uid, 4] == table[uid, 4] else 0
-    have = torch.tensor([1.0 if (rank == owner and uid in held) else 0.0], dtype=torch.float32, device=device)
+    owner = int(table[uid, 4]) if (table[uid, 4] == table[uid, 4] and table[uid, 4] >= 0) else 0
+    have = torch.tensor([1.0 if (rank == owner and uid in held) else 0.0], dtype=torch.float32, device=collective_device(device))
     if dist.is_initialized() and (world > 1 or force_collectives):
         dist.all_reduce(have, op=dist.ReduceOp.SUM)
     if float(have.item()) <= 0:

@@ -326,6 +326,55 @@ def gen_function_goldens(R, out):
     print(f"[golden] functions: {len(A)} arrays")
 
 
+FINETUNE_FREEZES = {"enc_frozen": {"encoders": True, "supervisors": False}, "sup_frozen": {"encoders": False, "supervisors": True}}
+
+
+def finetune_specs():
+    return {"DirectPred": Spec("DirectPred", [("a", 33), ("b", 21)], 5, 0.4, 3, [("c", "categorical", 4), ("y", "numerical", 1)]),
+            "supervised_vae": Spec("supervised_vae", [("a", 30), ("b", 18)], 6, 0.3, 3, [("y", "numerical", 1)])}
+
+
+def gen_finetune_goldens(R, out):
+    """The FineTuner's optimisation step (reference main.py:530-539 requires_grad flags per parameter group, :562-566 Adam over the
+    trainable parameters only, :591-600 a Trainer WITHOUT gradient clipping), recorded from the reference's own model classes for
+    both freeze configurations: two consecutive steps, losses, the set and values of the gradients, post-step state.  The fixture
+    travels to the GPU box (the live pin in tests/test_oracle_pinning.py does not)."""
+    lr, B = 3e-3, 6
+    arrays = {"lr": np.array(lr), "n_steps": np.array(2)}
+    for mname, spec in finetune_specs().items():
+        dat, ann, vt = make_cohort(spec, 30, seed=9, missing=False)
+        ds = ref_capture.make_dataset(R, dat, ann, vt)
+        cfg = {"latent_dim": spec.latent_dim, "hidden_dim_factor": spec.hidden_dim_factor, "lr": lr,
+               "supervisor_hidden_dim": spec.supervisor_hidden_dim, "epochs": 1, "batch_size": B}
+        st0 = perturbed_state(spec, seed=3)
+        batches = make_batches(spec, dat, ann, B, 2, seed=4, missing=False)
+        arrays[f"{mname}/spec_json"] = np.array(json.dumps(dataclasses.asdict(spec)))
+        for k, v in st0.items():
+            arrays[f"{mname}/state0/{k}"] = _np(v)
+        for s, b in enumerate(batches):
+            for i, x in enumerate(b["x"]):
+                arrays[f"{mname}/batch/{s}/x/{i}"] = _np(x)
+            for k, v in b["y"].items():
+                arrays[f"{mname}/batch/{s}/y/{k}"] = _np(v)
+        for fname, freeze in FINETUNE_FREEZES.items():
+            torch.manual_seed(21)
+            model = ref_capture.build_reference_model(R, spec, ds, cfg)
+            model.load_state_dict(st0)
+            recs = ref_capture.reference_train_steps(R, spec, model, batches, lr, clip=False, freeze=freeze)
+            for s, r in enumerate(recs):
+                pre = f"{mname}/{fname}/{s}"
+                arrays[f"{pre}/total"] = _np(r.total).reshape(())
+                arrays[f"{pre}/grad_norm"] = _np(r.grad_norm).reshape(())
+                for k, v in r.draws.items():
+                    arrays[f"{pre}/draws/{k}"] = _np(v)
+                for k, v in r.grads.items():
+                    arrays[f"{pre}/grad/{k}"] = _np(v)
+                for k, v in r.state.items():
+                    arrays[f"{pre}/state/{k}"] = _np(v)
+            print(f"[golden] finetune_step {mname} {fname}: totals", [float(r.total) for r in recs])
+    np.savez_compressed(os.path.join(out, "finetune_step.npz"), **arrays)
+
+
 def main():
     if not ref_shim.available():
         sys.exit("reference not present; goldens can only be regenerated in the build container")
@@ -338,6 +387,8 @@ def main():
             gen_model_case(R, name, cfg, OUT)
     if not only or "functions" in only:
         gen_function_goldens(R, OUT)
+    if not only or "finetune_step" in only:
+        gen_finetune_goldens(R, OUT)
 
 
 if __name__ == "__main__":

@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r4m
-timeout 300 python scripts/dom_context.py > gpurun_out/r4m/context_new.txt 2>&1
-FX_FUSED_MAP=1 FX_FUSED_PRIO=1 FX_FUSED_RUNS=6 timeout 300 python scripts/dom_context.py > gpurun_out/r4m/context_old.txt 2>&1
+O=gpurun_out/$1; mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_multiproc.py -x -q -m gpu > $O/pytest_multiproc.txt 2>&1

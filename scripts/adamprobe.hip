@@ -189,10 +189,11 @@ __global__ void fill_random(float* p, long n, unsigned seed) {
 }
 
 int main(int argc, char** argv) {
-  const int H = 5000, F = 20000; const long ld = 20000;
+  const int H = 5000, F = 20000; long ld = 20000;
   const bool random_data = argc > 1;
+  const bool pitch_sweep = argc > 2;      // `adamprobe r pitch`: only the persistent / rows-fastest / cols-fastest patterns, by row pitch
   float *W, *M, *V;
-  const size_t bytes = (size_t)H * ld * 4;
+  const size_t bytes = (size_t)H * (pitch_sweep ? 24576 : ld) * 4;
   CK(hipMalloc(&W, bytes)); CK(hipMalloc(&M, bytes)); CK(hipMalloc(&V, bytes));
   CK(hipMemset(W, 0, bytes)); CK(hipMemset(M, 0, bytes)); CK(hipMemset(V, 0, bytes));
   if (random_data) {   // the arrays hold noise instead of zeros (data-dependent power: zeros are the easy case)
@@ -216,6 +217,22 @@ int main(int argc, char** argv) {
   };
 #define TILES(R, C, ORDER, LDSB, label) run(label, [&] { const int g = ((H + R - 1) / R) * ((F + C - 1) / C); \
     hipLaunchKernelGGL((adam_tiles<R, C, ORDER, LDSB>), dim3(g), dim3(512), 0, 0, W, M, V, H, F, ld); });
+  if (pitch_sweep) {
+    // Is the pool's "pattern-sensitive" kind of box sensitive to the ROW PITCH?  (A vertical band of tiles -- what persistent runs
+    // and rows-fastest grids touch at any instant -- is a stride-`pitch` address pattern; an uneven channel / bank hash of that
+    // stride would show as a pitch dependence.)
+    for (long p : {20000L, 20032L, 20064L, 20096L, 20128L, 20224L, 20256L, 20480L, 20512L, 21504L, 24576L}) {
+      ld = p;
+      char nm[160];
+      snprintf(nm, 160, "pitch %5ld floats (%6ld B): persistent S=6 interleaved", p, p * 4);
+      run(nm, [&] { hipLaunchKernelGGL((adam_runs<65536>), dim3(79 * 6), dim3(512), 0, 0, W, M, V, H, F, ld, 6, 0); });
+      snprintf(nm, 160, "pitch %5ld floats (%6ld B): 64x128 rows fastest", p, p * 4);
+      TILES(64, 128, 0, 65536, nm)
+      snprintf(nm, 160, "pitch %5ld floats (%6ld B): 64x128 cols fastest", p, p * 4);
+      TILES(64, 128, 1, 65536, nm)
+    }
+    return 0;
+  }
   TILES(128, 128, 0, 65536, "tile 128x128 (512 B segs), rows fastest, 2 WG/CU")
   TILES(128, 128, 1, 65536, "tile 128x128 (512 B segs), cols fastest, 2 WG/CU")
   TILES(64, 128, 0, 65536, "tile  64x128 (512 B segs), rows fastest, 2 WG/CU")

@@ -28,7 +28,25 @@ FULL = {
                  variables=[("c", "categorical", 4), ("event", "numerical", 1)], surv=("event", "time"), steps=2),
     "cfg4": dict(model="MultiTripletNetwork", layers=[("gex", 30000), ("cnv", 30000), ("meth", 30000)],
                  variables=[("c", "categorical", 4)], surv=(None, None), steps=2),
+    # cfg2 under --fusion_type early (reference data.py:234-257: the layers are concatenated into one, "all"): a single
+    # [10000, 40000] weight of 1.6 GB (157 row blocks x 313 column tiles, 3-4 runs per row block)
+    "cfg2_early": dict(model="DirectPred", layers=[("all", 40000)], variables=[("y", "numerical", 1)], surv=(None, None), steps=1),
 }
+
+
+def _assert_no_bad_tile(bad, what):
+    """The 0.1 % of elements a wide weight may miss are SCATTERED (entries at the split-bf16 noise floor whose Adam step flips
+    sign).  A localised defect -- one 64 x 128 tile of the dW + Adam kernels, or one wave's 32 x 32 block of it -- would put
+    thousands of misses into one tile and still pass a global 0.1 % count (12 whole tiles at cfg2): bound the misses per tile
+    (<= 3 %) and per 32 x 32 block (<= 12.5 %) as well."""
+    H, F = bad.shape
+    Hp, Fp = -(-H // 64) * 64, -(-F // 128) * 128
+    pad = torch.zeros(Hp, Fp, dtype=torch.float32, device=bad.device)
+    pad[:H, :F] = bad.float()
+    per_tile = pad.view(Hp // 64, 64, Fp // 128, 128).sum(dim=(1, 3))
+    per_blk = pad.view(Hp // 32, 32, Fp // 32, 32).sum(dim=(1, 3))
+    assert float(per_tile.max()) <= 256, f"{what}: {int(per_tile.max())} of 8192 elements of one 64 x 128 tile differ (tile {divmod(int(per_tile.argmax()), Fp // 128)})"
+    assert float(per_blk.max()) <= 128, f"{what}: {int(per_blk.max())} of 1024 elements of one 32 x 32 block differ"
 
 
 def _state_close(got, ref, g, gnorm, lr, what):
@@ -58,7 +76,7 @@ def _state_close(got, ref, g, gnorm, lr, what):
                                        f"{float(err.max()):.3e}")
 
 
-@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4"])
+@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4", "cfg2_early"])
 def test_fullsize_step_vs_oracle(name):
     """The shapes bench.py times, with supplied draws: named losses <= 1e-4 relative (the north-star gate), grad norm vs
     the fp64 norm of the oracle's gradients, >= 99.9 % of every wide weight's elements tight after the step, update
@@ -113,6 +131,7 @@ def test_fullsize_step_vs_oracle(name):
             a, b_ = sd[k].double(), st[k].double()
             bad = (a - b_).abs() > 2e-5 + 1e-3 * b_.abs()
             assert float(bad.double().mean()) <= 1e-3, f"{name} {k} step{step}: {int(bad.sum())} of {bad.numel()} elements differ"
+            _assert_no_bad_tile(bad, f"{name} {k} step{step}")
             upd_ref = b_ - st_prev[k].double()
             assert float((a - b_).norm() / upd_ref.norm()) <= 2e-2, f"{name} {k} step{step}: update norm mismatch"
             del a, b_, bad, upd_ref
@@ -179,6 +198,7 @@ def test_timed_schedule_vs_oracle_cfg2():
             a, b_ = sd[k].double(), st_ref[k].double()
             bad = (a - b_).abs() > 2e-5 + 1e-3 * b_.abs()
             assert float(bad.double().mean()) <= 1e-3, f"{k} step{step}: {int(bad.sum())} of {bad.numel()} elements differ"
+            _assert_no_bad_tile(bad, f"{k} step{step}")
             upd_ref = b_ - st_prev[k].double()
             assert float((a - b_).norm() / upd_ref.norm()) <= 2e-2, f"{k} step{step}: update norm mismatch"
             del a, b_, bad, upd_ref

@@ -222,8 +222,17 @@ def _worker(rank, world, port, out):
     def stateless(tid, p):
         return (0.25 if tid == 3 else 5.0 + tid), 1, (None if tid == 3 else {"w": torch.zeros(2, 3), "bn.num_batches_tracked": torch.tensor(0)})
     _, best2, state2 = trials.run_sweep(params, stateless, costs=[1.0] * 7, device="cpu", state_shapes=shapes)
+    # ranks that disagree about the sweep (here: its costs) fail TOGETHER before any unit runs -- no silently split queue
+    try:
+        trials.run_units(3, lambda u: (1.0, 1, None), costs=[1.0, 2.0, 3.0 + rank], device="cpu")
+        mismatch = "no error"
+    except RuntimeError as e:
+        mismatch = str(e)
+    # ... and the next, consistent sweep works again (fresh queue id from rank 0)
+    t3, _ = trials.run_units(4, lambda u: (float(u), 1, None), costs=[4.0, 3.0, 2.0, 1.0], device="cpu")
     out.put((rank, list(dat.keys()), float(dat["zeta"].sum()), table.tolist(), best,
-             state["w"].tolist(), int(state["bn.num_batches_tracked"]), best2, state2 is None))
+             state["w"].tolist(), int(state["bn.num_batches_tracked"]), best2, state2 is None, mismatch, t3[:, 1].tolist(),
+             sorted(set(t3[:, 4].tolist()))))
     dist.destroy_process_group()
 
 
@@ -248,6 +257,8 @@ def test_trial_sharding_gloo_world2():
     assert r0[4] == r1[4] == 2 and table[2, 1] == 0.5
     assert r0[5] == r1[5] == [[2.0] * 3] * 2 and r0[6] == r1[6] == 6   # winner's weights reached both ranks
     assert r0[7] == r1[7] == 3 and r0[8] and r1[8]                      # stateless winner: None everywhere, no hang
+    assert "do not agree" in r0[9] and "do not agree" in r1[9]
+    assert r0[10] == r1[10] == [0.0, 1.0, 2.0, 3.0] and set(r0[11]) <= {0.0, 1.0}
 
 
 def test_kfold_indices_are_a_partition_with_sklearn_fold_sizes():

@@ -219,6 +219,33 @@ def test_live_reference_finetune_step_matches_oracle(freeze):
                               what=f"{spec.model} {k}")
 
 
+@pytest.mark.parametrize("model", ["DirectPred", "supervised_vae"])
+@pytest.mark.parametrize("freeze", ["enc_frozen", "sup_frozen"])
+def test_finetune_step_fixture_pins_the_oracles_frozen_mode(model, freeze):
+    """The same pin as the live test above, from the committed fixture (tests/golden/finetune_step.npz, generated from the
+    reference's own classes): it travels to the GPU box, where the engine's frozen plans are checked against it."""
+    from golden_io import FinetuneGolden
+    G = FinetuneGolden(model)
+    spec, frozen = G.spec, FinetuneGolden.FREEZES[freeze]
+    st0 = G.state0()
+    st, opt = st0, {}
+    for s in range(2):
+        exp = G.step(freeze, s)
+        st, opt, info = O.train_step(spec, st, opt, G.batch(s), exp["draws"], G.lr, clip=False, frozen=frozen)
+        close(info["losses"]["total"], exp["total"], rtol=1e-5, what=f"{model} {freeze} total step {s}")
+        assert set(info["grads"]) == set(exp["grads"]), set(info["grads"]) ^ set(exp["grads"])
+        close(info["grad_norm"], exp["grad_norm"], rtol=1e-4, what="grad norm")
+        for k, v in exp["grads"].items():        # per tensor in norm (the MMD term's cancellations make single entries of small
+            d = (info["grads"][k].double() - v.double()).norm() / max(float(v.double().norm()), 1e-30)     # tensors reduction-order noise)
+            if float(v.double().norm()) > 1e-6 * float(exp["grad_norm"]):      # else: a true-zero gradient (a bias in front of a BatchNorm), noise
+                assert float(d) <= 5e-3, (k, float(d))
+        for k, v in exp["state"].items():
+            if k.startswith(frozen) and not O.is_buffer(k):
+                assert torch.equal(st[k], st0[k]) and torch.equal(v, st0[k]), k       # frozen: bit-identical, in the reference too
+            elif s == 0:
+                close(st[k], v, rtol=1e-4, atol=shadow_atol(exp["grads"].get(k), exp["grad_norm"], G.lr, 1, 2e-6), what=f"{model} {k}")
+
+
 # ---- one HPO trial's loop (oracle/loop.py) vs the reference model driven through the same schedule ---------------
 def _loop_golden(name="directpred"):
     import json
