@@ -13,6 +13,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 import torch
 
+from . import ops
 from .data import DeviceCohort
 from .engine import PipelinedStep, StepPlan
 
@@ -26,14 +27,25 @@ class FitResult:
     steps: int = 0
 
 
+_COHORT_LOCK = __import__("threading").Lock()
+
+
 def _cohort_of(dataset, device) -> DeviceCohort:
+    """The dataset's HBM-resident copy, built once and cached on the dataset object.  Fits in flight on several host threads
+    share it: it is built under a lock, and PUBLISHED only after the stream that converted / uploaded it has finished -- another
+    thread's stream is not ordered behind that one."""
     c = getattr(dataset, "_fx_cohort", None)
-    if c is None or c.device != torch.device(device):
-        c = DeviceCohort.from_dataset(dataset, device)
-        try:
-            dataset._fx_cohort = c
-        except Exception:
-            pass
+    if c is not None and c.device == torch.device(device):
+        return c
+    with _COHORT_LOCK:
+        c = getattr(dataset, "_fx_cohort", None)
+        if c is None or c.device != torch.device(device):
+            c = DeviceCohort.from_dataset(dataset, device)
+            torch.cuda.current_stream(torch.device(device)).synchronize()
+            try:
+                dataset._fx_cohort = c
+            except Exception:
+                pass
     return c
 
 
@@ -142,6 +154,13 @@ def fit(model, dataset, train_idx: Sequence[int], val_idx: Optional[Sequence[int
     fn(epoch, batch) -> (positive rows, negative rows) replaces the device triplet sampler, "val_draws" / "val_triplets":
     fn(epoch, chunk) the same for the validation batches (epoch == number of epochs run addresses the final validation).
     The schedule (pipelined batch assembly, hipGraph replay, fused kernels) is the production one."""
+    if use_graph and ops.in_flight_thread():
+        # a fit running beside others on this GPU (trials.run_units(in_flight > 1)) must not capture: a hipGraph capture is
+        # process-wide on ROCm and the neighbours synchronise and launch all the time.  Same launches, issued eagerly.
+        import warnings
+        warnings.warn("fit(use_graph=True) inside trials.run_units(in_flight > 1): launching eagerly instead "
+                      "(hipGraph capture is process-wide; pass use_graph=False to silence this)", RuntimeWarning, stacklevel=2)
+        use_graph = False
     store = model._bind(device)
     # streams, events and graph capture are keyed on torch's current device: make it the model's for the whole fit
     with torch.cuda.device(store.device):
@@ -188,7 +207,13 @@ def _fit(model, store, dataset, train_idx, val_idx, **kw) -> FitResult:
     try:
         return _fit_impl(model, store, dataset, train_idx, val_idx, owned=owned, **kw)
     finally:
-        torch.cuda.synchronize(store.device)      # the last replay has finished before its graphs are released
+        # the last launches have finished before the plans (and their graphs) are released.  With other fits in flight on this GPU
+        # only THIS fit's streams are waited for -- a device-wide synchronisation would stall the neighbours (and is illegal while
+        # one of them captures)
+        if ops.in_flight_thread():
+            torch.cuda.current_stream(store.device).synchronize()
+        else:
+            torch.cuda.synchronize(store.device)
         for o in owned:
             o.close()
 

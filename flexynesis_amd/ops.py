@@ -92,6 +92,52 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 # tape segment, group 1 = the detached prefetch fork of PipelinedStep, group 2 = graph capture.
 _POOLS: dict = {}
 _GROUP = 8
+_POOL_LOCK = __import__("threading").Lock()
+
+# Host threads that run fits CONCURRENTLY on one GPU (trials.run_units(in_flight > 1)) mark themselves here.  Graph capture is a
+# process-wide affair on ROCm -- a device synchronisation, a graph destructor or another capture on ANY thread while one stream
+# captures terminates the process -- so such a thread must launch eagerly: fit() consults
+# ``in_flight_thread()`` and downgrades ``use_graph`` there, StepPlan / PipelinedStep.capture refuse outright.
+_TLS = __import__("threading").local()
+
+
+def in_flight_thread() -> bool:
+    return bool(getattr(_TLS, "in_flight", False))
+
+
+class in_flight_scope:
+    """``with ops.in_flight_scope(): ...`` in a worker thread of trials.run_units: no hipGraph capture on this thread, and the
+    thread's side-stream pool is released when it leaves."""
+
+    def __init__(self, stream=None):
+        self.stream = stream            # the worker's own launch stream: no other thread's side-stream pool may hand it out
+
+    def __enter__(self):
+        _TLS.in_flight = True
+        if self.stream is not None:
+            with _POOL_LOCK:
+                _WORKER_STREAMS.add(self.stream.cuda_stream)
+        return self
+
+    def __exit__(self, *exc):
+        _TLS.in_flight = False
+        if self.stream is not None:
+            with _POOL_LOCK:
+                _WORKER_STREAMS.discard(self.stream.cuda_stream)
+        release_thread_streams()
+        return False
+
+
+_WORKER_STREAMS: set = set()
+
+
+def release_thread_streams():
+    """Drop the calling thread's side-stream pools (all devices): a finished worker thread must not leave its entries behind."""
+    import threading
+    me = threading.get_ident()
+    with _POOL_LOCK:
+        for key in [k for k in _POOLS if k[1] == me]:
+            del _POOLS[key]
 
 
 def side_streams(n: int, group: int = 0) -> List["torch.cuda.Stream"]:
@@ -99,21 +145,25 @@ def side_streams(n: int, group: int = 0) -> List["torch.cuda.Stream"]:
     # one pool per (device, host thread): trials in flight on several threads (trials.run_units(in_flight=...)) must not share
     # side streams -- a shared stream would order one trial's batch assembly behind the other's
     dev = (torch.cuda.current_device(), threading.get_ident())
-    pool = _POOLS.setdefault(dev, [])
     need = group * _GROUP + n
     if n > _GROUP:
         raise FxError(f"at most {_GROUP} parallel branches per tape segment (got {n})")
-    tries = 0
-    while len(pool) < need:
-        st = torch.cuda.Stream()
-        tries += 1
-        taken = {p.cuda_stream for p in pool} | {torch.cuda.current_stream().cuda_stream, torch.cuda.default_stream().cuda_stream}
-        if st.cuda_stream in taken:
-            if tries > 64:
-                raise FxError("could not obtain enough distinct HIP streams from torch's stream pool")
-            continue
-        pool.append(st)
-    return pool[group * _GROUP: group * _GROUP + n]
+    with _POOL_LOCK:
+        pool = _POOLS.setdefault(dev, [])
+        tries = 0
+        while len(pool) < need:
+            st = torch.cuda.Stream()
+            tries += 1
+            # distinct from every stream ANY thread's pool holds on this device (torch hands its 32 streams out round-robin: two
+            # threads could otherwise be given the same HIP stream), from the current and from the default stream
+            taken = {p.cuda_stream for key, pl in _POOLS.items() if key[0] == dev[0] for p in pl}
+            taken |= {torch.cuda.current_stream().cuda_stream, torch.cuda.default_stream().cuda_stream} | _WORKER_STREAMS
+            if st.cuda_stream in taken:
+                if tries > 96:
+                    raise FxError("could not obtain enough distinct HIP streams from torch's stream pool")
+                continue
+            pool.append(st)
+        return pool[group * _GROUP: group * _GROUP + n]
 
 
 def capture_stream() -> "torch.cuda.Stream":
@@ -153,6 +203,9 @@ class graph_capture:
 
     def __enter__(self):
         import gc
+        if in_flight_thread():
+            raise FxError("hipGraph capture on a thread that runs fits concurrently with others (trials.run_units(in_flight > 1)): "
+                          "a capture is process-wide on ROCm; launch eagerly there (fit(use_graph=False))")
         self._ctx.__enter__()              # (torch collects garbage and empties the cache before capture_begin)
         self._gc = gc.isenabled()
         gc.disable()

@@ -242,8 +242,14 @@ def run_units(n: int, unit_fn: Callable[[int], Tuple[float, int, Optional[dict]]
     def worker(own_stream: bool):
         if dev.type == "cuda":
             torch.cuda.set_device(dev)                      # (the current device is per host thread)
-        ctx = torch.cuda.stream(torch.cuda.Stream(dev)) if (own_stream and dev.type == "cuda") else contextlib.nullcontext()
-        with ctx:
+        if own_stream and dev.type == "cuda":
+            from . import ops as _ops
+            own = torch.cuda.Stream(dev)
+            ctx = torch.cuda.stream(own)
+            scope = _ops.in_flight_scope(own)      # no hipGraph capture on this thread; its side streams are released at the end
+        else:
+            ctx = scope = contextlib.nullcontext()
+        with scope, ctx:
             while True:
                 with lock:
                     uid = next(claims, None)

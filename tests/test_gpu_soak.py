@@ -221,3 +221,53 @@ def test_trials_in_flight_match_one_at_a_time():
     assert c["trials_in_flight_per_gpu"] == 2 and not c["hipgraph_replay"]
     with pytest.raises(ValueError):
         run_cfg5(DEV, in_flight=2, use_graph=True, **kw)
+
+
+def test_units_in_flight_never_capture_and_share_one_cohort():
+    """a user trial_fn that calls the fit entry points with their DEFAULT use_graph=True from
+    trials.run_units(in_flight=2).  A hipGraph capture is process-wide on ROCm, so such a fit is downgraded to eager launches
+    (with a RuntimeWarning) instead of capturing beside a neighbour that synchronises; the resident cohort is built once, under
+    a lock, and published only after its upload stream has finished; results equal the one-at-a-time run with graphs; the
+    worker threads' stream pools are gone afterwards; an explicit capture on such a thread is refused."""
+    import warnings
+    import flexynesis_amd.models as M
+    from flexynesis_amd import ops, trials
+    from flexynesis_amd._lib import FxError
+    from flexynesis_amd.data import MultiOmicDataset
+    from flexynesis_amd.fit import run_trial
+    g = torch.Generator().manual_seed(5)
+    n = 320
+    dat = {"gex": torch.randn(n, 1200, generator=g), "cnv": torch.randn(n, 800, generator=g)}
+    ann = {"y": dat["gex"][:, :8].sum(1) + 0.1 * torch.randn(n, generator=g)}
+    feats = {k: [f"{k}{i}" for i in range(v.shape[1])] for k, v in dat.items()}
+    plist = trials.draw_search_space(6, seed=11, epochs=2)
+
+    def sweep(in_flight):
+        ds = MultiOmicDataset(dat, ann, {"y": "numerical"}, feats, [f"s{i}" for i in range(n)], {})     # fresh: no cached cohort
+        refused = []
+
+        def unit(uid):
+            if in_flight > 1 and not refused:
+                try:
+                    with ops.graph_capture(torch.cuda.CUDAGraph()):
+                        pass
+                except FxError as e:
+                    refused.append(str(e))
+            val, ep, model, info = run_trial(M.DirectPred, plist[uid], ds, ["y"], early_stop_patience=0, seed=100 + uid, device="cuda")
+            assert "error" not in info, info
+            del model
+            return val, ep, None
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            table, _ = trials.run_units(len(plist), unit, device=DEV, in_flight=in_flight)
+        return table[:, 1].tolist(), [x for x in w if issubclass(x.category, RuntimeWarning) and "launching eagerly" in str(x.message)], refused, ds
+
+    before = set(ops._POOLS)
+    one, w1, _, _ = sweep(1)
+    two, w2, refused, ds2 = sweep(2)
+    assert one == two and all(np.isfinite(v) for v in one)
+    assert not w1 and len(w2) >= 1                         # downgraded (and said so) only where fits run side by side
+    assert refused and "capture" in refused[0]
+    assert getattr(ds2, "_fx_cohort", None) is not None    # built once, shared by both threads
+    assert set(ops._POOLS) <= before | {k for k in ops._POOLS if k[1] == __import__("threading").get_ident()}, "worker pools leaked"
+    assert not ops._WORKER_STREAMS
