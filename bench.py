@@ -111,11 +111,11 @@ def _engine_leg(config, B, dev, precision, steps, warmup, lr, rank=0, features=0
     torch.manual_seed(1000 + rank)
     store = ParamStore(spec, dev, materialize_big_grads=False)
     pipe = PipelinedStep(store, B, cohort=cohort, n_batches=n_batches, seed=17 + rank, precision=precision)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(4321 + rank)
+    from flexynesis_amd import ops as _ops
+    gen = _ops.DeviceRng(4321 + rank)
 
     def reshuffle():
-        perm = torch.randperm(n_train, generator=gen, device=dev)
+        perm = _ops.randperm(n_train, gen, dev)              # fx_randperm: Philox keys + bitonic sort, one launch
         pipe.idx.copy_(perm[:n_batches * rows_per_batch])
 
     reshuffle()
@@ -242,12 +242,11 @@ def main():
     dominant = "fx_linear_dw_adam_bf16x3" if a.precision == "bf16x3" else "fx_linear_dw_adam_f32"
     if pipe.plans[0]._next_fwd:
         dominant = "fx_linear_dw_adam_fwd_bf16x3"       # the same optimiser step + the next step's wide forward
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(4321 + rank)
+    gen = ops.DeviceRng(4321 + rank)
 
     def reshuffle():
-        """shuffle=True: a fresh permutation of the training split per epoch, drawn on the device."""
-        perm = torch.randperm(n_train, generator=gen, device=dev)
+        """shuffle=True: a fresh permutation of the training split per epoch, drawn on the device (fx_randperm: one launch)."""
+        perm = ops.randperm(n_train, gen, dev)
         pipe.idx.copy_(perm[:n_batches * rows_per_batch])
 
     reshuffle()

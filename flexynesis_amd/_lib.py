@@ -27,6 +27,7 @@ U64 = C.c_ulonglong
 PROTOTYPES = {
     "fx_last_error_string": (C.c_char_p, []),
     "fx_version": (I, []),
+    "fx_hip_runtime_version": (I, []),
     "fx_source_hash": (C.c_char_p, []),
     "fx_gather_rows": (I, [P, P, P, I, I, L, L, P, L, P]),
     "fx_gemm_workspace_bytes": (L, [I, I, I]),
@@ -77,6 +78,9 @@ PROTOTYPES = {
     "fx_reparam": (I, [P, P, P, P, P, L, U64, U64, P, P]),
     "fx_mul": (I, [P, P, P, L, P]),
     "fx_fill_normal": (I, [P, L, U64, U64, P, P]),
+    "fx_randperm_scratch_bytes": (L, [L]),
+    "fx_randperm": (I, [P, P, L, U64, U64, P, L, P]),
+    "fx_triplet_sample": (I, [P, P, P, L, P, P, P, P, P, I, U64, U64, P, P]),
     "fx_mse_masked": (I, [P, P, P, P, I, L, L, P, F, P]),
     "fx_ce_masked": (I, [P, P, P, P, I, I, L, L, P, F, P]),
     "fx_cox_ph": (I, [P, P, P, P, P, I, L, L, P, F, P]),
@@ -164,6 +168,30 @@ def _load():
 
 
 lib = _load()
+
+
+# The hipGraph lifetime rules (a graph destructor synchronises the device, fatal during another capture) and
+# the fork shapes the tapes use (every branch forks from the capture stream) were established on these HIP runtimes.  Another
+# runtime is not refused -- the library's kernels do not depend on it -- but it is said once, where a crash report would look.
+VALIDATED_HIP_RUNTIMES = ((7, 0), (7, 2))
+
+
+def hip_runtime_version():
+    v = int(lib.fx_hip_runtime_version())
+    return None if v < 0 else (v // 10_000_000, (v // 100_000) % 100, v % 100_000)
+
+
+def _check_runtime():
+    import warnings
+    try:
+        v = hip_runtime_version()
+    except Exception:
+        v = None
+    if v is not None and (v[0], v[1]) not in VALIDATED_HIP_RUNTIMES:
+        warnings.warn(f"flexynesis_amd: HIP runtime {v[0]}.{v[1]}.{v[2]} -- the hipGraph capture / release rules of the engine were "
+                      f"validated on {', '.join('%d.%d' % x for x in VALIDATED_HIP_RUNTIMES)} (set FX_LEVEL1_GRAPHS=0 and "
+                      "fit(use_graph=False) if captures misbehave)", RuntimeWarning, stacklevel=3)
+    return v
 
 
 def last_error() -> str:

@@ -193,7 +193,14 @@ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0;
 extern "C" {
 
 const char* fx_last_error_string(void) { return g_err; }
-int fx_version(void) { return 200; }  // 0.2.0
+int fx_version(void) { return 300; }  // 0.3.0
+// the HIP RUNTIME the process runs on (hipRuntimeGetVersion: major * 10^7 + minor * 10^5 + patch), which on the GPU boxes differs
+// from the hipcc that built this library; the host logs it against the versions the hipGraph workarounds were validated on
+int fx_hip_runtime_version(void) {
+  int v = 0;
+  if (hipRuntimeGetVersion(&v) != hipSuccess) return -1;
+  return v;
+}
 
 // SHA-256 of the sources this library was built from (csrc/build.py defines FX_SOURCE_HASH); build.py finds the literal
 // in the binary behind the marker and rebuilds when the sources have changed.

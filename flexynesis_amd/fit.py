@@ -80,7 +80,18 @@ class TripletSampler:
         if self.n_groups < 2:
             raise ValueError("triplet sampling needs at least two label groups")
 
-    def sample(self, anchors: torch.Tensor, gen: torch.Generator):
+    def sample(self, anchors: torch.Tensor, gen):
+        """``gen``: an ops.DeviceRng -- one HIP launch (fx_triplet_sample) on the GPU, the training path; or a torch.Generator: the
+        same arithmetic stated with torch ops, which is what the host-side semantics tests (and only they) run on CPU tensors."""
+        if isinstance(gen, ops.DeviceRng):
+            if getattr(self, "_err", None) is None:
+                self._err = torch.zeros(1, dtype=torch.int32, device=anchors.device)
+            pos, neg = ops.triplet_sample(anchors.contiguous(), self.gid, self.order, self.starts, self.counts, self.rank_in_group,
+                                          self.n_groups, gen, self._err)
+            if int(self._err.item()):
+                self._err.zero_()
+                raise ValueError("a label group has a single member: no positive sample exists for its anchor")
+            return pos, neg
         g = self.gid[anchors]
         cnt = self.counts[g]
         if bool((cnt < 2).any()):
@@ -228,8 +239,7 @@ def _fit_impl(model, store, dataset, train_idx, val_idx, *, batch_size, epochs, 
     spec = model.spec
     trip = spec.model == "MultiTripletNetwork"
     passes = 3 if trip else 1
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(int(seed))
+    gen = ops.DeviceRng(int(seed))              # Philox stream of this fit's shuffles and triplet draws (HIP kernels, no torch RNG)
     sampler = None
     tr = torch.as_tensor(np.asarray(train_idx), dtype=torch.int64, device=dev)
     va = torch.as_tensor(np.asarray(val_idx), dtype=torch.int64, device=dev) if val_idx is not None and len(val_idx) else None
@@ -280,7 +290,7 @@ def _fit_impl(model, store, dataset, train_idx, val_idx, *, batch_size, epochs, 
             e = min(tables_written[0], len(supplied["perms"]) - 1)      # (the table after the last epoch is never trained on)
             perm = tr[torch.as_tensor(supplied["perms"][e], dtype=torch.int64).to(dev)]
         else:
-            perm = tr[torch.randperm(tr.numel(), generator=gen, device=dev)]
+            perm = ops.randperm(tr.numel(), gen, dev, src=tr)
         e_written = tables_written[0]
         tables_written[0] += 1
         if pipe is not None:

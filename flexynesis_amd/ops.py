@@ -15,6 +15,7 @@ import torch
 from . import _lib
 from ._lib import lib, FxError
 
+HIP_RUNTIME = _lib._check_runtime()        # (major, minor, patch) of the runtime the process runs on; warns once if unvalidated
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 CTRL_FLOATS = 64
@@ -90,7 +91,7 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 # live one -- including the graph-capture stream itself, which crashed hipGraph replay (4th fit() in one process).
 # All tapes therefore share one small set of streams that are checked to be pairwise distinct: group 0 = branches of a
 # tape segment, group 1 = the detached prefetch fork of PipelinedStep, group 2 = graph capture.
-_POOLS: dict = {}
+_POOLS: dict = {}          # (device, thread id) -> {(group, slot): stream}
 _GROUP = 8
 _POOL_LOCK = __import__("threading").Lock()
 
@@ -143,27 +144,30 @@ def release_thread_streams():
 def side_streams(n: int, group: int = 0) -> List["torch.cuda.Stream"]:
     import threading
     # one pool per (device, host thread): trials in flight on several threads (trials.run_units(in_flight=...)) must not share
-    # side streams -- a shared stream would order one trial's batch assembly behind the other's
+    # side streams -- a shared stream would order one trial's batch assembly behind the other's.  Streams are created on demand,
+    # slot by slot: torch hands out 32 HIP streams per device round-robin, and every slot of every live thread must be a different
+    # one (main thread, autograd's backward thread, worker threads: a handful of slots each)
     dev = (torch.cuda.current_device(), threading.get_ident())
-    need = group * _GROUP + n
     if n > _GROUP:
         raise FxError(f"at most {_GROUP} parallel branches per tape segment (got {n})")
     with _POOL_LOCK:
-        pool = _POOLS.setdefault(dev, [])
-        tries = 0
-        while len(pool) < need:
-            st = torch.cuda.Stream()
-            tries += 1
-            # distinct from every stream ANY thread's pool holds on this device (torch hands its 32 streams out round-robin: two
-            # threads could otherwise be given the same HIP stream), from the current and from the default stream
-            taken = {p.cuda_stream for key, pl in _POOLS.items() if key[0] == dev[0] for p in pl}
-            taken |= {torch.cuda.current_stream().cuda_stream, torch.cuda.default_stream().cuda_stream} | _WORKER_STREAMS
-            if st.cuda_stream in taken:
-                if tries > 96:
-                    raise FxError("could not obtain enough distinct HIP streams from torch's stream pool")
-                continue
-            pool.append(st)
-        return pool[group * _GROUP: group * _GROUP + n]
+        pool = _POOLS.setdefault(dev, {})
+        out = []
+        for i in range(n):
+            st = pool.get((group, i))
+            tries = 0
+            while st is None:
+                cand = torch.cuda.Stream()
+                tries += 1
+                taken = {p.cuda_stream for key, pl in _POOLS.items() if key[0] == dev[0] for p in pl.values()}
+                taken |= {torch.cuda.current_stream().cuda_stream, torch.cuda.default_stream().cuda_stream} | _WORKER_STREAMS
+                if cand.cuda_stream not in taken:
+                    st = pool[(group, i)] = cand
+                elif tries > 96:
+                    raise FxError("could not obtain enough distinct HIP streams from torch's stream pool "
+                                  f"({len(taken)} in use by this process's threads on device {dev[0]})")
+            out.append(st)
+        return out
 
 
 def capture_stream() -> "torch.cuda.Stream":
@@ -1244,3 +1248,57 @@ def bn_rows_bwd(rec, da, dgamma, dbeta, x, gamma, beta, save_mean, save_invstd, 
     rec.emit("fx_bn_rows_bwd", da.data_ptr(), _ptr(dgamma), _ptr(dbeta), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
              save_mean.data_ptr(), save_invstd.data_ptr(), _ptr(mask), R, C_, int(act), float(drop_p), int(seed),
              int(offset), _ptr(ctrl), ws.data_ptr())
+
+
+# ---- index sampling (csrc/fx_sampling.hip) -------------------------------------------------------------------------------------
+class DeviceRng:
+    """A Philox stream position on the host: ``seed`` plus a running offset.  Every sampling launch consumes a disjoint range of
+    counters, so a fit seeded the same way draws the same permutations and triplets whatever else runs beside it."""
+
+    def __init__(self, seed: int):
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.offset = 0
+
+    def take(self, n_counters: int) -> int:
+        o = self.offset
+        self.offset += int(n_counters) + 1
+        return o
+
+
+_RP_SCRATCH: dict = {}
+
+
+def randperm(n: int, rng: DeviceRng, device, src: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """A uniformly random permutation of range(n) (``src`` given: of src's first n entries), int64 on ``device``, launched on the
+    current stream: DataLoader(shuffle=True)'s per-epoch torch.randperm (reference main.py:289-298) as one HIP launch."""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise FxError("randperm: flexynesis_amd samples on the GPU only (no CPU fallback)")
+    if out is None:
+        out = torch.empty(int(n), dtype=torch.int64, device=dev)
+    if src is not None and not (src.is_cuda and src.dtype == torch.int64 and src.is_contiguous() and src.numel() >= n):
+        raise FxError("randperm: src must be a contiguous int64 tensor on the GPU with at least n entries")
+    need = int(lib.fx_randperm_scratch_bytes(int(n)))
+    scratch = None
+    if need:
+        import threading
+        key = (dev.index, threading.get_ident())
+        scratch = _RP_SCRATCH.get(key)
+        if scratch is None or scratch.numel() < need:
+            scratch = _RP_SCRATCH[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+    _lib.call("fx_randperm", out.data_ptr(), _ptr(src), int(n), rng.seed, rng.take((int(n) + 3) // 4), _ptr(scratch),
+              need, _stream())
+    return out
+
+
+def triplet_sample(anchors: torch.Tensor, gid, order, starts, counts, rank_in_group, n_groups: int, rng: DeviceRng, err_flag: torch.Tensor):
+    """Positive / negative sample indices for ``anchors`` (TripletMultiOmicDataset.__getitem__, reference data.py:1106-1131)."""
+    n = anchors.numel()
+    pos, neg = torch.empty_like(anchors), torch.empty_like(anchors)
+    for t in (anchors, gid, order, starts, counts, rank_in_group):
+        if not (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous()):
+            raise FxError("triplet_sample: contiguous int64 GPU tensors expected")
+    _lib.call("fx_triplet_sample", pos.data_ptr(), neg.data_ptr(), anchors.data_ptr(), n, gid.data_ptr(), order.data_ptr(),
+              starts.data_ptr(), counts.data_ptr(), rank_in_group.data_ptr(), int(n_groups), rng.seed, rng.take(n),
+              err_flag.data_ptr(), _stream())
+    return pos, neg

@@ -48,6 +48,8 @@ typedef struct ihipStream_t* fx_stream_t; /* == hipStream_t */
 
 const char* fx_last_error_string(void);
 int fx_version(void);
+/* hipRuntimeGetVersion() of the process (major * 10^7 + minor * 10^5 + patch), -1 if unavailable */
+int fx_hip_runtime_version(void);
 /* SHA-256 (hex) of the HIP sources the library was built from; csrc/build.py rebuilds when it no longer matches */
 const char* fx_source_hash(void);
 
@@ -413,6 +415,21 @@ int fx_bn_rows_fwd(float* out, const float* x, const float* gamma, const float* 
 int fx_bn_rows_bwd(float* da, float* dgamma, float* dbeta, const float* x, const float* gamma, const float* beta,
                    const float* save_mean, const float* save_invstd, const float* mask, long R, int C, int act, float drop_p,
                    unsigned long long seed, unsigned long long offset, const float* ctrl, void* ws, fx_stream_t stream);
+
+/* ---- index sampling on the device (csrc/fx_sampling.hip) ------------------------------------------------------------------
+ * fx_randperm: out[i] = src[perm[i]] (src NULL: perm[i]) for a uniformly random permutation of 0..n-1 drawn from Philox4x32-10
+ * (seed, offset): torch.randperm behind DataLoader(shuffle=True) (reference main.py:289-298).  n <= 4096: one launch; larger n
+ * needs fx_randperm_scratch_bytes(n) bytes of scratch.
+ * fx_triplet_sample: TripletMultiOmicDataset.__getitem__'s draws (reference data.py:1106-1131) for n anchors: positive = uniform
+ * among the other members of the anchor's label group, negative = uniform member of a uniformly chosen other group.  gid[sample]
+ * = group id, order = samples sorted by group, starts / counts per group, rank_in_group[sample]; *err_flag |= 1 if an anchor's
+ * group has no other member (the reference raises). */
+long fx_randperm_scratch_bytes(long n);
+int fx_randperm(long* out, const long* src, long n, unsigned long long seed, unsigned long long offset, void* scratch,
+                long scratch_bytes, fx_stream_t stream);
+int fx_triplet_sample(long* pos, long* neg, const long* anchors, long n, const long* gid, const long* order, const long* starts,
+                      const long* counts, const long* rank_in_group, int n_groups, unsigned long long seed,
+                      unsigned long long offset, int* err_flag, fx_stream_t stream);
 
 #ifdef __cplusplus
 }

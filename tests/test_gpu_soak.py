@@ -7,6 +7,8 @@ These tests exercise (2) and (3) directly and then soak the process the way an H
 validation graphs and level-1 tape graphs ON (their defaults)."""
 import gc
 
+import numpy as np
+
 import pytest
 import torch
 
