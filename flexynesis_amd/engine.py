@@ -415,7 +415,21 @@ class StepPlan:
         if not self.fuse_tail or self.passes != 1 or self.R > 128 or n > 4 or L > 128 or L % 4 != 0 or n * L > 512:
             return False
         wide = "layer_1" if "encoders.0.layer_1.weight" in st.shapes else "hidden_layers.0"      # MLP / VAE encoder
-        return all(st.shapes[f"encoders.{i}.{wide}.weight"][0] % 4 == 0 for i in range(n))
+        if not all(st.shapes[f"encoders.{i}.{wide}.weight"][0] % 4 == 0 for i in range(n)):
+            return False
+        # the Linear layers behind the block (layer_out; FC_mean / FC_var) are read as plain [L, H] arena tensors by the grouped
+        # kernel: a non-default big_threshold / big_min_dim that turned one of them into a padded "wide" weight, or an arena
+        # offset that is not 16-byte aligned, falls back to the per-layer path instead of failing the plan build
+        for i in range(n):
+            for nm in (("layer_out",) if wide == "layer_1" else ("FC_mean", "FC_var")):
+                k = f"encoders.{i}.{nm}.weight"
+                if k in st.big:
+                    return False
+                if k in st.shapes:
+                    t = st.p(k)
+                    if not t.is_contiguous() or t.data_ptr() % 16:
+                        return False
+        return True
 
     def _vae_tails_fwd(self, rec, enc, L, mcat, vcat, mean, logv):
         """All VAE encoders' tails in one launch -- slab sum + bias, LeakyReLU, BatchNorm and the column blocks' shares of
