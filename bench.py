@@ -265,6 +265,11 @@ def main():
                 reshuffle()          # the epoch's last step prefetches the first batch of the next permutation
             step()
 
+    # The first windows after the eager step and the two captures run 3-5 % slower than the steady state (the clocks are still
+    # settling; `repeat_stats` below shows it): a training run is thousands of steps, so the untimed part is long enough to get
+    # there -- SETTLE replays before the W warm-up steps the caller asked for (reported in config.untimed_settle_steps).
+    SETTLE = 40 if use_graph else 0
+    run(SETTLE)
     run(a.warmup)
     torch.cuda.synchronize()
     if use_pg:
@@ -439,7 +444,7 @@ def main():
                                    f"hidden_dim_factor 0.25, lr {a.lr}, clip 1.0 + Adam, "
                                    f"{'hipGraph replay' if use_graph else 'eager tapes'}",
                        "params": P, "global_batch": B * world, "parallelism": f"{world} independent trials (trial sharding)",
-                       "launches_per_step": n_launch, "algorithmic_bytes_per_step": bytes_step,
+                       "launches_per_step": n_launch, "untimed_settle_steps": SETTLE, "algorithmic_bytes_per_step": bytes_step,
                        "step_hbm_frac_of_8TBs": round(bytes_step / (ms_per_step * 1e-3) / 8e12, 4),
                        # the bytes THIS schedule must move (24 instead of 28 B/param where the next forward is fused)
                        "schedule_bytes_per_step": bytes_moved,

@@ -43,24 +43,41 @@ enum FxCtrl {
 #define FX_BN_EPS 1e-5f
 #define FX_BN_MOMENTUM 0.1f
 
-// ---- Adam update (torch.optim.Adam, single-tensor form: lerp / addcmul / sqrt / div / add eps / addcdiv) -----------------------
+// ---- Adam update (torch.optim.Adam defaults: lerp / addcmul / sqrt / div / add eps / addcdiv) --------------------------------
 // One definition for every optimiser kernel (fx_adam_flat*, the dW + Adam epilogues, the fused dW + Adam + next-forward kernel),
-// so that they stay bit-identical to each other.  The IEEE sqrt and the two IEEE divisions of the textbook form are 32 of its 54
-// VALU instructions per element, and the wide kernels are VALU-bound in their Adam phase.  Here:
-// hardware approximations (v_sqrt_f32 / v_rcp_f32, 1 ulp) plus ONE fused-multiply-add residual correction each, which yields the
-// correctly rounded result unless the exact value lies within ~1e-7 ulp of a rounding boundary (Markstein: q' = q + (a - q b) r
-// with r within 1 ulp of 1 / b) -- about one element in 10^7 differs from the IEEE result, by one ulp.  16 instructions.
+// so that they stay bit-identical to each other.
+//
+// The wide kernels run at the package's POWER limit (1.36-1.40 kW while fx_linear_dw_adam_fwd_bf16x3 runs back to back, DESIGN.md
+// section 3.9): their time is their energy, and every VALU instruction per element of a 100 M-element weight is worth ~1.4 us of a
+// 450 us launch.  The textbook form with IEEE sqrt and two IEEE divisions is 54 instructions per element (32 of them the
+// compiler's div_scale / div_fmas / div_fixup / refinement sequences); this one is 10:
+//     m' = fma(g, (1 - b1) c, b1 m)          v' = fma(g g, (1 - b2) c^2, b2 v)          (c = clip coefficient)
+//     d  = fma(v_sqrt_f32(v'), 1 / sqrt(1 - b2^t), eps)                  p' = fma(-lr / (1 - b1^t), m' v_rcp_f32(d), p)
+// v_sqrt_f32 and v_rcp_f32 are accurate to 1 ulp, so the update differs from torch's by <= ~4 ulp (5e-7 relative) of a step of
+// size ~lr -- two orders of magnitude below the 3e-5 relative error the split-bf16 products leave in the gradient itself, and far
+// inside every parity tolerance (losses 1e-4).  m', v' differ from torch's lerp / addcmul sequence by 1 ulp.  Special values fall
+// out right without fix-up code: v' = 0 gives d = eps; v' = inf (overflowed gradients) gives rcp(inf) = 0, a zero step like m / inf;
+// NaN gradients propagate.  -DFX_ADAM_EXACT (scripts/build_variant.py) keeps the correctly rounded form of the first half of round 4
+// (hardware approximations + one Markstein residual correction each, exact unless the true value lies within ~1e-7 ulp of a rounding
+// boundary; 38 instructions) for A/B measurements.
 struct FxAdamK {
-  float coef, step_size, bc2s, rbc2s;
+  float c1, c2, nstep, rbc2s;
+#ifdef FX_ADAM_EXACT
+  float coef, step_size, bc2s;
+#endif
 };
 __device__ __forceinline__ FxAdamK fx_adam_consts(float lr, float bc1, float bc2s, float coef) {
   FxAdamK k;
-  k.coef = coef;
-  k.step_size = lr / bc1;
-  k.bc2s = bc2s;
-  k.rbc2s = 1.0f / bc2s;          // IEEE: the correctly rounded reciprocal the constant division below needs
+  k.c1 = (1.0f - FX_BETA1) * coef;
+  k.c2 = (1.0f - FX_BETA2) * coef * coef;
+  k.nstep = -(lr / bc1);
+  k.rbc2s = 1.0f / bc2s;          // IEEE, once per thread and launch
+#ifdef FX_ADAM_EXACT
+  k.coef = coef; k.step_size = lr / bc1; k.bc2s = bc2s;
+#endif
   return k;
 }
+#ifdef FX_ADAM_EXACT
 __device__ __forceinline__ float fx_sqrt_rn(float x) {
   const float s0 = __builtin_amdgcn_sqrtf(x);
   const float r = __builtin_amdgcn_rcpf(s0);
@@ -74,21 +91,29 @@ __device__ __forceinline__ float fx_div_rn(float a, float b) {       // b finite
   const float e = __builtin_fmaf(-q0, b, a);
   return __builtin_fmaf(e, r, q0);
 }
-__device__ __forceinline__ void fx_adam_update(float& p, float& m, float& v, float g_raw, const FxAdamK& k) {
-  const float gr = g_raw * k.coef;
+#endif
+__device__ __forceinline__ void fx_adam_update(float& p, float& m, float& v, float g, const FxAdamK& k) {
+#ifdef FX_ADAM_EXACT
+  const float gr = g * k.coef;
   const float m2 = m + (gr - m) * (1.0f - FX_BETA1);
   const float v2 = v * FX_BETA2 + (1.0f - FX_BETA2) * gr * gr;
-#ifdef FX_ADAM_IEEE       /* A/B timing only (scripts/build_variant.py): the compiler's IEEE sqrt / division expansions */
+#ifdef FX_ADAM_IEEE       /* rounds 1-3: the compiler's IEEE sqrt / division expansions (54 instructions per element) */
   p = p - k.step_size * (m2 / (sqrtf(v2) / k.bc2s + FX_ADAM_EPS));
   m = m2;
   v = v2;
   return;
 #endif
   const float s = fx_sqrt_rn(v2);
-  const float q0 = s * k.rbc2s;                                      // s / bc2s, divisor constant over the launch
+  const float q0 = s * k.rbc2s;
   const float d0 = __builtin_fmaf(__builtin_fmaf(-q0, k.bc2s, s), k.rbc2s, q0) + FX_ADAM_EPS;
-  const float d = fminf(d0, 3.0e38f);                                // v = inf (overflowed gradients): the step is 0, as m / inf
+  const float d = fminf(d0, 3.0e38f);
   p = p - k.step_size * fx_div_rn(m2, d);
+#else
+  const float m2 = __builtin_fmaf(g, k.c1, m * FX_BETA1);
+  const float v2 = __builtin_fmaf(g * g, k.c2, v * FX_BETA2);
+  const float d = __builtin_fmaf(__builtin_amdgcn_sqrtf(v2), k.rbc2s, FX_ADAM_EPS);
+  p = __builtin_fmaf(k.nstep, m2 * __builtin_amdgcn_rcpf(d), p);
+#endif
   m = m2;
   v = v2;
 }

@@ -330,6 +330,9 @@ __global__ __launch_bounds__(128 * WN) void fx_gemm_bf16x3_kernel(XGemmArgs g) {
       }
     }
   } else {
+#ifdef FX_EPI_PRIO      /* experiment (scripts/build_variant.py): the workgroup that is in its memory phase outranks the one in its K-loop */
+    __builtin_amdgcn_s_setprio(FX_EPI_PRIO);
+#endif
     // descriptors rebased to the tile's first row: offsets stay below TM * ldc * 4 bytes whatever the weight's size
     const long bytes = (long)max(min(TM, g.M - m0), 0) * g.ldc * 4;
     const long rbase = (long)m0 * g.ldc;

@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/$1; mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_soak.py -x -q -m gpu -k "units_in_flight" > $O/pytest_a.txt 2>&1
-timeout 1500 python -m pytest tests -q -m gpu --deselect tests/test_gpu_soak.py::test_units_in_flight_never_capture_and_share_one_cohort -x --lf > $O/pytest_lf.txt 2>&1
+timeout 2400 python -m pytest tests -x -q -m gpu > $O/pytest_all.txt 2>&1
+timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench.txt 2> $O/bench.err
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1

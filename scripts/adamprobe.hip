@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -92,6 +93,58 @@ __global__ __launch_bounds__(512) void adam_runs(float* __restrict__ W, float* _
       __builtin_nontemporal_store(po, (f4*)W + off[i]);
       __builtin_nontemporal_store(mo, (f4*)M + off[i]);
       __builtin_nontemporal_store(vo, (f4*)V + off[i]);
+    }
+  }
+}
+
+// persistent runs (the fused kernel's schedule) over INTERLEAVED storage: mode 1 = W separate [H][ld], m / v interleaved per 128-float
+// segment ([H][F/128][2][128]: a tile row reads 1 KB contiguous of m | v); mode 2 = all three interleaved ([H][F/128][3][128]: 1.5 KB
+// contiguous per tile row, ONE read and ONE write stream).  Is it the number of streams that the pattern-sensitive boxes dislike?
+template <int LDSB>
+__global__ __launch_bounds__(512) void adam_runs_il(float* __restrict__ W, float* __restrict__ MV, int H, int F, long ld, int S, int mode) {
+  __shared__ char pad[LDSB];
+  if (threadIdx.x == 9999) pad[threadIdx.x % LDSB] = 1;
+  constexpr int R = 64, C = 128, UPR = 32, PER = 4;
+  const int tiles_m = (H + R - 1) / R, tiles_n = (F + C - 1) / C;
+  const int tm = blockIdx.x % tiles_m, c = blockIdx.x / tiles_m;
+  for (int tn = c; tn < tiles_n; tn += S) {
+    f4 p[PER], m[PER], v[PER];
+    long op[PER], om[PER], ov[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int u = threadIdx.x + 512 * i, r = u / UPR, c4 = u % UPR;
+      const int row = tm * R + r, col = tn * C + 4 * c4;
+      const bool ok = row < H && col < F;
+      if (mode == 1) {
+        op[i] = ok ? ((long)row * ld + col) / 4 : -1;
+        om[i] = (((long)row * tiles_n + tn) * 2 + 0) * 32 + c4;        // f4 units: 128 floats = 32 f4
+        ov[i] = (((long)row * tiles_n + tn) * 2 + 1) * 32 + c4;
+      } else {
+        op[i] = ok ? (((long)row * tiles_n + tn) * 3 + 0) * 32 + c4 : -1;
+        om[i] = (((long)row * tiles_n + tn) * 3 + 1) * 32 + c4;
+        ov[i] = (((long)row * tiles_n + tn) * 3 + 2) * 32 + c4;
+      }
+      if (op[i] >= 0) {
+        p[i] = __builtin_nontemporal_load((const f4*)(mode == 1 ? W : MV) + op[i]);
+        m[i] = __builtin_nontemporal_load((const f4*)MV + om[i]);
+        v[i] = __builtin_nontemporal_load((const f4*)MV + ov[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      if (op[i] < 0) continue;
+      f4 po, mo, vo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float g = 1e-3f;
+        const float m2 = m[i][j] + (g - m[i][j]) * 0.1f;
+        const float v2 = v[i][j] * 0.999f + 0.001f * g * g;
+        po[j] = p[i][j] - 1e-3f * (m2 / (sqrtf(v2) + 1e-8f));
+        mo[j] = m2; vo[j] = v2;
+      }
+      __builtin_nontemporal_store(po, (f4*)(mode == 1 ? W : MV) + op[i]);
+      __builtin_nontemporal_store(mo, (f4*)MV + om[i]);
+      __builtin_nontemporal_store(vo, (f4*)MV + ov[i]);
     }
   }
 }
@@ -191,9 +244,10 @@ __global__ void fill_random(float* p, long n, unsigned seed) {
 int main(int argc, char** argv) {
   const int H = 5000, F = 20000; long ld = 20000;
   const bool random_data = argc > 1;
-  const bool pitch_sweep = argc > 2;      // `adamprobe r pitch`: only the persistent / rows-fastest / cols-fastest patterns, by row pitch
+  const bool pitch_sweep = argc > 2 && !strcmp(argv[2], "pitch");      // `adamprobe r pitch`: only the persistent / rows-fastest / cols-fastest patterns, by row pitch
   float *W, *M, *V;
-  const size_t bytes = (size_t)H * (pitch_sweep ? 24576 : ld) * 4;
+  const size_t bytes = (size_t)H * (pitch_sweep ? 65600 : ld) * 4;
+  setvbuf(stdout, NULL, _IOLBF, 0);
   CK(hipMalloc(&W, bytes)); CK(hipMalloc(&M, bytes)); CK(hipMalloc(&V, bytes));
   CK(hipMemset(W, 0, bytes)); CK(hipMemset(M, 0, bytes)); CK(hipMemset(V, 0, bytes));
   if (random_data) {   // the arrays hold noise instead of zeros (data-dependent power: zeros are the easy case)
@@ -217,11 +271,44 @@ int main(int argc, char** argv) {
   };
 #define TILES(R, C, ORDER, LDSB, label) run(label, [&] { const int g = ((H + R - 1) / R) * ((F + C - 1) / C); \
     hipLaunchKernelGGL((adam_tiles<R, C, ORDER, LDSB>), dim3(g), dim3(512), 0, 0, W, M, V, H, F, ld); });
+  if (argc > 3 && !strcmp(argv[2], "loop")) {
+    // `adamprobe r loop cols|rows|pers <seconds>`: one pattern back to back for a while (scripts/clocks_under_load.sh samples power meanwhile)
+    const double secs = argc > 4 ? atof(argv[4]) : 8.0;
+    const int g64 = ((H + 63) / 64) * ((F + 127) / 128);
+    long n = 0;
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    CK(hipEventRecord(a));
+    float ms = 0.f;
+    while (ms < secs * 1e3) {
+      for (int i = 0; i < 200; ++i) {
+        if (!strcmp(argv[3], "cols")) hipLaunchKernelGGL((adam_tiles<64, 128, 1, 65536>), dim3(g64), dim3(512), 0, 0, W, M, V, H, F, ld);
+        else if (!strcmp(argv[3], "rows")) hipLaunchKernelGGL((adam_tiles<64, 128, 0, 65536>), dim3(g64), dim3(512), 0, 0, W, M, V, H, F, ld);
+        else hipLaunchKernelGGL((adam_runs<65536>), dim3(79 * 6), dim3(512), 0, 0, W, M, V, H, F, ld, 6, 0);
+      }
+      n += 200;
+      CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms, a, b));
+    }
+    printf("%s: %ld launches, %.1f us per launch\n", argv[3], n, ms * 1e3 / n);
+    return 0;
+  }
+  if (argc > 2 && !strcmp(argv[2], "streams")) {
+    // `adamprobe r streams`: the persistent pattern with 3 + 3, 2 + 2 and 1 + 1 read + write streams (interleaved storage), and the plain one
+    float* MV; CK(hipMalloc(&MV, (size_t)H * 157 * 3 * 128 * 4 + 4096));
+    hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, MV, (long)H * 157 * 3 * 128, 5u);
+    CK(hipDeviceSynchronize());
+    for (int rep = 0; rep < 2; ++rep) {
+      run("persistent S=6, W / m / v separate arrays (3 + 3 streams)", [&] { hipLaunchKernelGGL((adam_runs<65536>), dim3(79 * 6), dim3(512), 0, 0, W, M, V, H, F, ld, 6, 0); });
+      run("persistent S=6, W separate, m | v interleaved per 512 B (2 + 2 streams)", [&] { hipLaunchKernelGGL((adam_runs_il<65536>), dim3(79 * 6), dim3(512), 0, 0, W, MV, H, F, ld, 6, 1); });
+      run("persistent S=6, W | m | v interleaved per 512 B (1 + 1 streams)", [&] { hipLaunchKernelGGL((adam_runs_il<65536>), dim3(79 * 6), dim3(512), 0, 0, W, MV, H, F, ld, 6, 2); });
+      TILES(64, 128, 1, 65536, "tile 64x128 cols fastest, separate arrays")
+    }
+    return 0;
+  }
   if (pitch_sweep) {
     // Is the pool's "pattern-sensitive" kind of box sensitive to the ROW PITCH?  (A vertical band of tiles -- what persistent runs
     // and rows-fastest grids touch at any instant -- is a stride-`pitch` address pattern; an uneven channel / bank hash of that
     // stride would show as a pitch dependence.)
-    for (long p : {20000L, 20032L, 20064L, 20096L, 20128L, 20224L, 20256L, 20480L, 20512L, 21504L, 24576L}) {
+    for (long p : {20000L, 20032L, 20480L, 24576L, 28672L, 32768L, 32800L, 40960L, 49152L, 65536L, 65568L}) {
       ld = p;
       char nm[160];
       snprintf(nm, 160, "pitch %5ld floats (%6ld B): persistent S=6 interleaved", p, p * 4);
