@@ -395,7 +395,7 @@ def _fine_tune_units(model, lrs, cfgs, n_splits):
 
 def fine_tune(model, dataset, *, n_splits: int = 5, batch_size: int = 32, learning_rates=None, max_epoch: int = 50,
               freeze_configs=None, seed: int = 0, device=None, use_graph: bool = True, verbose: bool = False,
-              sharded: bool = False, schedule: str = "queue", comm_device=None):
+              sharded: bool = False, schedule: str = "queue", comm_device=None, supplied_for=None, details: Optional[dict] = None):
     """The reference's ``FineTuner.run_experiments`` (main.py:575-659) on the engine: for every learning rate x
     freeze configuration, k-fold cross-validated short fits of a deep copy of ``model`` (fresh Adam, no gradient
     clipping, partial last batch kept, early stopping with patience 3), pick the configuration with the lowest mean
@@ -407,6 +407,9 @@ def fine_tune(model, dataset, *, n_splits: int = 5, batch_size: int = 32, learni
     ``trials.run_units`` (claimed longest-first from a shared counter); one all_gather collects (val_loss, stopped
     epoch); the rank that ran the LAST fit, from which the reference continues (main.py:647), trains the final model
     and broadcasts its weights.  Rank 0's starting weights are broadcast first, so every rank fine-tunes the same model.
+
+    ``supplied_for(unit)`` (parity tests; unit = (lr index, configuration index, fold) or "final") returns the ``supplied`` dict of that
+    fit (recorded shuffles / dropout draws, see fit()); ``details``, if given, receives {unit: (val_loss, stopped_epoch)}.
 
     Returns (final_model, best, results) with ``results`` = the reference's ``val_loss_results`` records."""
     import copy
@@ -422,12 +425,18 @@ def fine_tune(model, dataset, *, n_splits: int = 5, batch_size: int = 32, learni
     def frozen_of(cfg):
         return tuple(FREEZE_PREFIXES[k] for k in ("encoders", "supervisors") if cfg.get(k))
 
+    def unit_key(lr, cfg, fi):
+        return (lrs.index(lr), cfgs.index(cfg), fi)
+
     def one_fit(lr, cfg, fi):
         m = copy.deepcopy(model)
         tr, va = folds[fi]
         res = fit(m, dataset, tr, va, batch_size=batch_size, epochs=max_epoch, lr=float(lr), patience=3,
                   seed=seed * 1000 + fi, use_graph=use_graph, device=device, clip=False, frozen=frozen_of(cfg),
-                  drop_last=False, fresh_optimizer=True)
+                  drop_last=False, fresh_optimizer=True,
+                  supplied=supplied_for(unit_key(lr, cfg, fi)) if supplied_for is not None else None)
+        if details is not None:
+            details[unit_key(lr, cfg, fi)] = (float(res.val_loss), int(res.stopped_epoch))
         return m, res
 
     def final_fit(last, best):
@@ -436,7 +445,7 @@ def fine_tune(model, dataset, *, n_splits: int = 5, batch_size: int = 32, learni
         if best["epochs"] > 0:
             fit(final, dataset, list(range(n)), None, batch_size=batch_size, epochs=best["epochs"], lr=float(best["learning_rate"]),
                 seed=seed * 1000 + 999, use_graph=use_graph, device=device, clip=False, frozen=frozen_of(best["freeze"]),
-                drop_last=False, fresh_optimizer=True)
+                drop_last=False, fresh_optimizer=True, supplied=supplied_for("final") if supplied_for is not None else None)
         return final
 
     def summarise(vals, eps):

@@ -98,3 +98,47 @@ class FinetuneGolden:
         pre = f"{freeze}/{s}"
         return dict(total=_t(self.z[f"{self.model}/{pre}/total"]), grad_norm=_t(self.z[f"{self.model}/{pre}/grad_norm"]),
                     draws=self.sub(pre + "/draws"), grads=self.sub(pre + "/grad"), state=self.sub(pre + "/state"))
+
+
+class FinetuneLoopGolden:
+    """tests/golden/finetune_loop.npz (oracle/gen_finetune_loop_golden.py): FineTuner.run_experiments (reference main.py:575-659) driven
+    over the reference's own DirectPred: 2 learning rates x 3 freeze configurations x 2 folds with early stopping, the results table, the
+    best configuration and the final model continued from the last cross-validation model."""
+
+    def __init__(self):
+        self.z = np.load(os.path.join(GOLDEN_DIR, "finetune_loop.npz"), allow_pickle=False)
+        self.keys = list(self.z.keys())
+        d = json.loads(str(self.z["spec_json"]))
+        d["layers"] = [tuple(x) for x in d["layers"]]
+        d["variables"] = [tuple(x) for x in d["variables"]]
+        self.spec = Spec(**d)
+        self.n, self.n_splits, self.B, self.max_epoch = (int(self.z[k]) for k in ("n", "n_splits", "batch_size", "max_epoch"))
+        self.kfold_seed = int(self.z["kfold_seed"])
+        self.lrs = [float(x) for x in self.z["lrs"]]
+        self.cfgs = json.loads(str(self.z["cfgs_json"]))
+        self.results = json.loads(str(self.z["results_json"]))
+        self.best = json.loads(str(self.z["best_json"]))
+        self.folds = [(self.z[f"fold/{i}/train"].tolist(), self.z[f"fold/{i}/val"].tolist()) for i in range(self.n_splits)]
+
+    def sub(self, prefix):
+        prefix = prefix.rstrip("/") + "/"
+        return {k[len(prefix):]: _t(self.z[k]) for k in self.keys if k.startswith(prefix)}
+
+    @staticmethod
+    def tag(unit):
+        return "final" if unit == "final" else "unit/%d/%d/%d" % tuple(unit)
+
+    def perms_fn(self, unit):
+        t = self.tag(unit)
+        last = max(int(k.split("/")[-1]) for k in self.keys if k.startswith(t + "/perm/"))
+        return lambda e: _t(self.z[f"{t}/perm/{min(e, last)}"])         # (epochs past the stopped one are never trained on)
+
+    def draws_fn(self, unit):
+        t = self.tag(unit)
+        last = max(int(k.split("/")[-1]) for k in self.keys if k.startswith(t + "/perm/"))
+        # (a pipelined consumer may ask for the first batch of the epoch AFTER the one that stopped: never trained on)
+        return lambda e, b: self.sub(f"{t}/draws/{min(e, last)}/{b}")
+
+    def unit(self, unit):
+        t = self.tag(unit)
+        return float(self.z[t + "/val_loss"]), int(self.z[t + "/stopped_epoch"]), [float(x) for x in self.z[t + "/val_losses"]]

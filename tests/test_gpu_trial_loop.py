@@ -169,3 +169,42 @@ def test_run_trial_returns_objective_triple():
         assert epochs2 == len(h) - 1 and h[-1] >= min(h[:-1])
     else:
         assert epochs2 == 5
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_fine_tune_matches_the_reference_run_experiments_golden(use_graph):
+    """fit.fine_tune -- FineTuner.run_experiments (reference main.py:575-659) on the engine -- against tests/golden/finetune_loop.npz,
+    recorded from the reference's own DirectPred: 2 learning rates x 3 freeze configurations x 2 folds with the recorded shuffles and
+    dropout masks; every fit's validation loss and early-stopping epoch, the results table, the best configuration and the final
+    model (continued from the LAST cross-validation model, supervisors frozen, for the best configuration's mean stopped epoch)."""
+    from golden_io import FinetuneLoopGolden
+    from test_oracle_pinning import finetune_loop_check
+    from flexynesis_amd import models as M
+    from flexynesis_amd.data import MultiOmicDataset
+    from flexynesis_amd.fit import fine_tune, kfold_indices
+    G = FinetuneLoopGolden()
+    spec = G.spec
+    assert kfold_indices(G.n, G.n_splits, G.kfold_seed) == G.folds          # the engine's folds are the golden's
+    dat, ann = G.sub("dat"), G.sub("ann")
+    vt = {v: ("categorical" if kind == "categorical" else "numerical") for (v, kind, _) in spec.variables}
+    feats = {k: [f"{k}_{j}" for j in range(v.shape[1])] for k, v in dat.items()}
+    ds = MultiOmicDataset(dict(dat), dict(ann), vt, feats, [f"s{i}" for i in range(G.n)], {})
+    cfg = {"latent_dim": spec.latent_dim, "hidden_dim_factor": spec.hidden_dim_factor, "lr": G.lrs[0],
+           "supervisor_hidden_dim": spec.supervisor_hidden_dim, "epochs": G.max_epoch, "batch_size": G.B}
+    m = M.DirectPred(cfg, ds, [v[0] for v in spec.variables], device_type="cuda")
+    m.load_state_dict(G.sub("state0"))
+
+    def supplied_for(unit):
+        pf = G.perms_fn(unit)
+        return {"perms": [pf(e) for e in range(G.max_epoch)], "draws": G.draws_fn(unit)}
+
+    details = {}
+    final, best, results = fine_tune(m, ds, n_splits=G.n_splits, batch_size=G.B, learning_rates=G.lrs, max_epoch=G.max_epoch,
+                                     freeze_configs=G.cfgs, seed=G.kfold_seed, device="cuda", use_graph=use_graph,
+                                     supplied_for=supplied_for, details=details)
+    assert len(details) == len(G.lrs) * len(G.cfgs) * G.n_splits
+    gfinal, last = finetune_loop_check(G, details, results, best, final.state_dict())
+    sd = final.state_dict()
+    for k in last:                                    # the final fit froze the supervisors: untouched since the last fold's fit
+        if k.startswith("MLPs.") and not k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            assert float((sd[k].cpu() - last[k]).abs().max()) <= 4.0 * G.lrs[-1] * (G.max_epoch * 3) ** 0.5, k

@@ -246,6 +246,55 @@ def test_finetune_step_fixture_pins_the_oracles_frozen_mode(model, freeze):
                 close(st[k], v, rtol=1e-4, atol=shadow_atol(exp["grads"].get(k), exp["grad_norm"], G.lr, 1, 2e-6), what=f"{model} {k}")
 
 
+def finetune_loop_check(G, per_unit, results, best, final, lr_tol=1.0):
+    """Shared by the CPU pin (oracle) and the GPU test (engine): the outcome of run_experiments against tests/golden/finetune_loop.npz.
+    Tolerances: the biases in front of a BatchNorm have a true gradient of exactly 0, every implementation computes rounding noise
+    for them and Adam turns it into +-lr steps; train-mode BatchNorm cancels them, eval-mode BatchNorm
+    (validation) lags behind by its running mean, so validation losses agree to a few lr (6e-3 at lr 1e-2 here) -- while the golden's
+    early-stopping decisions have margins of 4e-3 (lr 1e-2) or cannot change the outcome (lr 2e-3)."""
+    for unit, (val, stopped) in per_unit.items():
+        gv, gs, _ = G.unit(unit)
+        assert stopped == gs, (unit, stopped, gs)
+        close(val, gv, rtol=1e-2 * lr_tol, what=f"unit {unit} val_loss")
+    assert {G.unit(u)[1] for u in per_unit} == {0, 3}                 # fits that stop early and fits that never do
+    assert [r["epochs"] for r in results] == [r["epochs"] for r in G.results]
+    assert [r["freeze"] for r in results] == [r["freeze"] for r in G.results]
+    assert [r["learning_rate"] for r in results] == [r["learning_rate"] for r in G.results]
+    for a, b in zip(results, G.results):
+        close(a["average_val_loss"], b["average_val_loss"], rtol=1e-2 * lr_tol, what="average_val_loss")
+    assert best["learning_rate"] == G.best["learning_rate"] and best["freeze"] == G.best["freeze"] and best["epochs"] == G.best["epochs"] > 0
+    gfinal, last = G.sub("state_final"), G.sub("state_last")
+    walk = 4.0 * G.lrs[-1] * (G.max_epoch * 3 + 6) ** 0.5            # a +-lr random walk over the last fit's and the final fit's steps
+    for k, v in gfinal.items():
+        got = torch.as_tensor(final[k]).detach().cpu()
+        if k.endswith("num_batches_tracked"):
+            assert int(got) == int(v), k
+        elif k.endswith("layer_1.bias") or k.endswith("layer_out.bias") or k == "fusion_block.bias" or k.endswith("running_mean"):
+            # (the running means track the pre-BatchNorm activations, which carry those biases)
+            close(got, v, rtol=0.0, atol=walk, what=f"final {k} (zero-gradient bias: noise walk)")
+        else:
+            close(got, v, rtol=2e-2, atol=3e-3, what=f"final {k}")
+    return gfinal, last
+
+
+def test_finetune_loop_fixture_pins_the_restated_run_experiments():
+    """oracle/loop.py::fine_tune_reference against the reference's own DirectPred driven through FineTuner.run_experiments
+    (tests/golden/finetune_loop.npz): every fit's final validation loss and stopped epoch, the results table, the best
+    configuration, the final model continued from the LAST fit with the best configuration's freeze flags."""
+    from golden_io import FinetuneLoopGolden
+    from oracle import loop
+    G = FinetuneLoopGolden()
+    final, best, results, per_unit = loop.fine_tune_reference(
+        G.spec, G.sub("state0"), G.sub("dat"), G.sub("ann"), G.n, folds=G.folds, batch_size=G.B, learning_rates=G.lrs,
+        freeze_configs=G.cfgs, max_epoch=G.max_epoch, perms_fn=G.perms_fn, draws_fn=G.draws_fn)
+    gfinal, last = finetune_loop_check(G, per_unit, results, best, final)
+    # frozen in the golden's final fit (supervisors): bit-identical to the last cross-validation model, in the reference itself
+    assert G.best["freeze"]["supervisors"]
+    for k in last:
+        if k.startswith("MLPs.") and not O.is_buffer(k):
+            assert torch.equal(gfinal[k], last[k]), k
+
+
 # ---- one HPO trial's loop (oracle/loop.py) vs the reference model driven through the same schedule ---------------
 def _loop_golden(name="directpred"):
     import json
