@@ -258,6 +258,7 @@ class StepPlan:
         # whole encoder-tail backward in one launch (fx_block_bwd); FX_BLOCK_BWD=0 is an A/B switch for benchmarks
         self.block_bwd = os.environ.get("FX_BLOCK_BWD", "1") != "0"
         self.block_bwd_passes = os.environ.get("FX_BLOCK_BWD_PASSES", "1") != "0"
+        self.gram_kb_wide = os.environ.get("FX_GRAM_KB_WIDE", "1") != "0"          # split-bf16 Gram kernel for wide activations / output gradients of <= 128 rows (A/B)
         self.gram_bf16x3 = os.environ.get("FX_GRAM_BF16X3", "1") != "0"              # X X^T of stacked rows on the split-bf16 kernel (A/B)    # ... also per pass of stacked rows (A/B)
         # all supervisor heads in one launch each way (fx_heads_fwd/bwd); FX_FUSE_HEADS=0 is an A/B switch for benchmarks
         self.fuse_heads = bool(fuse_heads) and os.environ.get("FX_FUSE_HEADS", "1") != "0"
@@ -653,9 +654,20 @@ class StepPlan:
             R = dy.shape[0]
             if self.clip:                                # the norm is only needed for the clip coefficient
                 gx = self._gram_x_for(rec, x)
-                nd = int(ops.lib.fx_gemm_splitk(R, R, dy.shape[1]))
-                gd = self._new(f"gram_dy/{key}", nd, R * R)
-                ops.gemm_slabs(rec, ops.GEMM_NT, gd, dy, dy, R, R)
+                if self._gram_kb_ok(dy):
+                    # dY dY^T of a wide output gradient (the decoders' FC_output: [B, 20000]) on the split-bf16 Gram kernel the
+                    # batch assembly uses for X X^T, instead of an exact-fp32 split-K GEMM (73-99 us beside the HBM-bound
+                    # data-gradient product, at the package's power limit): one K-blocked split + one launch, slabs consumed un-reduced
+                    sd = ops.new_split_kb(R, dy.shape[1], self.dev)
+                    ops.split_bf16(rec, sd[0], sd[1], dy)
+                    nd = ops.gram_kb_slices(dy.shape[1])
+                    gd = self._new(f"gram_dy/{key}", nd, R * R)
+                    ops.gram_kb_group(rec, [sd], [gd], [dy.shape[1]], R)
+                    self.buf[f"gram_dy_split/{key}"], self.buf[f"gram_dy_split_lo/{key}"] = sd
+                else:
+                    nd = int(ops.lib.fx_gemm_splitk(R, R, dy.shape[1]))
+                    gd = self._new(f"gram_dy/{key}", nd, R * R)
+                    ops.gemm_slabs(rec, ops.GEMM_NT, gd, dy, dy, R, R)
                 nb = ops.gram_hadamard_blocks(R * R)
                 ops.gram_hadamard(rec, self.slots[self._slot_o:self._slot_o + nb], gx[0], gx[1], gd, nd, R * R)
                 self._slot_o += nb
@@ -752,6 +764,10 @@ class StepPlan:
         elif not self._is_frozen(wkey) and grp is None:
             ops.linear_bwd_w(rec, st.g(wkey), dy, x_in, self.ws)
 
+    def _gram_kb_ok(self, t) -> bool:
+        """The split-bf16 Gram kernel (fx_gram_kb_group) applies: one M-tile of rows, a wide contiguous operand, bf16x3 precision."""
+        return (self.precision == "bf16x3" and self.gram_kb_wide and t.shape[0] <= 128 and t.shape[1] >= 2048 and t.is_contiguous())
+
     def _gram_x_for(self, rec, x):
         """X X^T split-K slabs (depends on the batch only): emitted once per operand, in whatever branch asks
         first -- the forward branch of the modality when possible, so it hides under the other modality's
@@ -768,6 +784,11 @@ class StepPlan:
                 # (reduced here, in the batch-assembly branch: fx_gram_hadamard on the critical chain then reads one slab, not 85)
                 gx = (self._new(f"gram_x/{x.data_ptr()}", 1, R * R), 1)
                 ops.linear_fwd_bf16x3(rec, gx[0].view(R, R), sp[0], sp[1], x, None, self.ws)
+            elif sp is not None and self._gram_kb_ok(x):
+                # a wide hidden activation whose K-blocked split the forward already made (the decoders' [B, 5000] input of FC_output)
+                nx = ops.gram_kb_slices(x.shape[1])
+                gx = (self._new(f"gram_x/{x.data_ptr()}", nx, R * R), nx)
+                ops.gram_kb_group(rec, [sp], [gx[0]], [x.shape[1]], R)
             else:
                 nx = int(ops.lib.fx_gemm_splitk(R, R, x.shape[1]))
                 gx = (self._new(f"gram_x/{x.data_ptr()}", nx, R * R), nx)
