@@ -47,6 +47,7 @@ PROTOTYPES = {
     "fx_enc_tail_blocks": (I, [I]),
     "fx_enc_tail_fwd": (I, [P, I, I, I, I, I, F, P, P]),
     "fx_fusion_fwd": (I, [P, L, P, L, P, P, P, P, I, P, P, I, I, P]),
+    "fx_fusion_fwd_pair": (I, [P, P, P, P, P, P, P, P, I, P, P, I, I, P]),
     "fx_block_bwd_group": (I, [P, I, I, I, I, F, P]),
     "fx_gather_split_group": (I, [P, I, P, I, P, L, P]),
     "fx_gram_kb_slices": (I, [I]),
@@ -66,11 +67,13 @@ PROTOTYPES = {
     "fx_linear_dw_adam_fwd_bf16x3_slabs_ex": (I, [I, I, I, I]),
     "fx_linear_dw_adam_fwd_bf16x3": (I, [P, P, P, P, P, P, P, I, I, I, L, L, L, P, P, P, L, I, P, L, I, P]),
     "fx_reduce_slabs": (I, [P, P, P, I, I, L, I, L, P]),
+    "fx_reduce_slabs_par": (I, [P, P, P, I, I, L, I, L, P]),
     "fx_linear_bwd_x_bf16x3": (I, [P, P, P, P, I, I, I, L, L, L, P, L, P]),
     "fx_bn_act_fwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, L, L, I, I, I, F, U64, U64, P, P]),
     "fx_bn_act_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, L, L, L, L, I, I, F, I, P]),
     "fx_small_linear_fwd": (I, [P, P, P, P, I, I, I, L, L, P]),
     "fx_small_linear_bwd": (I, [P, P, P, P, P, P, I, I, I, L, L, L, I, P]),
+    "fx_small_linear_bwd_group": (I, [P, I, P]),
     "fx_bn_eval_bwd": (I, [P, P, P, P, P, P, I, I, L, L, L, L, I, I, P]),
     "fx_sigmoid": (I, [P, P, L, P]),
     "fx_sigmoid_bwd": (I, [P, P, P, L, P]),
@@ -89,6 +92,8 @@ PROTOTYPES = {
     "fx_mmd_rows": (I, [P, P, P, P, I, I, I, L, P, F, P]),
     "fx_recon_blocks": (I, [L]),
     "fx_recon_sigmoid": (I, [P, P, P, P, P, L, P, F, P]),
+    "fx_recon_sigmoid_slabs_blocks": (I, [I, I]),
+    "fx_recon_sigmoid_slabs": (I, [P, P, P, P, P, I, L, P, P, I, I, L, P, F, P]),
     "fx_mmd_finalize": (I, [P, P, I, I, P, I, F, F, I, P]),
     "fx_total_loss": (I, [P, I, I, P, P, P, P, P]),
     "fx_step_begin": (I, [P, F, I, P]),
@@ -118,8 +123,15 @@ PROTOTYPES = {
 }
 
 # functions whose int return value is a size/count, not an error code
-_QUERIES = {"fx_version", "fx_gnn_row_blocks", "fx_rowlin_wgrad_workspace_bytes", "fx_bn_rows_workspace_bytes", "fx_col_moments_chunks", "fx_col_moments_workspace_bytes", "fx_block_bwd_blocks", "fx_enc_tail_blocks", "fx_gram_kb_slices", "fx_gemm_splitk", "fx_linear_fwd_bf16x3_splitk", "fx_gram_hadamard_blocks", "fx_gemm_workspace_bytes", "fx_linear_fwd_bf16x3_workspace_bytes", "fx_mmd_workspace_floats", "fx_recon_blocks", "fx_sumsq_blocks",
+_QUERIES = {"fx_version", "fx_gnn_row_blocks", "fx_rowlin_wgrad_workspace_bytes", "fx_bn_rows_workspace_bytes", "fx_col_moments_chunks", "fx_col_moments_workspace_bytes", "fx_block_bwd_blocks", "fx_enc_tail_blocks", "fx_gram_kb_slices", "fx_gemm_splitk", "fx_linear_fwd_bf16x3_splitk", "fx_gram_hadamard_blocks", "fx_gemm_workspace_bytes", "fx_linear_fwd_bf16x3_workspace_bytes", "fx_mmd_workspace_floats", "fx_recon_blocks", "fx_recon_sigmoid_slabs_blocks", "fx_sumsq_blocks",
             "fx_last_error_string"}
+
+
+class SmallLinearJob(C.Structure):
+    """include/fxhip.h: fx_small_linear_job."""
+    _fields_ = [("dx", C.c_void_p), ("gW", C.c_void_p), ("gb", C.c_void_p), ("dy", C.c_void_p), ("dy_mul", C.c_void_p),
+                ("x", C.c_void_p), ("W", C.c_void_p), ("R", C.c_int), ("O", C.c_int), ("K", C.c_int), ("dx_accumulate", C.c_int),
+                ("ldx", C.c_long), ("lddy", C.c_long), ("ldmul", C.c_long), ("lddx", C.c_long)]
 
 
 class HeadDesc(C.Structure):

@@ -327,9 +327,7 @@ struct FusionArgs {
 };
 
 #define FU_KC 64
-__global__ __launch_bounds__(FU_T) void fx_fusion_fwd_kernel(FusionArgs a) {
-  __shared__ __attribute__((aligned(16))) float es[FU_ROWS][FU_MAXK + 4];      // this workgroup's rows of ecat
-  __shared__ float wfs[FU_KC][ET_MAXL + 1];                                    // one 64-column chunk of W_f, transposed [k][l]
+__device__ __forceinline__ void fx_fusion_body(const FusionArgs& a, float (*es)[FU_MAXK + 4], float (*wfs)[ET_MAXL + 1]) {
   const int t = threadIdx.x, r0 = blockIdx.x * FU_ROWS;
   const int B = a.B, Kf = a.Kf, L = a.L;
   // ---- first W_f chunk: requested before the slab sums, stored after them.  element idx -> (l = idx / 64, k = idx % 64)
@@ -412,6 +410,20 @@ __global__ __launch_bounds__(FU_T) void fx_fusion_fwd_kernel(FusionArgs a) {
   if (own && r0 + rr < B) a.emb[(long)(r0 + rr) * a.ldemb + l] = acc;
 }
 
+__global__ __launch_bounds__(FU_T) void fx_fusion_fwd_kernel(FusionArgs a) {
+  __shared__ __attribute__((aligned(16))) float es[FU_ROWS][FU_MAXK + 4];      // this workgroup's rows of ecat
+  __shared__ float wfs[FU_KC][ET_MAXL + 1];                                    // one 64-column chunk of W_f, transposed [k][l]
+  fx_fusion_body(a, es, wfs);
+}
+
+// two independent fusion layers over the same rows in one launch (blockIdx.y): the VAE's FC_mean over mcat and FC_log_var over vcat
+struct FusionPair { FusionArgs a[2]; };
+__global__ __launch_bounds__(FU_T) void fx_fusion_fwd_pair_kernel(FusionPair p) {
+  __shared__ __attribute__((aligned(16))) float es[FU_ROWS][FU_MAXK + 4];
+  __shared__ float wfs[FU_KC][ET_MAXL + 1];
+  fx_fusion_body(p.a[blockIdx.y], es, wfs);
+}
+
 extern "C" {
 
 struct fx_enc_tail_desc;   // include/fxhip.h; layout identical to EncTailDesc
@@ -451,12 +463,10 @@ int fx_enc_tail_fwd(const void* descs_, int n, int B, int pre_act, int post_act,
   return fx_check_launch("fx_enc_tail_fwd");
 }
 
-int fx_fusion_fwd(float* emb, long ldemb, float* ecat, long ldecat, const float* const* parts, const int* n_parts,
-                  const float* const* part_bias, const int* widths, int n_layers, const float* Wf, const float* bf, int B, int L,
-                  hipStream_t stream) {
+static int fusion_args(FusionArgs& a, float* emb, long ldemb, float* ecat, long ldecat, const float* const* parts, const int* n_parts,
+                       const float* const* part_bias, const int* widths, int n_layers, const float* Wf, const float* bf, int B, int L) {
   FX_REQUIRE(parts && n_parts && widths && n_layers > 0 && n_layers <= FU_MAX_LAYERS, "fx_fusion_fwd: 1..%d layers", FU_MAX_LAYERS);
   FX_REQUIRE(B > 0 && (ecat || Wf), "fx_fusion_fwd: nothing to write");
-  FusionArgs a{};
   int Kf = 0;
   for (int i = 0; i < n_layers; ++i) {
     FX_REQUIRE(parts[i] && n_parts[i] > 0 && widths[i] > 0 && widths[i] % 4 == 0 && (((uintptr_t)parts[i]) & 15) == 0,
@@ -472,8 +482,35 @@ int fx_fusion_fwd(float* emb, long ldemb, float* ecat, long ldecat, const float*
   FX_REQUIRE(!Wf || L <= ET_MAXL, "fx_fusion_fwd: latent width %d exceeds %d", L, ET_MAXL);
   a.emb = emb; a.ldemb = ldemb; a.ecat = ecat; a.ldecat = ldecat; a.n_layers = n_layers; a.Wf = Wf; a.bf = bf;
   a.B = B; a.L = L; a.Kf = Kf;
+  return 0;
+}
+
+int fx_fusion_fwd(float* emb, long ldemb, float* ecat, long ldecat, const float* const* parts, const int* n_parts,
+                  const float* const* part_bias, const int* widths, int n_layers, const float* Wf, const float* bf, int B, int L,
+                  hipStream_t stream) {
+  FusionArgs a{};
+  const int rc = fusion_args(a, emb, ldemb, ecat, ldecat, parts, n_parts, part_bias, widths, n_layers, Wf, bf, B, L);
+  if (rc) return rc;
   hipLaunchKernelGGL(fx_fusion_fwd_kernel, dim3((B + FU_ROWS - 1) / FU_ROWS), dim3(FU_T), 0, stream, a);
   return fx_check_launch("fx_fusion_fwd");
+}
+
+// Two fusion layers over the same B rows in ONE launch: every per-layer argument of fx_fusion_fwd doubled (index 0 / 1; parts, n_parts
+// and part_bias hold the first layer's n_layers entries, then the second's).  The VAE's mean = FC_mean(mcat) and log_var =
+// FC_log_var(vcat) (reference supervised_vae.py:172-176).
+int fx_fusion_fwd_pair(float* const* emb, const long* ldemb, float* const* ecat, const long* ldecat, const float* const* parts,
+                       const int* n_parts, const float* const* part_bias, const int* widths, int n_layers, const float* const* Wf,
+                       const float* const* bf, int B, int L, hipStream_t stream) {
+  FX_REQUIRE(emb && ldemb && ecat && ldecat && Wf && bf, "fx_fusion_fwd_pair: null argument arrays");
+  FusionPair p{};
+  for (int j = 0; j < 2; ++j) {
+    const int rc = fusion_args(p.a[j], emb[j], ldemb[j], ecat[j], ldecat[j], parts ? parts + j * n_layers : nullptr,
+                               n_parts ? n_parts + j * n_layers : nullptr, part_bias ? part_bias + j * n_layers : nullptr, widths, n_layers,
+                               Wf[j], bf[j], B, L);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(fx_fusion_fwd_pair_kernel, dim3((B + FU_ROWS - 1) / FU_ROWS, 2), dim3(FU_T), 0, stream, p);
+  return fx_check_launch("fx_fusion_fwd_pair");
 }
 
 }  // extern "C"

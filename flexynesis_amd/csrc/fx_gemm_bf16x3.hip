@@ -776,6 +776,54 @@ __global__ __launch_bounds__(256) void fx_split_bf16_t_kernel(__bf16* __restrict
   }
 }
 
+// Reconstruction epilogue of a decoder's FC_output forward (reference supervised_vae.py:301-313, modules.py:99-103): the ordered
+// sum of the forward's split-K slabs + bias = logits (never stored), x_hat = sigmoid(logits), per-block sums of (x_hat - x)^2,
+// dlogits = w (x_hat - x) x_hat (1 - x_hat) in fp32 (the weight-gradient operands are made from it) and dlogits' K-blocked bf16
+// split (fx_split_bf16's layout: the A operand of the data-gradient product through FC_output).  One pass instead of
+// fx_reduce_slabs4 -> fx_recon_sigmoid -> fx_split_bf16.  Same summation order and formulas as those kernels.
+__global__ __launch_bounds__(256) void fx_recon_sigmoid_slabs_kernel(float* __restrict__ partial, float* __restrict__ dlogits,
+                                                                     __bf16* __restrict__ hi, __bf16* __restrict__ lo,
+                                                                     const float* __restrict__ slabs, int nslabs, long slab_stride,
+                                                                     const float* __restrict__ bias, const float* __restrict__ x,
+                                                                     int F, int Cp, long Rp, const float* logvar, float extra_scale, float n) {
+  __shared__ float sm[16];
+  const int r = blockIdx.y;
+  const float w = (logvar ? expf(-logvar[0]) : 1.0f) * extra_scale * 2.0f / n;      // (fx_recon_sigmoid's expression, term for term)
+  float acc = 0.f;
+  for (int c4 = blockIdx.x * blockDim.x + threadIdx.x; c4 < Cp / 4; c4 += gridDim.x * blockDim.x) {
+    f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
+    if (4 * c4 < F) {
+      const long e = (long)r * F + 4 * c4;
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+      int z = 0;
+      for (; z + 4 <= nslabs; z += 4) {
+        f32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4*>(slabs + (long)(z + j) * slab_stride + e);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += v[j];
+      }
+      for (; z < nslabs; ++z) s += *reinterpret_cast<const f32x4*>(slabs + (long)z * slab_stride + e);
+      if (bias) s += *reinterpret_cast<const f32x4*>(bias + 4 * c4);
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + e);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float xh = 1.0f / (1.0f + expf(-s[j]));
+        const float d = xh - xv[j];
+        acc += d * d;
+        d4[j] = w * d * xh * (1.0f - xh);
+      }
+      if (dlogits) *reinterpret_cast<f32x4*>(dlogits + e) = d4;
+    }
+    if (hi) {          // columns F..Cp-1 are written as zeros, like fx_split_bf16
+      const long o = ((long)(c4 >> 3) * Rp + r) * 32 + 4 * (c4 & 7);
+      split_store4(__builtin_bit_cast(u32x4, d4), hi + o, lo + o);
+    }
+  }
+  acc = fx_block_sum(acc, sm);
+  if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = acc;
+}
+
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // Tuning knobs of the wide kernels.  They are ARGUMENTS of the *_ex entry points (0 = the shipped choice); the library
@@ -823,6 +871,32 @@ int fx_split_bf16(void* hi, void* lo, const float* x, int R, int C, long ldx, lo
   hipLaunchKernelGGL(fx_split_bf16_kernel, dim3(bx, R), dim3(256), 0, stream, (__bf16*)hi, (__bf16*)lo, x, R, C, Cp, ldx,
                      rows_padded);
   return fx_check_launch("fx_split_bf16");
+}
+
+static int recon_slabs_bx(int F) {
+  const int Cp = (F + 31) / 32 * 32;
+  int bx = (Cp / 4 + 255) / 256;
+  return bx > 32 ? 32 : bx;
+}
+
+// number of per-block partial sums fx_recon_sigmoid_slabs writes (the n_partial of fx_mmd_finalize)
+int fx_recon_sigmoid_slabs_blocks(int B, int F) { return B * recon_slabs_bx(F); }
+
+// slabs [nslabs][B * F] (the output of fx_linear_fwd_bf16x3_slabs), bias [F], x [B, F] contiguous; dlogits [B, F] and / or the
+// K-blocked split (hi, lo: fx_split_bf16 layout with rows_padded rows) may be null.  w = exp(-logvar) * extra_scale * 2 / (B F).
+int fx_recon_sigmoid_slabs(float* partial, float* dlogits, void* hi, void* lo, const float* slabs, int nslabs, long slab_stride,
+                           const float* bias, const float* x, int B, int F, long rows_padded, const float* logvar, float extra_scale,
+                           hipStream_t stream) {
+  FX_REQUIRE(partial && slabs && x && B > 0 && F > 0 && nslabs > 0, "fx_recon_sigmoid_slabs: bad args");
+  FX_REQUIRE(F % 4 == 0 && slab_stride % 4 == 0 && aligned16(slabs) && aligned16(x) && (!bias || aligned16(bias)) &&
+             (!dlogits || aligned16(dlogits)), "fx_recon_sigmoid_slabs: F (%d) and the slab stride must be multiples of 4, bases 16-byte aligned", F);
+  FX_REQUIRE((hi == nullptr) == (lo == nullptr), "fx_recon_sigmoid_slabs: hi and lo come together");
+  FX_REQUIRE(!hi || (rows_padded >= B && rows_padded % 128 == 0 && aligned16(hi) && aligned16(lo)),
+             "fx_recon_sigmoid_slabs: rows_padded %ld must be a multiple of 128 and >= %d", rows_padded, B);
+  const int Cp = (F + 31) / 32 * 32;
+  hipLaunchKernelGGL(fx_recon_sigmoid_slabs_kernel, dim3(recon_slabs_bx(F), B), dim3(256), 0, stream, partial, dlogits, (__bf16*)hi,
+                     (__bf16*)lo, slabs, nslabs, slab_stride, bias, x, F, Cp, rows_padded, logvar, extra_scale, (float)((long)B * F));
+  return fx_check_launch("fx_recon_sigmoid_slabs");
 }
 
 int fx_split_bf16_t(void* hiT, void* loT, const float* x, int R, int C, long ldx, long ldo, hipStream_t stream) {

@@ -20,6 +20,8 @@ struct SmallLinArgs {
   long ldx, ldy, lddx, lddy;       // leading dimensions of x, y, dx, dy (W / gW are contiguous [O, K])
   int tiles_dx;                    // backward: workgroups [0, tiles_dx) compute dx tiles, the rest gW (+ gb) tiles
   int dx_accumulate;
+  const float* dy_mul; long ldmul; // backward: the upstream gradient is dy[r, o] * dy_mul[r, o] (NULL: dy as it is)
+  int grid;                        // grouped launch: workgroups of this job
 };
 
 // stage a [rows x cols] block of src (row stride ld) into dst[rows][SL_KC + 1]; out-of-range elements become 0.  Addresses
@@ -69,17 +71,22 @@ __global__ __launch_bounds__(SL_T) void fx_small_linear_fwd_kernel(SmallLinArgs 
       if (r0 + rg + 4 * i < a.R) a.y[(long)(r0 + rg + 4 * i) * a.ldy + o0 + ol] = acc[i];
 }
 
-__global__ __launch_bounds__(SL_T) void fx_small_linear_bwd_kernel(SmallLinArgs a) {
-  __shared__ float s1[SL_KC][SL_KC + 1];      // dx: W chunk [o][k]        gW: x chunk [r][k]
-  __shared__ float s2[SL_KC][SL_TR + 1];      // dx: dy tile, transposed [o][r]   gW: dy chunk [r][o]
+// upstream gradient element (clamped address, unconditional loads)
+__device__ __forceinline__ float sl_dy(const SmallLinArgs& a, int r, int o) {
+  const int rc = min(r, a.R - 1), oc = min(o, a.O - 1);
+  const float v = a.dy[(long)rc * a.lddy + oc];
+  return a.dy_mul ? v * a.dy_mul[(long)rc * a.ldmul + oc] : v;
+}
+
+__device__ __forceinline__ void sl_bwd_body(const SmallLinArgs& a, const int bid, float (*s1)[SL_KC + 1], float (*s2)[SL_TR + 1]) {
   const int tiles_k = (a.K + SL_TC - 1) / SL_TC;
   const int kl = threadIdx.x & 63, g4 = threadIdx.x >> 6;
   float acc[SL_TR / 4];
 #pragma unroll
   for (int i = 0; i < SL_TR / 4; ++i) acc[i] = 0.f;
-  if ((int)blockIdx.x < a.tiles_dx) {
+  if (bid < a.tiles_dx) {
     // ---- dx tile: rows r0.., columns k0..: sum over outputs o
-    const int r0 = (blockIdx.x / tiles_k) * SL_TR, k0 = (blockIdx.x % tiles_k) * SL_TC;
+    const int r0 = (bid / tiles_k) * SL_TR, k0 = (bid % tiles_k) * SL_TC;
     for (int o0 = 0; o0 < a.O; o0 += SL_KC) {
       __syncthreads();
       sl_stage<SL_KC>(s1, a.W, a.K, o0, a.O, k0, a.K);                 // s1[o][k]
@@ -89,7 +96,7 @@ __global__ __launch_bounds__(SL_T) void fx_small_linear_bwd_kernel(SmallLinArgs 
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
           const int idx = threadIdx.x + SL_T * i, rr = idx / SL_KC, oo = idx % SL_KC;
-          v[i] = a.dy[(long)min(r0 + rr, a.R - 1) * a.lddy + min(o0 + oo, a.O - 1)];
+          v[i] = sl_dy(a, r0 + rr, o0 + oo);
         }
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
@@ -117,7 +124,7 @@ __global__ __launch_bounds__(SL_T) void fx_small_linear_bwd_kernel(SmallLinArgs 
     return;
   }
   // ---- gW tile: outputs o0.., columns k0..: sum over rows r; the k-tile 0 workgroups also produce gb
-  const int t = blockIdx.x - a.tiles_dx;
+  const int t = bid - a.tiles_dx;
   const int o0 = (t / tiles_k) * SL_TR, k0 = (t % tiles_k) * SL_TC;
   float accb = 0.f;
   for (int r0 = 0; r0 < a.R; r0 += SL_KC) {
@@ -129,7 +136,7 @@ __global__ __launch_bounds__(SL_T) void fx_small_linear_bwd_kernel(SmallLinArgs 
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         const int idx = threadIdx.x + SL_T * i, rr = idx / SL_TR, oo = idx % SL_TR;
-        v[i] = a.dy[(long)min(r0 + rr, a.R - 1) * a.lddy + min(o0 + oo, a.O - 1)];
+        v[i] = sl_dy(a, r0 + rr, o0 + oo);
       }
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
@@ -154,6 +161,23 @@ __global__ __launch_bounds__(SL_T) void fx_small_linear_bwd_kernel(SmallLinArgs 
       if (o < a.O) a.gW[(long)o * a.K + k0 + kl] = acc[i];
     }
   if (k0 == 0 && a.gb && threadIdx.x < SL_TR && o0 + (int)threadIdx.x < a.O) a.gb[o0 + threadIdx.x] = accb;
+}
+
+__global__ __launch_bounds__(SL_T) void fx_small_linear_bwd_kernel(SmallLinArgs a) {
+  __shared__ float s1[SL_KC][SL_KC + 1];      // dx: W chunk [o][k]        gW: x chunk [r][k]
+  __shared__ float s2[SL_KC][SL_TR + 1];      // dx: dy tile, transposed [o][r]   gW: dy chunk [r][o]
+  sl_bwd_body(a, blockIdx.x, s1, s2);
+}
+
+// several layers' backward in one launch (blockIdx.y = layer): the VAE's FC_mean and FC_log_var
+#define SL_MAX_GROUP 4
+struct SmallLinGroup { SmallLinArgs job[SL_MAX_GROUP]; };
+__global__ __launch_bounds__(SL_T) void fx_small_linear_bwd_group_kernel(SmallLinGroup g) {
+  __shared__ float s1[SL_KC][SL_KC + 1];
+  __shared__ float s2[SL_KC][SL_TR + 1];
+  const SmallLinArgs& a = g.job[blockIdx.y];
+  if ((int)blockIdx.x >= a.grid) return;
+  sl_bwd_body(a, blockIdx.x, s1, s2);
 }
 
 extern "C" {
@@ -185,6 +209,36 @@ int fx_small_linear_bwd(float* dx, float* gW, float* gb, const float* dy, const 
   const int grid = a.tiles_dx + ((O + SL_TR - 1) / SL_TR) * tiles_k;
   hipLaunchKernelGGL(fx_small_linear_bwd_kernel, dim3(grid), dim3(SL_T), 0, stream, a);
   return fx_check_launch("fx_small_linear_bwd");
+}
+
+// The same for up to 4 layers in ONE launch.  jobs: fx_small_linear_job[n] (include/fxhip.h; host memory, read during the call);
+// a job's upstream gradient is dy[r, o] * dy_mul[r, o] when dy_mul is given (the reparameterisation's d log_var = dz * eps,
+// reference supervised_vae.py:190-200, without a launch of its own).
+struct SmallLinJob {
+  float* dx; float* gW; float* gb; const float* dy; const float* dy_mul; const float* x; const float* W;
+  int R, O, K, dx_accumulate;
+  long ldx, lddy, ldmul, lddx;
+};
+int fx_small_linear_bwd_group(const void* jobs_, int n, hipStream_t stream) {
+  const SmallLinJob* jobs = (const SmallLinJob*)jobs_;
+  FX_REQUIRE(jobs && n > 0 && n <= SL_MAX_GROUP, "fx_small_linear_bwd_group: 1..%d jobs", SL_MAX_GROUP);
+  SmallLinGroup g{};
+  int grid = 0;
+  for (int i = 0; i < n; ++i) {
+    const SmallLinJob& j = jobs[i];
+    FX_REQUIRE(j.gW && j.dy && j.x && j.W && j.R > 0 && j.O > 0 && j.K > 0 && j.ldx >= j.K && j.lddy >= j.O && (!j.dx || j.lddx >= j.K) &&
+               (!j.dy_mul || j.ldmul >= j.O), "fx_small_linear_bwd_group: bad args in job %d", i);
+    FX_REQUIRE(j.R <= 4096 && j.O <= 4096 && j.K <= 4096, "fx_small_linear_bwd_group: meant for small layers (got %d x %d x %d)", j.R, j.O, j.K);
+    SmallLinArgs& a = g.job[i];
+    a.dx = j.dx; a.gW = j.gW; a.gb = j.gb; a.dy = j.dy; a.dy_mul = j.dy_mul; a.x = j.x; a.W = j.W; a.R = j.R; a.O = j.O; a.K = j.K;
+    a.ldx = j.ldx; a.lddy = j.lddy; a.ldmul = j.ldmul; a.lddx = j.lddx; a.dx_accumulate = j.dx_accumulate;
+    const int tiles_k = (j.K + SL_TC - 1) / SL_TC;
+    a.tiles_dx = j.dx ? ((j.R + SL_TR - 1) / SL_TR) * tiles_k : 0;
+    a.grid = a.tiles_dx + ((j.O + SL_TR - 1) / SL_TR) * tiles_k;
+    if (a.grid > grid) grid = a.grid;
+  }
+  hipLaunchKernelGGL(fx_small_linear_bwd_group_kernel, dim3(grid, n), dim3(SL_T), 0, stream, g);
+  return fx_check_launch("fx_small_linear_bwd_group");
 }
 
 }  // extern "C"

@@ -233,8 +233,11 @@ class StepPlan:
                  supplied_draws: bool = False, seed: int = 0, cohort=None, n_batches: int = 0,
                  epoch_acc: bool = False, precision: str = "bf16x3", branches: bool = True, share: "StepPlan" = None,
                  fuse_heads: bool = True, frozen: Tuple[str, ...] = (), fuse_next_fwd: bool = False,
-                 attribution: bool = False, clip_norm: float = CLIP_MAX_NORM):
+                 attribution: bool = False, clip_norm: float = CLIP_MAX_NORM, forward_alone: bool = False):
         self.store, self.spec, self.B, self.train = store, store.spec, int(B), train
+        # the forward tape may be run on its own and must leave every loss (the total included) behind: the level-1 path, whose
+        # caller reads the loss between ``forward()`` and ``backward()``.  Otherwise loss bookkeeping may ride in the backward tape.
+        self.forward_alone = bool(forward_alone)
         self.fused = bool(fused) and train
         self.clip = clip
         self.clip_norm = float(clip_norm)       # gradient_clip_val of the caller's Trainer (the reference uses 1.0)
@@ -459,10 +462,13 @@ class StepPlan:
             hs.append(h)
         ops.enc_tail_fwd(rec, descs, R, ACT_LEAKY, ACT_NONE, self.train, 0.0, ctrl=st.ctrl)
         n = len(enc)
-        ops.fusion_fwd(rec, mean, mcat, parts_m, [st.p(f"encoders.{i}.FC_mean.bias") for i in range(n)], st.p("FC_mean.weight"),
-                       st.p("FC_mean.bias"))
-        ops.fusion_fwd(rec, logv, vcat, parts_v, [st.p(f"encoders.{i}.FC_var.bias") for i in range(n)], st.p("FC_log_var.weight"),
-                       st.p("FC_log_var.bias"))
+        bm, bv = [st.p(f"encoders.{i}.FC_mean.bias") for i in range(n)], [st.p(f"encoders.{i}.FC_var.bias") for i in range(n)]
+        if os.environ.get("FX_VAE_FUSION_PAIR", "1") != "0":        # mean and log_var in one launch (A/B: two launches back to back)
+            ops.fusion_fwd_pair(rec, (mean, logv), (mcat, vcat), (parts_m, parts_v), (bm, bv),
+                                (st.p("FC_mean.weight"), st.p("FC_log_var.weight")), (st.p("FC_mean.bias"), st.p("FC_log_var.bias")))
+        else:
+            ops.fusion_fwd(rec, mean, mcat, parts_m, bm, st.p("FC_mean.weight"), st.p("FC_mean.bias"))
+            ops.fusion_fwd(rec, logv, vcat, parts_v, bv, st.p("FC_log_var.weight"), st.p("FC_log_var.bias"))
         return hs
 
     def _mlp_tails_fwd(self, rec, n, L, ecat):
@@ -535,19 +541,24 @@ class StepPlan:
         if dx is not None:
             ops.linear_bwd_x(rec, dx, dh, st.p(prefix + ".hidden_layers.0.weight"), self.ws, accumulate=dx_accumulate)
 
-    def _lin_fwd(self, rec, y, x, wkey, bkey, want_slabs=False):
+    def _lin_fwd(self, rec, y, x, wkey, bkey, want_slabs=False, raw_slabs=False, gram_after=False):
         """nn.Linear forward; wide weights take the split-bf16 MFMA path when precision == 'bf16x3'.
         With ``want_slabs`` the wide path leaves its split-K partial sums unreduced and returns
         (slab buffer, n_slabs) so that the following BatchNorm kernel folds reduction + bias into its own pass
-        (``y`` is then written by that kernel)."""
+        (``y`` is then written by that kernel).  ``raw_slabs``: the stand-alone split-bf16 product only, its split-K slabs left for
+        the caller's epilogue kernel (returns (slabs, n) -- or None with nothing recorded when that path does not apply).
+        ``gram_after``: the caller records the batch-only Gram factor of ``x`` (``_want_gram``) itself, behind the product."""
         st = self.store
+        if raw_slabs and not (self.precision == "bf16x3" and wkey in st.big and not self._can_fuse_next(wkey, x)):
+            return None
         if self.precision == "bf16x3" and wkey in st.big:
             sp = self._split_cache.get(("fwd", x.data_ptr()))
             if sp is None:
                 sp = ops.new_split_kb(x.shape[0], x.shape[1], self.dev)
                 self._split_cache[("fwd", x.data_ptr())] = sp
                 ops.split_bf16(rec, sp[0], sp[1], x)
-            self._want_gram(rec, x, wkey, x.shape[0], self.passes if x.shape[0] == self.R else 1)
+            if not gram_after:
+                self._want_gram(rec, x, wkey, x.shape[0], self.passes if x.shape[0] == self.R else 1)
             if self._can_fuse_next(wkey, x):
                 M, N = y.shape
                 S = ops.dw_adam_fwd_slabs(N, x.shape[1], ops.pad32(x.shape[0]))
@@ -564,11 +575,14 @@ class StepPlan:
             stagger = self.branches and isinstance(rec, TapeRecorder) and len(rec.segments[-1]) > 1
             if stagger and getattr(self, "_last_wide_ev", None) is not None:
                 rec.wait_event(self._last_wide_ev)
-            if want_slabs and os.environ.get("FX_BN_SLABS_UNFUSED", "0") == "1":      # (measured: no gain with the stand-alone forward)
+            if raw_slabs or (want_slabs and os.environ.get("FX_BN_SLABS_UNFUSED", "0") == "1"):      # (BN: no gain with the stand-alone forward)
                 M, N = y.shape
                 ns = int(ops.lib.fx_linear_fwd_bf16x3_splitk(M, N, x.shape[1]))
                 sbuf = self._new(f"slabs/{wkey}", ns, M * N)
                 ops.linear_fwd_bf16x3_slabs(rec, sbuf, sp[0], sp[1], st.p(wkey), M)
+                if stagger:              # (right behind the product: the next branch's weight read does not wait for this one's epilogue)
+                    self._last_wide_ev = torch.cuda.Event()
+                    rec.record_event(self._last_wide_ev)
                 return sbuf, ns
             ops.linear_fwd_bf16x3(rec, y, sp[0], sp[1], st.p(wkey), st.p(bkey), self.ws)
             if stagger:
@@ -610,9 +624,12 @@ class StepPlan:
         [20000, 5000])."""
         W = self.store.p(wkey)
         if self.precision == "bf16x3" and wkey in self.store.big:
-            sp = ops.new_split_kb(dy.shape[0], dy.shape[1], self.dev)
-            self.buf[f"dy_kb/{wkey}"], self.buf[f"dy_kb_lo/{wkey}"] = sp
-            ops.split_bf16(rec, sp[0], sp[1], dy)
+            if f"dy_kb/{wkey}" in self.buf:        # (the producer of dy wrote its split as well: fx_recon_sigmoid_slabs)
+                sp = self.buf[f"dy_kb/{wkey}"], self.buf[f"dy_kb_lo/{wkey}"]
+            else:
+                sp = ops.new_split_kb(dy.shape[0], dy.shape[1], self.dev)
+                self.buf[f"dy_kb/{wkey}"], self.buf[f"dy_kb_lo/{wkey}"] = sp
+                ops.split_bf16(rec, sp[0], sp[1], dy)
             ops.linear_bwd_x_bf16x3(rec, dx, sp[0], sp[1], W, self.ws)
         else:
             ops.linear_bwd_x(rec, dx, dy, W, self.ws)
@@ -658,8 +675,11 @@ class StepPlan:
                     # dY dY^T of a wide output gradient (the decoders' FC_output: [B, 20000]) on the split-bf16 Gram kernel the
                     # batch assembly uses for X X^T, instead of an exact-fp32 split-K GEMM (73-99 us beside the HBM-bound
                     # data-gradient product, at the package's power limit): one K-blocked split + one launch, slabs consumed un-reduced
-                    sd = ops.new_split_kb(R, dy.shape[1], self.dev)
-                    ops.split_bf16(rec, sd[0], sd[1], dy)
+                    if f"dy_kb/{key}" in self.buf:            # (made for the data-gradient product, or by the producer of dy)
+                        sd = self.buf[f"dy_kb/{key}"], self.buf[f"dy_kb_lo/{key}"]
+                    else:
+                        sd = ops.new_split_kb(R, dy.shape[1], self.dev)
+                        ops.split_bf16(rec, sd[0], sd[1], dy)
                     nd = ops.gram_kb_slices(dy.shape[1])
                     gd = self._new(f"gram_dy/{key}", nd, R * R)
                     ops.gram_kb_group(rec, [sd], [gd], [dy.shape[1]], R)
@@ -1379,7 +1399,13 @@ class StepPlan:
         self.mean = mean
         # dz arrives in 1 + nd shares added in this order at the start of the backward tape: the heads' (written by the heads
         # launch, or zero-filled), then each decoder's MMD term (supervised_vae.py:309-313) computed inside that decoder's branch
-        dzs = self._new("dz_shares", 1 + nd, B * L)
+        # ... and, with the fused latent backward, each decoder's split-K partial sums of dh . W_hidden behind them (written in the
+        # decoder's own backward branch), all consumed by ONE ordered reduce after the branches join (FX_VAE_LATENT_FUSED=0: one
+        # accumulating product + reduce per decoder on the main chain, then mul, then one launch each for FC_mean / FC_log_var)
+        lat_fused = bool(self.train and os.environ.get("FX_VAE_LATENT_FUSED", "1") != "0")
+        dz_ns = [int(ops.lib.fx_gemm_splitk(B, L, st.shapes[f"decoders.{i}.hidden_layers.0.weight"][0])) if lat_fused else 0
+                 for i in range(nd)]
+        dzs = self._new("dz_shares", 1 + nd + sum(dz_ns), B * L)
         dz = dzs[0].view(B, L)
         lv_mmd = self._logvar("mmd_loss")
         hd, logits = [], []
@@ -1388,58 +1414,99 @@ class StepPlan:
         # explicit zero-fill takes their place.
         self.xhat = [self._new(f"xhat.{i}", B, spec.layers[dec[i]][1]) for i in range(nd)] if not self.train else None
         priors, rec_parts, row_sums = [], [], []
-        with rf.parallel(nd if vae_par else 1) as par:      # one graph branch per decoder
+        # Schedule of a training plan with decoder branches (the engine's own step: forward and backward tapes always run together).
+        # The chain is  z -> decoder 0's hidden layer -> FC_output products of decoder 0, 1, .. back to back (HBM-bound: one after the
+        # other) -> last reconstruction epilogue -> data-gradient products of decoder 0, 1, .. -> latent backward;  everything else
+        # is placed where nothing on that chain waits for it:
+        #   * the supervisor heads need z only: a branch of their own in the forward tape (forward, losses, backward and their share
+        #     of dz in one launch) instead of 68 us behind the last decoder;
+        #   * the MMD terms (prior draw, kernel rows, dz share: 36 us each) and the loss bookkeeping (MMD finalize, total) need z and
+        #     the reconstruction sums: a side branch of the BACKWARD tape, beside the data-gradient products;
+        #   * what the optimiser needs of decoder 0's FC_output (Gram norm share, transposed operand splits, bias gradient) follows
+        #     its reconstruction epilogue in the forward tape, under decoder 1's product; the other decoders prepare their input side
+        #     before their product (under decoder 0's) and their output-gradient side before their data-gradient product.
+        # FX_VAE_HEADS_BRANCH=0 restores round 3's order (heads, MMD finalize and total on the main chain after the decoders' join, MMD
+        # rows first in each decoder branch, decoder 0 preparing behind its data-gradient product).  Level-1 plans (forward_alone)
+        # keep that order: their caller reads the total loss between the tapes.
+        heads_aside = bool(self.train and vae_par and not self.forward_alone and os.environ.get("FX_VAE_HEADS_BRANCH", "1") != "0")
+        prep0_fwd = bool(heads_aside and self.fused and nd > 1 and os.environ.get("FX_VAE_PREP0_FWD", "1") != "0")
+        mmd_terms = []
+        with rf.parallel((nd + 1 if heads_aside else nd) if vae_par else 1) as par:      # one graph branch per decoder
             for i in range(nd):
                 if vae_par:
                     self._enter_branch(par, i)
                 p = f"decoders.{i}"
                 F = spec.layers[dec[i]][1]
                 # The decoder's MMD prior sample (supervised_vae.py:420-426) and, behind FC_output, its reconstruction term
-                # with dlogits overwriting the logits (:301-313) ride in the decoder's own branch; the main chain after the join
-                # is heads -> MMD rows / finalize per decoder -> total.
+                # with dlogits overwriting the logits (:301-313) ride in the decoder's own branch
+                prng = None
                 if self.supplied:
                     pr = self._draw(f"prior.{i}", MMD_PRIOR, L)
                 else:
                     pr = self._new(f"prior.{i}", MMD_PRIOR, L)
-                    seed, off = self._rng()
-                    ops.fill_normal(rf, pr, seed, off, ctrl=st.ctrl)
+                    prng = self._rng()
                 priors.append(pr)
                 rs = self._new(f"mmd_rows.{i}", 2 * (MMD_PRIOR + B))
                 row_sums.append(rs)
                 dzm = dzs[1 + i].view(B, L)
-                if self.train:
-                    ops.fill(rf, dzm, 0.0)
-                ops.mmd_rows(rf, rs, dzm if self.train else None, pr, z, lv_mmd, 1.0 / nd)
+
+                def mmd_term(rec, pr=pr, rs=rs, dzm=dzm, prng=prng):
+                    if prng is not None:
+                        ops.fill_normal(rec, pr, prng[0], prng[1], ctrl=st.ctrl)
+                    if self.train:
+                        ops.fill(rec, dzm, 0.0)
+                    ops.mmd_rows(rec, rs, dzm if self.train else None, pr, z, lv_mmd, 1.0 / nd)
+                if heads_aside:
+                    mmd_terms.append(mmd_term)
+                else:
+                    mmd_term(rf)
                 h = self._hidden_fwd(rf, p, z, B)
                 hd.append(h)
                 if self.train and vae_par and i > 0 and os.environ.get("FX_VAE_PREP_X", "1") != "0":
-                    # (beside decoder 0's FC_output product; decoder 0 itself heads the critical chain and prepares in the backward)
+                    # (beside decoder 0's FC_output product; decoder 0 itself heads the critical chain)
                     self._weight_grad_prep_x(rf, p + ".FC_output.weight", h)
                 lg = self._new(p + "/logits", B, F)
                 logits.append(lg)
-                self._lin_fwd(rf, lg, h, p + ".FC_output.weight", p + ".FC_output.bias")
-                rp = self._new(f"recon_part.{i}", 1024)
-                rec_parts.append(rp)
-                ops.recon_sigmoid(rf, rp, lg if self.train else None, self.xhat[i] if self.xhat else None, lg, self.X[dec[i]], lv_mmd,
-                                  1.0 / nd)
+                wkey = p + ".FC_output.weight"
+                # training: the reconstruction term, dlogits and their bf16 split as ONE epilogue pass over the product's split-K slabs
+                # (FX_RECON_EPILOGUE=0: reduce -> recon -> split, three launches on the chain between the forward and the data gradient).
+                # gram_after: the batch-only Gram factor FC_output's optimiser step needs is the un-reduced one _weight_grad asks for
+                # (_gram_x_for), not the reduced [B, B] one fx_block_bwd consumes -- _want_gram made the latter here, unused.
+                epi = None
+                if (self.train and F % 4 == 0 and self.X[dec[i]].is_contiguous() and not self._is_frozen(wkey)
+                        and os.environ.get("FX_RECON_EPILOGUE", "1") != "0"):
+                    epi = self._lin_fwd(rf, lg, h, wkey, p + ".FC_output.bias", raw_slabs=True, gram_after=True)
+                if epi is not None:
+                    dsp = ops.new_split_kb(B, F, self.dev)
+                    self.buf[f"dy_kb/{wkey}"], self.buf[f"dy_kb_lo/{wkey}"] = dsp
+                    nblk = ops.recon_sigmoid_slabs_blocks(B, F)
+                    rp = self._new(f"recon_part.{i}", nblk)
+                    ops.recon_sigmoid_slabs(rf, rp, lg, dsp, epi[0], epi[1], st.p(p + ".FC_output.bias"), self.X[dec[i]], lv_mmd, 1.0 / nd)
+                else:
+                    self._lin_fwd(rf, lg, h, wkey, p + ".FC_output.bias", gram_after=True)
+                    nblk = int(ops.lib.fx_recon_blocks(B * F))
+                    rp = self._new(f"recon_part.{i}", 1024)
+                    ops.recon_sigmoid(rf, rp, lg if self.train else None, self.xhat[i] if self.xhat else None, lg, self.X[dec[i]], lv_mmd,
+                                      1.0 / nd)
+                rec_parts.append((rp, nblk))
+                if prep0_fwd and i == 0:
+                    self._weight_grad(rf, wkey, lg, h)
+                    ops.colsum(rf, st.g(p + ".FC_output.bias"), lg)
+            if heads_aside:
+                self._enter_branch(par, nd)
+                self._svae_heads(rf, z, dz)
         self._branch = 0
-        stepped = self._heads_step(rf, z, dz, with_total=False)    # (the total needs the MMD term computed below)
-        if not stepped:
-            self._head_losses(rf, z)
-        if self.train:
-            if stepped:
-                pass
-            elif spec.variables:
-                self._head_bwd(rf, z, dz, first_accumulate=False)  # emitted into the forward tape: see note above
-            else:
-                # unsupervised run (reference __main__.py:997 accepts supervised_vae / CrossModalPred without target
-                # variables): no head overwrites dz, and every later contribution accumulates into it
-                ops.fill(rf, dz, 0.0)
-        for i in range(nd):       # mmd_loss = mean over the reconstructed layers (supervised_vae.py:309-313)
-            F = spec.layers[dec[i]][1]
-            nblk = int(ops.lib.fx_recon_blocks(B * F))
-            ops.mmd_finalize(rf, self.loss_vec[0:1], row_sums[i], MMD_PRIOR, B, rec_parts[i], nblk, float(B * F), 1.0 / nd, i > 0)
-        self._total(rf)
+        if not heads_aside:
+            self._svae_heads(rf, z, dz)
+
+        def bookkeeping(rec):
+            for i in range(nd):       # mmd_loss = mean over the reconstructed layers (supervised_vae.py:309-313)
+                F = spec.layers[dec[i]][1]
+                rp, nblk = rec_parts[i]
+                ops.mmd_finalize(rec, self.loss_vec[0:1], row_sums[i], MMD_PRIOR, B, rp, nblk, float(B * F), 1.0 / nd, i > 0)
+            self._total(rec)
+        if not heads_aside:
+            bookkeeping(rf)
         if not self.train:
             if self.attribution:
                 self._build_svae_attr(enc, hs, mcat, vcat, eps_used, L)
@@ -1448,17 +1515,24 @@ class StepPlan:
         # decoder (the narrow launches around one decoder's FC_output products run beside the other's); their shares of dz
         # are added on the main chain afterwards, in decoder order.
         dz_sum = self._new("dz", B, L)
-        ops.reduce_slabs(rb, dz_sum, dzs, None, 1 + nd)          # heads + MMD terms, in share order
+        if not heads_aside and not lat_fused:
+            ops.reduce_slabs(rb, dz_sum, dzs, None, 1 + nd)          # heads + MMD terms, in share order
         dz = dz_sum
         dhs = []
         # One graph branch per decoder.  Each holds the data-gradient product through FC_output (a full read of the weight:
         # HBM-bound, two of them side by side take as long as one after the other) with the hidden layer's backward behind it, and
-        # ~90 us of narrow launches that only the optimiser tape needs of this weight (Gram norm share = two B x B products +
-        # their Hadamard sum, transposed operand splits, bias gradient).  Decoder 0 reads its weight FIRST and prepares afterwards,
-        # the others prepare first: every branch's narrow work then runs under another branch's weight read.  (As extra branches
-        # the preparation cost more in fork / join edges than it hid: 2.93 vs 2.89 ms; behind an event with the rest of the
-        # backward as a further branch the runtime's four hardware queues serialised it again.)
-        with rb.parallel(nd if vae_par else 1) as par:
+        # the narrow launches that only the optimiser tape needs of this weight (Gram norm share = two B x B products + their
+        # Hadamard sum, transposed operand splits, bias gradient).  Decoder 0 reads its weight FIRST (its preparation ran in the
+        # forward tape, or follows here), the others prepare first: every branch's narrow work runs under another branch's weight
+        # read.  (As extra branches the preparation cost more in fork / join edges than it hid: 2.93 vs 2.89 ms.)
+        with rb.parallel((nd + 1 if heads_aside else nd) if vae_par else 1) as par:
+            if heads_aside:       # (nothing in the decoder branches reads dz or the losses; the join precedes the latent backward)
+                self._enter_branch(par, nd)
+                for term in mmd_terms:
+                    term(rb)
+                if not lat_fused:
+                    ops.reduce_slabs(rb, dz_sum, dzs, None, 1 + nd)
+                bookkeeping(rb)
             for i in range(nd):
                 p = f"decoders.{i}"
                 dh = self._new(p + "/dh", B, st.shapes[p + ".hidden_layers.0.weight"][0])
@@ -1471,25 +1545,59 @@ class StepPlan:
                     ops.colsum(rb, st.g(p + ".FC_output.bias"), logits[i])
                 self._lin_bwd_x(rb, dh, logits[i], p + ".FC_output.weight")
                 self._hidden_bwd(rb, p, z, dh)
-                if not prep_first:
+                if lat_fused:
+                    o = 1 + nd + sum(dz_ns[:i])
+                    ops.gemm_slabs(rb, ops.GEMM_NN, dzs[o:o + dz_ns[i]], dh, st.p(p + ".hidden_layers.0.weight"), B, L)
+                if not prep_first and not (prep0_fwd and i == 0):
                     self._weight_grad(rb, p + ".FC_output.weight", logits[i], hd[i])
                     ops.colsum(rb, st.g(p + ".FC_output.bias"), logits[i])
         self._branch = 0
-        self._svae_bwd_latent(rb, enc, hs, mcat, vcat, dz, dhs, eps_used, n, nd, L, B)
+        if lat_fused:
+            n_all = 1 + nd + sum(dz_ns)                  # heads, MMD terms, decoder 0's partial sums, decoder 1's, ...
+            if L % 4 == 0 and n_all >= 16:
+                ops.reduce_slabs_par(rb, dz_sum, dzs, None, n_all)
+            else:
+                ops.reduce_slabs(rb, dz_sum, dzs, None, n_all)
+        self._svae_bwd_latent(rb, enc, hs, mcat, vcat, dz, dhs, eps_used, n, nd, L, B, dz_complete=lat_fused)
 
-    def _svae_bwd_latent(self, rb, enc, hs, mcat, vcat, dz, dhs, eps_used, n, nd, L, B):
+    def _svae_heads(self, rec, z, dz):
+        """The supervisor heads of a VAE plan: losses and, when training, their backward with dz's first share (the total needs the
+        MMD terms and is recorded separately)."""
+        stepped = self._heads_step(rec, z, dz, with_total=False)
+        if not stepped:
+            self._head_losses(rec, z)
+        if self.train and not stepped:
+            if self.spec.variables:
+                self._head_bwd(rec, z, dz, first_accumulate=False)  # emitted into the forward tape: dz's first share
+            else:
+                # unsupervised run (reference __main__.py:997 accepts supervised_vae / CrossModalPred without target
+                # variables): no head overwrites dz, and every later contribution accumulates into it
+                ops.fill(rec, dz, 0.0)
+
+    def _svae_bwd_latent(self, rb, enc, hs, mcat, vcat, dz, dhs, eps_used, n, nd, L, B, dz_complete=False):
         """dz shares of the decoders (in decoder order), the reparameterisation, the top-level FC_mean / FC_log_var and the
         encoder tails (supervised_vae.py:172-200 backwards)."""
         st = self.store
-        for i in range(nd):
-            ops.linear_bwd_x(rb, dz, dhs[i], st.p(f"decoders.{i}.hidden_layers.0.weight"), self.ws, accumulate=True)
-        # z = mean + log_var * eps
-        dlv = self._new("dlog_var", B, L)
-        ops.mul(rb, dlv, dz, eps_used)
+        if not dz_complete:
+            for i in range(nd):
+                ops.linear_bwd_x(rb, dz, dhs[i], st.p(f"decoders.{i}.hidden_layers.0.weight"), self.ws, accumulate=True)
         dmcat, dvcat = self._new("dmcat", B, n * L), self._new("dvcat", B, n * L)
         enc_frozen = self._is_frozen("encoders.0.FC_mean.weight")    # FineTuner "encoders": True -- the encoders need no gradient
-        self._small_bwd(rb, dmcat, dz, mcat, "FC_mean.weight", "FC_mean.bias", need_dx=not enc_frozen)
-        self._small_bwd(rb, dvcat, dlv, vcat, "FC_log_var.weight", "FC_log_var.bias", need_dx=not enc_frozen)
+        tops = ("FC_mean.weight", "FC_log_var.weight")
+        if (dz_complete and self.small_linear and not any(k in st.big or self._is_frozen(k) for k in tops)
+                and ops.small_linear_ok(mcat, st.p(tops[0])) and ops.small_linear_ok(vcat, st.p(tops[1]))):
+            # z = mean + log_var * eps: d mean = dz, d log_var = dz * eps -- both layers' three gradients in one launch, the product
+            # with eps taken where the kernel reads its upstream gradient
+            ops.small_linear_bwd_group(rb, [
+                dict(dx=None if enc_frozen else dmcat, gW=st.g("FC_mean.weight"), gb=st.g("FC_mean.bias"), dy=dz, x=mcat,
+                     W=st.p("FC_mean.weight")),
+                dict(dx=None if enc_frozen else dvcat, gW=st.g("FC_log_var.weight"), gb=st.g("FC_log_var.bias"), dy=dz, dy_mul=eps_used,
+                     x=vcat, W=st.p("FC_log_var.weight"))])
+        else:
+            dlv = self._new("dlog_var", B, L)
+            ops.mul(rb, dlv, dz, eps_used)
+            self._small_bwd(rb, dmcat, dz, mcat, "FC_mean.weight", "FC_mean.bias", need_dx=not enc_frozen)
+            self._small_bwd(rb, dvcat, dlv, vcat, "FC_log_var.weight", "FC_log_var.bias", need_dx=not enc_frozen)
         if enc_frozen:
             return
         if not self._block_ok(B, 1):

@@ -376,7 +376,7 @@ class FxModel(_Base):
         key = (int(B), bool(train), bool(fused))
         if key not in self._plans:
             self._plans[key] = StepPlan(store, B, train=train, fused=fused, supplied_draws=False,
-                                        seed=self._seed + len(self._plans))
+                                        seed=self._seed + len(self._plans), forward_alone=True)
             # Training plans of the level-1 path (driven tape by tape from an external loop) replay their tapes as hipGraphs
             # from the third use on (fused drop-in 70.9 -> 77.6 k samples/s at cfg2); FX_LEVEL1_GRAPHS=0 launches eagerly.
             # (Opt-in in round 2, when the test suite crashed intermittently with it: the cause was graph objects dying during

@@ -472,6 +472,29 @@ def small_linear_bwd(rec, dx, gW, gb, dy, x, W, dx_accumulate=False):
              _ld(x), _ld(dy), _ld(dx) if dx is not None else K, int(bool(dx_accumulate)))
 
 
+def small_linear_bwd_group(rec, jobs):
+    """Several small layers' backward in ONE launch.  jobs = [dict(dx=, gW=, gb=, dy=, dy_mul=, x=, W=)]: as small_linear_bwd, the
+    upstream gradient being dy * dy_mul elementwise when dy_mul is given."""
+    n = len(jobs)
+    arr = (_lib.SmallLinearJob * n)()
+    for a, j in zip(arr, jobs):
+        dy, x, W, gW, dx, mulv = j["dy"], j["x"], j["W"], j["gW"], j.get("dx"), j.get("dy_mul")
+        for t, nm in ((dy, "dy"), (x, "x"), (W, "W"), (gW, "gW")):
+            _chk2d(t, "small_linear_bwd_group." + nm)
+        R, K = x.shape
+        O = W.shape[0]
+        if W.shape != (O, K) or dy.shape != (R, O) or gW.shape != W.shape or not (W.is_contiguous() and gW.is_contiguous()):
+            raise FxError("small_linear_bwd_group: shape mismatch")
+        if (dx is not None and dx.shape != (R, K)) or (mulv is not None and mulv.shape != dy.shape):
+            raise FxError("small_linear_bwd_group: dx / dy_mul shape mismatch")
+        a.dx, a.gW, a.gb, a.dy, a.dy_mul, a.x, a.W = _ptr(dx), gW.data_ptr(), _ptr(j.get("gb")), dy.data_ptr(), _ptr(mulv), x.data_ptr(), W.data_ptr()
+        a.R, a.O, a.K, a.dx_accumulate = R, O, K, 0
+        a.ldx, a.lddy, a.ldmul, a.lddx = _ld(x), _ld(dy), _ld(mulv) if mulv is not None else O, _ld(dx) if dx is not None else K
+    if hasattr(rec, "keep"):
+        rec.keep(arr)
+    rec.emit("fx_small_linear_bwd_group", C.addressof(arr), n)
+
+
 def linear_dw_adam(rec, W, m, v, dy, x, ctrl):
     for t, n in ((W, "W"), (m, "m"), (v, "v"), (dy, "dY"), (x, "X")):
         _chk2d(t, "linear_dw_adam." + n)
@@ -630,6 +653,15 @@ def reduce_slabs(rec, y, slabs, bias, n_slabs):
     if slabs.numel() < n_slabs * M * N:
         raise FxError("reduce_slabs: slab buffer too small")
     rec.emit("fx_reduce_slabs", y.data_ptr(), slabs.data_ptr(), _ptr(bias), M, N, _ld(y), int(n_slabs), M * N)
+
+
+def reduce_slabs_par(rec, y, slabs, bias, n_slabs):
+    """reduce_slabs for many slabs of a small output: partial sums over contiguous ranges of slabs, combined in range order."""
+    _chk2d(y, "reduce_slabs_par.y")
+    M, N = y.shape
+    if slabs.numel() < n_slabs * M * N:
+        raise FxError("reduce_slabs_par: slab buffer too small")
+    rec.emit("fx_reduce_slabs_par", y.data_ptr(), slabs.data_ptr(), _ptr(bias), M, N, _ld(y), int(n_slabs), M * N)
 
 
 def gemm_slabs(rec, layout, slabs, A, Bm, M, N):
@@ -885,6 +917,33 @@ def fusion_fwd(rec, emb, ecat, parts, biases, W=None, b=None):
              int(W.shape[0]) if W is not None else 0)
 
 
+def fusion_fwd_pair(rec, embs, ecats, parts2, biases2, Ws, bs):
+    """Two fusion_fwd calls over the same rows in one launch: embs / ecats / Ws / bs are pairs, parts2 / biases2 pairs of the per-layer
+    lists (same widths in both)."""
+    n = len(parts2[0])
+    B = ecats[0].shape[0]
+    wd0 = [int(p.shape[-1]) for p, _ in parts2[0]]
+    if len(parts2[1]) != n or [int(p.shape[-1]) for p, _ in parts2[1]] != wd0:
+        raise FxError("fusion_fwd_pair: both layers take the same number and widths of parts")
+    for W in Ws:
+        if not W.is_contiguous() or W.shape[1] != sum(wd0) or W.shape[0] != Ws[0].shape[0]:
+            raise FxError("fusion_fwd_pair: fusion weights must be contiguous [L, sum of widths]")
+    em = (C.c_void_p * 2)(*[e.data_ptr() for e in embs])
+    le = (C.c_long * 2)(*[_ld(e) for e in embs])
+    ec = (C.c_void_p * 2)(*[e.data_ptr() for e in ecats])
+    lc = (C.c_long * 2)(*[_ld(e) for e in ecats])
+    pp = (C.c_void_p * (2 * n))(*[p.data_ptr() for ps in parts2 for p, _ in ps])
+    nb = (C.c_int * (2 * n))(*[int(k) for ps in parts2 for _, k in ps])
+    bb = (C.c_void_p * (2 * n))(*[_ptr(x) for bsl in biases2 for x in bsl])
+    wd = (C.c_int * n)(*wd0)
+    ww = (C.c_void_p * 2)(*[W.data_ptr() for W in Ws])
+    wb = (C.c_void_p * 2)(*[_ptr(b) for b in bs])
+    if hasattr(rec, "keep"):
+        rec.keep(em, le, ec, lc, pp, nb, bb, wd, ww, wb)
+    rec.emit("fx_fusion_fwd_pair", C.addressof(em), C.addressof(le), C.addressof(ec), C.addressof(lc), C.addressof(pp), C.addressof(nb),
+             C.addressof(bb), C.addressof(wd), n, C.addressof(ww), C.addressof(wb), int(B), int(Ws[0].shape[0]))
+
+
 def heads_bwd_scratch(n_heads: int, B: int, L: int, device) -> torch.Tensor:
     """Zero-filled scratch for fx_heads_bwd's per-head dx workgroups (shares + arrival counter)."""
     return torch.zeros(n_heads * B * L + 4, dtype=torch.float32, device=device)
@@ -1014,6 +1073,26 @@ def recon_sigmoid(rec, partial, dlogits, xhat_out, logits, x, logvar=None, extra
         raise FxError("recon_sigmoid: logits and x must be contiguous")
     rec.emit("fx_recon_sigmoid", partial.data_ptr(), _ptr(dlogits), _ptr(xhat_out), logits.data_ptr(), x.data_ptr(),
              logits.numel(), _ptr(logvar), float(extra_scale))
+
+
+def recon_sigmoid_slabs_blocks(B, F) -> int:
+    return int(lib.fx_recon_sigmoid_slabs_blocks(int(B), int(F)))
+
+
+def recon_sigmoid_slabs(rec, partial, dlogits, split, slabs, nslabs, bias, x, logvar=None, extra_scale=1.0):
+    """The reconstruction term as the epilogue of FC_output's forward: slabs [nslabs, B * F] -> partial sums of (x_hat - x)^2,
+    dlogits [B, F] and their K-blocked bf16 split (``split`` = new_split_kb(B, F) or None)."""
+    _chk2d(x, "recon_sigmoid_slabs.x")
+    B, F = x.shape
+    if not x.is_contiguous() or (dlogits is not None and (dlogits.shape != x.shape or not dlogits.is_contiguous())):
+        raise FxError("recon_sigmoid_slabs: x and dlogits must be contiguous [B, F]")
+    if slabs.numel() < int(nslabs) * B * F or partial.numel() < recon_sigmoid_slabs_blocks(B, F):
+        raise FxError("recon_sigmoid_slabs: slab / partial buffers too small")
+    if split is not None:
+        _chk_kb(split[0], split[1], B, F, "recon_sigmoid_slabs")
+    rec.emit("fx_recon_sigmoid_slabs", partial.data_ptr(), _ptr(dlogits), _ptr(split[0]) if split is not None else None,
+             _ptr(split[1]) if split is not None else None, slabs.data_ptr(), int(nslabs), B * F, _ptr(bias), x.data_ptr(), B, F,
+             split[0].shape[1] if split is not None else 0, _ptr(logvar), float(extra_scale))
 
 
 def mmd_finalize(rec, loss_acc, row_sums, P, B, recon_partial, n_partial, n_recon, extra_scale, accumulate):

@@ -131,6 +131,10 @@ int fx_linear_dw_adam_fwd_bf16x3(float* W, float* adam_m, float* adam_v, const v
 /* Y[M,N] = sum_z slabs[z][M][N] (+ bias[N]), summed in slab order (deterministic) */
 int fx_reduce_slabs(float* Y, const float* slabs, const float* bias, int M, int N, long ldy, int n_slabs, long slab_stride,
                     fx_stream_t stream);
+/* the same sum for MANY slabs of a SMALL output (the VAE's dz: 83 slabs of [128, 64]): 8 lanes per four outputs, each over a contiguous range
+ * of slabs, combined in range order -- deterministic, but not fx_reduce_slabs' serial order.  N, ldy, slab_stride % 4 == 0, 16-byte bases. */
+int fx_reduce_slabs_par(float* Y, const float* slabs, const float* bias, int M, int N, long ldy, int n_slabs, long slab_stride,
+                        fx_stream_t stream);
 
 /* ---- launch-fusion variants (same reference ops, fewer passes): GEMMs that leave their split-K partial sums in
  *      slabs [splitk][M][N] for a consumer that reduces them in its own pass; Gram-norm Hadamard sum straight
@@ -194,6 +198,11 @@ int fx_enc_tail_fwd(const fx_enc_tail_desc* descs, int n_modalities, int B, int 
 int fx_fusion_fwd(float* emb, long ldemb, float* ecat, long ldecat, const float* const* parts, const int* n_parts,
                   const float* const* part_bias, const int* widths, int n_layers, const float* Wf, const float* bf, int B, int L,
                   fx_stream_t stream);
+/* Two such layers over the same B rows in ONE launch (the VAE's mean = FC_mean(mcat), log_var = FC_log_var(vcat): supervised_vae.py:172-176):
+ * every per-layer argument doubled (index 0 / 1); parts / n_parts / part_bias hold the first layer's n_layers entries, then the second's. */
+int fx_fusion_fwd_pair(float* const* emb, const long* ldemb, float* const* ecat, const long* ldecat, const float* const* parts,
+                       const int* n_parts, const float* const* part_bias, const int* widths, int n_layers, const float* const* Wf,
+                       const float* const* bf, int B, int L, fx_stream_t stream);
 /* x[r, :] = src[idx[r], :] (x optional) plus both splits in one pass (MultiOmicDataset.__getitem__ + default_collate,
  * data.py:1015-1027, and the operand preparation of the wide kernels).  hi / lo / hiT / loT 16-byte aligned, ldt % 8 == 0 and
  * >= n_rows rounded up to 32; 16-byte accesses when n_cols, ld_src and ldx are multiples of 4 (scalar otherwise). */
@@ -280,6 +289,14 @@ int fx_small_linear_fwd(float* y, const float* x, const float* W, const float* b
                         fx_stream_t stream);
 int fx_small_linear_bwd(float* dx, float* gW, float* gb, const float* dy, const float* x, const float* W, int R, int O, int K,
                         long ldx, long lddy, long lddx, int dx_accumulate, fx_stream_t stream);
+/* Up to 4 such layers' backward in ONE launch (the VAE's FC_mean and FC_log_var: supervised_vae.py:172-176 backwards).  A job's upstream
+ * gradient is dy[r, o] * dy_mul[r, o] when dy_mul is given: d log_var = dz * eps of the reparameterisation (:190-200) needs no launch. */
+typedef struct fx_small_linear_job {
+  float* dx; float* gW; float* gb; const float* dy; const float* dy_mul; const float* x; const float* W;
+  int R, O, K, dx_accumulate;
+  long ldx, lddy, ldmul, lddx;
+} fx_small_linear_job;
+int fx_small_linear_bwd_group(const void* jobs /* fx_small_linear_job[n], host */, int n, fx_stream_t stream);
 
 /* ---- BatchNorm1d (+LeakyReLU before | +ReLU+Dropout after), train & eval (modules.py:25-34,145-148) */
 int fx_bn_act_fwd(float* out, const float* x, const float* gamma, const float* beta, float* running_mean,
@@ -325,6 +342,14 @@ int fx_mmd_rows(float* row_sums, float* dz, const float* prior, const float* z, 
 int fx_recon_blocks(long n);
 int fx_recon_sigmoid(float* partial, float* dlogits, float* xhat_out, const float* logits, const float* x, long n,
                      const float* logvar, float extra_scale, fx_stream_t stream);
+/* The reconstruction term as the epilogue of the decoder's FC_output forward (reference supervised_vae.py:301-313 with modules.py:99-103):
+ * ordered sum of the split-K slabs fx_linear_fwd_bf16x3_slabs left + bias -> sigmoid -> per-block sums of (x_hat - x)^2 (n_partial =
+ * fx_recon_sigmoid_slabs_blocks) -> dlogits [B, F] fp32 and / or their K-blocked bf16 split (fx_split_bf16 layout, rows_padded rows):
+ * one launch for fx_reduce_slabs + fx_recon_sigmoid + fx_split_bf16.  F % 4 == 0. */
+int fx_recon_sigmoid_slabs_blocks(int B, int F);
+int fx_recon_sigmoid_slabs(float* partial, float* dlogits, void* hi, void* lo, const float* slabs, int nslabs, long slab_stride,
+                           const float* bias, const float* x, int B, int F, long rows_padded, const float* logvar, float extra_scale,
+                           fx_stream_t stream);
 int fx_mmd_finalize(float* loss_acc, const float* row_sums, int P, int B, const float* recon_partial, int n_partial,
                     float n_recon, float extra_scale, int accumulate, fx_stream_t stream);
 int fx_total_loss(float* total_out, int n, int weighted, const float* const* losses, const float* const* logvars,

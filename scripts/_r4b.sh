@@ -1,8 +1,12 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/$1; mkdir -p $O
-timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_production.py tests/test_gpu_api.py -x -q -m gpu -k "vae or svae or cross or cfg3 or supervised or golden or fullsize" > $O/pytest.txt 2>&1
+timeout 600 python -m pytest tests/test_gpu_vae_chain.py -x -q -m gpu > $O/pytest_new.txt 2>&1
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_production.py tests/test_gpu_api.py -x -q -m gpu -k "vae or svae or cross or cfg3 or supervised or golden or fullsize or random" > $O/pytest.txt 2>&1
 Q="--steps 30 --warmup 10 --no-cpu-baseline --sweep-trials-per-gpu 0 --no-other --repeats 5 --config cfg3"
 for rep in 1 2 3; do
 python bench.py $Q 2>/dev/null | tail -1 > $O/cfg3_new_$rep.json
-FX_GRAM_KB_WIDE=0 python bench.py $Q 2>/dev/null | tail -1 > $O/cfg3_old_$rep.json
+FX_RECON_EPILOGUE=0 FX_VAE_LATENT_FUSED=0 FX_VAE_HEADS_BRANCH=0 python bench.py $Q 2>/dev/null | tail -1 > $O/cfg3_old_$rep.json
 done
+FX_RECON_EPILOGUE=0 python bench.py $Q 2>/dev/null | tail -1 > $O/cfg3_norecon.json
+FX_VAE_LATENT_FUSED=0 python bench.py $Q 2>/dev/null | tail -1 > $O/cfg3_nolatent.json
+FX_VAE_HEADS_BRANCH=0 python bench.py $Q 2>/dev/null | tail -1 > $O/cfg3_noheads.json
