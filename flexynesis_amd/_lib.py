@@ -90,6 +90,7 @@ PROTOTYPES = {
     "fx_triplet": (I, [P, P, P, P, P, P, P, I, I, L, F, P, F, P]),
     "fx_mmd_workspace_floats": (L, [I, I]),
     "fx_mmd_rows": (I, [P, P, P, P, I, I, I, L, P, F, P]),
+    "fx_mmd_rows_ex": (I, [P, P, P, P, I, I, I, L, P, F, I, P]),
     "fx_recon_blocks": (I, [L]),
     "fx_recon_sigmoid": (I, [P, P, P, P, P, L, P, F, P]),
     "fx_recon_sigmoid_slabs_blocks": (I, [I, I]),

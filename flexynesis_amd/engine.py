@@ -1417,21 +1417,25 @@ class StepPlan:
         # Schedule of a training plan with decoder branches (the engine's own step: forward and backward tapes always run together).
         # The chain is  z -> decoder 0's hidden layer -> FC_output products of decoder 0, 1, .. back to back (HBM-bound: one after the
         # other) -> last reconstruction epilogue -> data-gradient products of decoder 0, 1, .. -> latent backward;  everything else
-        # is placed where nothing on that chain waits for it:
-        #   * the supervisor heads need z only: a branch of their own in the forward tape (forward, losses, backward and their share
-        #     of dz in one launch) instead of 68 us behind the last decoder;
-        #   * the MMD terms (prior draw, kernel rows, dz share: 36 us each) and the loss bookkeeping (MMD finalize, total) need z and
-        #     the reconstruction sums: a side branch of the BACKWARD tape, beside the data-gradient products;
-        #   * what the optimiser needs of decoder 0's FC_output (Gram norm share, transposed operand splits, bias gradient) follows
-        #     its reconstruction epilogue in the forward tape, under decoder 1's product; the other decoders prepare their input side
-        #     before their product (under decoder 0's) and their output-gradient side before their data-gradient product.
-        # FX_VAE_HEADS_BRANCH=0 restores round 3's order (heads, MMD finalize and total on the main chain after the decoders' join, MMD
-        # rows first in each decoder branch, decoder 0 preparing behind its data-gradient product).  Level-1 plans (forward_alone)
-        # keep that order: their caller reads the total loss between the tapes.
-        heads_aside = bool(self.train and vae_par and not self.forward_alone and os.environ.get("FX_VAE_HEADS_BRANCH", "1") != "0")
-        prep0_fwd = bool(heads_aside and self.fused and nd > 1 and os.environ.get("FX_VAE_PREP0_FWD", "1") != "0")
-        mmd_terms = []
-        with rf.parallel((nd + 1 if heads_aside else nd) if vae_par else 1) as par:      # one graph branch per decoder
+        # is placed where nothing on that chain waits for it, WITHOUT further graph branches (one per decoder, as since round 2):
+        #   * the supervisor heads need z only: behind decoder 0's reconstruction epilogue in ITS branch, under decoder 1's product
+        #     (forward, losses, backward and their share of dz in one launch) instead of 68 us behind the last decoder's join;
+        #   * the MMD terms (prior draw, kernel rows, dz share: 36 us each) need z only as well: decoder 0's moves to the head of the
+        #     LAST decoder's branch, which waits for the earlier products anyway; they start on an idle chip, before decoder 0's
+        #     product fills it;
+        #   * the loss bookkeeping (MMD finalize, total) needs every reconstruction sum: the tail of decoder 0's BACKWARD branch;
+        #   * what the optimiser needs of a decoder's FC_output (Gram norm share, transposed operand splits, bias gradient): input
+        #     side before its product (decoders > 0: under decoder 0's), output-gradient side before its data-gradient product
+        #     (decoders > 0) or behind it (decoder 0).
+        # A branch of their own for the heads / the bookkeeping measured 1-2 % faster still, but hipGraphLaunch of the step graph then
+        # segfaulted in some test sequences (ROCm 7.x; never with one branch per decoder) -- DESIGN.md section 4.1.
+        # FX_VAE_HEADS_BRANCH=0 restores round 3's order (MMD rows first in each decoder branch; heads, MMD finalize and total on the
+        # main chain after the decoders' join).  Level-1 plans (forward_alone) keep that order: their caller reads the total loss
+        # between the tapes.
+        heads_aside = bool(self.train and vae_par and nd > 1 and not self.forward_alone
+                           and os.environ.get("FX_VAE_HEADS_BRANCH", "1") != "0")
+        deferred_mmd = []
+        with rf.parallel(nd if vae_par else 1) as par:      # one graph branch per decoder
             for i in range(nd):
                 if vae_par:
                     self._enter_branch(par, i)
@@ -1453,17 +1457,18 @@ class StepPlan:
                 def mmd_term(rec, pr=pr, rs=rs, dzm=dzm, prng=prng):
                     if prng is not None:
                         ops.fill_normal(rec, pr, prng[0], prng[1], ctrl=st.ctrl)
-                    if self.train:
-                        ops.fill(rec, dzm, 0.0)
-                    ops.mmd_rows(rec, rs, dzm if self.train else None, pr, z, lv_mmd, 1.0 / nd)
-                if heads_aside:
-                    mmd_terms.append(mmd_term)
+                    ops.mmd_rows(rec, rs, dzm if self.train else None, pr, z, lv_mmd, 1.0 / nd, overwrite=True)
+                if heads_aside and i == 0:
+                    deferred_mmd.append(mmd_term)
                 else:
                     mmd_term(rf)
+                    if heads_aside and i == nd - 1:
+                        for term in deferred_mmd:
+                            term(rf)
                 h = self._hidden_fwd(rf, p, z, B)
                 hd.append(h)
                 if self.train and vae_par and i > 0 and os.environ.get("FX_VAE_PREP_X", "1") != "0":
-                    # (beside decoder 0's FC_output product; decoder 0 itself heads the critical chain)
+                    # (beside decoder 0's FC_output product; decoder 0 itself heads the critical chain and prepares in the backward)
                     self._weight_grad_prep_x(rf, p + ".FC_output.weight", h)
                 lg = self._new(p + "/logits", B, F)
                 logits.append(lg)
@@ -1489,12 +1494,8 @@ class StepPlan:
                     ops.recon_sigmoid(rf, rp, lg if self.train else None, self.xhat[i] if self.xhat else None, lg, self.X[dec[i]], lv_mmd,
                                       1.0 / nd)
                 rec_parts.append((rp, nblk))
-                if prep0_fwd and i == 0:
-                    self._weight_grad(rf, wkey, lg, h)
-                    ops.colsum(rf, st.g(p + ".FC_output.bias"), lg)
-            if heads_aside:
-                self._enter_branch(par, nd)
-                self._svae_heads(rf, z, dz)
+                if heads_aside and i == 0:
+                    self._svae_heads(rf, z, dz)
         self._branch = 0
         if not heads_aside:
             self._svae_heads(rf, z, dz)
@@ -1515,24 +1516,17 @@ class StepPlan:
         # decoder (the narrow launches around one decoder's FC_output products run beside the other's); their shares of dz
         # are added on the main chain afterwards, in decoder order.
         dz_sum = self._new("dz", B, L)
-        if not heads_aside and not lat_fused:
+        if not lat_fused:
             ops.reduce_slabs(rb, dz_sum, dzs, None, 1 + nd)          # heads + MMD terms, in share order
         dz = dz_sum
         dhs = []
         # One graph branch per decoder.  Each holds the data-gradient product through FC_output (a full read of the weight:
         # HBM-bound, two of them side by side take as long as one after the other) with the hidden layer's backward behind it, and
         # the narrow launches that only the optimiser tape needs of this weight (Gram norm share = two B x B products + their
-        # Hadamard sum, transposed operand splits, bias gradient).  Decoder 0 reads its weight FIRST (its preparation ran in the
-        # forward tape, or follows here), the others prepare first: every branch's narrow work runs under another branch's weight
-        # read.  (As extra branches the preparation cost more in fork / join edges than it hid: 2.93 vs 2.89 ms.)
-        with rb.parallel((nd + 1 if heads_aside else nd) if vae_par else 1) as par:
-            if heads_aside:       # (nothing in the decoder branches reads dz or the losses; the join precedes the latent backward)
-                self._enter_branch(par, nd)
-                for term in mmd_terms:
-                    term(rb)
-                if not lat_fused:
-                    ops.reduce_slabs(rb, dz_sum, dzs, None, 1 + nd)
-                bookkeeping(rb)
+        # Hadamard sum, transposed operand splits, bias gradient).  Decoder 0 reads its weight FIRST and prepares afterwards, the
+        # others prepare first: every branch's narrow work runs under another branch's weight read.  (As extra branches the
+        # preparation cost more in fork / join edges than it hid: 2.93 vs 2.89 ms.)
+        with rb.parallel(nd if vae_par else 1) as par:
             for i in range(nd):
                 p = f"decoders.{i}"
                 dh = self._new(p + "/dh", B, st.shapes[p + ".hidden_layers.0.weight"][0])
@@ -1548,9 +1542,11 @@ class StepPlan:
                 if lat_fused:
                     o = 1 + nd + sum(dz_ns[:i])
                     ops.gemm_slabs(rb, ops.GEMM_NN, dzs[o:o + dz_ns[i]], dh, st.p(p + ".hidden_layers.0.weight"), B, L)
-                if not prep_first and not (prep0_fwd and i == 0):
+                if not prep_first:
                     self._weight_grad(rb, p + ".FC_output.weight", logits[i], hd[i])
                     ops.colsum(rb, st.g(p + ".FC_output.bias"), logits[i])
+                if heads_aside and i == 0:
+                    bookkeeping(rb)
         self._branch = 0
         if lat_fused:
             n_all = 1 + nd + sum(dz_ns)                  # heads, MMD terms, decoder 0's partial sums, decoder 1's, ...

@@ -8,6 +8,7 @@ training step can be re-issued with almost no host work -- or captured once into
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional
 
 import torch
@@ -40,6 +41,7 @@ TUNE = {
     "fused_runs": _env_int("FX_FUSED_RUNS", 0),   # runs (= partial-sum slabs) per row block; 0 = the library's choice
     "fused_map": _env_int("FX_FUSED_MAP", 0),     # fx_linear_dw_adam_fwd_bf16x3 workgroup mapping: 0 auto, 1 plain, 2 XCD-grouped, 3 XCD-contiguous row blocks
     "fused_prio": _env_int("FX_FUSED_PRIO", 0),   # 1 = the two workgroups of a CU alternate s_setprio per tile (experiment)
+    "mmd_tiled": _env_int("FX_MMD_TILED", 1),     # fx_mmd_rows_ex: 16-byte row loads + overwrite flag (0: fx_mmd_rows behind a zero-fill)
 }
 
 
@@ -1061,9 +1063,19 @@ def triplet(rec, loss_out, da, dp, dn, a, p, n, margin=1.0, logvar=None, extra_s
              float(extra_scale))
 
 
-def mmd_rows(rec, row_sums, dz, prior, z, logvar=None, extra_scale=1.0):
+def mmd_rows(rec, row_sums, dz, prior, z, logvar=None, extra_scale=1.0, tiled=None, overwrite=False):
+    """MMD(prior, z) row sums and (dz given) the gradient with respect to z, added to dz -- or stored, with ``overwrite``.
+    tiled: fx_mmd_rows_ex (16-byte row loads, bit-identical results, the default); TUNE["mmd_tiled"] / FX_MMD_TILED=0: the first entry."""
     if not prior.is_contiguous():
         raise FxError("mmd_rows: prior must be contiguous")
+    if tiled is None:
+        tiled = TUNE["mmd_tiled"]
+    if tiled:
+        rec.emit("fx_mmd_rows_ex", row_sums.data_ptr(), _ptr(dz), prior.data_ptr(), z.data_ptr(), prior.shape[0], z.shape[0],
+                 z.shape[1], _ld(z), _ptr(logvar), float(extra_scale), int(bool(overwrite)))
+        return
+    if overwrite and dz is not None:
+        fill(rec, dz, 0.0)
     rec.emit("fx_mmd_rows", row_sums.data_ptr(), _ptr(dz), prior.data_ptr(), z.data_ptr(), prior.shape[0], z.shape[0],
              z.shape[1], _ld(z), _ptr(logvar), float(extra_scale))
 

@@ -24,3 +24,17 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _graphs_die_between_tests(request):
+    """hipGraph lifetime: objects of a finished GPU test that own captured graphs (models with level-1 tape
+    graphs, plans) are collected HERE, with the device idle, not by the collector run torch makes on entry to the next test's capture."""
+    yield
+    if "gpu" in request.keywords:
+        import gc
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+            gc.collect()
+            torch.cuda.synchronize()

@@ -152,7 +152,34 @@ def test_fusion_fwd_pair_matches_two_launches():
         assert torch.equal(embs[j], ref[j][0]) and torch.equal(ecats[j], ref[j][1])
 
 
-SWITCHES = ("FX_RECON_EPILOGUE", "FX_VAE_LATENT_FUSED", "FX_VAE_HEADS_BRANCH", "FX_VAE_PREP0_FWD", "FX_VAE_FUSION_PAIR")
+@pytest.mark.parametrize("P,B,L", [(200, 128, 64), (200, 50, 77), (64, 7, 16), (200, 128, 256), (200, 128, 5)])
+def test_mmd_rows_ex_matches_the_first_kernel(P, B, L):
+    from flexynesis_amd import ops
+    dev = _dev()
+    g = torch.Generator(device=dev)
+    g.manual_seed(P + B + L)
+    prior = torch.randn(P, L, generator=g, device=dev)
+    zbig = torch.randn(B, L + 3, generator=g, device=dev)
+    z = zbig[:, :L]                                        # row stride != L
+    lv = torch.tensor([0.2], device=dev)
+    rs0, rs1 = torch.zeros(2 * (P + B), device=dev), torch.full((2 * (P + B),), float("nan"), device=dev)
+    base = torch.randn(B, L + 3, generator=g, device=dev)
+    dz0, dz1 = base.clone(), base.clone()
+    ops.mmd_rows(ops.IMMEDIATE, rs0, dz0[:, :L], prior, z, lv, 0.5, tiled=False)
+    ops.mmd_rows(ops.IMMEDIATE, rs1, dz1[:, :L], prior, z, lv, 0.5, tiled=True)
+    assert torch.equal(rs1, rs0)                           # same sums in the same order
+    # the gradient term is bit-identical; added to different values of dz it may round differently by one ulp of dz
+    d0, d1 = torch.zeros(B, L + 3, device=dev), torch.full((B, L + 3), 9.0, device=dev)
+    ops.mmd_rows(ops.IMMEDIATE, rs0, d0[:, :L], prior, z, lv, 0.5, tiled=False)
+    ops.mmd_rows(ops.IMMEDIATE, rs1, d1[:, :L], prior, z, lv, 0.5, tiled=True, overwrite=True)
+    assert torch.equal(d1[:, :L], d0[:, :L]) and bool((d1[:, L:] == 9.0).all())
+    assert torch.equal(dz1, dz0)
+    rs2 = torch.empty_like(rs1)
+    ops.mmd_rows(ops.IMMEDIATE, rs2, None, prior, z, tiled=True)       # evaluation: no gradient
+    assert torch.equal(rs2, rs1)
+
+
+SWITCHES = ("FX_RECON_EPILOGUE", "FX_VAE_LATENT_FUSED", "FX_VAE_HEADS_BRANCH", "FX_VAE_FUSION_PAIR")
 
 
 def _svae_steps(monkeypatch, off, model="supervised_vae", use_graph=False):
@@ -180,7 +207,7 @@ def _svae_steps(monkeypatch, off, model="supervised_vae", use_graph=False):
         idx = torch.randperm(256, generator=gen)
         y = {k: ann[k][idx[:B]].to(dev) for k in plan.y}
         draws = {}
-        for name, t in plan.draws.items():
+        for name, t in sorted(plan.draws.items()):          # (by name: the schedules create their draw slots in different orders)
             if name == "eps" or name.startswith("prior."):
                 draws[name] = torch.randn(t.shape, generator=gen).to(dev)
             else:
@@ -199,10 +226,13 @@ def test_vae_chain_schedules_agree(monkeypatch, model):
     assert "fx_recon_sigmoid_slabs" in n1 and "fx_small_linear_bwd_group" in n1 and "fx_mul" not in n1
     assert "fx_recon_sigmoid_slabs" not in n0 and "fx_small_linear_bwd_group" not in n0 and "fx_mul" in n0
     assert len(n1) <= len(n0) - 4, (len(n1), len(n0))
-    for (a, ga), (b, gb) in zip(l1, l0):
+    for step, ((a, ga), (b, gb)) in enumerate(zip(l1, l0)):
+        # (from the second step on the parameters differ by the Adam steps of elements at the rounding floor: see below)
         for k in a:
-            close(a[k], b[k], 2e-6, 1e-7, f"loss {k}")
-        close(ga, gb, 1e-5, 0.0, "grad norm")
+            # (mmd_loss: the kernel row sums and reconstruction partial sums are grouped differently, and the MMD estimate is a
+            # difference of three of them)
+            close(a[k], b[k], (5e-5 if k == "mmd_loss" else 2e-6) if step == 0 else 1e-4, 1e-7, f"step {step} loss {k}")
+        close(ga, gb, 1e-5 if step == 0 else 1e-3, 0.0, "grad norm")
     for k in sd1:
         a, b = sd1[k].double(), sd0[k].double()
         if a.numel() < 2 or not k.endswith("weight"):
@@ -214,6 +244,6 @@ def test_vae_chain_schedules_agree(monkeypatch, model):
     # each switch alone builds and runs as well
     for sw in SWITCHES:
         _, ls, _ = _svae_steps(monkeypatch, (sw,), model)
-        for (a, _), (b, _) in zip(ls, l1):
+        for step, ((a, _), (b, _)) in enumerate(zip(ls, l1)):
             for k in a:
-                close(a[k], b[k], 2e-6, 1e-7, f"{sw}=0 loss {k}")
+                close(a[k], b[k], (5e-5 if k == "mmd_loss" else 2e-6) if step == 0 else 1e-4, 1e-7, f"{sw}=0 step {step} loss {k}")
