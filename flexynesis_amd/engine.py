@@ -684,6 +684,17 @@ class StepPlan:
                     gd = self._new(f"gram_dy/{key}", nd, R * R)
                     ops.gram_kb_group(rec, [sd], [gd], [dy.shape[1]], R)
                     self.buf[f"gram_dy_split/{key}"], self.buf[f"gram_dy_split_lo/{key}"] = sd
+                elif (self.precision == "bf16x3" and R > 128 and dy.shape[1] >= 4096 and dy.shape[1] % 4 == 0 and self.gram_bf16x3
+                      and self.gram_kb_wide and dy.is_contiguous()):
+                    # stacked rows (the triplet network's 3 B = 384): dY dY^T like X X^T in _gram_x_for -- dY's K-blocked split against dY
+                    # itself as the fp32 "weight" on the split-bf16 forward kernel, instead of the exact-fp32 GEMM (100 us per modality
+                    # on the chain between the encoder tails' backward and the clip coefficient)
+                    sd = ops.new_split_kb(R, dy.shape[1], self.dev)
+                    ops.split_bf16(rec, sd[0], sd[1], dy)
+                    self.buf[f"gram_dy_split/{key}"], self.buf[f"gram_dy_split_lo/{key}"] = sd
+                    nd = 1
+                    gd = self._new(f"gram_dy/{key}", 1, R * R)
+                    ops.linear_fwd_bf16x3(rec, gd.view(R, R), sd[0], sd[1], dy, None, self.ws)
                 else:
                     nd = int(ops.lib.fx_gemm_splitk(R, R, dy.shape[1]))
                     gd = self._new(f"gram_dy/{key}", nd, R * R)
