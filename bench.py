@@ -376,6 +376,7 @@ def main():
     # rank 0, LPT assignment, engine trials, all_gather of the records, winner state_dict broadcast (flexynesis_amd/sweep.py)
     # everything the legs below need from the headline objects has been read: release them (graphs first, at a known point)
     pipe.close()
+    placement = dict(store.placement)
     del pipe, store, cohort
     torch.cuda.empty_cache()
     sweep = None
@@ -449,6 +450,9 @@ def main():
                        # the bytes THIS schedule must move (24 instead of 28 B/param where the next forward is fused)
                        "schedule_bytes_per_step": bytes_moved,
                        "schedule_hbm_frac_of_8TBs": round(bytes_moved / (ms_per_step * 1e-3) / 8e12, 4),
+                       # wide weights: probe times (us per pass of the dW + Adam traffic pattern) of the candidate placements of W / m / v
+                       # that ParamStore tried at allocation, and which one it kept (FX_PLACEMENT_TRIES=1: first)
+                       "placement": placement,
                        "loss_finite": finite, "last_losses": {k: round(v, 6) for k, v in losses.items()}},
             "roofline": roof, "cpu_baseline": cpu, "repeat_stats": repeat_stats, "other": other, "sweep": sweep,
         }

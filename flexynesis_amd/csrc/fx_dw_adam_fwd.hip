@@ -499,6 +499,45 @@ int fx_linear_dw_adam_fwd_bf16x3(float* W, float* adam_m, float* adam_v, const v
   return fx_check_launch("fx_linear_dw_adam_fwd_bf16x3");
 }
 
+// ---- placement probe -----------------------------------------------------------------------------------------------------------
+// The GEMM-free twin of fx_dw_adam_fwd_kernel's memory schedule: the same runs of 64 x 128 tiles, two workgroups per CU, W / m / v read
+// with 16-byte non-temporal loads and written back UNCHANGED (idempotent: safe on live parameters).  Its time depends on WHERE the three
+// arrays landed in physical memory: 400 to 494 us for the [5000, 20000] weight on one and the same MI355X, by nothing but the
+// allocation history of the process (scripts/adamprobe.hip `r placement`, profiles/r04_placement.txt) -- what rounds 2-4 had
+// taken for two kinds of box.  The host allocates a few candidates, probes each and keeps the fastest (engine.ParamStore).
+__global__ __launch_bounds__(512, 2) void fx_placement_probe_kernel(float* __restrict__ W, float* __restrict__ M, float* __restrict__ V,
+                                                                    int H, int F, long ld, int S, int n_hi) {
+  __shared__ char pad[65536];                                      // the fused kernel's LDS footprint: two workgroups per CU
+  if (threadIdx.x == 9999) pad[threadIdx.x] = 1;
+  const int tiles_m = (H + 63) / 64, tiles_n = (F + 127) / 128;
+  int tm, c, runs = S;
+  const int n_lo = tiles_m - n_hi, low = n_lo * S;
+  if ((int)blockIdx.x < low) { tm = blockIdx.x % n_lo; c = blockIdx.x / n_lo; }
+  else { const int b2 = blockIdx.x - low; tm = n_lo + b2 % n_hi; c = b2 / n_hi; runs = S + 1; }
+  for (int tn = c; tn < tiles_n; tn += runs) {
+    f32x4 p[4], m[4], v[4];
+    long off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int u = threadIdx.x + 512 * i, r = u >> 5, c4 = u & 31;
+      const int row = tm * 64 + r, col = tn * 128 + 4 * c4;
+      off[i] = (row < H && col < F) ? ((long)row * ld + col) >> 2 : -1;
+      if (off[i] >= 0) {
+        p[i] = __builtin_nontemporal_load((const f32x4*)W + off[i]);
+        m[i] = __builtin_nontemporal_load((const f32x4*)M + off[i]);
+        v[i] = __builtin_nontemporal_load((const f32x4*)V + off[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (off[i] < 0) continue;
+      __builtin_nontemporal_store(p[i], (f32x4*)W + off[i]);
+      __builtin_nontemporal_store(m[i], (f32x4*)M + off[i]);
+      __builtin_nontemporal_store(v[i], (f32x4*)V + off[i]);
+    }
+  }
+}
+
 // Many slabs, small output (the VAE's dz: 3 shares + 2 x 40 split-K partial sums of [128, 64]): with one thread per four outputs the
 // ordered sum is ~20 dependent rounds of loads on 8 workgroups (23 us).  Here RP_SUB neighbouring lanes share four outputs, each sums a
 // contiguous range of the slabs, and the ranges are combined in range order -- a fixed order (deterministic), but not the serial one.
@@ -544,6 +583,19 @@ int fx_reduce_slabs(float* Y, const float* slabs, const float* bias, int M, int 
   FX_REQUIRE(Y && slabs && M > 0 && N > 0 && n_slabs > 0 && ldy >= N && slab_stride >= (long)M * N, "fx_reduce_slabs: bad args");
   fx_launch_reduce_slabs(Y, slabs, bias, M, N, ldy, n_slabs, slab_stride, 0, stream);
   return fx_check_launch("fx_reduce_slabs");
+}
+
+// One pass of the fused kernel's W / m / v traffic pattern without the GEMMs; contents unchanged.  W, m, v [n_out, k_in] with row pitch
+// ldw (k_in % 4 == 0, ldw % 4 == 0, 16-byte aligned bases).  The caller times it (HIP events) to rate a placement of the three arrays.
+int fx_placement_probe(float* W, float* m, float* v, int n_out, int k_in, long ldw, hipStream_t stream) {
+  FX_REQUIRE(W && m && v && n_out > 0 && k_in > 0 && ldw >= k_in, "fx_placement_probe: bad args");
+  FX_REQUIRE(k_in % 4 == 0 && ldw % 4 == 0 && ((((uintptr_t)W) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0,
+             "fx_placement_probe: k_in and ldw must be multiples of 4 and the bases 16-byte aligned");
+  const int tiles_m = (n_out + 63) / 64, tiles_n = (k_in + 127) / 128;
+  const FtPlan pl = ft_plan(tiles_m, tiles_n, FT_G);
+  const int grid = (tiles_m - pl.n_hi) * pl.S_lo + pl.n_hi * (pl.S_lo + 1);
+  hipLaunchKernelGGL(fx_placement_probe_kernel, dim3(grid), dim3(512), 0, stream, W, m, v, n_out, k_in, ldw, pl.S_lo, pl.n_hi);
+  return fx_check_launch("fx_placement_probe");
 }
 
 // The same sum for MANY slabs of a SMALL output (N, ldy, slab_stride multiples of 4, 16-byte aligned bases): 8 lanes per four outputs, each

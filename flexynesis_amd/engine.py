@@ -25,6 +25,7 @@ from __future__ import annotations
 
 import math
 import os
+import threading
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -43,6 +44,26 @@ TRIPLET_MARGIN = 1.0
 
 def _align4(n: int) -> int:
     return (n + 3) // 4 * 4
+
+
+_PLACEMENT = threading.local()
+
+
+class placement_tries:
+    """``with placement_tries(n): ...``: ParamStores created by this thread inside the block try at most n placements per wide weight
+    (ParamStore._place_big).  HPO trials use a small n: a fit of a few dozen steps does not earn back a long search."""
+
+    def __init__(self, n: int):
+        self.n = int(n)
+
+    def __enter__(self):
+        self._old = getattr(_PLACEMENT, "tries", None)
+        _PLACEMENT.tries = self.n
+        return self
+
+    def __exit__(self, *exc):
+        _PLACEMENT.tries = self._old
+        return False
 
 
 class ParamStore:
@@ -95,10 +116,10 @@ class ParamStore:
         # arbitrary offsets inside a 128-byte line, every 512-byte row segment of the dW+Adam kernel then straddles a
         # fifth line (reads) and partial lines (writes) -- the decoders' [20000, 5000] weights took 510-630 us per launch
         # instead of ~430.  "W"/"M"/"V"/"G" are the [out, in] VIEWS (state_dict layout), "_W".. the padded buffers.
+        self.placement: Dict[str, dict] = {}          # per wide weight: probe times of the candidate placements (us), the kept one
         for k in self.big_keys:
             self.big[k] = {}
-            for name in ("W", "M", "V"):
-                self._big_alloc(k, name)
+            self._place_big(k)
             self.big[k]["G"] = None
             if materialize_big_grads:
                 self._big_alloc(k, "G")
@@ -132,6 +153,73 @@ class ParamStore:
         buf = torch.zeros(out, (fin + 31) // 32 * 32, dtype=torch.float32, device=self.device)
         self.big[key]["_" + name] = buf
         self.big[key][name] = buf[:, :fin]
+
+    # Placement of a wide weight's three arrays.  The dW + Adam kernels stream W, m and v of a 64 x 128 tile together, ~500 tiles at a
+    # time; how fast that goes depends on which physical pages the three allocations happen to get -- 400 to 494 us for the same
+    # kernel on the same [5000, 20000] arrays of the same MI355X, by the allocation history of the process alone (DESIGN.md section
+    # 3.10, profiles/r04_placement.txt).  So: allocate a candidate triple, time one pass of that traffic pattern over it
+    # (fx_placement_probe: contents untouched), keep it if it runs at the good rate, otherwise hold it (the next candidate then gets
+    # other pages) and try again; the fastest of at most FX_PLACEMENT_TRIES stays, the rest go back to the driver.
+    PLACE_MIN_ELEMS = 1 << 24           # 64 MB per array: smaller weights are a few tiles per workgroup, placement is in the noise
+    PLACE_GOOD_TBS = 5.9                # W / m / v read + written (24 B per element) per probe pass: stop searching at this rate
+
+    def _place_big(self, key):
+        out, fin = self.shapes[key]
+        ld = (fin + 31) // 32 * 32
+        tries = getattr(_PLACEMENT, "tries", None)
+        if tries is None or "FX_PLACEMENT_TRIES" in os.environ:
+            tries = int(os.environ.get("FX_PLACEMENT_TRIES", "8"))
+        probe = tries > 1 and out * fin >= self.PLACE_MIN_ELEMS and fin % 4 == 0
+
+        def triple():
+            return [torch.zeros(out, ld, dtype=torch.float32, device=self.device) for _ in range(3)]
+        if not probe:
+            bufs = triple()
+        else:
+            good_us = 24.0 * out * fin / (self.PLACE_GOOD_TBS * 1e12) * 1e6
+            # Each try: a spacer of a different size in front (it decides which physical blocks the driver hands out next), the
+            # triple, one probe.  A rejected triple and its spacer go back to the DRIVER before the next try (torch's cache would hand
+            # the same blocks out again); holding the rejects instead and allocating on top of them explores badly -- eight
+            # candidates in a row then land alike (profiles/r04_placement.txt).
+            spacer_mb = (0, 6, 3, 254, 5, 777, 30, 2, 333, 14, 100, 62, 1022, 126, 510, 2046)
+            probes, best = [], None
+            with torch.cuda.device(self.device):
+                for t in range(tries):
+                    sp = torch.empty(spacer_mb[t % len(spacer_mb)] << 20, dtype=torch.uint8, device=self.device) if t else None
+                    b = triple()
+                    us = ops.placement_probe_us(b[0][:, :fin], b[1][:, :fin], b[2][:, :fin])
+                    probes.append(round(us, 1))
+                    last = t == tries - 1
+                    if us <= good_us or (last and (best is None or us < best[0])):
+                        best = (us, b, t)
+                        break
+                    if last:
+                        break
+                    if best is None or us < best[0]:
+                        # keep the best so far alive only as a fallback: it is re-made at the end if nothing better turns up
+                        best = (us, None, t)
+                    del b, sp
+                    torch.cuda.empty_cache()
+                if best[1] is None:
+                    # nothing reached the good rate: take the last candidate if it is the best seen, else re-create the best spacer's
+                    # placement (same spacer, same allocation sequence: it lands the same way in practice; probed again to make sure)
+                    del b, sp
+                    torch.cuda.empty_cache()
+                    t = best[2]
+                    sp = torch.empty(spacer_mb[t % len(spacer_mb)] << 20, dtype=torch.uint8, device=self.device) if t else None
+                    b = triple()
+                    us = ops.placement_probe_us(b[0][:, :fin], b[1][:, :fin], b[2][:, :fin])
+                    probes.append(round(us, 1))
+                    best = (us, b, t)
+                bufs = best[1]
+                self.placement[key] = {"probe_us": probes, "kept_us": round(best[0], 1), "spacer_mb": spacer_mb[best[2] % len(spacer_mb)],
+                                       "good_us": round(good_us, 1)}
+                del sp, b
+                if len(probes) > 1:
+                    torch.cuda.empty_cache()          # the spacer goes back to the driver as well
+        for name, buf in zip(("W", "M", "V"), bufs):
+            self.big[key]["_" + name] = buf
+            self.big[key][name] = buf[:, :fin]
 
     def ensure_big_grads(self):
         for k, d in self.big.items():

@@ -10,6 +10,8 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence
 
+import os
+
 import numpy as np
 import torch
 
@@ -543,6 +545,21 @@ def trial_splits(n: int, val_size: float, seed: int, use_cv: bool = False, n_spl
     return kfold_indices(n, n_splits, seed) if use_cv else [split_indices(n, val_size, seed)]
 
 
+def _short_fit_placement(fn):
+    """HPO trials are short fits (a few dozen steps) that do not earn back a search over placements of their wide weights (each
+    rejected candidate costs ~10 ms and a trip of its blocks back to the driver): their ParamStores take the first placement
+    (engine.placement_tries(1); FX_PLACEMENT_TRIES_TRIAL=<n> searches, FX_PLACEMENT_TRIES overrides everything)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **kw):
+        from .engine import placement_tries
+        with placement_tries(int(os.environ.get("FX_PLACEMENT_TRIES_TRIAL", "1"))):
+            return fn(*a, **kw)
+    return wrapped
+
+
+@_short_fit_placement
 def run_trial_fold(model_class, params: dict, dataset, target_variables, train_idx, val_idx, batch_variables=None,
                    surv_event_var=None, surv_time_var=None, use_loss_weighting=True, early_stop_patience: int = 10,
                    seed: int = 0, device=None, use_graph: bool = True, **model_kwargs):
@@ -567,6 +584,7 @@ _CTOR_LOCK = __import__("threading").Lock()
 FOLD_SEED_STRIDE = 7919      # fold i of a trial seeds its model / shuffles with seed + i * stride (fold 0 = the single split's seed)
 
 
+@_short_fit_placement
 def run_trial(model_class, params: dict, dataset, target_variables, batch_variables=None, surv_event_var=None,
               surv_time_var=None, use_loss_weighting=True, val_size: float = 0.2, early_stop_patience: int = 10,
               seed: int = 0, device=None, use_graph: bool = True, use_cv: bool = False, n_splits: int = 5, **model_kwargs):

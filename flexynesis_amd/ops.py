@@ -657,6 +657,27 @@ def reduce_slabs(rec, y, slabs, bias, n_slabs):
     rec.emit("fx_reduce_slabs", y.data_ptr(), slabs.data_ptr(), _ptr(bias), M, N, _ld(y), int(n_slabs), M * N)
 
 
+def placement_probe_us(W, m, v, launches: int = 3) -> float:
+    """Microseconds per pass of the fused dW + Adam kernel's W / m / v traffic pattern over these three arrays (contents unchanged):
+    a rating of WHERE they landed in physical memory (include/fxhip.h: fx_placement_probe).  Synchronises the current stream."""
+    for t in (W, m, v):
+        _chk2d(t, "placement_probe")
+    n_out, k_in = W.shape
+    args = (W.data_ptr(), m.data_ptr(), v.data_ptr(), n_out, k_in, _ld(W))
+    if not (_ld(m) == _ld(W) == _ld(v)) or m.shape != W.shape or v.shape != W.shape:
+        raise FxError("placement_probe: W / m / v must share shape and leading dimension")
+    IMMEDIATE.emit("fx_placement_probe", *args)
+    best = float("inf")
+    for _ in range(max(1, launches)):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        IMMEDIATE.emit("fx_placement_probe", *args)
+        e1.record()
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3)
+    return best
+
+
 def reduce_slabs_par(rec, y, slabs, bias, n_slabs):
     """reduce_slabs for many slabs of a small output: partial sums over contiguous ranges of slabs, combined in range order."""
     _chk2d(y, "reduce_slabs_par.y")

@@ -136,6 +136,11 @@ int fx_reduce_slabs(float* Y, const float* slabs, const float* bias, int M, int 
 int fx_reduce_slabs_par(float* Y, const float* slabs, const float* bias, int M, int N, long ldy, int n_slabs, long slab_stride,
                         fx_stream_t stream);
 
+/* ---- placement probe: one pass of fx_linear_dw_adam_fwd_bf16x3's W / m / v traffic pattern without the GEMMs, contents unchanged.  Its
+ *      time depends on where the three arrays landed in physical memory (400-494 us for [5000, 20000] on one MI355X): the host allocates a
+ *      few candidates, times this with HIP events and keeps the fastest (flexynesis_amd.engine.ParamStore, FX_PLACEMENT_TRIES). */
+int fx_placement_probe(float* W, float* m, float* v, int n_out, int k_in, long ldw, fx_stream_t stream);
+
 /* ---- launch-fusion variants (same reference ops, fewer passes): GEMMs that leave their split-K partial sums in
  *      slabs [splitk][M][N] for a consumer that reduces them in its own pass; Gram-norm Hadamard sum straight
  *      from two slab sets; cohort gather fused with the bf16 splits the wide-layer kernels consume. */

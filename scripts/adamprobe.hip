@@ -291,6 +291,52 @@ int main(int argc, char** argv) {
     printf("%s: %ld launches, %.1f us per launch\n", argv[3], n, ms * 1e3 / n);
     return 0;
   }
+  if (argc > 2 && !strcmp(argv[2], "offsets")) {
+    // `adamprobe r offsets`: do the RELATIVE placements of W, m and v matter?  The three arrays of a tile are read (and written) together;
+    // separate allocations are 2 MB aligned, i.e. equal in their low 21 address bits.  One arena, m and v shifted by d and 2 d bytes.
+    const size_t slot = ((bytes + (2u << 20) - 1) >> 21 << 21) + (8u << 20);
+    char* arena; CK(hipMalloc(&arena, 3 * slot + (64u << 20)));
+    const long deltas[] = {0, 256, 1024, 4096, 16384, 65536, 262144, 1048576, 1048576 + 4096 + 256, 3 * 1048576 + 7 * 4096 + 512};
+    for (int rep = 0; rep < 2; ++rep)
+      for (long d : deltas) {
+        float* w = (float*)arena; float* m = (float*)(arena + slot + d); float* v = (float*)(arena + 2 * slot + 2 * d);
+        hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, w, (long)H * ld, 1u);
+        hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, m, (long)H * ld, 2u);
+        hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, v, (long)H * ld, 3u);
+        CK(hipDeviceSynchronize());
+        char name[128];
+        snprintf(name, sizeof name, "persistent S=6, one arena, m +%ld B, v +%ld B", d, 2 * d);
+        run(name, [&] { hipLaunchKernelGGL((adam_runs<65536>), dim3(79 * 6), dim3(512), 0, 0, w, m, v, H, F, ld, 6, 0); });
+        snprintf(name, sizeof name, "cols fastest,   one arena, m +%ld B, v +%ld B", d, 2 * d);
+        const int g64 = ((H + 63) / 64) * ((F + 127) / 128);
+        run(name, [&] { hipLaunchKernelGGL((adam_tiles<64, 128, 1, 65536>), dim3(g64), dim3(512), 0, 0, w, m, v, H, F, ld); });
+      }
+    run("persistent S=6, three hipMalloc allocations", [&] { hipLaunchKernelGGL((adam_runs<65536>), dim3(79 * 6), dim3(512), 0, 0, W, M, V, H, F, ld, 6, 0); });
+    return 0;
+  }
+  if (argc > 2 && !strcmp(argv[2], "placement")) {
+    // `adamprobe r placement`: does WHERE the three arrays land matter?  A dummy allocation of varying size in front of them shifts their
+    // virtual (and physical) placement; everything else is identical.
+    CK(hipFree(W)); CK(hipFree(M)); CK(hipFree(V));
+    const size_t shifts[] = {0, 2u << 20, 6u << 20, 14u << 20, 30u << 20, 62u << 20, 126u << 20, 254u << 20, 510u << 20, (size_t)1022 << 20,
+                             (size_t)2046 << 20, 3u << 20, 5u << 20, 100u << 20, 333u << 20, 777u << 20};
+    for (size_t sh : shifts) {
+      char* dummy = nullptr;
+      if (sh) CK(hipMalloc(&dummy, sh));
+      float *w, *m, *v;
+      CK(hipMalloc(&w, bytes)); CK(hipMalloc(&m, bytes)); CK(hipMalloc(&v, bytes));
+      hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, w, (long)H * ld, 1u);
+      hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, m, (long)H * ld, 2u);
+      hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, v, (long)H * ld, 3u);
+      CK(hipDeviceSynchronize());
+      char name[128];
+      snprintf(name, sizeof name, "persistent S=6, %4zu MB allocated in front (W at %p)", sh >> 20, (void*)w);
+      run(name, [&] { hipLaunchKernelGGL((adam_runs<65536>), dim3(79 * 6), dim3(512), 0, 0, w, m, v, H, F, ld, 6, 0); });
+      CK(hipFree(w)); CK(hipFree(m)); CK(hipFree(v));
+      if (dummy) CK(hipFree(dummy));
+    }
+    return 0;
+  }
   if (argc > 2 && !strcmp(argv[2], "streams")) {
     // `adamprobe r streams`: the persistent pattern with 3 + 3, 2 + 2 and 1 + 1 read + write streams (interleaved storage), and the plain one
     float* MV; CK(hipMalloc(&MV, (size_t)H * 157 * 3 * 128 * 4 + 4096));

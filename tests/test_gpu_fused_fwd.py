@@ -255,3 +255,42 @@ def test_small_linear_kernels_vs_fp64(R, O, K):
     dx2 = torch.ones(R, K, device=dev)
     ops.small_linear_bwd(ops.IMMEDIATE, dx2, gW2, gb, dy, x, W, dx_accumulate=True)
     close(dx2, 1.0 + dy.double() @ W.double(), 1e-5, 2e-5, "dx accumulate")
+
+
+def test_placement_probe_leaves_contents_alone_and_store_search_is_transparent(monkeypatch):
+    """fx_placement_probe walks W / m / v in the fused kernel's pattern and writes back what it read; ParamStore's search over
+    candidate placements changes WHERE the wide weights live, never what they hold."""
+    from flexynesis_amd import ops
+    from flexynesis_amd.arch import ArchSpec
+    from flexynesis_amd.engine import ParamStore, placement_tries
+    dev = _dev()
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    for (n_out, k_in) in ((300, 1100), (5000, 20000), (64, 128)):
+        ld = ops.pad32(k_in)
+        bufs = [torch.randn(n_out, ld, generator=g, device=dev) for _ in range(3)]
+        ref = [b.clone() for b in bufs]
+        us = ops.placement_probe_us(*[b[:, :k_in] for b in bufs])
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(bufs, ref))
+        assert 0.5 < us < 5000
+        if (n_out, k_in) == (5000, 20000):
+            assert 24.0 * n_out * k_in / (us * 1e-6) > 3.0e12, us          # streams at HBM rates (observed 4.9-6.1 TB/s)
+    with pytest.raises(ops.FxError):
+        ops.placement_probe_us(torch.zeros(8, 6, device=dev), torch.zeros(8, 6, device=dev), torch.zeros(8, 6, device=dev))   # k_in % 4
+    spec = ArchSpec("DirectPred", [("gex", 20000)], 64, 0.25, 16, [("y", "numerical", 1)], None, None, True)
+    monkeypatch.delenv("FX_PLACEMENT_TRIES", raising=False)
+    states = []
+    for tries in (1, 4):
+        with placement_tries(tries):
+            st = ParamStore(spec, dev, materialize_big_grads=False)
+        st.reset_parameters(seed=5)
+        info = st.placement.get("encoders.0.layer_1.weight")
+        if tries == 1:
+            assert info is None
+        else:
+            assert info is not None and 1 <= len(info["probe_us"]) <= 5 and info["kept_us"] == info["probe_us"][-1]
+        states.append(st.state_dict())
+        assert st.p("encoders.0.layer_1.weight").data_ptr() % 16 == 0
+    for k in states[0]:
+        assert torch.equal(states[0][k], states[1][k]), k
