@@ -158,8 +158,9 @@ class ParamStore:
     # time; how fast that goes depends on which physical pages the three allocations happen to get -- 400 to 494 us for the same
     # kernel on the same [5000, 20000] arrays of the same MI355X, by the allocation history of the process alone (DESIGN.md section
     # 3.10, profiles/r04_placement.txt).  So: allocate a candidate triple, time one pass of that traffic pattern over it
-    # (fx_placement_probe: contents untouched), keep it if it runs at the good rate, otherwise hold it (the next candidate then gets
-    # other pages) and try again; the fastest of at most FX_PLACEMENT_TRIES stays, the rest go back to the driver.
+    # (fx_placement_probe: contents untouched), stop if it runs at the good rate, otherwise try another placement; the fastest
+    # candidate stays, the rest go back to the driver.  FX_PLACEMENT_TRIES (default 12; up to three times that while nothing within
+    # 4 % of the good rate has turned up; 1 = take the first placement, as rounds 1-3 did).
     PLACE_MIN_ELEMS = 1 << 24           # 64 MB per array: smaller weights are a few tiles per workgroup, placement is in the noise
     PLACE_GOOD_TBS = 5.9                # W / m / v read + written (24 B per element) per probe pass: stop searching at this rate
 
@@ -168,7 +169,7 @@ class ParamStore:
         ld = (fin + 31) // 32 * 32
         tries = getattr(_PLACEMENT, "tries", None)
         if tries is None or "FX_PLACEMENT_TRIES" in os.environ:
-            tries = int(os.environ.get("FX_PLACEMENT_TRIES", "8"))
+            tries = int(os.environ.get("FX_PLACEMENT_TRIES", "12"))
         probe = tries > 1 and out * fin >= self.PLACE_MIN_ELEMS and fin % 4 == 0
 
         def triple():
@@ -176,47 +177,37 @@ class ParamStore:
         if not probe:
             bufs = triple()
         else:
-            good_us = 24.0 * out * fin / (self.PLACE_GOOD_TBS * 1e12) * 1e6
+            good_us = 24.0 * out * fin / (float(os.environ.get("FX_PLACEMENT_GOOD_TBS", self.PLACE_GOOD_TBS)) * 1e12) * 1e6
             # Each try: a spacer of a different size in front (it decides which physical blocks the driver hands out next), the
             # triple, one probe.  A rejected triple and its spacer go back to the DRIVER before the next try (torch's cache would hand
             # the same blocks out again); holding the rejects instead and allocating on top of them explores badly -- eight
             # candidates in a row then land alike (profiles/r04_placement.txt).
-            spacer_mb = (0, 6, 3, 254, 5, 777, 30, 2, 333, 14, 100, 62, 1022, 126, 510, 2046)
-            probes, best = [], None
+            # (sizes from a few MB to a few GB: which ones land well depends on the state of the driver's allocator -- on a freshly
+            # booted box a dozen MB-sized spacers in a row can all land alike)
+            spacer_mb = (0, 6, 3, 254, 1201, 5, 777, 2403, 30, 3607, 2, 333, 4811, 14, 100, 6005, 62, 1022, 7217, 126, 510, 2046,
+                         9001, 391, 1777, 12013, 47, 683, 2999, 5501, 210, 8191, 1333, 17, 4099, 950)
+            soft = tries
+            hard = tries if tries < 4 else 3 * tries       # keep going past `tries` only while nothing decent has turned up
+            probes, best = [], None                    # best = (us, triple, spacer index): kept ALIVE while the search goes on
             with torch.cuda.device(self.device):
-                for t in range(tries):
+                for t in range(hard):
+                    if t >= soft and best[0] <= 1.04 * good_us:
+                        break
                     sp = torch.empty(spacer_mb[t % len(spacer_mb)] << 20, dtype=torch.uint8, device=self.device) if t else None
                     b = triple()
                     us = ops.placement_probe_us(b[0][:, :fin], b[1][:, :fin], b[2][:, :fin])
                     probes.append(round(us, 1))
-                    last = t == tries - 1
-                    if us <= good_us or (last and (best is None or us < best[0])):
-                        best = (us, b, t)
-                        break
-                    if last:
-                        break
                     if best is None or us < best[0]:
-                        # keep the best so far alive only as a fallback: it is re-made at the end if nothing better turns up
-                        best = (us, None, t)
+                        best = (us, b, t)              # (the previous best, if any, is released with the names below)
                     del b, sp
-                    torch.cuda.empty_cache()
-                if best[1] is None:
-                    # nothing reached the good rate: take the last candidate if it is the best seen, else re-create the best spacer's
-                    # placement (same spacer, same allocation sequence: it lands the same way in practice; probed again to make sure)
-                    del b, sp
-                    torch.cuda.empty_cache()
-                    t = best[2]
-                    sp = torch.empty(spacer_mb[t % len(spacer_mb)] << 20, dtype=torch.uint8, device=self.device) if t else None
-                    b = triple()
-                    us = ops.placement_probe_us(b[0][:, :fin], b[1][:, :fin], b[2][:, :fin])
-                    probes.append(round(us, 1))
-                    best = (us, b, t)
+                    if t:
+                        torch.cuda.empty_cache()       # spacer and rejected triple: back to the driver
+                    if best[0] <= good_us:
+                        break
                 bufs = best[1]
                 self.placement[key] = {"probe_us": probes, "kept_us": round(best[0], 1), "spacer_mb": spacer_mb[best[2] % len(spacer_mb)],
                                        "good_us": round(good_us, 1)}
-                del sp, b
-                if len(probes) > 1:
-                    torch.cuda.empty_cache()          # the spacer goes back to the driver as well
+                del best
         for name, buf in zip(("W", "M", "V"), bufs):
             self.big[key]["_" + name] = buf
             self.big[key][name] = buf[:, :fin]

@@ -314,6 +314,27 @@ int main(int argc, char** argv) {
     run("persistent S=6, three hipMalloc allocations", [&] { hipLaunchKernelGGL((adam_runs<65536>), dim3(79 * 6), dim3(512), 0, 0, W, M, V, H, F, ld, 6, 0); });
     return 0;
   }
+  if (argc > 2 && !strcmp(argv[2], "arena")) {
+    // `adamprobe r arena`: ONE allocation, W at 0, m at `gap`, v at 2 * gap: which spacings of the three arrays run fast?
+    CK(hipFree(W)); CK(hipFree(M)); CK(hipFree(V));
+    char* arena; CK(hipMalloc(&arena, (size_t)3 << 30));
+    const size_t b2 = (bytes + (2u << 20) - 1) >> 21 << 21;       // 384 MB
+    const size_t gaps[] = {b2, bytes, b2 + 4096, b2 + 65536, b2 + (1u << 20), b2 + (2u << 20), b2 + (6u << 20), b2 + (16u << 20) + 4096,
+                           b2 + (50u << 20), b2 + (64u << 20), b2 + (100u << 20) + 12288, b2 + (127u << 20), b2 + (128u << 20),
+                           b2 + (200u << 20) + 8192, (size_t)512 << 20, ((size_t)512 << 20) + (2u << 20), (size_t)640 << 20, (size_t)700 << 20,
+                           (size_t)777 << 20, (size_t)1000 << 20};
+    for (size_t gap : gaps) {
+      float* w = (float*)arena; float* m = (float*)(arena + gap); float* v = (float*)(arena + 2 * gap);
+      hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, w, (long)H * ld, 1u);
+      hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, m, (long)H * ld, 2u);
+      hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, v, (long)H * ld, 3u);
+      CK(hipDeviceSynchronize());
+      char name[128];
+      snprintf(name, sizeof name, "persistent S=6, one arena, gap %zu B (= 384 MB + %ld)", gap, (long)gap - (long)b2);
+      run(name, [&] { hipLaunchKernelGGL((adam_runs<65536>), dim3(79 * 6), dim3(512), 0, 0, w, m, v, H, F, ld, 6, 0); });
+    }
+    return 0;
+  }
   if (argc > 2 && !strcmp(argv[2], "placement")) {
     // `adamprobe r placement`: does WHERE the three arrays land matter?  A dummy allocation of varying size in front of them shifts their
     // virtual (and physical) placement; everything else is identical.
