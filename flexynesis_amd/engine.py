@@ -193,8 +193,20 @@ class ParamStore:
                 for t in range(hard):
                     if t >= soft and best[0] <= 1.04 * good_us:
                         break
-                    sp = torch.empty(spacer_mb[t % len(spacer_mb)] << 20, dtype=torch.uint8, device=self.device) if t else None
-                    b = triple()
+                    sp = None
+                    if t:
+                        try:           # (a spacer is a means, not a need: on a nearly full device the search goes on without it)
+                            sp = torch.empty(spacer_mb[t % len(spacer_mb)] << 20, dtype=torch.uint8, device=self.device)
+                        except torch.OutOfMemoryError:
+                            sp = None
+                    try:
+                        b = triple()
+                    except torch.OutOfMemoryError:
+                        if best is None:
+                            raise
+                        del sp
+                        torch.cuda.empty_cache()
+                        break
                     us = ops.placement_probe_us(b[0][:, :fin], b[1][:, :fin], b[2][:, :fin])
                     probes.append(round(us, 1))
                     if best is None or us < best[0]:
