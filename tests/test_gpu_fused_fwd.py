@@ -289,7 +289,8 @@ def test_placement_probe_leaves_contents_alone_and_store_search_is_transparent(m
         if tries == 1:
             assert info is None
         else:
-            assert info is not None and 1 <= len(info["probe_us"]) <= 4 and info["kept_us"] == min(info["probe_us"])
+            # (up to 3 x the asked-for candidates while nothing decent has turned up)
+            assert info is not None and 1 <= len(info["probe_us"]) <= 12 and info["kept_us"] == min(info["probe_us"])
         states.append(st.state_dict())
         assert st.p("encoders.0.layer_1.weight").data_ptr() % 16 == 0
     for k in states[0]:
