@@ -450,8 +450,8 @@ def main():
                        # the bytes THIS schedule must move (24 instead of 28 B/param where the next forward is fused)
                        "schedule_bytes_per_step": bytes_moved,
                        "schedule_hbm_frac_of_8TBs": round(bytes_moved / (ms_per_step * 1e-3) / 8e12, 4),
-                       # wide weights: probe times (us per pass of the dW + Adam traffic pattern) of the candidate placements of W / m / v
-                       # that ParamStore tried at allocation, and which one it kept (FX_PLACEMENT_TRIES=1: first)
+                       # wide weights: probe times (us per pass of the dW + Adam traffic pattern over ONE array) of the candidate placements
+                       # ParamStore tried at allocation, the three it kept and their time together (FX_PLACEMENT_TRIES=1: first)
                        "placement": placement,
                        "loss_finite": finite, "last_losses": {k: round(v, 6) for k, v in losses.items()}},
             "roofline": roof, "cpu_baseline": cpu, "repeat_stats": repeat_stats, "other": other, "sweep": sweep,

@@ -524,16 +524,16 @@ __global__ __launch_bounds__(512, 2) void fx_placement_probe_kernel(float* __res
       off[i] = (row < H && col < F) ? ((long)row * ld + col) >> 2 : -1;
       if (off[i] >= 0) {
         p[i] = __builtin_nontemporal_load((const f32x4*)W + off[i]);
-        m[i] = __builtin_nontemporal_load((const f32x4*)M + off[i]);
-        v[i] = __builtin_nontemporal_load((const f32x4*)V + off[i]);
+        if (M) m[i] = __builtin_nontemporal_load((const f32x4*)M + off[i]);
+        if (V) v[i] = __builtin_nontemporal_load((const f32x4*)V + off[i]);
       }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (off[i] < 0) continue;
       __builtin_nontemporal_store(p[i], (f32x4*)W + off[i]);
-      __builtin_nontemporal_store(m[i], (f32x4*)M + off[i]);
-      __builtin_nontemporal_store(v[i], (f32x4*)V + off[i]);
+      if (M) __builtin_nontemporal_store(m[i], (f32x4*)M + off[i]);
+      if (V) __builtin_nontemporal_store(v[i], (f32x4*)V + off[i]);
     }
   }
 }
@@ -588,7 +588,7 @@ int fx_reduce_slabs(float* Y, const float* slabs, const float* bias, int M, int 
 // One pass of the fused kernel's W / m / v traffic pattern without the GEMMs; contents unchanged.  W, m, v [n_out, k_in] with row pitch
 // ldw (k_in % 4 == 0, ldw % 4 == 0, 16-byte aligned bases).  The caller times it (HIP events) to rate a placement of the three arrays.
 int fx_placement_probe(float* W, float* m, float* v, int n_out, int k_in, long ldw, hipStream_t stream) {
-  FX_REQUIRE(W && m && v && n_out > 0 && k_in > 0 && ldw >= k_in, "fx_placement_probe: bad args");
+  FX_REQUIRE(W && n_out > 0 && k_in > 0 && ldw >= k_in, "fx_placement_probe: bad args");       // m / v may be NULL: one array on its own
   FX_REQUIRE(k_in % 4 == 0 && ldw % 4 == 0 && ((((uintptr_t)W) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0,
              "fx_placement_probe: k_in and ldw must be multiples of 4 and the bases 16-byte aligned");
   const int tiles_m = (n_out + 63) / 64, tiles_n = (k_in + 127) / 128;

@@ -157,12 +157,11 @@ class ParamStore:
     # Placement of a wide weight's three arrays.  The dW + Adam kernels stream W, m and v of a 64 x 128 tile together, ~500 tiles at a
     # time; how fast that goes depends on which physical pages the three allocations happen to get -- 400 to 494 us for the same
     # kernel on the same [5000, 20000] arrays of the same MI355X, by the allocation history of the process alone (DESIGN.md section
-    # 3.10, profiles/r04_placement.txt).  So: allocate a candidate triple, time one pass of that traffic pattern over it
-    # (fx_placement_probe: contents untouched), stop if it runs at the good rate, otherwise try another placement; the fastest
-    # candidate stays, the rest go back to the driver.  FX_PLACEMENT_TRIES (default 12; up to three times that while nothing within
-    # 4 % of the good rate has turned up; 1 = take the first placement, as rounds 1-3 did).
+    # 3.10, profiles/r04_placement.txt).  So: allocate candidate arrays, time one pass of that traffic pattern over each
+    # (fx_placement_probe: contents untouched), keep the fast ones; the rest go back to the driver.  FX_PLACEMENT_TRIES (default 12:
+    # at most 36 candidate arrays per weight; 1 = take the first placement, as rounds 1-3 did).
     PLACE_MIN_ELEMS = 1 << 24           # 64 MB per array: smaller weights are a few tiles per workgroup, placement is in the noise
-    PLACE_GOOD_TBS = 5.9                # W / m / v read + written (24 B per element) per probe pass: stop searching at this rate
+    PLACE_GOOD_TBS = 5.65               # an array read + written (8 B per element) per probe pass: arrays at this rate are kept
 
     def _place_big(self, key):
         out, fin = self.shapes[key]
@@ -177,22 +176,20 @@ class ParamStore:
         if not probe:
             bufs = triple()
         else:
-            good_us = 24.0 * out * fin / (float(os.environ.get("FX_PLACEMENT_GOOD_TBS", self.PLACE_GOOD_TBS)) * 1e12) * 1e6
-            # Each try: a spacer of a different size in front (it decides which physical blocks the driver hands out next), the
-            # triple, one probe.  A rejected triple and its spacer go back to the DRIVER before the next try (torch's cache would hand
-            # the same blocks out again); holding the rejects instead and allocating on top of them explores badly -- eight
-            # candidates in a row then land alike (profiles/r04_placement.txt).
-            # (sizes from a few MB to a few GB: which ones land well depends on the state of the driver's allocator -- on a freshly
-            # booted box a dozen MB-sized spacers in a row can all land alike)
+            # The quality of a placement is, to a good approximation, a property of each ARRAY on its own (scripts/placement_single.py:
+            # arrays probed alone fall into a fast group, 134-141 us for the 100 M-element array = 5.7-5.9 TB/s of its 8 B per element,
+            # and a slow one, 161-168 us; the three fastest of 14 together probe 397-400 us, the three slowest 486-490).  So the
+            # arrays are placed one by one: a spacer of varying size (it decides which physical blocks the driver hands out next; sizes
+            # from MBs to GBs, because on a freshly booted box a dozen MB-sized spacers in a row can land alike), the array, one
+            # probe of it alone; fast ones are kept, the others and every spacer go back to the DRIVER (torch's cache would hand the
+            # same blocks out again), except that the best rejects stay alive as the fallback.  At most 3 x FX_PLACEMENT_TRIES arrays.
+            rate = float(os.environ.get("FX_PLACEMENT_GOOD_TBS", self.PLACE_GOOD_TBS))
+            good_one_us = 8.0 * out * fin / (rate * 1e12) * 1e6
             spacer_mb = (0, 6, 3, 254, 1201, 5, 777, 2403, 30, 3607, 2, 333, 4811, 14, 100, 6005, 62, 1022, 7217, 126, 510, 2046,
                          9001, 391, 1777, 12013, 47, 683, 2999, 5501, 210, 8191, 1333, 17, 4099, 950)
-            soft = tries
-            hard = tries if tries < 4 else 3 * tries       # keep going past `tries` only while nothing decent has turned up
-            probes, best = [], None                    # best = (us, triple, spacer index): kept ALIVE while the search goes on
+            probes, kept, spare = [], [], []           # kept / spare: (us, array), alive
             with torch.cuda.device(self.device):
-                for t in range(hard):
-                    if t >= soft and best[0] <= 1.04 * good_us:
-                        break
+                for t in range(3 * tries):
                     sp = None
                     if t:
                         try:           # (a spacer is a means, not a need: on a nearly full device the search goes on without it)
@@ -200,26 +197,38 @@ class ParamStore:
                         except torch.OutOfMemoryError:
                             sp = None
                     try:
-                        b = triple()
+                        a = torch.zeros(out, ld, dtype=torch.float32, device=self.device)
                     except torch.OutOfMemoryError:
-                        if best is None:
+                        if len(kept) + len(spare) < 3:
                             raise
                         del sp
-                        torch.cuda.empty_cache()
                         break
-                    us = ops.placement_probe_us(b[0][:, :fin], b[1][:, :fin], b[2][:, :fin])
+                    us = ops.placement_probe_us(a[:, :fin])
                     probes.append(round(us, 1))
-                    if best is None or us < best[0]:
-                        best = (us, b, t)              # (the previous best, if any, is released with the names below)
-                    del b, sp
+                    if us <= good_one_us:
+                        kept.append((us, a))
+                    else:
+                        spare.append((us, a))
+                        spare.sort(key=lambda c: c[0])
+                    del a, sp
+                    del spare[max(3 - len(kept), 0):]          # only as many rejects as could still be needed stay alive
                     if t:
-                        torch.cuda.empty_cache()       # spacer and rejected triple: back to the driver
-                    if best[0] <= good_us:
+                        torch.cuda.empty_cache()               # spacer and dropped rejects: back to the driver
+                    if len(kept) >= 3:
                         break
-                bufs = best[1]
-                self.placement[key] = {"probe_us": probes, "kept_us": round(best[0], 1), "spacer_mb": spacer_mb[best[2] % len(spacer_mb)],
-                                       "good_us": round(good_us, 1)}
-                del best
+                    if t + 1 >= tries:
+                        # a shape whose fast placements do not reach the absolute rate (other tile counts per run): after `tries`
+                        # candidates, three arrays within 3 % of the fastest one seen are as good as it gets
+                        top = sorted(kept + spare, key=lambda c: c[0])[:3]
+                        if len(top) == 3 and top[2][0] <= 1.03 * min(probes):
+                            break
+                chosen = sorted(kept + spare, key=lambda c: c[0])[:3]
+                bufs = [c[1] for c in chosen]
+                together = ops.placement_probe_us(bufs[0][:, :fin], bufs[1][:, :fin], bufs[2][:, :fin])
+                self.placement[key] = {"probe_us": probes, "kept_single_us": [round(c[0], 1) for c in chosen], "kept_us": round(together, 1),
+                                       "good_single_us": round(good_one_us, 1)}
+                del kept, spare, chosen
+                torch.cuda.empty_cache()
         for name, buf in zip(("W", "M", "V"), bufs):
             self.big[key]["_" + name] = buf
             self.big[key][name] = buf[:, :fin]

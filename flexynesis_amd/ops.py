@@ -657,15 +657,17 @@ def reduce_slabs(rec, y, slabs, bias, n_slabs):
     rec.emit("fx_reduce_slabs", y.data_ptr(), slabs.data_ptr(), _ptr(bias), M, N, _ld(y), int(n_slabs), M * N)
 
 
-def placement_probe_us(W, m, v, launches: int = 3) -> float:
+def placement_probe_us(W, m=None, v=None, launches: int = 3) -> float:
     """Microseconds per pass of the fused dW + Adam kernel's W / m / v traffic pattern over these three arrays (contents unchanged):
     a rating of WHERE they landed in physical memory (include/fxhip.h: fx_placement_probe).  Synchronises the current stream."""
     for t in (W, m, v):
-        _chk2d(t, "placement_probe")
+        if t is not None:
+            _chk2d(t, "placement_probe")
     n_out, k_in = W.shape
-    args = (W.data_ptr(), m.data_ptr(), v.data_ptr(), n_out, k_in, _ld(W))
-    if not (_ld(m) == _ld(W) == _ld(v)) or m.shape != W.shape or v.shape != W.shape:
-        raise FxError("placement_probe: W / m / v must share shape and leading dimension")
+    args = (W.data_ptr(), _ptr(m), _ptr(v), n_out, k_in, _ld(W))
+    for t in (m, v):          # (None: W on its own)
+        if t is not None and (_ld(t) != _ld(W) or t.shape != W.shape):
+            raise FxError("placement_probe: W / m / v must share shape and leading dimension")
     IMMEDIATE.emit("fx_placement_probe", *args)
     best = float("inf")
     for _ in range(max(1, launches)):
