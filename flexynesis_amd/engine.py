@@ -159,7 +159,7 @@ class ParamStore:
     # kernel on the same [5000, 20000] arrays of the same MI355X, by the allocation history of the process alone (DESIGN.md section
     # 3.10, profiles/r04_placement.txt).  So: allocate candidate arrays, time one pass of that traffic pattern over each
     # (fx_placement_probe: contents untouched), keep the fast ones; the rest go back to the driver.  FX_PLACEMENT_TRIES (default 12:
-    # at most 36 candidate arrays per weight; 1 = take the first placement, as rounds 1-3 did).
+    # at most 60 candidate arrays per weight; 1 = take the first placement, as rounds 1-3 did).
     PLACE_MIN_ELEMS = 1 << 24           # 64 MB per array: smaller weights are a few tiles per workgroup, placement is in the noise
     PLACE_GOOD_TBS = 5.65               # an array read + written (8 B per element) per probe pass: arrays at this rate are kept
 
@@ -182,14 +182,14 @@ class ParamStore:
             # arrays are placed one by one: a spacer of varying size (it decides which physical blocks the driver hands out next; sizes
             # from MBs to GBs, because on a freshly booted box a dozen MB-sized spacers in a row can land alike), the array, one
             # probe of it alone; fast ones are kept, the others and every spacer go back to the DRIVER (torch's cache would hand the
-            # same blocks out again), except that the best rejects stay alive as the fallback.  At most 3 x FX_PLACEMENT_TRIES arrays.
+            # same blocks out again), except that the best rejects stay alive as the fallback.  At most 5 x FX_PLACEMENT_TRIES arrays.
             rate = float(os.environ.get("FX_PLACEMENT_GOOD_TBS", self.PLACE_GOOD_TBS))
             good_one_us = 8.0 * out * fin / (rate * 1e12) * 1e6
             spacer_mb = (0, 6, 3, 254, 1201, 5, 777, 2403, 30, 3607, 2, 333, 4811, 14, 100, 6005, 62, 1022, 7217, 126, 510, 2046,
                          9001, 391, 1777, 12013, 47, 683, 2999, 5501, 210, 8191, 1333, 17, 4099, 950)
             probes, kept, spare = [], [], []           # kept / spare: (us, array), alive
             with torch.cuda.device(self.device):
-                for t in range(3 * tries):
+                for t in range(5 * tries):
                     sp = None
                     if t:
                         try:           # (a spacer is a means, not a need: on a nearly full device the search goes on without it)
@@ -219,8 +219,10 @@ class ParamStore:
                     if t + 1 >= tries:
                         # a shape whose fast placements do not reach the absolute rate (other tile counts per run): after `tries`
                         # candidates, three arrays within 3 % of the fastest one seen are as good as it gets
+                        # (only if that fastest one is itself out of the slow group: a dozen candidates in a row at 4.8-4.95 TB/s
+                        # happen, and three of THOSE are not a placement to settle for)
                         top = sorted(kept + spare, key=lambda c: c[0])[:3]
-                        if len(top) == 3 and top[2][0] <= 1.03 * min(probes):
+                        if len(top) == 3 and top[2][0] <= 1.03 * min(probes) and min(probes) <= good_one_us * rate / 5.3:
                             break
                 chosen = sorted(kept + spare, key=lambda c: c[0])[:3]
                 bufs = [c[1] for c in chosen]
