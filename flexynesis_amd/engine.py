@@ -161,7 +161,7 @@ class ParamStore:
     # (fx_placement_probe: contents untouched), keep the fast ones; the rest go back to the driver.  FX_PLACEMENT_TRIES (default 12:
     # at most 60 candidate arrays per weight; 1 = take the first placement, as rounds 1-3 did).
     PLACE_MIN_ELEMS = 1 << 24           # 64 MB per array: smaller weights are a few tiles per workgroup, placement is in the noise
-    PLACE_GOOD_TBS = 5.65               # an array read + written (8 B per element) per probe pass: arrays at this rate are kept
+    PLACE_GOOD_TBS = 5.75               # an array read + written (8 B per element) per probe pass: arrays at this rate are kept
 
     def _place_big(self, key):
         out, fin = self.shapes[key]
@@ -180,13 +180,18 @@ class ParamStore:
             # arrays probed alone fall into a fast group, 134-141 us for the 100 M-element array = 5.7-5.9 TB/s of its 8 B per element,
             # and a slow one, 161-168 us; the three fastest of 14 together probe 397-400 us, the three slowest 486-490).  So the
             # arrays are placed one by one: a spacer of varying size (it decides which physical blocks the driver hands out next; sizes
-            # from MBs to GBs, because on a freshly booted box a dozen MB-sized spacers in a row can land alike), the array, one
+            # from MBs to tens of GBs), the array, one
             # probe of it alone; fast ones are kept, the others and every spacer go back to the DRIVER (torch's cache would hand the
             # same blocks out again), except that the best rejects stay alive as the fallback.  At most 5 x FX_PLACEMENT_TRIES arrays.
             rate = float(os.environ.get("FX_PLACEMENT_GOOD_TBS", self.PLACE_GOOD_TBS))
             good_one_us = 8.0 * out * fin / (rate * 1e12) * 1e6
-            spacer_mb = (0, 6, 3, 254, 1201, 5, 777, 2403, 30, 3607, 2, 333, 4811, 14, 100, 6005, 62, 1022, 7217, 126, 510, 2046,
-                         9001, 391, 1777, 12013, 47, 683, 2999, 5501, 210, 8191, 1333, 17, 4099, 950)
+            # Spacer sizes: a fixed list of small ones first, then log-uniform draws between 4 MB and ~45 % of the free memory (at most
+            # 96 GB): whole regions of the physical address space hand out slow arrays only -- on one freshly acquired box 60
+            # candidates behind spacers of up to 12 GB were ALL slow, for both weights -- so the search has to be able to leave them.
+            free_b = torch.cuda.mem_get_info(self.device)[0]
+            cap_mb = max(16, min(int(0.45 * free_b) >> 20, 96 << 10))
+            rs = np.random.RandomState(20240 + len(self.big))
+            spacer_mb = [0, 6, 3, 254, 1201, 5, 777, 2403] + [int(np.exp(rs.uniform(np.log(4.0), np.log(float(cap_mb))))) for _ in range(5 * tries)]
             probes, kept, spare = [], [], []           # kept / spare: (us, array), alive
             with torch.cuda.device(self.device):
                 for t in range(5 * tries):
