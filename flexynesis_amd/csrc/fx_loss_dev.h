@@ -147,6 +147,19 @@ __device__ __forceinline__ void loss_cox_body(float* loss_out, float* __restrict
   // chain role and the weight-gradient role compute the same numbers and both store them), so a "zero everything, then scatter"
   // sequence lets one workgroup's zeros land between the other's final store and its read-back -- seen as run-to-run differences
   // of the Cox head's weight gradients once the two workgroups ran skewed (beside a wide product).
+#ifdef FX_COX_TWO_PHASE          // (the round-3 form, kept for scripts/build_variant.py: the regression test must fail on it)
+  for (int i = threadIdx.x; i < B; i += blockDim.x) dout[(long)i * ldd] = 0.f;
+  __syncthreads();
+  if (ok)
+    for (int i = threadIdx.x; i < P; i += blockDim.x)
+      if (idx[i] >= 0) {
+        const float e1 = (ev[idx[i]] == 1.0f) ? 1.f : 0.f;
+        const double gr = -((double)e1 - (double)key[i] * scan[i]) / esum;
+        dout[(long)idx[i] * ldd] = w * (float)gr;
+      }
+  if (threadIdx.x == 0) loss_out[0] = ok ? total : 0.f;
+  return;
+#endif
   for (int i = threadIdx.x; i < P; i += blockDim.x) {
     if (idx[i] >= 0) {          // valid rows, by sorted position
       const float e1 = (ev[idx[i]] == 1.0f) ? 1.f : 0.f;

@@ -247,3 +247,4 @@ def test_vae_chain_schedules_agree(monkeypatch, model):
         for step, ((a, _), (b, _)) in enumerate(zip(ls, l1)):
             for k in a:
                 close(a[k], b[k], (5e-5 if k == "mmd_loss" else 2e-6) if step == 0 else 1e-4, 1e-7, f"{sw}=0 step {step} loss {k}")
+
