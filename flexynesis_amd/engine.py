@@ -159,7 +159,7 @@ class ParamStore:
     # kernel on the same [5000, 20000] arrays of the same MI355X, by the allocation history of the process alone (DESIGN.md section
     # 3.10, profiles/r04_placement.txt).  So: allocate candidate arrays, time one pass of that traffic pattern over each
     # (fx_placement_probe: contents untouched), keep the fast ones; the rest go back to the driver.  FX_PLACEMENT_TRIES (default 12:
-    # at most 60 candidate arrays per weight; 1 = take the first placement, as rounds 1-3 did).
+    # at most 96 candidate arrays per weight; 1 = take the first placement, as rounds 1-3 did).
     PLACE_MIN_ELEMS = 1 << 24           # 64 MB per array: smaller weights are a few tiles per workgroup, placement is in the noise
     PLACE_GOOD_TBS = 5.75               # an array read + written (8 B per element) per probe pass: arrays at this rate are kept
 
@@ -182,7 +182,7 @@ class ParamStore:
             # arrays are placed one by one: a spacer of varying size (it decides which physical blocks the driver hands out next; sizes
             # from MBs to tens of GBs), the array, one
             # probe of it alone; fast ones are kept, the others and every spacer go back to the DRIVER (torch's cache would hand the
-            # same blocks out again), except that the best rejects stay alive as the fallback.  At most 5 x FX_PLACEMENT_TRIES arrays.
+            # same blocks out again), except that the best rejects stay alive as the fallback.  At most 8 x FX_PLACEMENT_TRIES arrays.
             rate = float(os.environ.get("FX_PLACEMENT_GOOD_TBS", self.PLACE_GOOD_TBS))
             good_one_us = 8.0 * out * fin / (rate * 1e12) * 1e6
             # Spacer sizes: a fixed list of small ones first, then log-uniform draws between 4 MB and ~45 % of the free memory (at most
@@ -191,10 +191,10 @@ class ParamStore:
             free_b = torch.cuda.mem_get_info(self.device)[0]
             cap_mb = max(16, min(int(0.45 * free_b) >> 20, 96 << 10))
             rs = np.random.RandomState(20240 + len(self.big))
-            spacer_mb = [0, 6, 3, 254, 1201, 5, 777, 2403] + [int(np.exp(rs.uniform(np.log(4.0), np.log(float(cap_mb))))) for _ in range(5 * tries)]
+            spacer_mb = [0, 6, 3, 254, 1201, 5, 777, 2403] + [int(np.exp(rs.uniform(np.log(4.0), np.log(float(cap_mb))))) for _ in range(8 * tries)]
             probes, kept, spare = [], [], []           # kept / spare: (us, array), alive
             with torch.cuda.device(self.device):
-                for t in range(5 * tries):
+                for t in range(8 * tries):
                     sp = None
                     if t:
                         try:           # (a spacer is a means, not a need: on a nearly full device the search goes on without it)

@@ -289,8 +289,8 @@ def test_placement_probe_leaves_contents_alone_and_store_search_is_transparent(m
         if tries == 1:
             assert info is None
         else:
-            # (arrays are placed one by one: at least three probes, at most 5 x the asked-for candidates)
-            assert info is not None and 3 <= len(info["probe_us"]) <= 20 and len(info["kept_single_us"]) == 3
+            # (arrays are placed one by one: at least three probes, at most 8 x the asked-for candidates)
+            assert info is not None and 3 <= len(info["probe_us"]) <= 32 and len(info["kept_single_us"]) == 3
             assert sorted(info["kept_single_us"])[0] == min(info["probe_us"])
         states.append(st.state_dict())
         assert st.p("encoders.0.layer_1.weight").data_ptr() % 16 == 0
