@@ -381,12 +381,15 @@ static inline bool ft_aligned16(const void* p) { return (((uintptr_t)p) & 15) ==
 
 // mapping actually used for a launch: 1 = XCD-grouped interleaved row blocks (K = 3 B: the dY^T tiles of an XCD's workgroups would
 // outgrow its L2), 2 = XCD-contiguous (large weights), 0 = plain
+// The XCD-contiguous grid is fixed at 8 x (FT_G / 8) workgroups, one run each: it reaches every row block only while an XCD's share of
+// row blocks fits its slots (n_out <= 32768); taller weights take the plain mapping, whose grid grows with the row blocks.
+static bool ft_contig_ok(int tiles_m) { return tiles_m >= 16 && (tiles_m + 7) / 8 <= FT_G / 8; }
 static int ft_mapping(int map_flag, int tiles_m, int batch_padded) {
   if (map_flag == 1) return 0;
   if (map_flag == 2) return 1;
-  if (map_flag == 3) return tiles_m >= 16 ? 2 : 0;
+  if (map_flag == 3) return ft_contig_ok(tiles_m) ? 2 : 0;
   if ((long)FT_M * batch_padded * 4 * 60 > (3L << 20)) return 1;
-  return tiles_m >= 16 ? 2 : 0;
+  return ft_contig_ok(tiles_m) ? 2 : 0;
 }
 static int ft_slabs_for(int mapping, int tiles_m, int tiles_n) {
   if (mapping == 1) return ft_plan(tiles_m, tiles_n, FT_G).S_lo;

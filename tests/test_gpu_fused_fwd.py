@@ -19,6 +19,8 @@ pytestmark = pytest.mark.gpu
     (700, 1500, 96, 200),         # two M-tiles of the next batch (rows padded to 256), K = 96
     (1875, 3000, 384, 384),       # triplet: 3 B stacked rows = three M-tiles, K = 384 (XCD-grouped row blocks)
     (7500, 30000, 384, 384),      # cfg4 shape
+    (33000, 512, 64, 64),         # > 32768 rows: an XCD's share of row blocks exceeds its 64 slots (the XCD-contiguous mapping must stand down)
+    (40100, 260, 32, 200),        # the same with ragged edges and two M-tiles of the next batch
 ])
 def test_dw_adam_fwd_matches_the_kernels_it_replaces(n_out, k_in, B, Bn):
     from flexynesis_amd import ops
