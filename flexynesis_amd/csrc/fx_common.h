@@ -51,7 +51,8 @@ enum FxCtrl {
 // section 3.9): their time is their energy, and every VALU instruction per element of a 100 M-element weight is worth ~1.4 us of a
 // 450 us launch.  The textbook form with IEEE sqrt and two IEEE divisions is 54 instructions per element (32 of them the
 // compiler's div_scale / div_fmas / div_fixup / refinement sequences); this one is 10:
-//     m' = fma(g, (1 - b1) c, b1 m)          v' = fma(g g, (1 - b2) c^2, b2 v)          (c = clip coefficient)
+//     m' = fma(g, (1 - b1) c, b1 m)          v' = fma(t, t, b2 v), t = g sqrt(1 - b2) c          (c = clip coefficient; t stays finite
+//                                            for every finite clipped gradient: g g overflowed beyond |g| = 1.8e19 whatever c was)
 //     d  = fma(v_sqrt_f32(v'), 1 / sqrt(1 - b2^t), eps)                  p' = fma(-lr / (1 - b1^t), m' v_rcp_f32(d), p)
 // v_sqrt_f32 and v_rcp_f32 are accurate to 1 ulp, so the update differs from torch's by <= ~4 ulp (5e-7 relative) of a step of
 // size ~lr -- two orders of magnitude below the 3e-5 relative error the split-bf16 products leave in the gradient itself, and far
@@ -69,7 +70,7 @@ struct FxAdamK {
 __device__ __forceinline__ FxAdamK fx_adam_consts(float lr, float bc1, float bc2s, float coef) {
   FxAdamK k;
   k.c1 = (1.0f - FX_BETA1) * coef;
-  k.c2 = (1.0f - FX_BETA2) * coef * coef;
+  k.c2 = 0.0316227766016837933f * coef;      // sqrt(1 - beta2) * coef: v' = fma(t, t, b2 v) with t = g * c2 stays finite for any finite clipped gradient (g * g did not)
   k.nstep = -(lr / bc1);
   k.rbc2s = 1.0f / bc2s;          // IEEE, once per thread and launch
 #ifdef FX_ADAM_EXACT
@@ -110,7 +111,8 @@ __device__ __forceinline__ void fx_adam_update(float& p, float& m, float& v, flo
   p = p - k.step_size * fx_div_rn(m2, d);
 #else
   const float m2 = __builtin_fmaf(g, k.c1, m * FX_BETA1);
-  const float v2 = __builtin_fmaf(g * g, k.c2, v * FX_BETA2);
+  const float t = g * k.c2;
+  const float v2 = __builtin_fmaf(t, t, v * FX_BETA2);
   const float d = __builtin_fmaf(__builtin_amdgcn_sqrtf(v2), k.rbc2s, FX_ADAM_EPS);
   p = __builtin_fmaf(k.nstep, m2 * __builtin_amdgcn_rcpf(d), p);
 #endif
