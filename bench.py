@@ -44,7 +44,19 @@ CONFIGS = {
     # cfg2 with --fusion_type early (reference data.py:234-257): ONE layer of 40000 features, a single [10000, 40000] weight
     "cfg2_early": dict(model="DirectPred", layers=[("all", 40000)], variables=[("y", "numerical", 1)], surv=(None, None),
                        n_samples=2048),
+    # cfg2 at a point the reference's search space really draws (config.py:7-15: latent_dim any integer in 16..128, hidden =
+    # int(F * U[0.2, 0.5])) on a cohort whose feature counts are multiples of nothing: widths odd mod 4 everywhere.  Hidden sizes
+    # 4968 / 5000, i.e. the headline's work within 0.3 %: the leg shows that the 14-launch schedule and the fused next-step forward
+    # do not depend on the widths (ArchSpec.engine_shapes)
+    "cfg2_odd": dict(model="DirectPred", layers=[("gex", 19873), ("cnv", 20001)], variables=[("y", "numerical", 1)], surv=(None, None),
+                     n_samples=2048, latent=61, factor=0.25, sup=13),
 }
+
+
+def _spec_of(cfg):
+    from flexynesis_amd.arch import ArchSpec
+    return ArchSpec(cfg["model"], cfg["layers"], cfg.get("latent", 64), cfg.get("factor", 0.25), cfg.get("sup", 16), cfg["variables"],
+                    cfg["surv"][0], cfg["surv"][1], True)
 PMC_FILE = "r04_pmc_traffic_cfg2.json"      # rocprofv3 --pmc passes of this command, this round, this kernel (scripts/profile_round.sh)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
@@ -103,7 +115,7 @@ def _engine_leg(config, B, dev, precision, steps, warmup, lr, rank=0, features=0
     cfg = dict(CONFIGS[config])
     if features:
         cfg["layers"] = [(n, features) for n, _ in cfg["layers"]]
-    spec = ArchSpec(cfg["model"], cfg["layers"], 64, 0.25, 16, cfg["variables"], cfg["surv"][0], cfg["surv"][1], True)
+    spec = _spec_of(cfg)
     cohort = synthetic_cohort(cfg["layers"], cfg["n_samples"], dev, seed=1234 + rank)
     n_train = cfg["n_samples"] - int(cfg["n_samples"] * 0.2)
     rows_per_batch = B * (3 if cfg["model"] == "MultiTripletNetwork" else 1)
@@ -144,6 +156,7 @@ def _engine_leg(config, B, dev, precision, steps, warmup, lr, rank=0, features=0
     rec = {"workload": f"{config}: {cfg['model']} {len(cfg['layers'])} x {cfg['layers'][0][1]} features, B={B}, {precision}, hipGraph replay",
            "samples_per_s": round(steps * B / dt, 1), "ms_per_step": round(ms, 4), "steps": steps,
            "step_hbm_frac_of_8TBs": round(bytes_step / (ms * 1e-3) / 8e12, 4), "params": P, "launches_per_step": pipe.n_launches(),
+           "next_forward_fused": sorted(pipe.plans[0]._next_fwd), "schedule": dict(pipe.plans[0].path),
            "loss_finite": all(v == v and abs(v) != float("inf") for v in losses.values())}
     return rec, pipe, store, run
 
@@ -231,7 +244,7 @@ def main():
     if a.features:
         cfg["layers"] = [(n, a.features) for n, _ in cfg["layers"]]
     B = a.batch
-    spec = ArchSpec(cfg["model"], cfg["layers"], 64, 0.25, 16, cfg["variables"], cfg["surv"][0], cfg["surv"][1], True)
+    spec = _spec_of(cfg)
     cohort = synthetic_cohort(cfg["layers"], cfg["n_samples"], dev, seed=1234 + rank)
     n_train = cfg["n_samples"] - int(cfg["n_samples"] * 0.2)           # 80/20 split, reference main.py:272-276
     rows_per_batch = B * (3 if cfg["model"] == "MultiTripletNetwork" else 1)
@@ -402,7 +415,8 @@ def main():
         other = {}
         with _stdout_to_stderr():
             for name, (cfgname, prec) in (("cfg1", ("cfg1", "bf16x3")), ("cfg3", ("cfg3", "bf16x3")), ("cfg4", ("cfg4", "bf16x3")),
-                                          ("cfg2_f32", ("cfg2", "f32")), ("cfg2_early_fusion", ("cfg2_early", "bf16x3"))):
+                                          ("cfg2_f32", ("cfg2", "f32")), ("cfg2_early_fusion", ("cfg2_early", "bf16x3")),
+                                          ("cfg2_odd", ("cfg2_odd", "bf16x3"))):
                 try:
                     rec, p_, s_, _ = _engine_leg(cfgname, B, dev, prec, 20, 5, a.lr)
                     p_.close()
@@ -422,7 +436,8 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
             from oracle import cpu_baseline, restate as O
-            ospec = O.Spec(cfg["model"], cfg["layers"], 64, 0.25, 16, cfg["variables"], cfg["surv"][0], cfg["surv"][1], True)
+            ospec = O.Spec(cfg["model"], cfg["layers"], cfg.get("latent", 64), cfg.get("factor", 0.25), cfg.get("sup", 16), cfg["variables"],
+                           cfg["surv"][0], cfg["surv"][1], True)
             threads = min(os.cpu_count() or 1, 64)
             steps = a.cpu_steps or (20 if a.config == "cfg2" else 100 if a.config == "cfg1" else 8)   # ~15 s of CPU work
             r = cpu_baseline.time_training(ospec, cfg["n_samples"], B, steps=steps, warmup=1, threads=threads, lr=a.lr)

@@ -9,6 +9,9 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
+import os as _os
+_ENGINE_PAD = _os.environ.get("FX_ENGINE_PAD", "1") != "0"      # A/B switch: 0 = the engine computes with the reference's widths (rounds 1-4)
+
 MODEL_KINDS = ("DirectPred", "supervised_vae", "MultiTripletNetwork", "CrossModalPred", "GNN")
 GNN_CONVS = ("GC", "SAGE", "GCN")        # --gnn_conv_type choices (reference __main__.py:536); GAT is not offered by the CLI
 
@@ -95,10 +98,36 @@ class ArchSpec:
     def param_count(self) -> int:
         return sum(int(np.prod(s)) if s else 1 for k, s in self.state_shapes().items() if not is_buffer_key(k))
 
+    # -- engine layout -----------------------------------------------------------------------------
+    # The engine's kernels move rows of activations and weights in 16-byte units, so it runs every model with its HIDDEN widths
+    # (int(F * hidden_dim_factor): any integer, direct_pred.py:78-80) and -- for the MLP family -- its INPUT widths (the feature
+    # count of a cohort layer: any integer, data.py:358-503) rounded up to multiples of 4.  The extra hidden units / input
+    # columns are inert: their weights, biases and BatchNorm affine parameters are zero, so they output zero, receive exactly
+    # zero gradients (every product that reaches them has a zero factor) and Adam leaves them at zero; nothing of them is
+    # visible in ``state_dict`` (``state_shapes`` stays the reference's ABI, ParamStore exposes logical views).
+    @property
+    def pads_features(self) -> bool:
+        return self.model in ("DirectPred", "MultiTripletNetwork")
+
+    def engine_hidden(self, i: int) -> int:
+        return pad4(self.hidden(i)) if (self.model != "GNN" and _ENGINE_PAD) else self.hidden(i)
+
+    def engine_features(self, i: int) -> int:
+        return pad4(self.layers[i][1]) if (self.pads_features and _ENGINE_PAD) else self.layers[i][1]
+
+    def engine_shapes(self) -> Dict[str, Tuple[int, ...]]:
+        """The shapes the engine computes with: ``state_shapes`` with hidden / encoder-input widths rounded up to 4."""
+        return self._shapes(True)
+
     # -- state_dict manifest ---------------------------------------------------------------------
     def state_shapes(self) -> Dict[str, Tuple[int, ...]]:
+        return self._shapes(False)
+
+    def _shapes(self, engine: bool) -> Dict[str, Tuple[int, ...]]:
         out: Dict[str, Tuple[int, ...]] = {}
         n, L, S = self.n_layers, self.latent_dim, self.sup_hidden
+        hidden = self.engine_hidden if engine else self.hidden
+        feats = self.engine_features if engine else (lambda i: self.layers[i][1])
 
         def bn(prefix, c):
             out[prefix + ".weight"] = (c,)
@@ -118,8 +147,8 @@ class ArchSpec:
         for name in self.logvar_names():
             out["log_vars." + name] = (1,)
         if self.model in ("DirectPred", "MultiTripletNetwork"):
-            for i, (_, F) in enumerate(self.layers):
-                mlp(f"encoders.{i}", F, self.hidden(i), L)
+            for i in range(len(self.layers)):
+                mlp(f"encoders.{i}", feats(i), hidden(i), L)
             if n > 1:
                 out["fusion_block.weight"] = (L, n * L)
                 out["fusion_block.bias"] = (L,)
@@ -141,7 +170,7 @@ class ArchSpec:
         else:
             n = len(self.enc_idx)
             for j, i in enumerate(self.enc_idx):
-                F, H, p = self.layers[i][1], self.hidden(i), f"encoders.{j}"
+                F, H, p = feats(i), hidden(i), f"encoders.{j}"
                 out[p + ".hidden_layers.0.weight"] = (H, F)
                 out[p + ".hidden_layers.0.bias"] = (H,)
                 bn(p + ".hidden_layers.2", H)
@@ -152,7 +181,7 @@ class ArchSpec:
                 out[fc + ".weight"] = (L, n * L)
                 out[fc + ".bias"] = (L,)
             for j, i in enumerate(self.dec_idx):
-                F, H, p = self.layers[i][1], self.hidden(i), f"decoders.{j}"
+                F, H, p = self.layers[i][1], hidden(i), f"decoders.{j}"       # (a reconstructed layer keeps its width: rows of FC_output)
                 out[p + ".hidden_layers.0.weight"] = (H, L)
                 out[p + ".hidden_layers.0.bias"] = (H,)
                 bn(p + ".hidden_layers.2", H)
@@ -161,6 +190,17 @@ class ArchSpec:
         for (v, _, C) in self.variables:
             mlp("MLPs." + v, L, S, C)
         return out
+
+
+def pad4(n: int) -> int:
+    return (int(n) + 3) // 4 * 4
+
+
+def is_tail_key(key: str) -> bool:
+    """Small Linears fed by an encoder's BatchNorm block ([latent, hidden]): the engine allocates their rows rounded up to 4
+    (zero rows), so that the grouped tail kernel can produce aligned partial products for any latent size."""
+    return key.startswith("encoders.") and key.endswith((".layer_out.weight", ".layer_out.bias", ".FC_mean.weight", ".FC_mean.bias",
+                                                         ".FC_var.weight", ".FC_var.bias"))
 
 
 def gnn_conv_keys(prefix: str, conv: str):

@@ -320,7 +320,9 @@ struct FusionArgs {
   float* emb; long ldemb;
   float* ecat; long ldecat;
   const float* part[FU_MAX_LAYERS]; const float* bias[FU_MAX_LAYERS]; int n_part[FU_MAX_LAYERS]; int width[FU_MAX_LAYERS];
-  int col0[FU_MAX_LAYERS];
+  int col0[FU_MAX_LAYERS];       // first ecat column of the layer (widths are ANY integers: a layer may start at an unaligned column)
+  int grp0[FU_MAX_LAYERS];       // first 4-column group of the layer in the unit index space (a part's row pitch = its width rounded up to 4)
+  int n_groups;
   int n_layers;
   const float* Wf; const float* bf;
   int B, L, Kf;
@@ -342,19 +344,21 @@ __device__ __forceinline__ void fx_fusion_body(const FusionArgs& a, float (*es)[
   // ---- ecat rows: unit = (row, 4 consecutive columns of one modality); its FU_SUB threads (neighbouring lanes) split the slab
   // range (4 rows x 8 sub-ranges: 32 workgroups at B = 128, ~10 slabs of 16 bytes per thread in 2-3 dependent rounds)
   const int sub = t & (FU_SUB - 1), unit0 = t / FU_SUB;
-  const int units = FU_ROWS * (Kf >> 2);
+  const int units = FU_ROWS * a.n_groups;
   for (int u = unit0; u < units; u += FU_T / FU_SUB) {
-    const int rr = u / (Kf >> 2), c = (u - rr * (Kf >> 2)) << 2;
+    const int rr = u / a.n_groups, gg = u - rr * a.n_groups;
     const int r = r0 + rr;
-    const float* part = a.part[0]; const float* bias = a.bias[0]; int np = a.n_part[0], wd = a.width[0], c0 = a.col0[0];
+    const float* part = a.part[0]; const float* bias = a.bias[0]; int np = a.n_part[0], wd = a.width[0], c0 = a.col0[0], g0 = 0;
 #pragma unroll
     for (int i = 1; i < FU_MAX_LAYERS; ++i)
-      if (i < a.n_layers && c >= a.col0[i]) { part = a.part[i]; bias = a.bias[i]; np = a.n_part[i]; wd = a.width[i]; c0 = a.col0[i]; }
+      if (i < a.n_layers && gg >= a.grp0[i]) { part = a.part[i]; bias = a.bias[i]; np = a.n_part[i]; wd = a.width[i]; c0 = a.col0[i]; g0 = a.grp0[i]; }
+    const int pc = (gg - g0) << 2, pw = (wd + 3) & ~3;         // column of the part, its row pitch
+    const int c = c0 + pc;                                     // first of (up to) four ecat columns
     const int per = (np + FU_SUB - 1) / FU_SUB, z0 = min(np, sub * per), z1 = min(np, z0 + per);
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (r < B) {
-      const float* src = part + (long)r * wd + (c - c0);
-      const long stride = (long)B * wd;
+      const float* src = part + (long)r * pw + pc;
+      const long stride = (long)B * pw;
       int z = z0;
       for (; z + 4 <= z1; z += 4) {
         f32x4 v[4];
@@ -376,9 +380,18 @@ __device__ __forceinline__ void fx_fusion_body(const FusionArgs& a, float (*es)[
       tot += sq;
     }
     if (sub == 0) {
-      if (bias) tot += *reinterpret_cast<const f32x4*>(bias + (c - c0));
-      *reinterpret_cast<f32x4*>(&es[rr][c]) = tot;
-      if (r < B && a.ecat) *reinterpret_cast<f32x4*>(a.ecat + (long)r * a.ldecat + c) = tot;
+      if (bias) tot += *reinterpret_cast<const f32x4*>(bias + pc);        // (bias arrays are allocated up to a multiple of 4: zeros)
+      if (((c | wd) & 3) == 0) {
+        *reinterpret_cast<f32x4*>(&es[rr][c]) = tot;
+        if (r < B && a.ecat) *reinterpret_cast<f32x4*>(a.ecat + (long)r * a.ldecat + c) = tot;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (pc + j < wd) {
+            es[rr][c + j] = tot[j];
+            if (r < B && a.ecat) a.ecat[(long)r * a.ldecat + c + j] = tot[j];
+          }
+      }
     }
   }
   if (!a.Wf) return;
@@ -434,7 +447,8 @@ int fx_enc_tail_fwd(const void* descs_, int n, int B, int pre_act, int post_act,
                     hipStream_t stream) {
   const EncTailDesc* descs = (const EncTailDesc*)descs_;
   FX_REQUIRE(descs && n > 0 && n <= ET_MAX_GROUP, "fx_enc_tail_fwd: 1..%d modalities per launch", ET_MAX_GROUP);
-  FX_REQUIRE(B > 0 && B <= ET_MAXB && (!train || B > 1), "fx_enc_tail_fwd: B=%d must be in %d..%d", B, train ? 2 : 1, ET_MAXB);
+  FX_REQUIRE(!(train && B == 1), "fx_enc_tail_fwd: BatchNorm1d training needs more than 1 value per channel");    // (torch's wording, as fx_bn_act_fwd)
+  FX_REQUIRE(B > 0 && B <= ET_MAXB, "fx_enc_tail_fwd: B=%d must be in 1..%d", B, ET_MAXB);
   EncTailArgs a{};
   int max_blocks = 0;
   for (int i = 0; i < n; ++i) {
@@ -467,17 +481,20 @@ static int fusion_args(FusionArgs& a, float* emb, long ldemb, float* ecat, long 
                        const float* const* part_bias, const int* widths, int n_layers, const float* Wf, const float* bf, int B, int L) {
   FX_REQUIRE(parts && n_parts && widths && n_layers > 0 && n_layers <= FU_MAX_LAYERS, "fx_fusion_fwd: 1..%d layers", FU_MAX_LAYERS);
   FX_REQUIRE(B > 0 && (ecat || Wf), "fx_fusion_fwd: nothing to write");
-  int Kf = 0;
+  int Kf = 0, ng = 0;
   for (int i = 0; i < n_layers; ++i) {
-    FX_REQUIRE(parts[i] && n_parts[i] > 0 && widths[i] > 0 && widths[i] % 4 == 0 && (((uintptr_t)parts[i]) & 15) == 0,
-               "fx_fusion_fwd: layer %d: width %d must be a multiple of 4 and the partial sums 16-byte aligned", i, widths[i]);
+    FX_REQUIRE(parts[i] && n_parts[i] > 0 && widths[i] > 0 && (((uintptr_t)parts[i]) & 15) == 0,
+               "fx_fusion_fwd: layer %d: width %d must be positive and the partial sums 16-byte aligned", i, widths[i]);
     a.part[i] = parts[i]; a.bias[i] = part_bias ? part_bias[i] : nullptr; a.n_part[i] = n_parts[i]; a.width[i] = widths[i];
     FX_REQUIRE(!a.bias[i] || (((uintptr_t)a.bias[i]) & 15) == 0, "fx_fusion_fwd: layer %d: bias must be 16-byte aligned", i);
     a.col0[i] = Kf;
+    a.grp0[i] = ng;
     Kf += widths[i];
+    ng += (widths[i] + 3) / 4;
   }
+  a.n_groups = ng;
   FX_REQUIRE(Kf <= FU_MAXK, "fx_fusion_fwd: concatenated width %d exceeds %d", Kf, FU_MAXK);
-  FX_REQUIRE(!ecat || (ldecat >= Kf && ldecat % 4 == 0 && (((uintptr_t)ecat) & 15) == 0), "fx_fusion_fwd: ecat must be 16-byte aligned, ld %% 4 == 0");
+  FX_REQUIRE(!ecat || (ldecat >= Kf && (((Kf | ldecat) & 3) != 0 || (((uintptr_t)ecat) & 15) == 0)), "fx_fusion_fwd: ecat: ld >= %d, 16-byte aligned when the widths are multiples of 4", Kf);
   FX_REQUIRE(!Wf || (emb && L > 0 && ldemb >= L), "fx_fusion_fwd: the fusion layer needs emb");
   FX_REQUIRE(!Wf || L <= ET_MAXL, "fx_fusion_fwd: latent width %d exceeds %d", L, ET_MAXL);
   a.emb = emb; a.ldemb = ldemb; a.ecat = ecat; a.ldecat = ldecat; a.n_layers = n_layers; a.Wf = Wf; a.bf = bf;

@@ -121,9 +121,30 @@ class DeviceCohort:
         if self.device.type != "cuda":
             raise RuntimeError("DeviceCohort lives in GPU memory (no CPU path)")
         self.layers = list(dat.keys())                 # order = dataset.dat.keys() (reference direct_pred.py:68)
-        self.dat = {k: torch.as_tensor(v).to(self.device, torch.float32).contiguous() for k, v in dat.items()}
+        # Rows are stored with a pitch of a multiple of 4 floats (the pad columns are zero): the batch assembly reads 16 bytes per
+        # lane whatever the layer's feature count is (engine.StepPlan gathers from ``source``); ``dat`` are the [N, F] views.
+        self._rows, self.dat = {}, {}
+        for k, v in dat.items():
+            v = torch.as_tensor(v)
+            F = int(v.shape[1])
+            Fp = (F + 3) // 4 * 4
+            if Fp == F:
+                buf = v.to(self.device, torch.float32).contiguous()
+            else:
+                buf = torch.zeros(v.shape[0], Fp, dtype=torch.float32, device=self.device)
+                buf[:, :F].copy_(v)
+            self._rows[k], self.dat[k] = buf, buf[:, :F]
         self.ann = {k: torch.as_tensor(v).to(self.device, torch.float32).contiguous() for k, v in ann.items()}
         self.n = next(iter(self.dat.values())).shape[0]
+
+    def source(self, name: str, width: int) -> torch.Tensor:
+        """Layer ``name`` as a [N, width] tensor for the batch assembly: width = its feature count, or that rounded up to 4 (zero columns)."""
+        buf = self._rows[name]
+        if width == buf.shape[1]:
+            return buf
+        if width == self.dat[name].shape[1]:
+            return self.dat[name]
+        raise ValueError(f"layer {name!r}: {self.dat[name].shape[1]} features, asked for a width of {width}")
 
     @classmethod
     def from_dataset(cls, ds, device):

@@ -32,7 +32,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .arch import ArchSpec, is_buffer_key
+from .arch import ArchSpec, is_buffer_key, is_tail_key, pad4
 from .ops import ACT_LEAKY, ACT_NONE, ACT_RELU, TapeRecorder, Workspace
 
 DROPOUT_P = 0.1          # nn.Dropout(p=0.1), reference modules.py:132
@@ -75,7 +75,12 @@ class ParamStore:
             raise RuntimeError("flexynesis_amd.ParamStore needs a GPU device (no CPU path)")
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
+        # ``shapes``: the reference's state_dict ABI; ``eshapes``: what the engine computes with (hidden widths and, for the MLP family,
+        # encoder input widths rounded up to 4: ArchSpec.engine_shapes).  p / g / m / v / b return the LOGICAL tensors (views of the
+        # top-left corner), ep / eg / em / ev / eb the engine's; everything outside the logical part is zero and stays zero (arch.py).
         self.shapes = spec.state_shapes()
+        self.eshapes = spec.engine_shapes()
+        self.padded = any(tuple(self.shapes[k]) != tuple(self.eshapes[k]) for k in self.shapes)
         self.param_keys = [k for k in self.shapes if not is_buffer_key(k)]
         self.buffer_keys = [k for k in self.shapes if is_buffer_key(k) and not k.endswith("num_batches_tracked")]
         self.nbt_keys = [k for k in self.shapes if k.endswith("num_batches_tracked")]
@@ -85,16 +90,19 @@ class ParamStore:
         # so such weights stay in the small-parameter arena.  An explicit big_threshold (tests) disables the rule.
         if big_min_dim is None:
             big_min_dim = 256 if big_threshold == (1 << 20) else 1
-        self.big_keys = [k for k in self.param_keys if len(self.shapes[k]) == 2
-                         and int(np.prod(self.shapes[k])) >= big_threshold and min(self.shapes[k]) >= big_min_dim]
+        self.big_keys = [k for k in self.param_keys if len(self.eshapes[k]) == 2
+                         and int(np.prod(self.eshapes[k])) >= big_threshold and min(self.eshapes[k]) >= big_min_dim]
         self.small_keys = [k for k in self.param_keys if k not in self.big_keys]
         # small arena
         self.off: Dict[str, Tuple[int, int]] = {}
         o = 0
         for k in self.small_keys:
-            n = int(np.prod(self.shapes[k])) if self.shapes[k] else 1
+            n = int(np.prod(self.eshapes[k])) if self.eshapes[k] else 1
             self.off[k] = (o, n)
-            o += _align4(n)
+            # (the small Linears behind an encoder's BatchNorm block get their ROWS allocated up to a multiple of 4 -- zero rows that
+            # the grouped tail kernel reads as further outputs, so that its partial products have an aligned pitch for any latent size)
+            alloc = pad4(self.eshapes[k][0]) * int(np.prod(self.eshapes[k][1:])) if (is_tail_key(k) and self.eshapes[k]) else n
+            o += _align4(alloc)
         self.n_small = max(o, 4)
         f = dict(dtype=torch.float32, device=self.device)
         self.P = torch.zeros(self.n_small, **f)
@@ -105,7 +113,7 @@ class ParamStore:
         self.boff: Dict[str, Tuple[int, int]] = {}
         o = 0
         for k in self.buffer_keys:
-            n = int(np.prod(self.shapes[k]))
+            n = int(np.prod(self.eshapes[k]))
             self.boff[k] = (o, n)
             o += _align4(n)
         self.Bf = torch.zeros(max(o, 4), **f)
@@ -130,26 +138,57 @@ class ParamStore:
     # -- views ------------------------------------------------------------------------------------
     def _view(self, arena, key):
         o, n = self.off[key]
-        return arena[o:o + n].view(self.shapes[key])
+        return arena[o:o + n].view(self.eshapes[key])
 
-    def p(self, key) -> torch.Tensor:
+    # engine tensors (what the kernels are given)
+    def ep(self, key) -> torch.Tensor:
         return self.big[key]["W"] if key in self.big else self._view(self.P, key)
 
-    def g(self, key) -> Optional[torch.Tensor]:
+    def eg(self, key) -> Optional[torch.Tensor]:
         return self.big[key]["G"] if key in self.big else self._view(self.G, key)
 
-    def m(self, key):
+    def em(self, key):
         return self.big[key]["M"] if key in self.big else self._view(self.M, key)
 
-    def v(self, key):
+    def ev(self, key):
         return self.big[key]["V"] if key in self.big else self._view(self.V, key)
 
-    def b(self, key) -> torch.Tensor:
+    def eb(self, key) -> torch.Tensor:
         o, n = self.boff[key]
-        return self.Bf[o:o + n].view(self.shapes[key])
+        return self.Bf[o:o + n].view(self.eshapes[key])
+
+    # logical views: the reference's shapes (state_dict ABI, nn.Parameter data of the level-1 classes, parameter initialisation)
+    def _logical(self, t: torch.Tensor, key) -> torch.Tensor:
+        ls = self.shapes[key]
+        if tuple(t.shape) == tuple(ls):
+            return t
+        return t[tuple(slice(0, n) for n in ls)]
+
+    def p(self, key) -> torch.Tensor:
+        return self._logical(self.ep(key), key)
+
+    def g(self, key) -> Optional[torch.Tensor]:
+        g = self.eg(key)
+        return None if g is None else self._logical(g, key)
+
+    def m(self, key):
+        return self._logical(self.em(key), key)
+
+    def v(self, key):
+        return self._logical(self.ev(key), key)
+
+    def b(self, key) -> torch.Tensor:
+        return self._logical(self.eb(key), key)
+
+    def rows4(self, key) -> torch.Tensor:
+        """A tail Linear's weight [L, H] (or bias [L]) with its rows up to the next multiple of 4 (zeros): see __init__."""
+        o, n = self.off[key]
+        shp = self.eshapes[key]
+        rows = pad4(shp[0])
+        return self.P[o:o + rows * int(np.prod(shp[1:]))].view((rows,) + tuple(shp[1:]))
 
     def _big_alloc(self, key, name):
-        out, fin = self.shapes[key]
+        out, fin = self.eshapes[key]
         buf = torch.zeros(out, (fin + 31) // 32 * 32, dtype=torch.float32, device=self.device)
         self.big[key]["_" + name] = buf
         self.big[key][name] = buf[:, :fin]
@@ -164,7 +203,7 @@ class ParamStore:
     PLACE_GOOD_TBS = 5.75               # an array read + written (8 B per element) per probe pass: arrays at this rate are kept
 
     def _place_big(self, key):
-        out, fin = self.shapes[key]
+        out, fin = self.eshapes[key]
         ld = (fin + 31) // 32 * 32
         tries = getattr(_PLACEMENT, "tries", None)
         if tries is None or "FX_PLACEMENT_TRIES" in os.environ:
@@ -254,6 +293,10 @@ class ParamStore:
         BatchNorm weight 1 / bias 0 / running stats 0,1, log_vars 0.  Drawn on the device."""
         gen = torch.Generator(device=self.device)
         gen.manual_seed(int(seed) if seed is not None else int(torch.initial_seed() % (2 ** 31)))
+        if self.padded:                   # whatever lies outside the logical tensors is zero (and stays zero: arch.py)
+            self.P.zero_(); self.Bf.zero_()
+            for d in self.big.values():
+                d["_W"].zero_()
         for k in self.param_keys:
             t, shp = self.p(k), self.shapes[k]
             if k.startswith("log_vars."):
@@ -314,9 +357,9 @@ class ParamStore:
             if k in self.nbt:
                 out[k] = torch.tensor(self.nbt[k], dtype=torch.int64)
             elif is_buffer_key(k):
-                out[k] = self.b(k).detach().to(device).clone()
+                out[k] = self.b(k).detach().to(device).clone(memory_format=torch.contiguous_format)
             else:
-                out[k] = self.p(k).detach().to(device).clone()
+                out[k] = self.p(k).detach().to(device).clone(memory_format=torch.contiguous_format)
         return out
 
     @torch.no_grad()
@@ -404,7 +447,7 @@ class StepPlan:
         else:
             self.epoch_acc = torch.zeros(n_terms + 2, **f) if epoch_acc else None
             self.idx = torch.zeros(max(self.R, 1) * max(self.n_batches, 1), dtype=torch.int64, device=self.dev)
-        self.X = [torch.zeros(self.R, F, **f) for _, F in spec.layers]
+        self.X = [torch.zeros(self.R, spec.engine_features(i), **f) for i in range(len(spec.layers))]   # (engine width: pad columns stay zero)
         self.y: Dict[str, torch.Tensor] = {}
         for (v, _, _) in spec.variables:
             self.y[v] = torch.zeros(self.B, **f)
@@ -420,6 +463,7 @@ class StepPlan:
         # weight change made outside the pipeline.
         self.fuse_next = bool(fuse_next_fwd) and self.fused and precision == "bf16x3" and cohort is not None
         self._next_fwd: Dict[str, tuple] = {}
+        self.path: Dict[str, bool] = {}       # which of the fused schedules this plan records (tests / bench: "did the fast path engage")
         self.t_boot = TapeRecorder()
         # attribution (eval plans): input-gradient tapes d head_output / d X for IntegratedGradients / GradientShap
         self.attribution = bool(attribution) and not train
@@ -440,19 +484,20 @@ class StepPlan:
         self._rng_ctr += 1
         return self.seed, (self._rng_ctr << 32)
 
-    def _draw(self, name, *shape):
-        """Supplied-randomness slot (parity mode): a static buffer the caller fills."""
+    def _draw(self, name, *shape, logical=None):
+        """Supplied-randomness slot (parity mode): a static buffer the caller fills.  ``logical``: the reference's shape when the
+        engine's buffer is wider (padded hidden width); the caller sees that view, the rest stays 1."""
         t = torch.ones(*shape, **self._f)
-        self.draws[name] = t
+        self.draws[name] = t if logical is None or tuple(logical) == tuple(shape) else t[tuple(slice(0, n) for n in logical)]
         return t
 
     def _logvar(self, name):
-        return self.store.p("log_vars." + name).view(-1) if (self.train and self.spec.weighted) else None
+        return self.store.ep("log_vars." + name).view(-1) if (self.train and self.spec.weighted) else None
 
     # ---- blocks ----------------------------------------------------------------------------------
     def _mlp_fwd(self, rec, prefix, x, out, rows, passes, tag_names):
         """Linear -> BN -> ReLU -> Dropout -> Linear   (reference modules.py:145-149)."""
-        st, H = self.store, self.store.shapes[prefix + ".layer_1.weight"][0]
+        st, H = self.store, self.store.eshapes[prefix + ".layer_1.weight"][0]
         y1 = self._new(prefix + "/y1", rows, H)
         a1 = self._new(prefix + "/a1", rows, H)
         sm = self._new(prefix + "/save_mean", passes, H)
@@ -462,28 +507,28 @@ class StepPlan:
                               want_slabs=self.bn_slabs and Bp <= 128)
         for p in range(passes):
             sl = slice(p * Bp, (p + 1) * Bp)
-            mask = self._draw(tag_names[p], Bp, H) if (self.supplied and self.train) else None
+            mask = self._draw(tag_names[p], Bp, H, logical=(Bp, st.shapes[prefix + ".layer_1.weight"][0])) if (self.supplied and self.train) else None
             seed, off = self._rng()
-            bn = (st.p(prefix + ".batchnorm.weight"), st.p(prefix + ".batchnorm.bias"),
-                  st.b(prefix + ".batchnorm.running_mean"), st.b(prefix + ".batchnorm.running_var"), sm[p], si[p],
+            bn = (st.ep(prefix + ".batchnorm.weight"), st.ep(prefix + ".batchnorm.bias"),
+                  st.eb(prefix + ".batchnorm.running_mean"), st.eb(prefix + ".batchnorm.running_var"), sm[p], si[p],
                   ACT_NONE, ACT_RELU, self.train, DROPOUT_P if self.train else 0.0)
             if slabs is not None:      # split-K reduction + bias folded into the BatchNorm pass
                 sbuf, ns = slabs
                 ops.bn_act_fwd_slabs(rec, a1[sl], y1[sl], sbuf.view(-1)[p * Bp * H:], ns, rows * H,
-                                     st.p(prefix + ".layer_1.bias"), *bn, mask=mask, seed=seed, offset=off, ctrl=st.ctrl)
+                                     st.ep(prefix + ".layer_1.bias"), *bn, mask=mask, seed=seed, offset=off, ctrl=st.ctrl)
             else:
                 ops.bn_act_fwd(rec, a1[sl], y1[sl], *bn, mask=mask, seed=seed, offset=off, ctrl=st.ctrl)
         bias_key = prefix + ".layer_out.bias"
-        ops.linear_fwd(rec, out, a1, st.p(prefix + ".layer_out.weight"),
-                       st.p(bias_key) if bias_key in st.shapes else None, self.ws)
+        ops.linear_fwd(rec, out, a1, st.ep(prefix + ".layer_out.weight"),
+                       st.ep(bias_key) if bias_key in st.eshapes else None, self.ws)
 
     def _mlp_bwd(self, rec, prefix, x, dout, rows, passes, dx=None, dx_accumulate=False):
-        st, H = self.store, self.store.shapes[prefix + ".layer_1.weight"][0]
+        st, H = self.store, self.store.eshapes[prefix + ".layer_1.weight"][0]
         y1, a1 = self.buf[prefix + "/y1"], self.buf[prefix + "/a1"]
         sm, si = self.buf[prefix + "/save_mean"], self.buf[prefix + "/save_invstd"]
         if dx is None and self._block_ok(rows, passes) and not self._is_frozen(prefix + ".layer_out.weight"):
             bias_key = prefix + ".layer_out.bias"
-            self._tail_bwd(rec, [(dout, prefix + ".layer_out.weight", bias_key if bias_key in st.shapes else None)], x, y1, a1,
+            self._tail_bwd(rec, [(dout, prefix + ".layer_out.weight", bias_key if bias_key in st.eshapes else None)], x, y1, a1,
                            (prefix + ".batchnorm", prefix), prefix + ".layer_1.bias", prefix + ".layer_1.weight",
                            ACT_NONE, ACT_RELU, DROPOUT_P)
             return
@@ -500,33 +545,34 @@ class StepPlan:
             dyt = ops.new_split(H, rows, self.dev) if want_t else None
             for p in range(passes):
                 sl = slice(p * Bp, (p + 1) * Bp)
-                ops.block_bwd(rec, [(dout[sl], st.p(wk), st.g(wk), st.g(bias_key) if bias_key in st.shapes else None)], y1[sl], a1[sl],
-                              st.p(prefix + ".batchnorm.weight"), sm[p], si[p], st.g(prefix + ".batchnorm.weight"),
-                              st.g(prefix + ".batchnorm.bias"), st.g(prefix + ".layer_1.bias"), ACT_NONE, ACT_RELU, DROPOUT_P,
+                ops.block_bwd(rec, [(dout[sl], st.ep(wk), st.eg(wk), st.eg(bias_key) if bias_key in st.eshapes else None)], y1[sl], a1[sl],
+                              st.ep(prefix + ".batchnorm.weight"), sm[p], si[p], st.eg(prefix + ".batchnorm.weight"),
+                              st.eg(prefix + ".batchnorm.bias"), st.eg(prefix + ".layer_1.bias"), ACT_NONE, ACT_RELU, DROPOUT_P,
                               dy=da1[sl], dyT=(dyt[0][:, p * Bp:], dyt[1][:, p * Bp:]) if want_t else None, accumulate=p > 0)
             self._weight_grad(rec, w1, da1, x, dyt=dyt)
             return
         self._weight_grad(rec, prefix + ".layer_out.weight", dout, a1)
-        if prefix + ".layer_out.bias" in st.shapes:
-            ops.colsum(rec, st.g(prefix + ".layer_out.bias"), dout)
-        ops.linear_bwd_x(rec, da1, dout, st.p(prefix + ".layer_out.weight"), self.ws)
+        if prefix + ".layer_out.bias" in st.eshapes:
+            ops.colsum(rec, st.eg(prefix + ".layer_out.bias"), dout)
+        ops.linear_bwd_x(rec, da1, dout, st.ep(prefix + ".layer_out.weight"), self.ws)
         for p in range(passes):
             sl = slice(p * Bp, (p + 1) * Bp)
-            ops.bn_act_bwd(rec, da1[sl], st.g(prefix + ".batchnorm.weight"), st.g(prefix + ".batchnorm.bias"),
-                           st.g(prefix + ".layer_1.bias"), da1[sl], y1[sl], a1[sl], st.p(prefix + ".batchnorm.weight"),
+            ops.bn_act_bwd(rec, da1[sl], st.eg(prefix + ".batchnorm.weight"), st.eg(prefix + ".batchnorm.bias"),
+                           st.eg(prefix + ".layer_1.bias"), da1[sl], y1[sl], a1[sl], st.ep(prefix + ".batchnorm.weight"),
                            sm[p], si[p], ACT_NONE, ACT_RELU, DROPOUT_P, accumulate=p > 0)
         self._weight_grad(rec, prefix + ".layer_1.weight", da1, x)
         if dx is not None:
-            ops.linear_bwd_x(rec, dx, da1, st.p(prefix + ".layer_1.weight"), self.ws, accumulate=dx_accumulate)
+            ops.linear_bwd_x(rec, dx, da1, st.ep(prefix + ".layer_1.weight"), self.ws, accumulate=dx_accumulate)
 
     def _tails_groupable(self, n, L) -> bool:
-        """fx_enc_tail_fwd + fx_fusion_fwd cover one BatchNorm pass of <= 128 rows, <= 4 modalities, block widths that are
-        multiples of 4, latent <= 128 (the reference's whole search space, config.py:7-15)."""
+        """fx_enc_tail_fwd + fx_fusion_fwd cover one BatchNorm pass of <= 128 rows, <= 4 modalities, latent <= 128 (the reference's
+        whole search space, config.py:7-15); block widths are multiples of 4 by construction (ArchSpec.engine_shapes), any latent
+        size goes (the tail Linears' rows are allocated up to a multiple of 4, ParamStore.rows4)."""
         st = self.store
-        if not self.fuse_tail or self.passes != 1 or self.R > 128 or n > 4 or L > 128 or L % 4 != 0 or n * L > 512:
+        if not self.fuse_tail or self.passes != 1 or self.R > 128 or n > 4 or L > 128 or n * L > 512:
             return False
-        wide = "layer_1" if "encoders.0.layer_1.weight" in st.shapes else "hidden_layers.0"      # MLP / VAE encoder
-        if not all(st.shapes[f"encoders.{i}.{wide}.weight"][0] % 4 == 0 for i in range(n)):
+        wide = "layer_1" if "encoders.0.layer_1.weight" in st.eshapes else "hidden_layers.0"      # MLP / VAE encoder
+        if not all(st.eshapes[f"encoders.{i}.{wide}.weight"][0] % 4 == 0 for i in range(n)):
             return False
         # the Linear layers behind the block (layer_out; FC_mean / FC_var) are read as plain [L, H] arena tensors by the grouped
         # kernel: a non-default big_threshold / big_min_dim that turned one of them into a padded "wide" weight, or an arena
@@ -536,8 +582,8 @@ class StepPlan:
                 k = f"encoders.{i}.{nm}.weight"
                 if k in st.big:
                     return False
-                if k in st.shapes:
-                    t = st.p(k)
+                if k in st.eshapes:
+                    t = st.ep(k)
                     if not t.is_contiguous() or t.data_ptr() % 16:
                         return False
         return True
@@ -551,31 +597,31 @@ class StepPlan:
         descs, parts_m, parts_v, hs = [], [], [], []
         for i, xi in enumerate(enc):
             p = f"encoders.{i}"
-            H = st.shapes[p + ".hidden_layers.0.weight"][0]
+            H = st.eshapes[p + ".hidden_layers.0.weight"][0]
             y, h = self._new(p + "/y", R, H), self._new(p + "/h", R, H)
             sm, si = self._new(p + "/save_mean", 1, H), self._new(p + "/save_invstd", 1, H)
             slabs = self._lin_fwd(rec, y, self.X[xi], p + ".hidden_layers.0.weight", p + ".hidden_layers.0.bias", want_slabs=True)
             nb = ops.enc_tail_blocks(H)
-            pm, pv = self._new(p + "/mean_parts", nb, R, L), self._new(p + "/var_parts", nb, R, L)
+            pm, pv = self._new(p + "/mean_parts", nb, R, pad4(L)), self._new(p + "/var_parts", nb, R, pad4(L))
             descs.append(ops.enc_tail_desc(
                 slabs=slabs[0] if slabs is not None else None, n_slabs=slabs[1] if slabs is not None else 0, slab_stride=R * H,
-                lin_bias=st.p(p + ".hidden_layers.0.bias") if slabs is not None else None, x=y, out=h,
-                gamma=st.p(p + ".hidden_layers.2.weight"), beta=st.p(p + ".hidden_layers.2.bias"),
-                running_mean=st.b(p + ".hidden_layers.2.running_mean"), running_var=st.b(p + ".hidden_layers.2.running_var"),
+                lin_bias=st.ep(p + ".hidden_layers.0.bias") if slabs is not None else None, x=y, out=h,
+                gamma=st.ep(p + ".hidden_layers.2.weight"), beta=st.ep(p + ".hidden_layers.2.bias"),
+                running_mean=st.eb(p + ".hidden_layers.2.running_mean"), running_var=st.eb(p + ".hidden_layers.2.running_var"),
                 save_mean=sm[0], save_invstd=si[0], mask=None,
-                ups=[(st.p(p + ".FC_mean.weight"), pm), (st.p(p + ".FC_var.weight"), pv)], seed=0, offset=0))
+                ups=[(st.rows4(p + ".FC_mean.weight"), pm), (st.rows4(p + ".FC_var.weight"), pv)], seed=0, offset=0))
             parts_m.append((pm, nb))
             parts_v.append((pv, nb))
             hs.append(h)
         ops.enc_tail_fwd(rec, descs, R, ACT_LEAKY, ACT_NONE, self.train, 0.0, ctrl=st.ctrl)
         n = len(enc)
-        bm, bv = [st.p(f"encoders.{i}.FC_mean.bias") for i in range(n)], [st.p(f"encoders.{i}.FC_var.bias") for i in range(n)]
+        bm, bv = [st.ep(f"encoders.{i}.FC_mean.bias") for i in range(n)], [st.ep(f"encoders.{i}.FC_var.bias") for i in range(n)]
         if os.environ.get("FX_VAE_FUSION_PAIR", "1") != "0":        # mean and log_var in one launch (A/B: two launches back to back)
             ops.fusion_fwd_pair(rec, (mean, logv), (mcat, vcat), (parts_m, parts_v), (bm, bv),
-                                (st.p("FC_mean.weight"), st.p("FC_log_var.weight")), (st.p("FC_mean.bias"), st.p("FC_log_var.bias")))
+                                (st.ep("FC_mean.weight"), st.ep("FC_log_var.weight")), (st.ep("FC_mean.bias"), st.ep("FC_log_var.bias")), width=L)
         else:
-            ops.fusion_fwd(rec, mean, mcat, parts_m, bm, st.p("FC_mean.weight"), st.p("FC_mean.bias"))
-            ops.fusion_fwd(rec, logv, vcat, parts_v, bv, st.p("FC_log_var.weight"), st.p("FC_log_var.bias"))
+            ops.fusion_fwd(rec, mean, mcat, parts_m, bm, st.ep("FC_mean.weight"), st.ep("FC_mean.bias"), width=L)
+            ops.fusion_fwd(rec, logv, vcat, parts_v, bv, st.ep("FC_log_var.weight"), st.ep("FC_log_var.bias"), width=L)
         return hs
 
     def _mlp_tails_fwd(self, rec, n, L, ecat):
@@ -587,52 +633,52 @@ class StepPlan:
         descs, parts, biases = [], [], []
         for i in range(n):
             prefix = f"encoders.{i}"
-            H = st.shapes[prefix + ".layer_1.weight"][0]
+            H = st.eshapes[prefix + ".layer_1.weight"][0]
             y1 = self._new(prefix + "/y1", R, H)
             a1 = self._new(prefix + "/a1", R, H)
             sm = self._new(prefix + "/save_mean", 1, H)
             si = self._new(prefix + "/save_invstd", 1, H)
             slabs = self._lin_fwd(rec, y1, self.X[i], prefix + ".layer_1.weight", prefix + ".layer_1.bias", want_slabs=True)
-            mask = self._draw(prefix, R, H) if (self.supplied and self.train) else None
+            mask = self._draw(prefix, R, H, logical=(R, st.shapes[prefix + ".layer_1.weight"][0])) if (self.supplied and self.train) else None
             seed, off = self._rng()
             nb = ops.enc_tail_blocks(H)
-            part = self._new(prefix + "/layer_out_parts", nb, R, L)
+            part = self._new(prefix + "/layer_out_parts", nb, R, pad4(L))
             descs.append(ops.enc_tail_desc(
                 slabs=slabs[0] if slabs is not None else None, n_slabs=slabs[1] if slabs is not None else 0, slab_stride=R * H,
-                lin_bias=st.p(prefix + ".layer_1.bias") if slabs is not None else None, x=y1, out=a1,
-                gamma=st.p(prefix + ".batchnorm.weight"), beta=st.p(prefix + ".batchnorm.bias"),
-                running_mean=st.b(prefix + ".batchnorm.running_mean"), running_var=st.b(prefix + ".batchnorm.running_var"),
-                save_mean=sm[0], save_invstd=si[0], mask=mask, ups=[(st.p(prefix + ".layer_out.weight"), part)], seed=seed, offset=off))
+                lin_bias=st.ep(prefix + ".layer_1.bias") if slabs is not None else None, x=y1, out=a1,
+                gamma=st.ep(prefix + ".batchnorm.weight"), beta=st.ep(prefix + ".batchnorm.bias"),
+                running_mean=st.eb(prefix + ".batchnorm.running_mean"), running_var=st.eb(prefix + ".batchnorm.running_var"),
+                save_mean=sm[0], save_invstd=si[0], mask=mask, ups=[(st.rows4(prefix + ".layer_out.weight"), part)], seed=seed, offset=off))
             parts.append((part, nb))
             bias_key = prefix + ".layer_out.bias"
-            biases.append(st.p(bias_key) if bias_key in st.shapes else None)
+            biases.append(st.ep(bias_key) if bias_key in st.eshapes else None)
         ops.enc_tail_fwd(rec, descs, R, ACT_NONE, ACT_RELU, self.train, DROPOUT_P if self.train else 0.0, ctrl=st.ctrl)
         # From here to the encoder-tail backward the chain is a few workgroups wide (16 for the fusion layer, one per head):
         # the next batch's assembly (PipelinedStep) forks HERE, under that part, instead of beside the wide backward kernels.
         rec.mark("fork_assembly")
         if n > 1:
             emb = self._new("emb", R, L)
-            ops.fusion_fwd(rec, emb, ecat, parts, biases, st.p("fusion_block.weight"), st.p("fusion_block.bias"))
+            ops.fusion_fwd(rec, emb, ecat, parts, biases, st.ep("fusion_block.weight"), st.ep("fusion_block.bias"), width=L)
             rec.mark("fork_issue_1")
             return emb
-        ops.fusion_fwd(rec, None, ecat, parts, biases)
+        ops.fusion_fwd(rec, None, ecat, parts, biases, width=L)
         rec.mark("fork_issue_1")
         return ecat
 
     def _hidden_fwd(self, rec, prefix, x, rows):
         """Linear -> LeakyReLU(0.2) -> BN   (reference modules.py:25-34 / :75-84)."""
-        st, H = self.store, self.store.shapes[prefix + ".hidden_layers.0.weight"][0]
+        st, H = self.store, self.store.eshapes[prefix + ".hidden_layers.0.weight"][0]
         y = self._new(prefix + "/y", rows, H)
         h = self._new(prefix + "/h", rows, H)
         sm = self._new(prefix + "/save_mean", 1, H)
         si = self._new(prefix + "/save_invstd", 1, H)
         slabs = self._lin_fwd(rec, y, x, prefix + ".hidden_layers.0.weight", prefix + ".hidden_layers.0.bias",
                               want_slabs=self.bn_slabs and rows <= 128)
-        bn = (st.p(prefix + ".hidden_layers.2.weight"), st.p(prefix + ".hidden_layers.2.bias"),
-              st.b(prefix + ".hidden_layers.2.running_mean"), st.b(prefix + ".hidden_layers.2.running_var"),
+        bn = (st.ep(prefix + ".hidden_layers.2.weight"), st.ep(prefix + ".hidden_layers.2.bias"),
+              st.eb(prefix + ".hidden_layers.2.running_mean"), st.eb(prefix + ".hidden_layers.2.running_var"),
               sm[0], si[0], ACT_LEAKY, ACT_NONE, self.train, 0.0)
         if slabs is not None:
-            ops.bn_act_fwd_slabs(rec, h, y, slabs[0], slabs[1], rows * H, st.p(prefix + ".hidden_layers.0.bias"), *bn)
+            ops.bn_act_fwd_slabs(rec, h, y, slabs[0], slabs[1], rows * H, st.ep(prefix + ".hidden_layers.0.bias"), *bn)
         else:
             ops.bn_act_fwd(rec, h, y, *bn)
         return h
@@ -641,12 +687,12 @@ class StepPlan:
         st = self.store
         y = self.buf[prefix + "/y"]
         sm, si = self.buf[prefix + "/save_mean"], self.buf[prefix + "/save_invstd"]
-        ops.bn_act_bwd(rec, dh, st.g(prefix + ".hidden_layers.2.weight"), st.g(prefix + ".hidden_layers.2.bias"),
-                       st.g(prefix + ".hidden_layers.0.bias"), dh, y, None, st.p(prefix + ".hidden_layers.2.weight"),
+        ops.bn_act_bwd(rec, dh, st.eg(prefix + ".hidden_layers.2.weight"), st.eg(prefix + ".hidden_layers.2.bias"),
+                       st.eg(prefix + ".hidden_layers.0.bias"), dh, y, None, st.ep(prefix + ".hidden_layers.2.weight"),
                        sm[0], si[0], ACT_LEAKY, ACT_NONE, 0.0)
         self._weight_grad(rec, prefix + ".hidden_layers.0.weight", dh, x)
         if dx is not None:
-            ops.linear_bwd_x(rec, dx, dh, st.p(prefix + ".hidden_layers.0.weight"), self.ws, accumulate=dx_accumulate)
+            ops.linear_bwd_x(rec, dx, dh, st.ep(prefix + ".hidden_layers.0.weight"), self.ws, accumulate=dx_accumulate)
 
     def _lin_fwd(self, rec, y, x, wkey, bkey, want_slabs=False, raw_slabs=False, gram_after=False):
         """nn.Linear forward; wide weights take the split-bf16 MFMA path when precision == 'bf16x3'.
@@ -672,9 +718,9 @@ class StepPlan:
                 slabs = self._new(f"yslabs/{wkey}", S, M, N)
                 self._next_fwd[wkey] = (slabs, S, sp)
                 if not want_slabs:
-                    ops.reduce_slabs(rec, y, slabs, st.p(bkey), S)      # the whole wide forward of this step
+                    ops.reduce_slabs(rec, y, slabs, st.ep(bkey), S)      # the whole wide forward of this step
                 ops.fill(self.t_boot, slabs, 0.0)                       # stand-alone: full forward (no bias) into slab 0
-                ops.linear_fwd_bf16x3(self.t_boot, slabs[0], sp[0], sp[1], st.p(wkey), None, self._ws[0])
+                ops.linear_fwd_bf16x3(self.t_boot, slabs[0], sp[0], sp[1], st.ep(wkey), None, self._ws[0])
                 return (slabs.view(S, M * N), S) if want_slabs else None
             # Stagger the HBM-bound wide kernels of the parallel modality branches: two of them side by side
             # take as long as back to back, but back to back lets modality i's narrow post-chain (reduce, BN,
@@ -686,16 +732,16 @@ class StepPlan:
                 M, N = y.shape
                 ns = int(ops.lib.fx_linear_fwd_bf16x3_splitk(M, N, x.shape[1]))
                 sbuf = self._new(f"slabs/{wkey}", ns, M * N)
-                ops.linear_fwd_bf16x3_slabs(rec, sbuf, sp[0], sp[1], st.p(wkey), M)
+                ops.linear_fwd_bf16x3_slabs(rec, sbuf, sp[0], sp[1], st.ep(wkey), M)
                 if stagger:              # (right behind the product: the next branch's weight read does not wait for this one's epilogue)
                     self._last_wide_ev = torch.cuda.Event()
                     rec.record_event(self._last_wide_ev)
                 return sbuf, ns
-            ops.linear_fwd_bf16x3(rec, y, sp[0], sp[1], st.p(wkey), st.p(bkey), self.ws)
+            ops.linear_fwd_bf16x3(rec, y, sp[0], sp[1], st.ep(wkey), st.ep(bkey), self.ws)
             if stagger:
                 self._last_wide_ev = torch.cuda.Event()
                 rec.record_event(self._last_wide_ev)
-        elif (self.precision == "bf16x3" and x.shape[1] >= 8192 and x.shape[1] % 8 == 0 and st.p(wkey).data_ptr() % 16 == 0
+        elif (self.precision == "bf16x3" and x.shape[1] >= 8192 and x.shape[1] % 8 == 0 and st.ep(wkey).data_ptr() % 16 == 0
               and x.is_contiguous()):
             # long contraction through a short-fat arena weight (the GNN's fc [latent, nodes * C]): the split-bf16 MFMA
             # forward streams it at ~2x the rate of the exact-fp32 GEMM's 1 x 1 output tiling (100 -> ~50 us at
@@ -705,9 +751,9 @@ class StepPlan:
                 sp = ops.new_split_kb(x.shape[0], x.shape[1], self.dev)
                 self._split_cache[("fwd", x.data_ptr())] = sp
                 ops.split_bf16(rec, sp[0], sp[1], x)
-            ops.linear_fwd_bf16x3(rec, y, sp[0], sp[1], st.p(wkey), st.p(bkey), self.ws)
+            ops.linear_fwd_bf16x3(rec, y, sp[0], sp[1], st.ep(wkey), st.ep(bkey), self.ws)
         else:
-            ops.linear_fwd(rec, y, x, st.p(wkey), st.p(bkey), self.ws)
+            ops.linear_fwd(rec, y, x, st.ep(wkey), st.ep(bkey), self.ws)
         return None
 
     def _can_fuse_next(self, wkey, x) -> bool:
@@ -729,7 +775,7 @@ class StepPlan:
         """dX = dY . W.  Through a WIDE weight this is a second full read of W (4 B/param on top of the forward's):
         it takes the split-bf16 MFMA path like the forward instead of the exact-fp32 one (293 -> ~115 us at
         [20000, 5000])."""
-        W = self.store.p(wkey)
+        W = self.store.ep(wkey)
         if self.precision == "bf16x3" and wkey in self.store.big:
             if f"dy_kb/{wkey}" in self.buf:        # (the producer of dy wrote its split as well: fx_recon_sigmoid_slabs)
                 sp = self.buf[f"dy_kb/{wkey}"], self.buf[f"dy_kb_lo/{wkey}"]
@@ -745,21 +791,21 @@ class StepPlan:
         """A small dense layer on the critical chain (fusion layer, VAE FC_mean / FC_log_var): one latency-lean launch
         (fx_small_linear_fwd) instead of the tiled MFMA GEMM (FX_SMALL_LINEAR=0: A/B switch)."""
         st = self.store
-        W = st.p(wkey)
+        W = st.ep(wkey)
         if self.small_linear and wkey not in st.big and ops.small_linear_ok(x, W):
-            ops.small_linear_fwd(rec, y, x, W, st.p(bkey))
+            ops.small_linear_fwd(rec, y, x, W, st.ep(bkey))
         else:
-            ops.linear_fwd(rec, y, x, W, st.p(bkey), self.ws)
+            ops.linear_fwd(rec, y, x, W, st.ep(bkey), self.ws)
 
     def _small_bwd(self, rec, dx, dy, x, wkey, bkey, need_dx=True):
         """All three gradients of such a layer in one launch (weight, bias, data) instead of three."""
         st = self.store
-        W = st.p(wkey)
+        W = st.ep(wkey)
         if self.small_linear and wkey not in st.big and not self._is_frozen(wkey) and ops.small_linear_ok(x, W):
-            ops.small_linear_bwd(rec, dx if need_dx else None, st.g(wkey), st.g(bkey), dy, x, W)
+            ops.small_linear_bwd(rec, dx if need_dx else None, st.eg(wkey), st.eg(bkey), dy, x, W)
             return
         self._weight_grad(rec, wkey, dy, x)
-        ops.colsum(rec, st.g(bkey), dy)
+        ops.colsum(rec, st.eg(bkey), dy)
         if need_dx:
             ops.linear_bwd_x(rec, dx, dy, W, self.ws)
 
@@ -824,7 +870,7 @@ class StepPlan:
                 self.buf[f"dyT/{key}"], self.buf[f"dyT_lo/{key}"] = dyt
             self._jobs[key] = (dy, x, dyt, xt)
         else:
-            ops.linear_bwd_w(rec, self.store.g(key), dy, x, self.ws)
+            ops.linear_bwd_w(rec, self.store.eg(key), dy, x, self.ws)
 
     def _weight_grad_prep_x(self, rec, key, x):
         """The pieces of _weight_grad that depend on the layer's INPUT only (X X^T slabs for the Gram norm, the transposed operand
@@ -879,16 +925,16 @@ class StepPlan:
             self._slot_o += nb
         sm, si = self.buf[bn_prefix[1] + "/save_mean"], self.buf[bn_prefix[1] + "/save_invstd"]
         bp = bn_prefix[0]
-        ups_t = [(dE, st.p(wk), st.g(wk), st.g(bk) if bk else None) for (dE, wk, bk) in ups]
+        ups_t = [(dE, st.ep(wk), st.eg(wk), st.eg(bk) if bk else None) for (dE, wk, bk) in ups]
         grp = getattr(self, "_bb_group", None)
         if grp is not None:              # several modalities' tails in one launch: the caller emits fx_block_bwd_group
-            grp[0].append(ops.block_bwd_desc(ups_t, y, out, st.p(bp + ".weight"), sm[0], si[0], st.g(bp + ".weight"),
-                                             st.g(bp + ".bias"), st.g(bias_key), dy=dy, dyT=dyT, gram_x=gx, slots=slots))
+            grp[0].append(ops.block_bwd_desc(ups_t, y, out, st.ep(bp + ".weight"), sm[0], si[0], st.eg(bp + ".weight"),
+                                             st.eg(bp + ".bias"), st.eg(bias_key), dy=dy, dyT=dyT, gram_x=gx, slots=slots))
             if not big and not self._is_frozen(wkey):
-                grp[1].append(lambda: ops.linear_bwd_w(rec, st.g(wkey), dy, x_in, self.ws))
+                grp[1].append(lambda: ops.linear_bwd_w(rec, st.eg(wkey), dy, x_in, self.ws))
         else:
-            ops.block_bwd(rec, ups_t, y, out, st.p(bp + ".weight"), sm[0], si[0], st.g(bp + ".weight"), st.g(bp + ".bias"),
-                          st.g(bias_key), pre_act, post_act, drop_p, dy=dy, dyT=dyT, gram_x=gx, slots=slots)
+            ops.block_bwd(rec, ups_t, y, out, st.ep(bp + ".weight"), sm[0], si[0], st.eg(bp + ".weight"), st.eg(bp + ".bias"),
+                          st.eg(bias_key), pre_act, post_act, drop_p, dy=dy, dyT=dyT, gram_x=gx, slots=slots)
         if big:
             xt = None
             if want_t:
@@ -900,7 +946,7 @@ class StepPlan:
                     ops.split_bf16_t(rec, xt[0], xt[1], x_in)
             self._jobs[wkey] = (dy, x_in, dyT, xt)
         elif not self._is_frozen(wkey) and grp is None:
-            ops.linear_bwd_w(rec, st.g(wkey), dy, x_in, self.ws)
+            ops.linear_bwd_w(rec, st.eg(wkey), dy, x_in, self.ws)
 
     def _gram_kb_ok(self, t) -> bool:
         """The split-bf16 Gram kernel (fx_gram_kb_group) applies: one M-tile of rows, a wide contiguous operand, bf16x3 precision."""
@@ -971,9 +1017,9 @@ class StepPlan:
             pre = "MLPs." + v
             bias_key = pre + ".layer_out.bias"
             do = self._new(f"MLPs.{v}/dout", B, C)
-            for field, t in (("dout", do), ("gW1", st.g(pre + ".layer_1.weight")), ("gb1", st.g(pre + ".layer_1.bias")),
-                             ("ggamma", st.g(pre + ".batchnorm.weight")), ("gbeta", st.g(pre + ".batchnorm.bias")),
-                             ("gW2", st.g(pre + ".layer_out.weight")), ("gb2", st.g(bias_key) if bias_key in st.shapes else None)):
+            for field, t in (("dout", do), ("gW1", st.eg(pre + ".layer_1.weight")), ("gb1", st.eg(pre + ".layer_1.bias")),
+                             ("ggamma", st.eg(pre + ".batchnorm.weight")), ("gbeta", st.eg(pre + ".batchnorm.bias")),
+                             ("gW2", st.eg(pre + ".layer_out.weight")), ("gb2", st.eg(bias_key) if bias_key in st.eshapes else None)):
                 setattr(d, field, t.data_ptr() if t is not None else None)
             if v == spec.surv_event_var:
                 kinds.append(ops.LOSS_COX); durs.append(self.y[spec.surv_time_var])
@@ -987,8 +1033,8 @@ class StepPlan:
             scratch = self.buf["heads/dx_scratch"] = ops.heads_bwd_scratch(len(self._head_descs), B, emb.shape[1], self.dev)
         weighted = self.train and spec.weighted
         tl = [self.loss_vec[i:i + 1] for i in range(len(names))] if with_total else []
-        tv = [st.p("log_vars." + n).view(-1) for n in names] if (with_total and weighted) else []
-        td = [st.g("log_vars." + n).view(-1) for n in names] if (with_total and weighted) else []
+        tv = [st.ep("log_vars." + n).view(-1) for n in names] if (with_total and weighted) else []
+        td = [st.eg("log_vars." + n).view(-1) for n in names] if (with_total and weighted) else []
         ops.heads_step(rec, self._head_descs, kinds, labels, durs, lvs, losses, emb, demb, B, emb.shape[1], DROPOUT_P, st.ctrl,
                        scratch, tl, tv, td, weighted, self.loss_vec[len(names):], self.epoch_acc if with_total else None,
                        dx_accumulate=first_accumulate)
@@ -1001,7 +1047,7 @@ class StepPlan:
         m, st = ops.HEADS_MAX, self.store
         if not self.fuse_heads or self.B > m["B"] or emb.shape[1] > m["L"] or not (0 < len(self.spec.variables) <= m["heads"]):
             return False
-        return all(st.shapes[f"MLPs.{v}.layer_1.weight"][0] <= m["hidden"] and C <= m["n_out"]
+        return all(st.eshapes[f"MLPs.{v}.layer_1.weight"][0] <= m["hidden"] and C <= m["n_out"]
                    for (v, _, C) in self.spec.variables)
 
     def _heads_fwd_fused(self, rec_f, emb):
@@ -1009,15 +1055,15 @@ class StepPlan:
         descs = []
         for (v, kind, C) in self.spec.variables:
             pre = "MLPs." + v
-            S = st.shapes[pre + ".layer_1.weight"][0]
+            S = st.eshapes[pre + ".layer_1.weight"][0]
             bias_key = pre + ".layer_out.bias"
             mask = self._draw(pre, B, S) if (self.supplied and self.train) else None
             seed, off = self._rng()
             descs.append(ops.head_desc(
-                W1=st.p(pre + ".layer_1.weight"), b1=st.p(pre + ".layer_1.bias"), gamma=st.p(pre + ".batchnorm.weight"),
-                beta=st.p(pre + ".batchnorm.bias"), running_mean=st.b(pre + ".batchnorm.running_mean"),
-                running_var=st.b(pre + ".batchnorm.running_var"), W2=st.p(pre + ".layer_out.weight"),
-                b2=st.p(bias_key) if bias_key in st.shapes else None, y1=self._new(pre + "/y1", B, S),
+                W1=st.ep(pre + ".layer_1.weight"), b1=st.ep(pre + ".layer_1.bias"), gamma=st.ep(pre + ".batchnorm.weight"),
+                beta=st.ep(pre + ".batchnorm.bias"), running_mean=st.eb(pre + ".batchnorm.running_mean"),
+                running_var=st.eb(pre + ".batchnorm.running_var"), W2=st.ep(pre + ".layer_out.weight"),
+                b2=st.ep(bias_key) if bias_key in st.eshapes else None, y1=self._new(pre + "/y1", B, S),
                 a1=self._new(pre + "/a1", B, S), save_mean=self._new(pre + "/save_mean", 1, S),
                 save_invstd=self._new(pre + "/save_invstd", 1, S), out=self._new(f"MLPs.{v}/out", B, C), mask=mask,
                 seed=seed, offset=off, hidden=S, n_out=C))
@@ -1031,10 +1077,10 @@ class StepPlan:
             for d, (v, kind, C) in zip(self._head_descs, self.spec.variables):
                 pre = "MLPs." + v
                 bias_key = pre + ".layer_out.bias"
-                for field, t in (("dout", self.buf[f"MLPs.{v}/dout"]), ("gW1", st.g(pre + ".layer_1.weight")),
-                                 ("gb1", st.g(pre + ".layer_1.bias")), ("ggamma", st.g(pre + ".batchnorm.weight")),
-                                 ("gbeta", st.g(pre + ".batchnorm.bias")), ("gW2", st.g(pre + ".layer_out.weight")),
-                                 ("gb2", st.g(bias_key) if bias_key in st.shapes else None)):
+                for field, t in (("dout", self.buf[f"MLPs.{v}/dout"]), ("gW1", st.eg(pre + ".layer_1.weight")),
+                                 ("gb1", st.eg(pre + ".layer_1.bias")), ("ggamma", st.eg(pre + ".batchnorm.weight")),
+                                 ("gbeta", st.eg(pre + ".batchnorm.bias")), ("gW2", st.eg(pre + ".layer_out.weight")),
+                                 ("gb2", st.eg(bias_key) if bias_key in st.eshapes else None)):
                     setattr(d, field, t.data_ptr() if t is not None else None)
             scratch = None
             if len(self._head_descs) > 1 and demb is not None and os.environ.get("FX_HEADS_SPLIT_DX", "1") != "0":
@@ -1054,8 +1100,8 @@ class StepPlan:
         names = spec.loss_names()
         weighted = self.train and spec.weighted
         losses = [self.loss_vec[i:i + 1] for i in range(len(names))]
-        lvs = [st.p("log_vars." + n).view(-1) for n in names] if weighted else []
-        dls = [st.g("log_vars." + n).view(-1) for n in names] if weighted else []
+        lvs = [st.ep("log_vars." + n).view(-1) for n in names] if weighted else []
+        dls = [st.eg("log_vars." + n).view(-1) for n in names] if weighted else []
         ops.total_loss(rec_f, self.loss_vec[len(names):], losses, lvs, dls, weighted, self.epoch_acc)
 
     # ---- model schedules ---------------------------------------------------------------------------
@@ -1076,7 +1122,8 @@ class StepPlan:
             if grouped:                      # (inside the tape's single segment: PipelinedStep issues it as one detached fork)
                 gpar.branch(0)
                 self._build_assembly_grouped(rg, cur, first_w, enc_pos)
-            for i, (name, F) in enumerate(spec.layers if not grouped else []):
+            for i, (name, _) in enumerate(spec.layers if not grouped else []):
+                F = spec.engine_features(i)
                 gpar.branch(i if gbr else 0)
                 wk = first_w.format(enc_pos[i]) if i in enc_pos else None      # layers that are only reconstructed have no encoder
                 if spec.model == "GNN":
@@ -1086,10 +1133,10 @@ class StepPlan:
                     sp, spt = ops.new_split_kb(self.R, F, self.dev), ops.new_split(F, self.R, self.dev)
                     self._split_cache[("fwd", self.X[i].data_ptr())] = sp
                     self._split_cache[("T", self.X[i].data_ptr())] = spt
-                    ops.gather_split(rg, self.X[i], sp[0], sp[1], spt[0], spt[1], self.cohort.dat[name], self.idx, cur, self.R,
+                    ops.gather_split(rg, self.X[i], sp[0], sp[1], spt[0], spt[1], self.cohort.source(name, F), self.idx, cur, self.R,
                                      n_rows=self.R)
                 else:
-                    ops.gather_rows(rg, self.X[i], self.cohort.dat[name], self.idx, cur, self.R)
+                    ops.gather_rows(rg, self.X[i], self.cohort.source(name, F), self.idx, cur, self.R)
                 if wk is not None:
                     self._branch = i if gbr else 0
                     while len(self._ws) <= self._branch:
@@ -1128,12 +1175,13 @@ class StepPlan:
     def _build_assembly_grouped(self, rg, cur, first_w, enc_pos):
         spec, st, R = self.spec, self.store, self.R
         items, splits, want = [], [], []
-        for i, (name, F) in enumerate(spec.layers):
+        for i, (name, _) in enumerate(spec.layers):
+            F = spec.engine_features(i)
             wk = first_w.format(enc_pos[i])
             sp, spt = ops.new_split_kb(R, F, self.dev), ops.new_split(F, R, self.dev)
             self._split_cache[("fwd", self.X[i].data_ptr())] = sp
             self._split_cache[("T", self.X[i].data_ptr())] = spt
-            items.append((self.X[i], sp[0], sp[1], spt[0], spt[1], self.cohort.dat[name]))
+            items.append((self.X[i], sp[0], sp[1], spt[0], spt[1], self.cohort.source(name, F)))
             splits.append(sp)
             want.append(self.fused and self.train and self.clip and not self._is_frozen(wk))
         ops.gather_split_group(rg, items, self.idx, cur, R, R)
@@ -1141,13 +1189,13 @@ class StepPlan:
             # X X^T [R, R] per modality (the batch-only factor of the Gram norm that fx_block_bwd consumes): partial sums on the
             # bf16 MFMA from the K-blocked splits just written, then one ordered reduce for all modalities
             sel = [i for i, w_ in enumerate(want) if w_]
-            slabs = [self._new(f"gram_x_slabs/{i}", ops.gram_kb_slices(spec.layers[i][1]), R * R) for i in sel]
-            ops.gram_kb_group(rg, [splits[i] for i in sel], slabs, [spec.layers[i][1] for i in sel], R)
+            slabs = [self._new(f"gram_x_slabs/{i}", ops.gram_kb_slices(spec.engine_features(i)), R * R) for i in sel]
+            ops.gram_kb_group(rg, [splits[i] for i in sel], slabs, [spec.engine_features(i) for i in sel], R)
             jobs = []
             for i, sl in zip(sel, slabs):
                 gx = self._new(f"gram_x_full/{self.X[i].data_ptr()}", R, R)
                 self._gram_x[("full", self.X[i].data_ptr())] = gx
-                jobs.append((gx, sl, ops.gram_kb_slices(spec.layers[i][1]), None))
+                jobs.append((gx, sl, ops.gram_kb_slices(spec.engine_features(i)), None))
             if (R * R) % 4 == 0:
                 ops.reduce_group(rg, jobs)
             else:
@@ -1192,7 +1240,8 @@ class StepPlan:
         trip = spec.model == "MultiTripletNetwork"
         tags = ["@a", "@p", "@n"] if trip else [""]
         ecat = self._new("ecat", R, n * L)
-        if self._tails_groupable(n, L):
+        self.path["grouped_tails"] = self._tails_groupable(n, L)
+        if self.path["grouped_tails"]:
             emb = self._mlp_tails_fwd(rf, n, L, ecat)
         else:
             with rf.parallel(n if self.branches else 1) as par:      # one graph branch per modality
@@ -1213,6 +1262,7 @@ class StepPlan:
             ops.triplet(rf, self.loss_vec[0:1], demb[:B], demb[B:2 * B], demb[2 * B:], emb[:B], emb[B:2 * B],
                         emb[2 * B:], TRIPLET_MARGIN, self._logvar("triplet_loss"))
         stepped = self._heads_step(rf, emb[:B], demb[:B], first_accumulate=trip)
+        self.path["heads_step"] = stepped
         if not stepped:
             self._head_losses(rf, emb[:B])
             self._total(rf)
@@ -1231,8 +1281,9 @@ class StepPlan:
             decat = demb
         if enc_frozen:
             return          # FineTuner "encoders": True -- nothing upstream of the fusion layer needs a gradient
-        if (self.group_bwd and 1 < n <= 4 and self._block_ok(R, self.passes)
-                and not any(self._is_frozen(f"encoders.{i}.layer_out.weight") for i in range(n))):
+        self.path["grouped_bwd"] = bool(self.group_bwd and 1 < n <= 4 and self._block_ok(R, self.passes)
+                                        and not any(self._is_frozen(f"encoders.{i}.layer_out.weight") for i in range(n)))
+        if self.path["grouped_bwd"]:
             # every modality's encoder-tail backward in ONE launch (fx_block_bwd_group): no graph fork / join on the chain
             self._bb_group = ([], [])
             for i in range(n):
@@ -1260,27 +1311,27 @@ class StepPlan:
         for (v, kind, C) in spec.variables:
             ra = self.t_attr_head[v] = TapeRecorder()
             pre = "MLPs." + v
-            S = st.shapes[pre + ".layer_1.weight"][0]
+            S = st.eshapes[pre + ".layer_1.weight"][0]
             do = self.attr_dout[v] = self._new(f"attr/dout.{v}", B, C)
             da1 = self._new(f"attr/{pre}/da1", B, S)
-            ops.linear_bwd_x(ra, da1, do, st.p(pre + ".layer_out.weight"), self._ws[0])
-            ops.bn_eval_bwd(ra, da1, da1, None, self.buf[pre + "/a1"][:B], st.p(pre + ".batchnorm.weight"),
-                            st.b(pre + ".batchnorm.running_var"), ACT_NONE, ACT_RELU)
-            ops.linear_bwd_x(ra, demb, da1, st.p(pre + ".layer_1.weight"), self._ws[0])
+            ops.linear_bwd_x(ra, da1, do, st.ep(pre + ".layer_out.weight"), self._ws[0])
+            ops.bn_eval_bwd(ra, da1, da1, None, self.buf[pre + "/a1"][:B], st.ep(pre + ".batchnorm.weight"),
+                            st.eb(pre + ".batchnorm.running_var"), ACT_NONE, ACT_RELU)
+            ops.linear_bwd_x(ra, demb, da1, st.ep(pre + ".layer_1.weight"), self._ws[0])
         rc = self.t_attr_common
         if n > 1:
             decat = self._new("attr/decat", B, n * L)
-            ops.linear_bwd_x(rc, decat, demb, st.p("fusion_block.weight"), self._ws[0])
+            ops.linear_bwd_x(rc, decat, demb, st.ep("fusion_block.weight"), self._ws[0])
         else:
             decat = demb
         for i in range(n):
             p = f"encoders.{i}"
-            H = st.shapes[p + ".layer_1.weight"][0]
+            H = st.eshapes[p + ".layer_1.weight"][0]
             da1 = self._new(f"attr/{p}/da1", B, H)
-            ops.linear_bwd_x(rc, da1, decat[:, i * L:(i + 1) * L], st.p(p + ".layer_out.weight"), self._ws[0])
-            ops.bn_eval_bwd(rc, da1, da1, None, self.buf[p + "/a1"][:B], st.p(p + ".batchnorm.weight"),
-                            st.b(p + ".batchnorm.running_var"), ACT_NONE, ACT_RELU)
-            dx = self._new(f"attr/dX.{i}", B, spec.layers[i][1])
+            ops.linear_bwd_x(rc, da1, decat[:, i * L:(i + 1) * L], st.ep(p + ".layer_out.weight"), self._ws[0])
+            ops.bn_eval_bwd(rc, da1, da1, None, self.buf[p + "/a1"][:B], st.ep(p + ".batchnorm.weight"),
+                            st.eb(p + ".batchnorm.running_var"), ACT_NONE, ACT_RELU)
+            dx = self._new(f"attr/dX.{i}", B, spec.engine_features(i))      # (engine width; the caller reads the logical columns)
             self._branch = 0
             self._lin_bwd_x(rc, dx, da1, p + ".layer_1.weight")
             self.dX.append(dx)
@@ -1295,28 +1346,28 @@ class StepPlan:
         for (v, kind, C) in spec.variables:
             ra = self.t_attr_head[v] = TapeRecorder()
             pre = "MLPs." + v
-            S = st.shapes[pre + ".layer_1.weight"][0]
+            S = st.eshapes[pre + ".layer_1.weight"][0]
             do = self.attr_dout[v] = self._new(f"attr/dout.{v}", B, C)
             da1 = self._new(f"attr/{pre}/da1", B, S)
-            ops.linear_bwd_x(ra, da1, do, st.p(pre + ".layer_out.weight"), self._ws[0])
-            ops.bn_eval_bwd(ra, da1, da1, None, self.buf[pre + "/a1"][:B], st.p(pre + ".batchnorm.weight"),
-                            st.b(pre + ".batchnorm.running_var"), ACT_NONE, ACT_RELU)
-            ops.linear_bwd_x(ra, dz, da1, st.p(pre + ".layer_1.weight"), self._ws[0])
+            ops.linear_bwd_x(ra, da1, do, st.ep(pre + ".layer_out.weight"), self._ws[0])
+            ops.bn_eval_bwd(ra, da1, da1, None, self.buf[pre + "/a1"][:B], st.ep(pre + ".batchnorm.weight"),
+                            st.eb(pre + ".batchnorm.running_var"), ACT_NONE, ACT_RELU)
+            ops.linear_bwd_x(ra, dz, da1, st.ep(pre + ".layer_1.weight"), self._ws[0])
         rc = self.t_attr_common
         dlv = self._new("attr/dlog_var", B, L)
         ops.mul(rc, dlv, dz, eps_used)                                    # z = mean + log_var * eps
         dmcat, dvcat = self._new("attr/dmcat", B, n * L), self._new("attr/dvcat", B, n * L)
-        ops.linear_bwd_x(rc, dmcat, dz, st.p("FC_mean.weight"), self._ws[0])
-        ops.linear_bwd_x(rc, dvcat, dlv, st.p("FC_log_var.weight"), self._ws[0])
+        ops.linear_bwd_x(rc, dmcat, dz, st.ep("FC_mean.weight"), self._ws[0])
+        ops.linear_bwd_x(rc, dvcat, dlv, st.ep("FC_log_var.weight"), self._ws[0])
         for i in range(n):
             p = f"encoders.{i}"
-            H = st.shapes[p + ".hidden_layers.0.weight"][0]
+            H = st.eshapes[p + ".hidden_layers.0.weight"][0]
             dh = self._new(f"attr/{p}/dh", B, H)
-            ops.linear_bwd_x(rc, dh, dmcat[:, i * L:(i + 1) * L], st.p(p + ".FC_mean.weight"), self._ws[0])
-            ops.linear_bwd_x(rc, dh, dvcat[:, i * L:(i + 1) * L], st.p(p + ".FC_var.weight"), self._ws[0], accumulate=True)
-            ops.bn_eval_bwd(rc, dh, dh, self.buf[p + "/y"][:B], None, st.p(p + ".hidden_layers.2.weight"),
-                            st.b(p + ".hidden_layers.2.running_var"), ACT_LEAKY, ACT_NONE)
-            dx = self._new(f"attr/dX.{i}", B, spec.layers[enc[i]][1])
+            ops.linear_bwd_x(rc, dh, dmcat[:, i * L:(i + 1) * L], st.ep(p + ".FC_mean.weight"), self._ws[0])
+            ops.linear_bwd_x(rc, dh, dvcat[:, i * L:(i + 1) * L], st.ep(p + ".FC_var.weight"), self._ws[0], accumulate=True)
+            ops.bn_eval_bwd(rc, dh, dh, self.buf[p + "/y"][:B], None, st.ep(p + ".hidden_layers.2.weight"),
+                            st.eb(p + ".hidden_layers.2.running_var"), ACT_LEAKY, ACT_NONE)
+            dx = self._new(f"attr/dX.{i}", B, spec.engine_features(enc[i]))
             self._branch = 0
             self._lin_bwd_x(rc, dx, dh, p + ".hidden_layers.0.weight")
             self.dX.append(dx)
@@ -1334,13 +1385,13 @@ class StepPlan:
         for (v, kind, Cv) in spec.variables:
             ra = self.t_attr_head[v] = TapeRecorder()
             pre = "MLPs." + v
-            S = st.shapes[pre + ".layer_1.weight"][0]
+            S = st.eshapes[pre + ".layer_1.weight"][0]
             do = self.attr_dout[v] = self._new(f"attr/dout.{v}", B, Cv)
             da1 = self._new(f"attr/{pre}/da1", B, S)
-            ops.linear_bwd_x(ra, da1, do, st.p(pre + ".layer_out.weight"), self._ws[0])
-            ops.bn_eval_bwd(ra, da1, da1, None, self.buf[pre + "/a1"][:B], st.p(pre + ".batchnorm.weight"),
-                            st.b(pre + ".batchnorm.running_var"), ACT_NONE, ACT_RELU)
-            ops.linear_bwd_x(ra, demb, da1, st.p(pre + ".layer_1.weight"), self._ws[0])
+            ops.linear_bwd_x(ra, da1, do, st.ep(pre + ".layer_out.weight"), self._ws[0])
+            ops.bn_eval_bwd(ra, da1, da1, None, self.buf[pre + "/a1"][:B], st.ep(pre + ".batchnorm.weight"),
+                            st.eb(pre + ".batchnorm.running_var"), ACT_NONE, ACT_RELU)
+            ops.linear_bwd_x(ra, demb, da1, st.ep(pre + ".layer_1.weight"), self._ws[0])
         rc = self.t_attr_common
         dh = self._new("attr/gnn/dh", B, nodes * C)
         self._branch = 0
@@ -1350,14 +1401,14 @@ class StepPlan:
         for k in reversed(range(len(layers))):
             h_in, y, sm, si, mask, seed, off, wa, ba, wr, bnp, agg = layers[k]
             d2, a2 = da.view(B * nodes, C), outs[k].view(B * nodes, C)
-            ops.bn_eval_bwd(rc, d2, d2, None, a2, st.p(bnp + ".weight"), st.b(bnp + ".running_var"), ACT_NONE, ACT_RELU)
+            ops.bn_eval_bwd(rc, d2, d2, None, a2, st.ep(bnp + ".weight"), st.eb(bnp + ".running_var"), ACT_NONE, ACT_RELU)
             cin = h_in.shape[2]
             t = self._new(f"attr/gnn/t{k}", B, nodes, cin)
-            ops.rowlin2(rc, t, da, st.p(wa), trans=True)
+            ops.rowlin2(rc, t, da, st.ep(wa), trans=True)
             dx = self._new(f"attr/gnn/dx{k}", B, nodes, cin)
             ops.spmm_rows(rc, dx, t, gop.s_rowptr, gop.s_idx, gop.s_w)
             if wr:
-                ops.rowlin2(rc, dx, da, st.p(wr), trans=True, accumulate=True)
+                ops.rowlin2(rc, dx, da, st.ep(wr), trans=True, accumulate=True)
             da = dx
         self.dX.append(da.view(B, nodes * da.shape[2]))
 
@@ -1398,13 +1449,13 @@ class StepPlan:
             agg = self._new(p + "/agg", B, nodes, cin)
             ops.spmm_rows(rf, agg, h, gop.t_rowptr, gop.t_idx, gop.t_w)
             y = self._new(p + "/y", B, nodes, C)
-            ops.rowlin2(rf, y, agg, st.p(wa), h if wr else None, st.p(wr) if wr else None, st.p(ba))
+            ops.rowlin2(rf, y, agg, st.ep(wa), h if wr else None, st.ep(wr) if wr else None, st.ep(ba))
             a = self._new(p + "/a", B, nodes, C)
             sm, si = self._new(bnp + "/save_mean", C), self._new(bnp + "/save_invstd", C)
             mask = self._draw(f"encoders.0.drop.{k}", B, nodes, C) if (self.supplied and self.train) else None
             seed, off = self._rng()
-            ops.bn_rows_fwd(rf, a, y, st.p(bnp + ".weight"), st.p(bnp + ".bias"), st.b(bnp + ".running_mean"),
-                            st.b(bnp + ".running_var"), sm if self.train else None, si if self.train else None, act,
+            ops.bn_rows_fwd(rf, a, y, st.ep(bnp + ".weight"), st.ep(bnp + ".bias"), st.eb(bnp + ".running_mean"),
+                            st.eb(bnp + ".running_var"), sm if self.train else None, si if self.train else None, act,
                             self.train, drop, scratch, mask=mask, seed=seed, offset=off, ctrl=st.ctrl)
             layers.append((h, y, sm, si, mask, seed, off, wa, ba, wr, bnp, agg))
             h = a
@@ -1427,7 +1478,7 @@ class StepPlan:
         if self._is_frozen("encoders.0.fc.weight"):
             return              # FineTuner "encoders": True
         self._weight_grad(rb, "encoders.0.fc.weight", demb, hflat)
-        ops.colsum(rb, st.g("encoders.0.fc.bias"), demb)
+        ops.colsum(rb, st.eg("encoders.0.fc.bias"), demb)
         dh = self._new("gnn/dh", B, nodes * C)
         self._lin_bwd_x(rb, dh, demb, "encoders.0.fc.weight")
         da = dh.view(B, nodes, C)
@@ -1441,8 +1492,8 @@ class StepPlan:
             par.branch(0)
             for k in reversed(range(K)):
                 h_in, y, sm, si, mask, seed, off, wa, ba, wr, bnp, agg = layers[k]
-                ops.bn_rows_bwd(rb, da, st.g(bnp + ".weight"), st.g(bnp + ".bias"), y, st.p(bnp + ".weight"),
-                                st.p(bnp + ".bias"), sm, si, act, drop, scratch, mask=mask, seed=seed, offset=off,
+                ops.bn_rows_bwd(rb, da, st.eg(bnp + ".weight"), st.eg(bnp + ".bias"), y, st.ep(bnp + ".weight"),
+                                st.ep(bnp + ".bias"), sm, si, act, drop, scratch, mask=mask, seed=seed, offset=off,
                                 ctrl=st.ctrl)                                                     # da <- dL/dy
                 ev = torch.cuda.Event() if two else None
                 if two:
@@ -1454,18 +1505,18 @@ class StepPlan:
                     # in the first layer
                     cin = h_in.shape[2]
                     t = self._new(f"encoders.0.convs.{k}/t", B, nodes, cin)
-                    ops.rowlin2(rb, t, da, st.p(wa), trans=True)
+                    ops.rowlin2(rb, t, da, st.ep(wa), trans=True)
                     dx = self._new(f"encoders.0.convs.{k}/dx", B, nodes, cin)
                     ops.spmm_rows(rb, dx, t, gop.s_rowptr, gop.s_idx, gop.s_w)
                     if wr:
-                        ops.rowlin2(rb, dx, da, st.p(wr), trans=True, accumulate=True)
+                        ops.rowlin2(rb, dx, da, st.ep(wr), trans=True, accumulate=True)
                     da = dx
             par.branch(1 if two else 0)
             for ev, dy, agg, h_in, wa, ba, wr in jobs:
                 if two:
                     rb.wait_event(ev)
-                ops.rowlin_wgrad(rb, st.g(wa), None, dy, agg, scratch_w)
-                ops.rowlin_wgrad(rb, st.g(wr) if wr else None, st.g(ba), dy, h_in, scratch_w)
+                ops.rowlin_wgrad(rb, st.eg(wa), None, dy, agg, scratch_w)
+                ops.rowlin_wgrad(rb, st.eg(wr) if wr else None, st.eg(ba), dy, h_in, scratch_w)
         self.buf["gnn/events"] = [j[0] for j in jobs]
 
     def _enter_branch(self, par, i):
@@ -1494,6 +1545,7 @@ class StepPlan:
         vae_par = self.branches and os.environ.get("FX_VAE_BRANCHES", "1") != "0"
         mean, logv, z = self._new("mean", B, L), self._new("log_var", B, L), self._new("z", B, L)
         vae_group = self._tails_groupable(n, L) and os.environ.get("FX_VAE_GROUP", "1") != "0"
+        self.path["grouped_tails"] = vae_group
         if vae_group:
             hs = self._vae_tails_fwd(rf, enc, L, mcat, vcat, mean, logv)
         else:
@@ -1504,8 +1556,8 @@ class StepPlan:
                     p = f"encoders.{i}"
                     h = self._hidden_fwd(rf, p, self.X[enc[i]], B)
                     hs.append(h)
-                    ops.linear_fwd(rf, mcat[:, i * L:(i + 1) * L], h, st.p(p + ".FC_mean.weight"), st.p(p + ".FC_mean.bias"), self.ws)
-                    ops.linear_fwd(rf, vcat[:, i * L:(i + 1) * L], h, st.p(p + ".FC_var.weight"), st.p(p + ".FC_var.bias"), self.ws)
+                    ops.linear_fwd(rf, mcat[:, i * L:(i + 1) * L], h, st.ep(p + ".FC_mean.weight"), st.ep(p + ".FC_mean.bias"), self.ws)
+                    ops.linear_fwd(rf, vcat[:, i * L:(i + 1) * L], h, st.ep(p + ".FC_var.weight"), st.ep(p + ".FC_var.bias"), self.ws)
             self._branch = 0
             self._small_fwd(rf, mean, mcat, "FC_mean.weight", "FC_mean.bias")
             self._small_fwd(rf, logv, vcat, "FC_log_var.weight", "FC_log_var.bias")
@@ -1521,7 +1573,7 @@ class StepPlan:
         # decoder's own backward branch), all consumed by ONE ordered reduce after the branches join (FX_VAE_LATENT_FUSED=0: one
         # accumulating product + reduce per decoder on the main chain, then mul, then one launch each for FC_mean / FC_log_var)
         lat_fused = bool(self.train and os.environ.get("FX_VAE_LATENT_FUSED", "1") != "0")
-        dz_ns = [int(ops.lib.fx_gemm_splitk(B, L, st.shapes[f"decoders.{i}.hidden_layers.0.weight"][0])) if lat_fused else 0
+        dz_ns = [int(ops.lib.fx_gemm_splitk(B, L, st.eshapes[f"decoders.{i}.hidden_layers.0.weight"][0])) if lat_fused else 0
                  for i in range(nd)]
         dzs = self._new("dz_shares", 1 + nd + sum(dz_ns), B * L)
         dz = dzs[0].view(B, L)
@@ -1604,7 +1656,7 @@ class StepPlan:
                     self.buf[f"dy_kb/{wkey}"], self.buf[f"dy_kb_lo/{wkey}"] = dsp
                     nblk = ops.recon_sigmoid_slabs_blocks(B, F)
                     rp = self._new(f"recon_part.{i}", nblk)
-                    ops.recon_sigmoid_slabs(rf, rp, lg, dsp, epi[0], epi[1], st.p(p + ".FC_output.bias"), self.X[dec[i]], lv_mmd, 1.0 / nd)
+                    ops.recon_sigmoid_slabs(rf, rp, lg, dsp, epi[0], epi[1], st.ep(p + ".FC_output.bias"), self.X[dec[i]], lv_mmd, 1.0 / nd)
                 else:
                     self._lin_fwd(rf, lg, h, wkey, p + ".FC_output.bias", gram_after=True)
                     nblk = int(ops.lib.fx_recon_blocks(B * F))
@@ -1647,22 +1699,22 @@ class StepPlan:
         with rb.parallel(nd if vae_par else 1) as par:
             for i in range(nd):
                 p = f"decoders.{i}"
-                dh = self._new(p + "/dh", B, st.shapes[p + ".hidden_layers.0.weight"][0])
+                dh = self._new(p + "/dh", B, st.eshapes[p + ".hidden_layers.0.weight"][0])
                 dhs.append(dh)
                 if vae_par:
                     self._enter_branch(par, i)
                 prep_first = vae_par and i > 0
                 if prep_first:
                     self._weight_grad(rb, p + ".FC_output.weight", logits[i], hd[i])
-                    ops.colsum(rb, st.g(p + ".FC_output.bias"), logits[i])
+                    ops.colsum(rb, st.eg(p + ".FC_output.bias"), logits[i])
                 self._lin_bwd_x(rb, dh, logits[i], p + ".FC_output.weight")
                 self._hidden_bwd(rb, p, z, dh)
                 if lat_fused:
                     o = 1 + nd + sum(dz_ns[:i])
-                    ops.gemm_slabs(rb, ops.GEMM_NN, dzs[o:o + dz_ns[i]], dh, st.p(p + ".hidden_layers.0.weight"), B, L)
+                    ops.gemm_slabs(rb, ops.GEMM_NN, dzs[o:o + dz_ns[i]], dh, st.ep(p + ".hidden_layers.0.weight"), B, L)
                 if not prep_first:
                     self._weight_grad(rb, p + ".FC_output.weight", logits[i], hd[i])
-                    ops.colsum(rb, st.g(p + ".FC_output.bias"), logits[i])
+                    ops.colsum(rb, st.eg(p + ".FC_output.bias"), logits[i])
                 if heads_aside and i == 0:
                     bookkeeping(rb)
         self._branch = 0
@@ -1694,19 +1746,19 @@ class StepPlan:
         st = self.store
         if not dz_complete:
             for i in range(nd):
-                ops.linear_bwd_x(rb, dz, dhs[i], st.p(f"decoders.{i}.hidden_layers.0.weight"), self.ws, accumulate=True)
+                ops.linear_bwd_x(rb, dz, dhs[i], st.ep(f"decoders.{i}.hidden_layers.0.weight"), self.ws, accumulate=True)
         dmcat, dvcat = self._new("dmcat", B, n * L), self._new("dvcat", B, n * L)
         enc_frozen = self._is_frozen("encoders.0.FC_mean.weight")    # FineTuner "encoders": True -- the encoders need no gradient
         tops = ("FC_mean.weight", "FC_log_var.weight")
         if (dz_complete and self.small_linear and not any(k in st.big or self._is_frozen(k) for k in tops)
-                and ops.small_linear_ok(mcat, st.p(tops[0])) and ops.small_linear_ok(vcat, st.p(tops[1]))):
+                and ops.small_linear_ok(mcat, st.ep(tops[0])) and ops.small_linear_ok(vcat, st.ep(tops[1]))):
             # z = mean + log_var * eps: d mean = dz, d log_var = dz * eps -- both layers' three gradients in one launch, the product
             # with eps taken where the kernel reads its upstream gradient
             ops.small_linear_bwd_group(rb, [
-                dict(dx=None if enc_frozen else dmcat, gW=st.g("FC_mean.weight"), gb=st.g("FC_mean.bias"), dy=dz, x=mcat,
-                     W=st.p("FC_mean.weight")),
-                dict(dx=None if enc_frozen else dvcat, gW=st.g("FC_log_var.weight"), gb=st.g("FC_log_var.bias"), dy=dz, dy_mul=eps_used,
-                     x=vcat, W=st.p("FC_log_var.weight"))])
+                dict(dx=None if enc_frozen else dmcat, gW=st.eg("FC_mean.weight"), gb=st.eg("FC_mean.bias"), dy=dz, x=mcat,
+                     W=st.ep("FC_mean.weight")),
+                dict(dx=None if enc_frozen else dvcat, gW=st.eg("FC_log_var.weight"), gb=st.eg("FC_log_var.bias"), dy=dz, dy_mul=eps_used,
+                     x=vcat, W=st.ep("FC_log_var.weight"))])
         else:
             dlv = self._new("dlog_var", B, L)
             ops.mul(rb, dlv, dz, eps_used)
@@ -1718,13 +1770,13 @@ class StepPlan:
             for i in range(n):
                 p = f"encoders.{i}"
                 dm, dv = dmcat[:, i * L:(i + 1) * L], dvcat[:, i * L:(i + 1) * L]
-                dh = self._new(p + "/dh", B, st.shapes[p + ".hidden_layers.0.weight"][0])
+                dh = self._new(p + "/dh", B, st.eshapes[p + ".hidden_layers.0.weight"][0])
                 self._weight_grad(rb, p + ".FC_mean.weight", dm, hs[i])
-                ops.colsum(rb, st.g(p + ".FC_mean.bias"), dm)
+                ops.colsum(rb, st.eg(p + ".FC_mean.bias"), dm)
                 self._weight_grad(rb, p + ".FC_var.weight", dv, hs[i])
-                ops.colsum(rb, st.g(p + ".FC_var.bias"), dv)
-                ops.linear_bwd_x(rb, dh, dm, st.p(p + ".FC_mean.weight"), self.ws)
-                ops.linear_bwd_x(rb, dh, dv, st.p(p + ".FC_var.weight"), self.ws, accumulate=True)
+                ops.colsum(rb, st.eg(p + ".FC_var.bias"), dv)
+                ops.linear_bwd_x(rb, dh, dm, st.ep(p + ".FC_mean.weight"), self.ws)
+                ops.linear_bwd_x(rb, dh, dv, st.ep(p + ".FC_var.weight"), self.ws, accumulate=True)
                 self._hidden_bwd(rb, p, self.X[enc[i]], dh)
             return
         # every encoder's tail backward in ONE launch (fx_block_bwd_group, two upstream Linears each); a single encoder: fx_block_bwd
@@ -1808,10 +1860,10 @@ class StepPlan:
         if parts is not None:      # triplet: (anchor, positive, negative) lists
             for j, xs in enumerate(parts):
                 for i, x in enumerate(xs):
-                    self.X[i][j * B:(j + 1) * B].copy_(x, non_blocking=True)
+                    self.X[i][j * B:(j + 1) * B, :x.shape[1]].copy_(x, non_blocking=True)
         elif x_list is not None:
             for i, x in enumerate(x_list):
-                self.X[i].copy_(x, non_blocking=True)
+                self.X[i][:, :x.shape[1]].copy_(x, non_blocking=True)      # (the engine's buffer may be wider: zero pad columns)
         if y is not None:
             for k, t in self.y.items():
                 t.copy_(torch.as_tensor(y[k]).to(torch.float32), non_blocking=True)

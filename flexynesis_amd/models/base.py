@@ -113,7 +113,7 @@ class _PlanLoss(torch.autograd.Function):
             if plan.fused and key in st.big:
                 grads.append(None)
                 continue
-            grads.append(st.g(key))          # a view into the gradient arena (overwritten by the next backward)
+            grads.append(st.g(key))         # a view into the gradient arena (overwritten by the next backward)
         return (None, None, *grads)
 
 
@@ -156,8 +156,8 @@ class FxAdam(torch.optim.Optimizer):
         sd = super().state_dict()
         keys = [k for k, p in m._param_items()]
         sd["fx"] = {"step": self._step_count(st), "fused": self.fused,
-                    "exp_avg": {k: st.m(k).detach().cpu().clone() for k in keys},
-                    "exp_avg_sq": {k: st.v(k).detach().cpu().clone() for k in keys}}
+                    "exp_avg": {k: st.m(k).detach().cpu().clone(memory_format=torch.contiguous_format) for k in keys},
+                    "exp_avg_sq": {k: st.v(k).detach().cpu().clone(memory_format=torch.contiguous_format) for k in keys}}
         return sd
 
     def load_state_dict(self, state_dict):
@@ -649,7 +649,7 @@ class FxModel(_Base):
                         do[:, c if num_class > 1 else 0] = 1.0
                         plan.input_gradient(target_var)
                         for j in range(len(layers)):
-                            acc[c][j].add_(plan.dX[j], alpha=float(w_i))
+                            acc[c][j].add_(plan.dX[j][:, :xs[j].shape[1]], alpha=float(w_i))     # (the engine's buffer may be wider: zero pad columns)
                 for c in range(num_class):
                     for j in range(len(layers)):
                         sums[c][j] += (acc[c][j] * xs[j]).abs().sum(0).double()

@@ -925,30 +925,41 @@ def enc_tail_fwd(rec, descs, B, pre_act, post_act, train, drop_p, ctrl=None):
     return arr
 
 
-def fusion_fwd(rec, emb, ecat, parts, biases, W=None, b=None):
-    """ecat = concatenated ordered sums of ``parts`` [(part [blocks, B, width], blocks)] (+ biases), emb = ecat W^T + b."""
+def _fusion_widths(parts, width):
+    """Logical width of every part [blocks, B, pitch]: ``width`` (one for all; the pitch is then that rounded up to 4) or the pitch."""
+    wd = [int(width) if width is not None else int(p.shape[-1]) for p, _ in parts]
+    for (p, _), w_ in zip(parts, wd):
+        if int(p.shape[-1]) != (w_ + 3) // 4 * 4:
+            raise FxError(f"fusion_fwd: a part of width {w_} must have a row pitch of {(w_ + 3) // 4 * 4} (got {int(p.shape[-1])})")
+    return wd
+
+
+def fusion_fwd(rec, emb, ecat, parts, biases, W=None, b=None, width=None):
+    """ecat = concatenated ordered sums of ``parts`` [(part [blocks, B, pitch], blocks)] (+ biases), emb = ecat W^T + b.  ``width``: the
+    number of columns of a part that are real (the latent size; pitch = that rounded up to 4), default the pitch."""
     n = len(parts)
     B = ecat.shape[0] if ecat is not None else emb.shape[0]
     pp = (C.c_void_p * n)(*[p.data_ptr() for p, _ in parts])
     nb = (C.c_int * n)(*[int(k) for _, k in parts])
     bb = (C.c_void_p * n)(*[_ptr(x) for x in biases])
-    wd = (C.c_int * n)(*[int(p.shape[-1]) for p, _ in parts])
+    wds = _fusion_widths(parts, width)
+    wd = (C.c_int * n)(*wds)
     if hasattr(rec, "keep"):
         rec.keep(pp, nb, bb, wd)
-    if W is not None and (not W.is_contiguous() or W.shape[1] != sum(int(p.shape[-1]) for p, _ in parts)):
+    if W is not None and (not W.is_contiguous() or W.shape[1] != sum(wds)):
         raise FxError("fusion_fwd: fusion weight must be contiguous [L, sum of widths]")
     rec.emit("fx_fusion_fwd", _ptr(emb), _ld(emb) if emb is not None else 0, _ptr(ecat), _ld(ecat) if ecat is not None else 0,
              C.addressof(pp), C.addressof(nb), C.addressof(bb), C.addressof(wd), n, _ptr(W), _ptr(b), int(B),
              int(W.shape[0]) if W is not None else 0)
 
 
-def fusion_fwd_pair(rec, embs, ecats, parts2, biases2, Ws, bs):
+def fusion_fwd_pair(rec, embs, ecats, parts2, biases2, Ws, bs, width=None):
     """Two fusion_fwd calls over the same rows in one launch: embs / ecats / Ws / bs are pairs, parts2 / biases2 pairs of the per-layer
     lists (same widths in both)."""
     n = len(parts2[0])
     B = ecats[0].shape[0]
-    wd0 = [int(p.shape[-1]) for p, _ in parts2[0]]
-    if len(parts2[1]) != n or [int(p.shape[-1]) for p, _ in parts2[1]] != wd0:
+    wd0 = _fusion_widths(parts2[0], width)
+    if len(parts2[1]) != n or _fusion_widths(parts2[1], width) != wd0:
         raise FxError("fusion_fwd_pair: both layers take the same number and widths of parts")
     for W in Ws:
         if not W.is_contiguous() or W.shape[1] != sum(wd0) or W.shape[0] != Ws[0].shape[0]:

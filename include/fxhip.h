@@ -200,7 +200,10 @@ int fx_enc_tail_fwd(const fx_enc_tail_desc* descs, int n_modalities, int B, int 
 /* ecat[B, sum widths] = for every layer i the ordered sum of parts[i] [n_parts[i]][B][widths[i]] (+ part_bias[i]) -- the
  * concatenated encoder outputs of direct_pred.py:118-121 from fx_enc_tail_fwd's partial products -- and, when Wf is given,
  * emb = ecat Wf^T + bf (the fusion Linear, direct_pred.py:122-124; Wf [L, sum widths] contiguous, L <= 128).  One workgroup
- * per 4 rows.  widths % 4 == 0, sum <= 512; ecat may be NULL when only emb is wanted. */
+ * per 4 rows.  widths: any positive integers (a latent size is one: config.py:8), sum <= 512; part i is [n_parts[i]][B][pitch] with
+ * pitch = widths[i] rounded up to 4 (what fx_enc_tail_fwd writes for a following Linear whose rows are allocated up to that multiple,
+ * zeros) and part_bias[i] readable up to that pitch; ecat rows hold the layers back to back (layer i from column sum of the widths
+ * before it: unaligned when those are not multiples of 4 -- scalar stores then).  ecat may be NULL when only emb is wanted. */
 int fx_fusion_fwd(float* emb, long ldemb, float* ecat, long ldecat, const float* const* parts, const int* n_parts,
                   const float* const* part_bias, const int* widths, int n_layers, const float* Wf, const float* bf, int B, int L,
                   fx_stream_t stream);

@@ -877,6 +877,10 @@ def _one_step_vs_oracle(c, seed, expect_big=False):
     if expect_big:
         assert len(store.big_keys) >= 1, "the wide sweep must reach the split-bf16 kernels"
     plan = StepPlan(store, B, train=True, fused=True, supplied_draws=True)
+    # which schedule ran: every one-pass model of <= 4 modalities and latent <= 128 takes the grouped encoder tails whatever its
+    # widths are mod 4 (hidden / input widths are rounded up inside the engine, the tail Linears' rows are allocated up to 4)
+    n_enc = len(aspec.enc_idx) if aspec.is_vae else len(c["layers"])
+    assert plan.path["grouped_tails"] == (c["model"] != "MultiTripletNetwork" and B <= 128 and n_enc * c["latent"] <= 512), (plan.path, c)
     gen = torch.Generator().manual_seed(seed + 2)
     y = {k: ann[k][:B].clone() for k in plan.y}
     if "y" in y and B > 4:

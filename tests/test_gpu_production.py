@@ -31,7 +31,17 @@ FULL = {
     # cfg2 under --fusion_type early (reference data.py:234-257: the layers are concatenated into one, "all"): a single
     # [10000, 40000] weight of 1.6 GB (157 row blocks x 313 column tiles, 3-4 runs per row block)
     "cfg2_early": dict(model="DirectPred", layers=[("all", 40000)], variables=[("y", "numerical", 1)], surv=(None, None), steps=1),
+    # what the reference's search space actually draws (config.py:7-15: latent_dim any integer in 16..128, hidden = int(F * U[0.2, 0.5]))
+    # on a cohort whose feature counts are not multiples of anything: H = 8823 / 8880, every width odd mod 4
+    "cfg2_odd": dict(model="DirectPred", layers=[("gex", 19873), ("cnv", 20001)], variables=[("y", "numerical", 1)], surv=(None, None),
+                     steps=2, latent=17, factor=0.444, sup=11),
 }
+
+
+def _arch(cfg):
+    from flexynesis_amd.arch import ArchSpec
+    return ArchSpec(cfg["model"], cfg["layers"], cfg.get("latent", 64), cfg.get("factor", 0.25), cfg.get("sup", 16), cfg["variables"],
+                    cfg["surv"][0], cfg["surv"][1], True)
 
 
 def _assert_no_bad_tile(bad, what):
@@ -76,7 +86,7 @@ def _state_close(got, ref, g, gnorm, lr, what):
                                        f"{float(err.max()):.3e}")
 
 
-@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4", "cfg2_early"])
+@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4", "cfg2_early", "cfg2_odd"])
 def test_fullsize_step_vs_oracle(name):
     """The shapes bench.py times, with supplied draws: named losses <= 1e-4 relative (the north-star gate), grad norm vs
     the fp64 norm of the oracle's gradients, >= 99.9 % of every wide weight's elements tight after the step, update
@@ -86,7 +96,7 @@ def test_fullsize_step_vs_oracle(name):
     from oracle import restate as O
     cfg, dev, B, N = FULL[name], _dev(), 128, 512
     layers, model = cfg["layers"], cfg["model"]
-    aspec = ArchSpec(model, layers, 64, 0.25, 16, cfg["variables"], cfg["surv"][0], cfg["surv"][1], True)
+    aspec = _arch(cfg)
     ospec = _oracle_spec(aspec)
     dat, ann = O.synthetic_cohort(layers, N, seed=1234)
     st = O.init_state(ospec, seed=5)
@@ -139,7 +149,8 @@ def test_fullsize_step_vs_oracle(name):
             _state_close(sd[k], st[k], info["grads"].get(k), exact, lr, f"{name} step{step} state {k}")
 
 
-def test_timed_schedule_vs_oracle_cfg2():
+@pytest.mark.parametrize("name", ["cfg2", "cfg2_odd"])
+def test_timed_schedule_vs_oracle_cfg2(name):
     """EXACTLY what bench.py times, against the oracle: PipelinedStep with the next step's wide forward fused into the dW + Adam
     launches, batch assembly one step ahead from the resident cohort, one eager step, then hipGraph replay -- five
     consecutive optimisation steps at 2 x 20000 / B = 128 with supplied draws.  Every step is compared with the oracle's
@@ -151,16 +162,20 @@ def test_timed_schedule_vs_oracle_cfg2():
     from flexynesis_amd.data import DeviceCohort
     from flexynesis_amd.engine import ParamStore, PipelinedStep
     from oracle import restate as O
-    cfg, dev, B, N, nb = FULL["cfg2"], _dev(), 128, 1024, 8
+    cfg, dev, B, N, nb = FULL[name], _dev(), 128, 1024, 8
     layers = cfg["layers"]
-    aspec = ArchSpec("DirectPred", layers, 64, 0.25, 16, cfg["variables"], None, None, True)
+    aspec = _arch(cfg)
     ospec = _oracle_spec(aspec)
     dat, ann = O.synthetic_cohort(layers, N, seed=77)
     cohort = DeviceCohort(dat, ann, dev)
     store = ParamStore(aspec, dev, materialize_big_grads=False)
     store.load_state(O.init_state(ospec, seed=9))
     pipe = PipelinedStep(store, B, cohort=cohort, n_batches=nb, seed=3, supplied_draws=True)
-    assert sorted(pipe.plans[0]._next_fwd) == sorted(store.big_keys) and len(store.big_keys) == 2     # the fused schedule
+    assert sorted(pipe.plans[0]._next_fwd) == sorted(store.big_keys) and len(store.big_keys) == 2     # the fused schedule ...
+    # ... in its 14 launches (gather + split, Gram, reduce, labels | tails, fusion, heads step | fusion backward, tails backward |
+    # clip + Adam of the small parameters, 2 x dW + Adam + next forward | step begin), whatever the widths are mod 4
+    assert pipe.n_launches() == 14 and pipe.plans[0].path == {"grouped_tails": True, "heads_step": True, "grouped_bwd": True}, \
+        (pipe.n_launches(), pipe.plans[0].path)
     gen = torch.Generator().manual_seed(99)
     table = torch.randperm(N, generator=gen)[: nb * B]
     pipe.idx.copy_(table.to(dev))
@@ -258,9 +273,10 @@ def test_dominant_kernel_fullsize_vs_fp64(n_out, k_in, K):
 def _bn_out(plan, prefix, rows, affine):
     """Recompute the BatchNorm output (before ReLU / dropout) of an MLP block from the saved tensors of the plan;
     ``affine`` = the block's (gamma, beta) as they were BEFORE the step (Adam has moved them since)."""
-    y1 = plan.buf[prefix + "/y1"][rows].double()
+    H = affine[prefix][0].shape[0]          # the reference's hidden width (the engine's buffers may be wider: inert zero columns)
+    y1 = plan.buf[prefix + "/y1"][rows, :H].double()
     p = rows.start // plan.B if prefix.startswith("encoders.") else 0
-    sm, si = plan.buf[prefix + "/save_mean"][p].double(), plan.buf[prefix + "/save_invstd"][p].double()
+    sm, si = plan.buf[prefix + "/save_mean"][p, :H].double(), plan.buf[prefix + "/save_invstd"][p, :H].double()
     return (y1 - sm) * si * affine[prefix][0] + affine[prefix][1]
 
 
@@ -272,7 +288,8 @@ def _affine_snapshot(store):
 def _mask_of(plan, prefix, rows, affine):
     """(kept, defined): the dropout decision can be read off wherever the ReLU output is safely positive."""
     bn = _bn_out(plan, prefix, rows, affine)
-    a1 = plan.buf[prefix + "/a1"][rows]
+    a1 = plan.buf[prefix + "/a1"][rows, :bn.shape[1]]
+    assert not bool(plan.buf[prefix + "/a1"][rows, bn.shape[1]:].any()), f"{prefix}: the engine's pad columns must stay zero"
     defined = bn > 1e-3
     kept = a1 != 0
     # kept elements carry exactly bn / 0.9
