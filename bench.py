@@ -82,6 +82,46 @@ class _stdout_to_stderr:
         return False
 
 
+def _live_traffic(want_prefix, args):
+    """HBM bytes per launch of the dominant kernel, measured NOW on this box: two more runs of this script under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, --kernel-trace only: MI355X_MICROARCH.md, HBM section), a few eager
+    steps each; FETCH_SIZE doubled (gfx950 counts the 128-byte requests of a wide streaming read as 64 bytes), as scripts/pmc_to_json.py
+    does for profiles/.  Returns (bytes | None, note)."""
+    import csv, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="fxpmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+               "--config", args.config, "--batch", str(args.batch), "--precision", args.precision, "--steps", "4", "--warmup", "1", "--no-graph",
+               "--no-cpu-baseline", "--sweep-trials-per-gpu", "0", "--no-other", "--repeats", "0", "--no-pmc"]
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+            path = None
+            for root, _, files in os.walk(d):
+                for f in files:
+                    if f.endswith("counter_collection.csv"):
+                        path = os.path.join(root, f)
+            got = []
+            for r in csv.DictReader(open(path)):
+                name = r["Kernel_Name"].replace("void ", "").split("(")[0]
+                if r["Counter_Name"] == counter and name.startswith(want_prefix):
+                    got.append(float(r["Counter_Value"]))
+            if not got:
+                return None, f"{counter}: no launch of {want_prefix} in the counter file"
+            vals[counter] = (sum(got) / len(got), len(got))
+        except Exception as e:
+            return None, f"{counter} pass failed: {e!r}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    fetch_kb, write_kb = vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]
+    return int(round((2.0 * fetch_kb + write_kb) * 1024)), (f"measured in this run: rocprofv3 --pmc FETCH_SIZE ({vals['FETCH_SIZE'][1]} launches, x 2: gfx950 "
+                                                          f"correction) + --pmc WRITE_SIZE ({vals['WRITE_SIZE'][1]} launches), separate passes of this script")
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,6 +140,9 @@ def parse():
     ap.add_argument("--repeats", type=int, default=25, help="after the timed region: this many more windows of --steps steps, "
                     "reported as median / min / max (0 = skip)")
     ap.add_argument("--no-other", action="store_true", help="skip the short legs of the other BASELINE configs / modes")
+    ap.add_argument("--no-pmc", action="store_true", help="do not re-run this script under rocprofv3 --pmc for roofline.traffic")
+    ap.add_argument("--settle", type=int, default=40, help="untimed hipGraph replays before the --warmup steps (the first windows after "
+                    "the captures run 3-5 %% slower while the clocks settle; reported as config.untimed_settle_steps)")
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "f32"],
                     help="wide-layer contraction: split-bf16 MFMA with fp32 accumulate (default) or exact fp32 MFMA")
     return ap.parse_args()
@@ -281,41 +324,42 @@ def main():
     # The first windows after the eager step and the two captures run 3-5 % slower than the steady state (the clocks are still
     # settling; `repeat_stats` below shows it): a training run is thousands of steps, so the untimed part is long enough to get
     # there -- SETTLE replays before the W warm-up steps the caller asked for (reported in config.untimed_settle_steps).
-    SETTLE = 40 if use_graph else 0
+    SETTLE = max(int(a.settle), 0) if use_graph else 0
     run(SETTLE)
     run(a.warmup)
-    torch.cuda.synchronize()
-    if use_pg:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(a.steps)
-    torch.cuda.synchronize()
-    if use_pg:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if use_pg:
-        t = torch.tensor([elapsed], device="cpu" if backend == "gloo" else dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    def window():
+        """EXACTLY --steps steps between barrier + synchronize on both sides, the maximum over the ranks (seconds)."""
+        torch.cuda.synchronize()
+        if use_pg:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(a.steps)
+        torch.cuda.synchronize()
+        if use_pg:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if use_pg:
+            t = torch.tensor([dt], device="cpu" if backend == "gloo" else dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    first_window = window()
     losses = pipe.losses()
     finite = all(v == v and abs(v) != float("inf") for v in losses.values())
 
-    # ---- the same window R more times (rank 0's own clock; the headline `value` stays the first window, timed as the contract says)
-    repeat_stats = None
-    if a.repeats > 0:
-        win = []
-        for _ in range(a.repeats):
-            torch.cuda.synchronize()
-            r0 = time.perf_counter()
-            run(a.steps)
-            torch.cuda.synchronize()
-            win.append(1e3 * (time.perf_counter() - r0) / a.steps)
-        win.sort()
-        repeat_stats = {"repeats": a.repeats, "steps_per_window": a.steps, "ms_per_step_median": round(win[len(win) // 2], 4),
-                        "ms_per_step_min": round(win[0], 4), "ms_per_step_max": round(win[-1], 4),
-                        "samples_per_s_median": round(B / (win[len(win) // 2] * 1e-3), 1)}
+    # ---- the same window R more times, timed the same way.  `value` is the MEDIAN window (the first one included): one 20-60 step
+    # window is 20-60 ms, within reach of a single clock / power-management event; the first window is printed beside it.
+    wins = [first_window] + [window() for _ in range(max(a.repeats, 0))]
+    srt = sorted(wins)
+    elapsed = srt[len(srt) // 2]
+    repeat_stats = {"windows": len(wins), "steps_per_window": a.steps, "first_window_ms_per_step": round(1e3 * first_window / a.steps, 4),
+                    "ms_per_step_median": round(1e3 * elapsed / a.steps, 4), "ms_per_step_min": round(1e3 * srt[0] / a.steps, 4),
+                    "ms_per_step_max": round(1e3 * srt[-1] / a.steps, 4),
+                    "first_window_samples_per_s": round(world * a.steps * B / first_window, 1)}
 
     # ---- dominant-kernel timing with HIP events on the launch stream (eager re-issue of the same tapes)
     roof = None
@@ -334,17 +378,22 @@ def main():
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
             # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), collected
             # in separate rocprofv3 --pmc passes of this same command and committed under profiles/.
-            traffic = None
-            try:
-                # only a PMC file collected THIS round with this kernel counts (else null: the figure is not re-measured here)
-                pm = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
-                if a.config == "cfg2" and B == 128 and a.precision == "bf16x3" and not a.features:
-                    want = "fx_dw_adam_fwd_kernel" if dominant.endswith("_fwd_bf16x3") else "fx_gemm_bf16x3_kernel<false, 1"
-                    for kname, d in pm["kernels"].items():
-                        if kname.startswith(want):
-                            traffic = d["hbm_bytes_per_launch_corrected"]
-            except Exception:
-                traffic = None
+            traffic = traffic_note = None
+            want = "fx_dw_adam_fwd_kernel" if dominant.endswith("_fwd_bf16x3") else "fx_gemm_bf16x3_kernel<false, 1"
+            if not a.no_pmc and world == 1 and not a.features:
+                traffic, traffic_note = _live_traffic(want, a)
+            if traffic is None:
+                try:
+                    # fallback: the PMC file committed under profiles/ (another box, labelled as such)
+                    pm = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
+                    if a.config == "cfg2" and B == 128 and a.precision == "bf16x3" and not a.features:
+                        for kname, d in pm["kernels"].items():
+                            if kname.startswith(want):
+                                traffic = d["hbm_bytes_per_launch_corrected"]
+                                traffic_note = (f"profiles/{PMC_FILE} (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on another "
+                                                f"box of the pool; not re-measured in this run" + (f": {traffic_note}" if traffic_note else "") + ")")
+                except Exception:
+                    traffic = None
             # Boxes of the pool differ by +-10 % in what their HBM delivers: record this box's plain device-to-device
             # copy rate (1 GiB read + 1 GiB write, HIP events) next to the kernel's figure.  `frac` stays relative to
             # the 8 TB/s vendor peak.
@@ -369,8 +418,7 @@ def main():
                 pass
             roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "traffic_source": (f"profiles/{PMC_FILE} (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
-                                       "on another box of the pool; not re-measured in this run)") if traffic else None,
+                    "traffic_source": traffic_note if traffic else None,
                     "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(ms),
                     "algorithmic_bytes_per_launch": bytes_per_launch, "device_copy_GBps_this_box": copy_gbs,
                     "torch_copy_GBps_this_box": copy_torch}

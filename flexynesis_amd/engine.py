@@ -66,6 +66,177 @@ class placement_tries:
         return False
 
 
+class PlacementPool:
+    """Rated arrays for wide weights, kept for the life of the process (per device and SHAPE).  ``take`` hands out fast arrays of exactly
+    the shape asked for, ``give`` takes them back -- only arrays rated at least ParamStore.PLACE_GOOD_TBS are kept, at most
+    FX_PLACEMENT_POOL_GB (default 64) per device; the rest go back to the allocator.  A rating does NOT travel to another shape: the
+    first half of a fast [10000, 20000] array, used as [5000, 20000], probes at 4.7-4.9 TB/s, slower than most fresh arrays of that shape
+    (profiles/r05_placement_pool.txt) -- so the pool serves series of models of ONE shape: the k folds of a cross-validated trial, the
+    lr x freeze x fold grid of the FineTuner (45 fits of one model), repeated fits in one process.  Thread-safe (trials in flight on
+    several host threads); an array handed back carries an event of the stream that last used it, and the taker's stream waits for it."""
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._free: Dict[int, list] = {}
+        self.stats = {"given": 0, "taken": 0, "dropped": 0}
+
+    def _cap_bytes(self) -> int:
+        return int(float(os.environ.get("FX_PLACEMENT_POOL_GB", "64")) * (1 << 30))
+
+    def take(self, device, shape: Tuple[int, int], count: int):
+        out = []
+        with self._lock:
+            free = self._free.get(device.index, [])
+            rest = []
+            for e in free:             # (by position: list.remove() would compare the entries' tensors element by element)
+                if len(out) < count and e[3] == tuple(shape):
+                    out.append(e)
+                else:
+                    rest.append(e)
+            free[:] = rest
+            self.stats["taken"] += len(out)
+        for e in out:
+            if e[2] is not None:
+                torch.cuda.current_stream(device).wait_event(e[2])
+        return [(e[0], e[1]) for e in out]
+
+    def give(self, device, shape: Tuple[int, int], arrays):
+        good = float(os.environ.get("FX_PLACEMENT_GOOD_TBS", ParamStore.PLACE_GOOD_TBS))
+        keep = [(flat, tbs) for flat, tbs in arrays if tbs is not None and tbs >= good]
+        if not keep or ops.capturing():       # (a store collected while a hipGraph capture is in progress: nothing may be recorded now)
+            return
+        ev = None
+        try:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(device))
+        except Exception:
+            ev = None
+        with self._lock:
+            free = self._free.setdefault(device.index, [])
+            held = sum(e[0].numel() * 4 for e in free)
+            for flat, tbs in keep:
+                if held + flat.numel() * 4 > self._cap_bytes():
+                    self.stats["dropped"] += 1
+                    continue
+                free.append((flat, tbs, ev, tuple(shape)))
+                held += flat.numel() * 4
+                self.stats["given"] += 1
+
+    def held(self, device) -> List[Tuple[Tuple[int, int], float]]:
+        with self._lock:
+            return [(e[3], e[1]) for e in self._free.get(device.index, [])]
+
+    def clear(self, device=None):
+        with self._lock:
+            if device is None:
+                self._free.clear()
+            else:
+                self._free.pop(device.index, None)
+
+
+POOL = PlacementPool()
+
+
+def search_arrays(device, out: int, fin: int, want: int, tries: int, seed: int = 20240):
+    """Up to ``want`` flat arrays of out x pad32(fin) floats that stream the dW + Adam traffic pattern at >= PLACE_GOOD_TBS, found among
+    at most 8 x tries candidates allocated behind spacers of varying size.  Returns ([(array, TB/s)], info); when the fast group is
+    out of reach (budget, memory, a shape whose fast placements do not reach the absolute rate) the best arrays seen fill up the
+    list.  Memory discipline: the spacer is capped by FX_PLACEMENT_SPACER_GB and by a quarter of what is free NOW, an allocation
+    failure drops the spacer and tries once more, and with less than ~6 arrays of free memory there is no search at all."""
+    import time
+    ld = (fin + 31) // 32 * 32
+    need = out * ld
+    good_tbs = float(os.environ.get("FX_PLACEMENT_GOOD_TBS", ParamStore.PLACE_GOOD_TBS))
+    budget = float(os.environ.get("FX_PLACEMENT_BUDGET_S", "0.6"))
+    cap_gb = float(os.environ.get("FX_PLACEMENT_SPACER_GB", "32"))
+    rs = np.random.RandomState(seed)
+    fixed_mb = [0, 6, 3, 254, 1201, 5, 777, 2403]
+    kept, spare, probes = [], [], []
+    s_per_mb = 0.0
+    t0 = time.perf_counter()
+
+    def tbs_of(us):
+        return 8.0 * out * fin / us / 1e6
+
+    def alloc():
+        try:
+            return torch.zeros(need, dtype=torch.float32, device=device)
+        except torch.OutOfMemoryError:
+            return None
+    with torch.cuda.device(device):
+        for t in range(8 * tries):
+            free_b = torch.cuda.mem_get_info(device)[0]
+            if free_b < 6 * need * 4:
+                break
+            sp = None
+            t_it = time.perf_counter()
+            sp_mb = 0
+            if t:
+                # Allocating and releasing a spacer costs time in proportion to its size (seconds for tens of GB): the cap follows what
+                # is left of the budget at the rate observed so far (2 GB before anything has been observed).
+                left = max(budget - (t_it - t0), 0.0)
+                time_mb = int(0.5 * left / s_per_mb) if s_per_mb > 0 else 2048
+                cap_mb = max(16, min(int(0.25 * free_b) >> 20, int(cap_gb * 1024), max(time_mb, 16)))
+                mb = fixed_mb[t] if t < len(fixed_mb) else int(np.exp(rs.uniform(np.log(4.0), np.log(float(cap_mb)))))
+                sp_mb = min(mb, cap_mb)
+                try:           # (a spacer is a means, not a need)
+                    sp = torch.empty(sp_mb << 20, dtype=torch.uint8, device=device)
+                except torch.OutOfMemoryError:
+                    sp = None
+            a = alloc()
+            if a is None and sp is not None:          # the spacer was in the way: without it
+                del sp
+                sp = None
+                torch.cuda.empty_cache()
+                a = alloc()
+            if a is None:
+                break
+            us = ops.placement_probe_us(a.view(out, ld)[:, :fin])
+            probes.append(round(tbs_of(us), 2))
+            (kept if tbs_of(us) >= good_tbs else spare).append((us, a))
+            spare.sort(key=lambda c: c[0])
+            del a, sp
+            del spare[max(want - len(kept), 0):]       # only as many rejects as could still be needed stay alive
+            if t:
+                torch.cuda.empty_cache()               # spacer and dropped rejects: back to the driver
+            if sp_mb >= 256:
+                s_per_mb = max(s_per_mb, (time.perf_counter() - t_it) / sp_mb)
+            if len(kept) >= want:
+                break
+            if t + 1 >= tries:
+                # a shape whose fast placements do not reach the absolute rate: after `tries` candidates, arrays within 3 % of the
+                # fastest one seen are as good as it gets (if that one is itself out of the slow group)
+                top = sorted(kept + spare, key=lambda c: c[0])[:want]
+                if len(top) == want and top[-1][0] <= 1.03 * top[0][0] and tbs_of(top[0][0]) >= 5.3:
+                    break
+            if time.perf_counter() - t0 > budget:
+                break
+    chosen = sorted(kept + spare, key=lambda c: c[0])[:want]
+    info = {"probed": len(probes), "probed_TBps": probes, "search_candidates_s": round(time.perf_counter() - t0, 3)}
+    return [(a, tbs_of(us)) for us, a in chosen], info
+
+
+def prewarm_placement(device, out: int, fin: int, count: int, tries: Optional[int] = None) -> dict:
+    """Put ``count`` rated fast arrays of out x pad32(fin) floats into the process-level pool BEFORE a series of short fits of models
+    with a wide weight of exactly that shape (a fine-tuning grid, the folds of a cross-validated trial): every model of the series
+    then takes them at no cost of its own, instead of the first placement the allocator offers."""
+    import time
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    t0 = time.perf_counter()
+    have = sum(1 for shp, _ in POOL.held(device) if shp == (out, fin))
+    if tries is None:
+        tries = int(os.environ.get("FX_PLACEMENT_TRIES", "12"))
+    found, info = ([], {"probed": 0})
+    if count > have and out * fin >= ParamStore.PLACE_MIN_ELEMS and fin % 4 == 0 and tries > 1:
+        found, info = search_arrays(device, out, fin, count - have, max(tries, (count - have) * 4), seed=777)
+        POOL.give(device, (out, fin), found)
+    return {"shape": [out, fin], "wanted": count, "already_pooled": have, "probed": info.get("probed", 0),
+            "pooled_TBps": [round(r, 2) for _, r in found if r >= float(os.environ.get("FX_PLACEMENT_GOOD_TBS", ParamStore.PLACE_GOOD_TBS))],
+            "seconds": round(time.perf_counter() - t0, 3)}
+
+
 class ParamStore:
     def __init__(self, spec: ArchSpec, device, big_threshold: int = 1 << 20, materialize_big_grads: bool = True,
                  big_min_dim: Optional[int] = None):
@@ -196,88 +367,72 @@ class ParamStore:
     # Placement of a wide weight's three arrays.  The dW + Adam kernels stream W, m and v of a 64 x 128 tile together, ~500 tiles at a
     # time; how fast that goes depends on which physical pages the three allocations happen to get -- 400 to 494 us for the same
     # kernel on the same [5000, 20000] arrays of the same MI355X, by the allocation history of the process alone (DESIGN.md section
-    # 3.10, profiles/r04_placement.txt).  So: allocate candidate arrays, time one pass of that traffic pattern over each
-    # (fx_placement_probe: contents untouched), keep the fast ones; the rest go back to the driver.  FX_PLACEMENT_TRIES (default 12:
-    # at most 96 candidate arrays per weight; 1 = take the first placement, as rounds 1-3 did).
+    # 3.10, profiles/r04_placement.txt).  The quality of a placement is, to a good approximation, a property of each ARRAY on its own
+    # (scripts/placement_single.py: arrays probed alone fall into a fast group, 5.7-5.9 TB/s of their 8 B per element, and a slow one,
+    # 4.8-5.0; the three fastest of 14 together probe 397-400 us, the three slowest 486-490) -- of the array AT ITS SHAPE: the same
+    # memory viewed with another shape rates differently (profiles/r05_placement_pool.txt).  So
+    #   * arrays are rated one by one with a timed pass of that traffic pattern (fx_placement_probe: contents untouched);
+    #   * a ParamStore takes its arrays from a PROCESS-LEVEL POOL of rated arrays of its shape first (PlacementPool: what earlier
+    #     models of this process -- folds, fine-tuning fits, repeated fits -- gave back when they were dropped, or prewarm_placement());
+    #   * what the pool cannot serve is searched for: candidate arrays behind spacer allocations of varying size (they decide which
+    #     physical blocks the driver hands out next), fast ones kept, the rest back to the DRIVER (torch's cache would hand the same
+    #     blocks out again) -- bounded by FX_PLACEMENT_TRIES candidates (default 12 x 8; 1 = no search: first placement, as rounds
+    #     1-3), FX_PLACEMENT_BUDGET_S seconds (default 0.6 per weight) and FX_PLACEMENT_SPACER_GB (default 32, and never more than a
+    #     quarter of what is free at that moment).
     PLACE_MIN_ELEMS = 1 << 24           # 64 MB per array: smaller weights are a few tiles per workgroup, placement is in the noise
     PLACE_GOOD_TBS = 5.75               # an array read + written (8 B per element) per probe pass: arrays at this rate are kept
 
     def _place_big(self, key):
+        import time
         out, fin = self.eshapes[key]
         ld = (fin + 31) // 32 * 32
+        need = out * ld
         tries = getattr(_PLACEMENT, "tries", None)
         if tries is None or "FX_PLACEMENT_TRIES" in os.environ:
             tries = int(os.environ.get("FX_PLACEMENT_TRIES", "12"))
-        probe = tries > 1 and out * fin >= self.PLACE_MIN_ELEMS and fin % 4 == 0
+        eligible = out * fin >= self.PLACE_MIN_ELEMS and fin % 4 == 0
+        got: List[Tuple[torch.Tensor, Optional[float]]] = []          # (flat array of >= need elements, its rate in TB/s or None)
+        t0 = time.perf_counter()
+        info = {}
+        with torch.cuda.device(self.device):
+            if eligible:
+                got = POOL.take(self.device, (out, fin), 3)
+                info["from_pool"] = len(got)
+            if eligible and tries > 1 and len(got) < 3:
+                found, sinfo = search_arrays(self.device, out, fin, 3 - len(got), tries, seed=20240 + len(self.big))
+                got += found
+                info.update(sinfo)
+            while len(got) < 3:
+                got.append((torch.zeros(need, dtype=torch.float32, device=self.device), None))
+            views = []
+            for name, (flat, tbs) in zip(("W", "M", "V"), got):
+                buf = flat[:need].view(out, ld)
+                if info.get("from_pool"):
+                    buf.zero_()
+                self.big[key]["_" + name] = buf
+                self.big[key][name] = buf[:, :fin]
+                views.append(buf[:, :fin])
+            self.big[key]["_arrays"] = ((out, fin), got)
+            if eligible and (info.get("from_pool") or info.get("probed")):
+                info["kept_TBps"] = [None if r is None else round(r, 2) for _, r in got]
+                info["kept_us"] = round(ops.placement_probe_us(*views), 1)
+                info["search_s"] = round(time.perf_counter() - t0, 3)
+                self.placement[key] = info
 
-        def triple():
-            return [torch.zeros(out, ld, dtype=torch.float32, device=self.device) for _ in range(3)]
-        if not probe:
-            bufs = triple()
-        else:
-            # The quality of a placement is, to a good approximation, a property of each ARRAY on its own (scripts/placement_single.py:
-            # arrays probed alone fall into a fast group, 134-141 us for the 100 M-element array = 5.7-5.9 TB/s of its 8 B per element,
-            # and a slow one, 161-168 us; the three fastest of 14 together probe 397-400 us, the three slowest 486-490).  So the
-            # arrays are placed one by one: a spacer of varying size (it decides which physical blocks the driver hands out next; sizes
-            # from MBs to tens of GBs), the array, one
-            # probe of it alone; fast ones are kept, the others and every spacer go back to the DRIVER (torch's cache would hand the
-            # same blocks out again), except that the best rejects stay alive as the fallback.  At most 8 x FX_PLACEMENT_TRIES arrays.
-            rate = float(os.environ.get("FX_PLACEMENT_GOOD_TBS", self.PLACE_GOOD_TBS))
-            good_one_us = 8.0 * out * fin / (rate * 1e12) * 1e6
-            # Spacer sizes: a fixed list of small ones first, then log-uniform draws between 4 MB and ~45 % of the free memory (at most
-            # 96 GB): whole regions of the physical address space hand out slow arrays only -- on one freshly acquired box 60
-            # candidates behind spacers of up to 12 GB were ALL slow, for both weights -- so the search has to be able to leave them.
-            free_b = torch.cuda.mem_get_info(self.device)[0]
-            cap_mb = max(16, min(int(0.45 * free_b) >> 20, 96 << 10))
-            rs = np.random.RandomState(20240 + len(self.big))
-            spacer_mb = [0, 6, 3, 254, 1201, 5, 777, 2403] + [int(np.exp(rs.uniform(np.log(4.0), np.log(float(cap_mb))))) for _ in range(8 * tries)]
-            probes, kept, spare = [], [], []           # kept / spare: (us, array), alive
-            with torch.cuda.device(self.device):
-                for t in range(8 * tries):
-                    sp = None
-                    if t:
-                        try:           # (a spacer is a means, not a need: on a nearly full device the search goes on without it)
-                            sp = torch.empty(spacer_mb[t % len(spacer_mb)] << 20, dtype=torch.uint8, device=self.device)
-                        except torch.OutOfMemoryError:
-                            sp = None
-                    try:
-                        a = torch.zeros(out, ld, dtype=torch.float32, device=self.device)
-                    except torch.OutOfMemoryError:
-                        if len(kept) + len(spare) < 3:
-                            raise
-                        del sp
-                        break
-                    us = ops.placement_probe_us(a[:, :fin])
-                    probes.append(round(us, 1))
-                    if us <= good_one_us:
-                        kept.append((us, a))
-                    else:
-                        spare.append((us, a))
-                        spare.sort(key=lambda c: c[0])
-                    del a, sp
-                    del spare[max(3 - len(kept), 0):]          # only as many rejects as could still be needed stay alive
-                    if t:
-                        torch.cuda.empty_cache()               # spacer and dropped rejects: back to the driver
-                    if len(kept) >= 3:
-                        break
-                    if t + 1 >= tries:
-                        # a shape whose fast placements do not reach the absolute rate (other tile counts per run): after `tries`
-                        # candidates, three arrays within 3 % of the fastest one seen are as good as it gets
-                        # (only if that fastest one is itself out of the slow group: a dozen candidates in a row at 4.8-4.95 TB/s
-                        # happen, and three of THOSE are not a placement to settle for)
-                        top = sorted(kept + spare, key=lambda c: c[0])[:3]
-                        if len(top) == 3 and top[2][0] <= 1.03 * min(probes) and min(probes) <= good_one_us * rate / 5.3:
-                            break
-                chosen = sorted(kept + spare, key=lambda c: c[0])[:3]
-                bufs = [c[1] for c in chosen]
-                together = ops.placement_probe_us(bufs[0][:, :fin], bufs[1][:, :fin], bufs[2][:, :fin])
-                self.placement[key] = {"probe_us": probes, "kept_single_us": [round(c[0], 1) for c in chosen], "kept_us": round(together, 1),
-                                       "good_single_us": round(good_one_us, 1)}
-                del kept, spare, chosen
-                torch.cuda.empty_cache()
-        for name, buf in zip(("W", "M", "V"), bufs):
-            self.big[key]["_" + name] = buf
-            self.big[key][name] = buf[:, :fin]
+    def release_big(self):
+        """Hand the rated arrays of the wide weights to the process-level pool (the next model of this process takes them instead of
+        whatever the allocator would give it).  Called when the store is dropped; the store is unusable afterwards."""
+        for k, d in list(self.big.items()):
+            arrs = d.pop("_arrays", None)
+            if arrs:
+                POOL.give(self.device, arrs[0], arrs[1])
+        self.big = {}
+
+    def __del__(self):
+        try:
+            self.release_big()
+        except Exception:
+            pass
 
     def ensure_big_grads(self):
         for k, d in self.big.items():

@@ -70,7 +70,6 @@ def run_cfg5(dev, n_trials: int = 64, epochs: int = 3, features: int = 20000, sa
     ds = MultiOmicDataset(dat, ann, {"y": "numerical"}, feats, [f"s{i}" for i in range(samples)], {})
     plist = trials.draw_search_space(n_trials, seed=seed, epochs=epochs)
     stats = {"samples": 0, "busy": 0.0}
-
     def shapes_of(params):
         return spec_from_dataset("DirectPred", params, ds, ["y"]).state_shapes()
 

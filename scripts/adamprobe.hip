@@ -97,6 +97,49 @@ __global__ __launch_bounds__(512) void adam_runs(float* __restrict__ W, float* _
   }
 }
 
+// persistent runs, XCD-contiguous row blocks (the shipped mapping), with a ROTATED start tile per run: do the ~500 concurrent streams have to
+// march through the same column position?  rot 0: all runs start at their first tile (shipped); 1: XCD x starts x / 8 of the way in;
+// 2: every row block at a pseudo-random position; 3: the row blocks of an XCD spread evenly over the run
+template <int LDSB>
+__global__ __launch_bounds__(512) void adam_runs_rot(float* __restrict__ W, float* __restrict__ M, float* __restrict__ V, int H, int F, long ld, int S, int rot) {
+  __shared__ char pad[LDSB];
+  if (threadIdx.x == 9999) pad[threadIdx.x % LDSB] = 1;
+  constexpr int R = 64, C = 128, UPR = 32, PER = 4;
+  const int tiles_m = (H + R - 1) / R, tiles_n = (F + C - 1) / C;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, rpx = (tiles_m + 7) >> 3;
+  const int tm = xcd * rpx + j % rpx, c = j / rpx;
+  if (tm >= tiles_m || c >= S) return;
+  const int T = (tiles_n - c + S - 1) / S;
+  int off = 0;
+  if (rot == 1) off = (xcd * T) / 8;
+  else if (rot == 2) off = (int)(((unsigned)tm * 2654435761u >> 8) % (unsigned)T);
+  else if (rot == 3) off = ((j % rpx) * T) / rpx;
+  for (int k = 0; k < T; ++k) {
+    int kk = k + off; if (kk >= T) kk -= T;
+    const int tn = c + kk * S;
+    f4 p[PER], m[PER], v[PER];
+    long o[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int u = threadIdx.x + 512 * i, r = u / UPR, c4 = u % UPR;
+      const int row = tm * R + r, col = tn * C + 4 * c4;
+      o[i] = (row < H && col < F) ? ((long)row * ld + col) / 4 : -1;
+      if (o[i] >= 0) {
+        p[i] = __builtin_nontemporal_load((const f4*)W + o[i]);
+        m[i] = __builtin_nontemporal_load((const f4*)M + o[i]);
+        v[i] = __builtin_nontemporal_load((const f4*)V + o[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      if (o[i] < 0) continue;
+      __builtin_nontemporal_store(p[i], (f4*)W + o[i]);
+      __builtin_nontemporal_store(m[i], (f4*)M + o[i]);
+      __builtin_nontemporal_store(v[i], (f4*)V + o[i]);
+    }
+  }
+}
+
 // persistent runs (the fused kernel's schedule) over INTERLEAVED storage: mode 1 = W separate [H][ld], m / v interleaved per 128-float
 // segment ([H][F/128][2][128]: a tile row reads 1 KB contiguous of m | v); mode 2 = all three interleaved ([H][F/128][3][128]: 1.5 KB
 // contiguous per tile row, ONE read and ONE write stream).  Is it the number of streams that the pattern-sensitive boxes dislike?
@@ -353,6 +396,29 @@ int main(int argc, char** argv) {
       char name[128];
       snprintf(name, sizeof name, "persistent S=6, %4zu MB allocated in front (W at %p)", sh >> 20, (void*)w);
       run(name, [&] { hipLaunchKernelGGL((adam_runs<65536>), dim3(79 * 6), dim3(512), 0, 0, w, m, v, H, F, ld, 6, 0); });
+      CK(hipFree(w)); CK(hipFree(m)); CK(hipFree(v));
+      if (dummy) CK(hipFree(dummy));
+    }
+    return 0;
+  }
+  if (argc > 2 && !strcmp(argv[2], "rotate")) {
+    // `adamprobe r rotate`: placements as in `placement`; per placement the persistent pattern with the start tile of the runs rotated
+    CK(hipFree(W)); CK(hipFree(M)); CK(hipFree(V));
+    const size_t shifts[] = {0, 2u << 20, 6u << 20, 30u << 20, 126u << 20, 254u << 20, 510u << 20, (size_t)1022 << 20, (size_t)2046 << 20, 3u << 20, 100u << 20, 777u << 20};
+    for (size_t sh : shifts) {
+      char* dummy = nullptr;
+      if (sh) CK(hipMalloc(&dummy, sh));
+      float *w, *m, *v;
+      CK(hipMalloc(&w, bytes)); CK(hipMalloc(&m, bytes)); CK(hipMalloc(&v, bytes));
+      hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, w, (long)H * ld, 1u);
+      hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, m, (long)H * ld, 2u);
+      hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, v, (long)H * ld, 3u);
+      CK(hipDeviceSynchronize());
+      for (int rot = 0; rot < 4; ++rot) {
+        char name[128];
+        snprintf(name, sizeof name, "%4zu MB in front, XCD-contiguous S=6, rotation %d", sh >> 20, rot);
+        run(name, [&] { hipLaunchKernelGGL((adam_runs_rot<65536>), dim3(8 * 10 * 6), dim3(512), 0, 0, w, m, v, H, F, ld, 6, rot); });
+      }
       CK(hipFree(w)); CK(hipFree(m)); CK(hipFree(v));
       if (dummy) CK(hipFree(dummy));
     }
