@@ -172,10 +172,11 @@ def search_arrays(device, out: int, fin: int, want: int, tries: int, seed: int =
             t_it = time.perf_counter()
             sp_mb = 0
             if t:
-                # Allocating and releasing a spacer costs time in proportion to its size (seconds for tens of GB): the cap follows what
-                # is left of the budget at the rate observed so far (2 GB before anything has been observed).
+                # Allocating a spacer beyond ~2 GB costs time in proportion to its size (measured 50-65 ms per GB: 0.26 s for 4 GB, 0.82 s
+                # for 16 GB; below 2 GB it is free): the cap follows what is left of the budget at that rate, or at the rate observed
+                # in this search if that is worse.
                 left = max(budget - (t_it - t0), 0.0)
-                time_mb = int(0.5 * left / s_per_mb) if s_per_mb > 0 else 2048
+                time_mb = 2048 + int(0.5 * left / max(s_per_mb, 65e-6))
                 cap_mb = max(16, min(int(0.25 * free_b) >> 20, int(cap_gb * 1024), max(time_mb, 16)))
                 mb = fixed_mb[t] if t < len(fixed_mb) else int(np.exp(rs.uniform(np.log(4.0), np.log(float(cap_mb)))))
                 sp_mb = min(mb, cap_mb)
@@ -199,8 +200,8 @@ def search_arrays(device, out: int, fin: int, want: int, tries: int, seed: int =
             del spare[max(want - len(kept), 0):]       # only as many rejects as could still be needed stay alive
             if t:
                 torch.cuda.empty_cache()               # spacer and dropped rejects: back to the driver
-            if sp_mb >= 256:
-                s_per_mb = max(s_per_mb, (time.perf_counter() - t_it) / sp_mb)
+            if sp_mb > 2048:
+                s_per_mb = max(s_per_mb, (time.perf_counter() - t_it) / (sp_mb - 2048))
             if len(kept) >= want:
                 break
             if t + 1 >= tries:
