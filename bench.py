@@ -140,6 +140,9 @@ def parse():
     ap.add_argument("--repeats", type=int, default=25, help="after the timed region: this many more windows of --steps steps, "
                     "reported as median / min / max (0 = skip)")
     ap.add_argument("--no-other", action="store_true", help="skip the short legs of the other BASELINE configs / modes")
+    ap.add_argument("--dry", action="store_true", help="multi-GPU day-one check instead of the benchmark: cohort broadcast, ONE one-epoch "
+                    "trial per rank, all_gather of the records, winner broadcast -- prints the seconds of every phase and each rank's "
+                    "placement of the cfg2 weights (one JSON line from rank 0)")
     ap.add_argument("--no-pmc", action="store_true", help="do not re-run this script under rocprofv3 --pmc for roofline.traffic")
     ap.add_argument("--settle", type=int, default=40, help="untimed hipGraph replays before the --warmup steps (the first windows after "
                     "the captures run 3-5 %% slower while the clocks settle; reported as config.untimed_settle_steps)")
@@ -288,6 +291,35 @@ def main():
         cfg["layers"] = [(n, a.features) for n, _ in cfg["layers"]]
     B = a.batch
     spec = _spec_of(cfg)
+    if a.dry:
+        # every collective of the cfg5 path once, with the seconds of each phase, so that a first N-GPU run measures instead of debugging
+        from flexynesis_amd.sweep import run_cfg5
+        t0 = time.perf_counter()
+        st = ParamStore(spec, dev, materialize_big_grads=False)          # this rank's placement of the headline weights (search on)
+        mine = {"rank": rank, "device": torch.cuda.get_device_name(dev), "store_build_s": round(time.perf_counter() - t0, 3),
+                "placement": {k: {kk: v.get(kk) for kk in ("probed", "kept_TBps", "kept_us", "search_s")} for k, v in st.placement.items()}}
+        del st
+        with _stdout_to_stderr():
+            try:
+                sw = run_cfg5(dev, n_trials=world, epochs=1, features=cfg["layers"][0][1], samples=cfg["n_samples"], seed=1, keep_winner=True,
+                              force_collectives=use_pg, in_flight=1)
+            except Exception as e:
+                sw = {"error": repr(e)}
+            ranks = [mine]
+            if use_pg:
+                ranks = [None] * world
+                dist.all_gather_object(ranks, mine)
+        if rank == 0:
+            print(json.dumps({"dry": True, "n_gpus": world, "backend": backend if use_pg else None,
+                              "phases_s": {"cohort_generate": sw.get("cohort_generate_s"), "cohort_broadcast": sw.get("cohort_broadcast_s"),
+                                           **(sw.get("rank0_phases_s") or {}), "sweep_wall": sw.get("sweep_wall_s")},
+                              "trials_ok": sw.get("trials_ok"), "trial_val_losses": sw.get("trial_val_losses"),
+                              "winner_state_tensors": sw.get("winner_state_tensors"), "error": sw.get("error"),
+                              "failed_units_rank0": sw.get("failed_units_rank0"), "ranks": ranks}), flush=True)
+        if use_pg:
+            with _stdout_to_stderr():
+                dist.destroy_process_group()
+        return
     cohort = synthetic_cohort(cfg["layers"], cfg["n_samples"], dev, seed=1234 + rank)
     n_train = cfg["n_samples"] - int(cfg["n_samples"] * 0.2)           # 80/20 split, reference main.py:272-276
     rows_per_batch = B * (3 if cfg["model"] == "MultiTripletNetwork" else 1)

@@ -1784,9 +1784,14 @@ class StepPlan:
                     if prng is not None:
                         ops.fill_normal(rec, pr, prng[0], prng[1], ctrl=st.ctrl)
                     ops.mmd_rows(rec, rs, dzm if self.train else None, pr, z, lv_mmd, 1.0 / nd, overwrite=True)
+                # FX_VAE_MMD_LATE (default on, round 5): a later decoder's branch FIRST computes its hidden layer (so that its FC_output
+                # product is ready the moment decoder 0's ends: the MMD rows kernels, 60 us each beside a product, used to stand in
+                # front of it and the second product started 50 us late, profiles/r05_timeline_cfg3.txt), then its own MMD term under
+                # decoder 0's product; decoder 0's term goes to the END of the last branch, behind the reconstruction epilogue.
+                mmd_late = heads_aside and os.environ.get("FX_VAE_MMD_LATE", "1") != "0"
                 if heads_aside and i == 0:
                     deferred_mmd.append(mmd_term)
-                else:
+                elif not mmd_late:
                     mmd_term(rf)
                     if heads_aside and i == nd - 1:
                         for term in deferred_mmd:
@@ -1796,6 +1801,8 @@ class StepPlan:
                 if self.train and vae_par and i > 0 and os.environ.get("FX_VAE_PREP_X", "1") != "0":
                     # (beside decoder 0's FC_output product; decoder 0 itself heads the critical chain and prepares in the backward)
                     self._weight_grad_prep_x(rf, p + ".FC_output.weight", h)
+                if mmd_late and i > 0:
+                    mmd_term(rf)
                 lg = self._new(p + "/logits", B, F)
                 logits.append(lg)
                 wkey = p + ".FC_output.weight"
@@ -1820,6 +1827,9 @@ class StepPlan:
                     ops.recon_sigmoid(rf, rp, lg if self.train else None, self.xhat[i] if self.xhat else None, lg, self.X[dec[i]], lv_mmd,
                                       1.0 / nd)
                 rec_parts.append((rp, nblk))
+                if mmd_late and i == nd - 1:
+                    for term in deferred_mmd:
+                        term(rf)
                 if heads_aside and i == 0:
                     self._svae_heads(rf, z, dz)
         self._branch = 0

@@ -59,7 +59,20 @@ def run_cfg5(dev, n_trials: int = 64, epochs: int = 3, features: int = 20000, sa
     layers = [("gex", features), ("cnv", features)]
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    dat, ann = _cohort(layers, samples, dev, 1234) if rank == 0 else (None, None)
+    # (a rank that fails BEFORE a collective leaves the others waiting in it: rank 0 announces whether it has a cohort first, and
+    # every rank returns the same error record instead of entering the broadcast)
+    gen_err = None
+    try:
+        dat, ann = _cohort(layers, samples, dev, 1234) if rank == 0 else (None, None)
+    except Exception as e:
+        dat, ann, gen_err = None, None, repr(e)
+    if world > 1 or (force_collectives and dist.is_initialized()):
+        msg = [gen_err]
+        dist.broadcast_object_list(msg, src=0)
+        gen_err = msg[0]
+    if gen_err is not None:
+        return {"error": f"rank 0 could not build the cohort: {gen_err}", "n_gpus": world, "trials": int(n_trials), "trials_ok": 0,
+                "trial_val_losses": [float("inf")] * int(n_trials), "aggregate_samples_per_s": 0.0}
     torch.cuda.synchronize(dev)
     t_gen = time.perf_counter() - t0
     t0 = time.perf_counter()
@@ -81,6 +94,10 @@ def run_cfg5(dev, n_trials: int = 64, epochs: int = 3, features: int = 20000, sa
             stats["samples"] += info["steps"] * int(params["batch_size"])
             stats["busy"] += time.perf_counter() - t
 
+    # device memory of the largest trial: 12 B per parameter (weights + Adam moments) and the split operands / activations on top
+    specs = [spec_from_dataset("DirectPred", p, ds, ["y"]) for p in plist]
+    unit_bytes = 1.25 * 12.0 * max(sp.param_count() for sp in specs) + (1 << 30)
+    phases: dict = {}
     t1 = time.perf_counter()
     if not use_cv:
         n_val = int(samples * 0.2)
@@ -103,7 +120,8 @@ def run_cfg5(dev, n_trials: int = 64, epochs: int = 3, features: int = 20000, sa
             return val, ep, sd
 
         table, best, state = trials.run_sweep(plist, trial_fn, costs, dev, shapes_of if keep_winner else None,
-                                              schedule=schedule, force_collectives=force_collectives, in_flight=in_flight)
+                                              schedule=schedule, force_collectives=force_collectives, in_flight=in_flight,
+                                              unit_bytes=unit_bytes, timings=phases)
         trial_vals = table[:, 1]
         ok = table[:, 3] == trials.STATUS_OK
     else:
@@ -122,7 +140,7 @@ def run_cfg5(dev, n_trials: int = 64, epochs: int = 3, features: int = 20000, sa
             return val, ep, None
 
         utable, _ = trials.run_units(len(units), unit_fn, costs, dev, keep=[], schedule=schedule, force_collectives=force_collectives,
-                                     in_flight=in_flight)
+                                     in_flight=in_flight, unit_bytes=unit_bytes, timings=phases)
         per_trial = utable[:, 1].reshape(n_trials, n_splits)
         trial_vals = per_trial.mean(axis=1)                       # main.py:327-333: the mean over the folds
         trial_eps = utable[:, 2].reshape(n_trials, n_splits).mean(axis=1).astype(int)
@@ -159,6 +177,7 @@ def run_cfg5(dev, n_trials: int = 64, epochs: int = 3, features: int = 20000, sa
         "trial_val_losses": [float(v) for v in trial_vals],
         "winner_state_tensors": len(state) if state is not None else 0,
         "cohort_generate_s": round(t_gen, 4), "cohort_broadcast_s": round(t_bcast, 4),
+        "rank0_phases_s": phases, "failed_units_rank0": dict(trials.LAST_ERRORS),
         "sweep_wall_s": round(float(allr[:, 1].max()), 3),
         "aggregate_samples_per_s": round(float(allr[:, 0].sum()) / float(allr[:, 1].max()), 1),
         "rank_busy_s": [round(float(b), 3) for b in busy],

@@ -211,9 +211,12 @@ class _Claims:
             yield self.order[k]
 
 
+LAST_ERRORS: Dict[int, str] = {}      # unit id -> repr of the exception that made it report +inf (this rank, the most recent run_units call)
+
+
 def run_units(n: int, unit_fn: Callable[[int], Tuple[float, int, Optional[dict]]], costs: Optional[Sequence[float]] = None,
               device="cpu", keep: Optional[Sequence[int]] = None, schedule: str = "queue", force_collectives: bool = False,
-              in_flight: int = 1):
+              in_flight: int = 1, unit_bytes: Optional[float] = None, timings: Optional[dict] = None):
     """Run units 0..n-1 (HPO trials, cross-validation folds, fine-tuning fits) sharded over the ranks:
     ``unit_fn(uid) -> (val_loss, epochs, state_dict | None)``.  Returns (table [n, 5]: uid, val_loss, epochs, status,
     rank that ran it; local: {uid: state} of the units this rank must hold on to).  ``keep`` = unit ids whose state is
@@ -224,7 +227,13 @@ def run_units(n: int, unit_fn: Callable[[int], Tuple[float, int, Optional[dict]]
     (eager launches: the units must not capture hipGraphs -- ``fit(use_graph=False)``).  One unit's latency-bound launches
     then run while the other's HBM-bound dW + Adam launches hold the memory system: +10 % aggregate samples/s at two units
     in flight on cfg5-style trials (scripts/bench_two_trials.py); the units' results are unchanged (every unit is seeded
-    on its own and deterministic)."""
+    on its own and deterministic).  ``unit_bytes``: device memory the LARGEST unit needs (weights, Adam moments, activations);
+    the number of units in flight is lowered until that many of them fit into 80 % of what is free now.
+    ``timings``, if given, receives {"units_s", "gather_s"} of this rank.  The exception behind a unit that reported +inf is kept in
+    ``trials.LAST_ERRORS`` (and warned about once per call)."""
+    import time as _time
+    import warnings
+    LAST_ERRORS.clear()
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     costs = list(costs) if costs is not None else [1.0] * n
@@ -238,6 +247,14 @@ def run_units(n: int, unit_fn: Callable[[int], Tuple[float, int, Optional[dict]]
     claims = iter(_Claims(costs, world, rank, schedule))
     lock = threading.Lock()
     dev = torch.device(device)
+    if int(in_flight) > 1 and unit_bytes and dev.type == "cuda":
+        free_b = torch.cuda.mem_get_info(dev)[0]
+        fit_n = max(int(0.8 * free_b // max(float(unit_bytes), 1.0)), 1)
+        if fit_n < int(in_flight):
+            warnings.warn(f"run_units: {in_flight} units in flight need ~{in_flight * unit_bytes / 2**30:.1f} GiB, {free_b / 2**30:.1f} GiB "
+                          f"are free: running {fit_n} at a time", RuntimeWarning, stacklevel=2)
+            in_flight = fit_n
+    t_units = _time.perf_counter()
 
     def worker(own_stream: bool):
         if dev.type == "cuda":
@@ -259,8 +276,10 @@ def run_units(n: int, unit_fn: Callable[[int], Tuple[float, int, Optional[dict]]
                     val, epochs, state = unit_fn(uid)
                     status = STATUS_OK if (val == val and math.isfinite(val)) else STATUS_FAILED
                     val = val if status == STATUS_OK else float("inf")
-                except Exception:                      # a broken unit reports +inf; the sweep goes on
+                except Exception as e:                 # a broken unit reports +inf; the sweep goes on
                     val, epochs, state, status = float("inf"), 0, None, STATUS_FAILED
+                    with lock:
+                        LAST_ERRORS[uid] = repr(e)
                 with lock:
                     local.append((uid, float(val), int(epochs), status))
                     if state is not None and status == STATUS_OK:
@@ -281,7 +300,15 @@ def run_units(n: int, unit_fn: Callable[[int], Tuple[float, int, Optional[dict]]
             t.start()
         for t in threads:
             t.join()
+    if LAST_ERRORS:
+        uid0 = sorted(LAST_ERRORS)[0]
+        warnings.warn(f"run_units: {len(LAST_ERRORS)} unit(s) failed on rank {rank} and report +inf; unit {uid0}: {LAST_ERRORS[uid0]}",
+                      RuntimeWarning, stacklevel=2)
+    t_gather = _time.perf_counter()
     table = gather_results(local, n, device, rank, force_collectives)
+    if timings is not None:
+        timings["units_s"] = round(t_gather - t_units, 4)
+        timings["gather_s"] = round(_time.perf_counter() - t_gather, 4)
     return table, held
 
 
@@ -303,20 +330,25 @@ def agree_and_broadcast_state(held: Dict[int, dict], uid: int, table: np.ndarray
 
 def run_sweep(param_list: List[dict], trial_fn: Callable[[int, dict], Tuple[float, int, Optional[dict]]],
               costs: Optional[Sequence[float]] = None, device="cpu", state_shapes: Optional[Dict[str, tuple]] = None,
-              schedule: str = "queue", force_collectives: bool = False, in_flight: int = 1):
+              schedule: str = "queue", force_collectives: bool = False, in_flight: int = 1, unit_bytes: Optional[float] = None,
+              timings: Optional[dict] = None):
     """Shard ``param_list`` over the ranks, run ``trial_fn(trial_id, params) -> (val_loss, epochs, state_dict)``
     locally, gather the result table, and (if ``state_shapes`` is given) broadcast the winner's weights.
     ``state_shapes`` may be a dict (all trials share one architecture) or a callable ``params -> {key: shape}``
     (HPO: latent size / hidden factor differ per trial, so the winner's layout is derived from its parameters on
     every rank).  Returns (table [n, 5], best_trial_id, best_state or None)."""
     n = len(param_list)
+    import time as _time
     table, held = run_units(n, lambda uid: trial_fn(uid, param_list[uid]), costs, device, keep=None, schedule=schedule,
-                            force_collectives=force_collectives, in_flight=in_flight)
+                            force_collectives=force_collectives, in_flight=in_flight, unit_bytes=unit_bytes, timings=timings)
     best = int(np.argmin(table[:, 1]))
     best_state = None
+    t0 = _time.perf_counter()
     if state_shapes is not None and math.isfinite(table[best, 1]):
         shapes = state_shapes(param_list[best]) if callable(state_shapes) else state_shapes
         best_state = agree_and_broadcast_state(held, best, table, shapes, device, force_collectives)
+    if timings is not None:
+        timings["winner_broadcast_s"] = round(_time.perf_counter() - t0, 4)
     return table, best, best_state
 
 

@@ -1,16 +1,16 @@
 # Round-end evidence: bench line, rocprofv3 kernel-trace stats per config, PMC traffic (FETCH_SIZE / WRITE_SIZE, separate passes).
 # usage (on the GPU box): bash scripts/profile_round.sh <tag>     -> gpurun_out/<tag>/
 set -x
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r04}; rm -rf $O; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r05}; rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
 cd $R
-bash scripts/boxinfo.sh ${1:-r04}/box > /dev/null 2>&1
+bash scripts/boxinfo.sh ${1:-r05}/box > /dev/null 2>&1
 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
-Q="--no-cpu-baseline --sweep-trials-per-gpu 0 --no-other --repeats 0"
+Q="--no-cpu-baseline --sweep-trials-per-gpu 0 --no-other --repeats 0 --no-pmc"
 for c in cfg2 cfg3 cfg4; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$c -- python bench.py --config $c --steps 40 --warmup 5 $Q > $O/bench_prof_$c.json 2> $O/bench_prof_$c.err
 done
-for c in cfg2 cfg4; do
+for c in cfg2 cfg3 cfg4; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_$c -- python bench.py --config $c --steps 6 --warmup 2 --no-graph $Q > $O/pmc_fetch_$c.json 2> $O/pmc_fetch_$c.err
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_$c -- python bench.py --config $c --steps 6 --warmup 2 --no-graph $Q > $O/pmc_write_$c.json 2> $O/pmc_write_$c.err
   cp $(find $O/pmc_fetch_$c -name "*counter_collection.csv" | head -1) $O/pmc_fetch_$c.csv

@@ -21,6 +21,7 @@ pytestmark = pytest.mark.gpu
     (7500, 30000, 384, 384),      # cfg4 shape
     (33000, 512, 64, 64),         # > 32768 rows: an XCD's share of row blocks exceeds its 64 slots (the XCD-contiguous mapping must stand down)
     (40100, 260, 32, 200),        # the same with ragged edges and two M-tiles of the next batch
+    (40000, 20000, 128, 128),     # hidden_dim_factor 2 on a 20 k-feature layer (the upper end of the shipped HPO configuration): 3.2 GB per array
 ])
 def test_dw_adam_fwd_matches_the_kernels_it_replaces(n_out, k_in, B, Bn):
     from flexynesis_amd import ops

@@ -222,7 +222,8 @@ def test_timed_schedule_vs_oracle_cfg2(name):
     assert pipe.graphs[0] is not None and pipe.done == 5
 
 
-@pytest.mark.parametrize("n_out,k_in,K", [(5000, 20000, 128), (7500, 30000, 384)])
+@pytest.mark.parametrize("n_out,k_in,K", [(5000, 20000, 128), (7500, 30000, 384),
+                                          (40000, 20000, 128)])      # hidden_dim_factor 2 (examples/configs/hpo_configuration.yaml:7): 3.2 GB per array
 def test_dominant_kernel_fullsize_vs_fp64(n_out, k_in, K):
     """fx_linear_dw_adam_bf16x3 at the cfg2 and cfg4 weight shapes (cfg4: K = 3B = 384 and an 11.5 MB dY^T operand, so
     the XCD-partitioned tile order engages by itself) against dW, m, v, W computed in fp64."""
@@ -611,6 +612,27 @@ def test_bench_with_forced_process_group_reports_sweep_object(tmp_path):
     sw = out["sweep"]
     assert "error" not in sw, sw
     assert sw["trials"] == 3 and sw["trials_ok"] == 3 and sw["winner_state_tensors"] > 10 and sw["aggregate_samples_per_s"] > 0
+
+
+def test_bench_dry_mode_runs_every_collective_once_and_reports_phases():
+    """`bench.py --gpus N --dry` (here N = 1 with the RCCL group forced): cohort broadcast, one 1-epoch trial per rank, all_gather of the
+    records, winner broadcast; one JSON line with the seconds of every phase and each rank's placement of the headline weights."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FX_BENCH_FORCE_PG="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dry", "--features", "3000"],
+                       capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["dry"] and out["n_gpus"] == 1 and out["error"] is None and out["trials_ok"] == 1 and out["winner_state_tensors"] > 10
+    ph = out["phases_s"]
+    assert all(ph[k] is not None and ph[k] >= 0 for k in ("cohort_generate", "cohort_broadcast", "units_s", "gather_s", "winner_broadcast_s", "sweep_wall"))
+    assert len(out["ranks"]) == 1 and out["ranks"][0]["rank"] == 0 and "placement" in out["ranks"][0]
 
 
 def test_integration_md_ctypes_binding_runs_as_written():
