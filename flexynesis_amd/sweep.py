@@ -168,6 +168,18 @@ def run_cfg5(dev, n_trials: int = 64, epochs: int = 3, features: int = 20000, sa
     else:
         allr = mine.cpu().numpy()[None]
     busy = allr[:, 2]
+    # What the trial list allows at best on this many GPUs: every optimisation step streams the trial's wide weights and Adam moments
+    # once (24 B per parameter) and every validation chunk its weights (4 B), at the rate the dominant kernel reaches on a fast
+    # placement (5.4 TB/s, bench.py roofline.achieved), nothing else costs anything, the ranks are perfectly balanced.
+    n_tr, n_va = samples - int(samples * 0.2), int(samples * 0.2)
+    stream_s, stream_samples = 0.0, 0
+    for sp, p_ in zip(specs, plist):
+        bsz = int(p_["batch_size"])
+        wide = float(sum(int(np.prod(shp)) for k, shp in sp.state_shapes().items() if len(shp) == 2 and int(np.prod(shp)) >= (1 << 20)))
+        steps = int(p_["epochs"]) * (n_tr // bsz) * (n_splits if use_cv else 1)
+        vals = (int(p_["epochs"]) + 1) * (-(-n_va // 64)) * (n_splits if use_cv else 1)
+        stream_s += (steps * 24.0 + vals * 4.0) * wide / 5.4e12
+        stream_samples += steps * bsz
     return {
         "workload": f"cfg5: {n_trials} DirectPred trials (2 x {features} features, N={samples}, {epochs} epochs"
                     + (f", {n_splits}-fold CV + final model on all samples" if use_cv else "") + f"), "
@@ -180,6 +192,9 @@ def run_cfg5(dev, n_trials: int = 64, epochs: int = 3, features: int = 20000, sa
         "rank0_phases_s": phases, "failed_units_rank0": dict(trials.LAST_ERRORS),
         "sweep_wall_s": round(float(allr[:, 1].max()), 3),
         "aggregate_samples_per_s": round(float(allr[:, 0].sum()) / float(allr[:, 1].max()), 1),
+        "stream_bound_samples_per_s": round(world * stream_samples / max(stream_s, 1e-9), 1),
+        "stream_bound_note": "trial list's steps x batch over the time to stream every step's wide weights + Adam moments (24 B/param; validation "
+                             "4 B/param) at 5.4 TB/s, no fixed cost per step or trial, perfect balance over the ranks",
         "rank_busy_s": [round(float(b), 3) for b in busy],
         "busy_over_wall": round(float(busy.sum()) / (world * max(int(in_flight), 1) * max(float(allr[:, 1].max()), 1e-9)), 4),
         "tail_imbalance": round(1.0 - float(busy.mean()) / max(float(busy.max()), 1e-9), 4),
