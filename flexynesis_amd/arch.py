@@ -100,20 +100,24 @@ class ArchSpec:
 
     # -- engine layout -----------------------------------------------------------------------------
     # The engine's kernels move rows of activations and weights in 16-byte units, so it runs every model with its HIDDEN widths
-    # (int(F * hidden_dim_factor): any integer, direct_pred.py:78-80) and -- for the MLP family -- its INPUT widths (the feature
-    # count of a cohort layer: any integer, data.py:358-503) rounded up to multiples of 4.  The extra hidden units / input
+    # (int(F * hidden_dim_factor): any integer, direct_pred.py:78-80) and the INPUT widths of its encoders (the feature count of a
+    # cohort layer: any integer, data.py:358-503) rounded up to multiples of 4 (a layer the VAE family reconstructs keeps its width
+    # as a TARGET: rows of FC_output; the engine holds a second, unpadded copy of such a batch).  The extra hidden units / input
     # columns are inert: their weights, biases and BatchNorm affine parameters are zero, so they output zero, receive exactly
     # zero gradients (every product that reaches them has a zero factor) and Adam leaves them at zero; nothing of them is
     # visible in ``state_dict`` (``state_shapes`` stays the reference's ABI, ParamStore exposes logical views).
     @property
     def pads_features(self) -> bool:
-        return self.model in ("DirectPred", "MultiTripletNetwork")
+        return self.model != "GNN"
 
     def engine_hidden(self, i: int) -> int:
         return pad4(self.hidden(i)) if (self.model != "GNN" and _ENGINE_PAD) else self.hidden(i)
 
     def engine_features(self, i: int) -> int:
-        return pad4(self.layers[i][1]) if (self.pads_features and _ENGINE_PAD) else self.layers[i][1]
+        """Width of cohort layer i as an ENCODER input (a layer that is only reconstructed keeps its width)."""
+        if not (self.pads_features and _ENGINE_PAD) or (self.is_vae and i not in self.enc_idx):
+            return self.layers[i][1]
+        return pad4(self.layers[i][1])
 
     def engine_shapes(self) -> Dict[str, Tuple[int, ...]]:
         """The shapes the engine computes with: ``state_shapes`` with hidden / encoder-input widths rounded up to 4."""

@@ -604,6 +604,12 @@ class StepPlan:
             self.epoch_acc = torch.zeros(n_terms + 2, **f) if epoch_acc else None
             self.idx = torch.zeros(max(self.R, 1) * max(self.n_batches, 1), dtype=torch.int64, device=self.dev)
         self.X = [torch.zeros(self.R, spec.engine_features(i), **f) for i in range(len(spec.layers))]   # (engine width: pad columns stay zero)
+        # reconstruction targets of the VAE family: the batch at the layer's own width, contiguous -- X itself unless the encoder input is padded
+        self.Xt = list(self.X)
+        if spec.is_vae:
+            for i in spec.dec_idx:
+                if self.X[i].shape[1] != spec.layers[i][1]:
+                    self.Xt[i] = torch.zeros(self.R, spec.layers[i][1], **f)
         self.y: Dict[str, torch.Tensor] = {}
         for (v, _, _) in spec.variables:
             self.y[v] = torch.zeros(self.B, **f)
@@ -1300,6 +1306,9 @@ class StepPlan:
                     self._want_gram(rg, self.X[i], wk, self.R, self.passes)   # batch-only half of the Gram norm: part of batch assembly
                     self._branch = 0
             gpar.branch(0)
+            for i, (name, F) in enumerate(spec.layers):
+                if self.Xt[i] is not self.X[i]:          # a padded encoder input that is a reconstruction target as well
+                    ops.gather_rows(rg, self.Xt[i], self.cohort.source(name, F), self.idx, cur, self.R)
             for k, t in self.y.items():      # labels of the anchors = first B indices of each batch row block
                 ops.gather_rows(rg, t, self.cohort.ann[k], self.idx, cur, self.R)
             gpar.__exit__(None, None, None)
@@ -1811,7 +1820,7 @@ class StepPlan:
                 # gram_after: the batch-only Gram factor FC_output's optimiser step needs is the un-reduced one _weight_grad asks for
                 # (_gram_x_for), not the reduced [B, B] one fx_block_bwd consumes -- _want_gram made the latter here, unused.
                 epi = None
-                if (self.train and F % 4 == 0 and self.X[dec[i]].is_contiguous() and not self._is_frozen(wkey)
+                if (self.train and F % 4 == 0 and self.Xt[dec[i]].is_contiguous() and not self._is_frozen(wkey)
                         and os.environ.get("FX_RECON_EPILOGUE", "1") != "0"):
                     epi = self._lin_fwd(rf, lg, h, wkey, p + ".FC_output.bias", raw_slabs=True, gram_after=True)
                 if epi is not None:
@@ -1819,12 +1828,12 @@ class StepPlan:
                     self.buf[f"dy_kb/{wkey}"], self.buf[f"dy_kb_lo/{wkey}"] = dsp
                     nblk = ops.recon_sigmoid_slabs_blocks(B, F)
                     rp = self._new(f"recon_part.{i}", nblk)
-                    ops.recon_sigmoid_slabs(rf, rp, lg, dsp, epi[0], epi[1], st.ep(p + ".FC_output.bias"), self.X[dec[i]], lv_mmd, 1.0 / nd)
+                    ops.recon_sigmoid_slabs(rf, rp, lg, dsp, epi[0], epi[1], st.ep(p + ".FC_output.bias"), self.Xt[dec[i]], lv_mmd, 1.0 / nd)
                 else:
                     self._lin_fwd(rf, lg, h, wkey, p + ".FC_output.bias", gram_after=True)
                     nblk = int(ops.lib.fx_recon_blocks(B * F))
                     rp = self._new(f"recon_part.{i}", 1024)
-                    ops.recon_sigmoid(rf, rp, lg if self.train else None, self.xhat[i] if self.xhat else None, lg, self.X[dec[i]], lv_mmd,
+                    ops.recon_sigmoid(rf, rp, lg if self.train else None, self.xhat[i] if self.xhat else None, lg, self.Xt[dec[i]], lv_mmd,
                                       1.0 / nd)
                 rec_parts.append((rp, nblk))
                 if mmd_late and i == nd - 1:
@@ -2030,6 +2039,8 @@ class StepPlan:
         elif x_list is not None:
             for i, x in enumerate(x_list):
                 self.X[i][:, :x.shape[1]].copy_(x, non_blocking=True)      # (the engine's buffer may be wider: zero pad columns)
+                if self.Xt[i] is not self.X[i]:
+                    self.Xt[i].copy_(x, non_blocking=True)
         if y is not None:
             for k, t in self.y.items():
                 t.copy_(torch.as_tensor(y[k]).to(torch.float32), non_blocking=True)

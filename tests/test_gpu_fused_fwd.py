@@ -107,6 +107,10 @@ def test_dw_adam_fwd_argument_checks():
     ("DirectPred", [("gex", 2600), ("cnv", 2200)], 128),
     ("DirectPred", [("gex", 4100), ("cnv", 3000)], 37),              # ragged batch: rows padded to 128 / 64
     ("supervised_vae", [("gex", 2600), ("cnv", 2200)], 64),          # encoders fused, decoders (activations as input) not
+    ("supervised_vae", [("gex", 2601), ("cnv", 2200)], 64),          # an odd feature count: encoder input padded inside the engine, target kept at F
+                                                                     # ((2601, 2203) is bit-reproducible either way and agrees to 1e-7 for two steps, then its
+                                                                     # fused / unfused trajectories separate to 8e-4 by step 9: Adam)
+    ("DirectPred", [("gex", 2601), ("cnv", 2203)], 100),             # ... and for the MLP family (hidden 650 / 550 -> 652 / 552)
     ("DirectPred", [("gex", 20000), ("cnv", 20000)], 128),           # cfg2: the shape bench.py times
     ("MultiTripletNetwork", [("gex", 2600), ("cnv", 2200)], 96),     # 3 B = 288 stacked rows: three M-tiles
 ])
