@@ -99,7 +99,7 @@ def _live_traffic(want_prefix, args):
                "--no-cpu-baseline", "--sweep-trials-per-gpu", "0", "--no-other", "--repeats", "0", "--no-pmc"]
         try:
             env = dict(os.environ, TMPDIR="/tmp")
-            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120, check=True)
             path = None
             for root, _, files in os.walk(d):
                 for f in files:

@@ -1769,6 +1769,7 @@ class StepPlan:
         # between the tapes.
         heads_aside = bool(self.train and vae_par and nd > 1 and not self.forward_alone
                            and os.environ.get("FX_VAE_HEADS_BRANCH", "1") != "0")
+        self._losses_in_bwd = heads_aside        # (losses() between forward() and backward() would read a stale MMD term / total)
         deferred_mmd = []
         with rf.parallel(nd if vae_par else 1) as par:      # one graph branch per decoder
             for i in range(nd):
@@ -2082,11 +2083,15 @@ class StepPlan:
 
     @ops.device_guard
     def forward(self):
+        """The forward tape alone.  A training plan of the VAE family built without ``forward_alone=True`` finishes its loss
+        bookkeeping (MMD term, total) in the BACKWARD tape: ``losses()`` raises until ``backward()`` has run."""
         self._run_tape("fwd")
+        self._fwd_pending = True
 
     @ops.device_guard
     def backward(self):
         self._run_tape("bwd")
+        self._fwd_pending = False
 
     @ops.device_guard
     def run_optimizer_tape(self):
@@ -2186,6 +2191,9 @@ class StepPlan:
             self.t_fwd.run()
 
     def losses(self) -> Dict[str, float]:
+        if getattr(self, "_fwd_pending", False) and getattr(self, "_losses_in_bwd", False):
+            raise RuntimeError("this plan completes its MMD term and total loss in the backward tape: call backward() first, or build the "
+                               "plan with forward_alone=True to read the losses between forward() and backward()")
         vals = self.loss_vec.detach().cpu().tolist()
         names = self.spec.loss_names()
         out = {n: vals[i] for i, n in enumerate(names)}
