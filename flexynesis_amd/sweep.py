@@ -40,7 +40,7 @@ def _cohort(layers, n, device, seed):
 
 def run_cfg5(dev, n_trials: int = 64, epochs: int = 3, features: int = 20000, samples: int = 2048, seed: int = 0,
              keep_winner: bool = True, schedule: str = "queue", force_collectives: bool = False, use_cv: bool = False,
-             n_splits: int = 5, in_flight: int = 2, use_graph: Optional[bool] = None) -> dict:
+             n_splits: int = 5, in_flight: Optional[int] = None, use_graph: Optional[bool] = None) -> dict:
     """The cfg5 workload on the CURRENT process group (or a single process): rank 0 builds the synthetic cohort and
     broadcasts it, the trials are claimed longest-first from a counter shared by the ranks (``schedule="static"``: the
     LPT assignment computed up front), every rank runs its trials with the engine loop, one all_gather collects the
@@ -50,6 +50,11 @@ def run_cfg5(dev, n_trials: int = 64, epochs: int = 3, features: int = 20000, sa
     ``in_flight`` trials run concurrently on every GPU (host threads with their own streams, eager launches:
     trials.run_units); ``use_graph`` (default: only with one trial in flight) replays hipGraphs inside a trial.
     Returns the summary dict (identical on every rank)."""
+    world0 = dist.get_world_size() if dist.is_initialized() else 1
+    if in_flight is None:
+        # four trials in flight per GPU when a rank has at least two rounds of them (8 trials per GPU: 27.0-29.2 k samples/s with two in
+        # flight, 26.9-29.4 k with three, 28.4-30.5 k with four, scripts/sweep_inflight_ab.py), fewer for short lists (tail imbalance)
+        in_flight = max(1, min(4, (int(n_trials) * (n_splits if use_cv else 1)) // (2 * world0)))
     use_graph = (int(in_flight) <= 1) if use_graph is None else bool(use_graph)
     if int(in_flight) > 1 and use_graph:
         raise ValueError("trials in flight on several threads must not capture hipGraphs: use_graph=False")
@@ -210,7 +215,7 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cv", type=int, default=0, help="k > 1: k-fold cross-validated trials (units = trial x fold)")
     ap.add_argument("--schedule", default="queue", choices=["queue", "static"])
-    ap.add_argument("--in-flight", type=int, default=2, help="trials running concurrently per GPU (host threads, eager launches)")
+    ap.add_argument("--in-flight", type=int, default=0, help="trials running concurrently per GPU (host threads, eager launches); 0 = up to four")
     a = ap.parse_args(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -224,7 +229,7 @@ def main(argv=None):
         else:
             dist.init_process_group("nccl", device_id=dev)
     out = run_cfg5(dev, a.trials, a.epochs, a.features, a.samples, a.seed, schedule=a.schedule, use_cv=a.cv > 1,
-                   n_splits=max(a.cv, 2), in_flight=a.in_flight)
+                   n_splits=max(a.cv, 2), in_flight=a.in_flight or None)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

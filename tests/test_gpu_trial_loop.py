@@ -208,3 +208,43 @@ def test_fine_tune_matches_the_reference_run_experiments_golden(use_graph):
     for k in last:                                    # the final fit froze the supervisors: untouched since the last fold's fit
         if k.startswith("MLPs.") and not k.endswith(("running_mean", "running_var", "num_batches_tracked")):
             assert float((sd[k].cpu() - last[k]).abs().max()) <= 4.0 * G.lrs[-1] * (G.max_epoch * 3) ** 0.5, k
+
+
+def test_validation_in_wide_chunks_is_the_same_number(monkeypatch):
+    """fit() validates a DirectPred model without survival head in chunks of 128 rows instead of batch_size when no validation row has a
+    missing label: the size-weighted average of per-batch means (Lightning's epoch reduction, main.py:323) is then the mean over all rows,
+    whatever the chunking.  Same val losses as with the reference's chunks; a missing label keeps the reference's chunks."""
+    import flexynesis_amd.models as M
+    from flexynesis_amd import fit as F
+    from test_gpu_api import _synthetic_ds
+    ds = _synthetic_ds(n=600, F=(301, 203), seed=2)
+    cfg = {"latent_dim": 17, "hidden_dim_factor": 0.3, "lr": 2e-3, "supervisor_hidden_dim": 9, "epochs": 3, "batch_size": 32}
+    tr, va = F.split_indices(len(ds), 0.2, 1)
+    seen = []
+    real = F._eval_loss
+
+    def spy(model, store, cohort, idx_rows, batch_size, *a, **k):
+        seen.append(int(batch_size))
+        return real(model, store, cohort, idx_rows, batch_size, *a, **k)
+    monkeypatch.setattr(F, "_eval_loss", spy)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FX_VAL_CHUNK", mode)
+        torch.manual_seed(3)
+        m = M.DirectPred(cfg, ds, ["y", "c"], device_type="cuda")
+        seen.clear()
+        res = F.fit(m, ds, tr, va, batch_size=32, epochs=3, lr=2e-3, seed=5)
+        out[mode] = ([h["val_loss"] for h in res.history] + [res.val_loss], sorted(set(seen)))
+    assert out["1"][1] == [128] and out["0"][1] == [32]
+    for a, b in zip(out["1"][0], out["0"][0]):
+        assert abs(a - b) <= 2e-6 * abs(b) + 1e-7, (out["1"][0], out["0"][0])
+    # a missing validation label: per-batch masked means weighted by batch size are not a global mean -> the reference's chunks stay
+    monkeypatch.setenv("FX_VAL_CHUNK", "1")
+    ds2 = _synthetic_ds(n=600, F=(301, 203), seed=2)              # (a fresh dataset object: the resident cohort of `ds` is cached)
+    ds2.ann["y"] = torch.as_tensor(ds2.ann["y"]).clone()
+    ds2.ann["y"][va[3]] = float("nan")
+    torch.manual_seed(3)
+    m = M.DirectPred(cfg, ds2, ["y", "c"], device_type="cuda")
+    seen.clear()
+    F.fit(m, ds2, tr, va, batch_size=32, epochs=1, lr=2e-3, seed=5)
+    assert sorted(set(seen)) == [32]
