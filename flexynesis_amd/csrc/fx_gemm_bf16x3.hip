@@ -734,6 +734,182 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// ---- stacked-rows forward, fourth design (round 5): X never enters the LDS ----------------------------------------------------------
+// profiles/r05_fwd_mt_power.txt: the DMA kernel above is LDS-bound on zeros (8 ds_read_b128 per 6 MFMA = 50 LDS cycles per 32-cycle MFMA,
+// measured 56) and POWER-bound on real operands (1400 W, 1.73 GHz).  Both say the same thing: move fewer bytes per product.  Here wave w
+// of eight owns rows 16 R w .. 16 R (w + 1) of the tile and ALL 128 columns, on v_mfma_f32_16x16x32_bf16 (one MFMA contracts a whole
+// 32-k block; same rate as 32x32x16):
+//  * its X fragments are shared with no other wave, so they go L2 -> registers directly, one block ahead: with 16-row MFMAs a fragment load is
+//    16 rows x 64 B of the K-blocked split = 1 KB contiguous.  No X in the LDS at all (it was 96 of the 128 KB written per 64 k);
+//  * W (the only operand the eight waves share) is loaded coalesced four blocks ahead, split once two blocks ahead, written as (hi, lo)
+//    fragments to one of three 16.5 KB buffers: one barrier per 32 k, and nothing right behind it waits for the LDS (the fragments of the
+//    next block's first half are read during this block's second half);
+//  * per block a wave reads 16 fragments of W for 24 R MFMAs (R = 3: 4.5 MFMA per ds_read_b128, at half the flops each; the DMA kernel: 0.75).
+// (A first version with FOUR waves, one per SIMD on 32x32x16 MFMAs and 96 x 128 per wave, ran 428 us on zeros / 509 on random operands at
+// the triplet shape against 396 / 565 shipped: with one wave per SIMD every load instruction's issue stalls the MFMA stream behind it --
+// timing ablations: no X loads 293 us, no W loads 335, no barrier 354, MFMAs alone 271 on zeros and 335 on random operands.)
+#define MFMA16_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+template <int R, int NT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void fx_fwd_bf16x3_reg_kernel(XGemmArgs g) {
+  constexpr int ROWS = 128 * R;                 // batch rows per workgroup: 8 waves x 16 R
+  constexpr int PLANE = 2048 + 64;              // one 8-k chunk of all 128 columns (16 B each) + a 16-bank shift per chunk: the split's 8-byte
+                                                // stores of 4 columns x 4 chunks (32 lanes) land on 64 distinct banks
+  constexpr int HALFB = 4 * PLANE, BUF = 2 * HALFB;
+  __shared__ __attribute__((aligned(16))) char smem[3 * BUF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int groups_m = (g.M + ROWS - 1) / ROWS;
+  int lin = blockIdx.x;
+  const int z = lin % g.splitk;
+  lin /= g.splitk;
+  const int gm = lin % groups_m, tn = lin / groups_m;
+  const int m0 = gm * ROWS + w * 16 * R, n0 = tn * 128;
+  const int k_begin = z * g.kchunk;
+  const int k_end = min(g.K, k_begin + g.kchunk);
+  const int nb = (k_end > k_begin) ? (k_end - k_begin) / TK : 0;
+  const __amdgpu_buffer_rsrc_t rAh = fx_rsrc(g.Ahi, (long)g.K * g.a_rp * 2), rAl = fx_rsrc(g.Alo, (long)g.K * g.a_rp * 2);
+  const __amdgpu_buffer_rsrc_t rB = fx_rsrc_uniform(g.Bf + (long)n0 * g.ldb, (long)max(min(128, g.N - n0), 0) * g.ldb * 4);   // rebased: W may exceed 4 GiB
+  // X fragment of row block r of block j: row m0 + 16 r + l15, 16-byte chunk kq of the row's 64 bytes
+  const unsigned a_src = (unsigned)(((long)(m0 + l15) * TK + 8 * kq) * 2);
+  const unsigned a_step = (unsigned)g.a_rp * (TK * 2u), a_kb = (unsigned)(k_begin / TK) * a_step;
+  // W: 8 lanes x 16 B = the 128 bytes a row contributes to a block; thread t loads rows t / 8 and t / 8 + 64
+  const int bn = tid >> 3, k4 = tid & 7;
+  const unsigned b_off = (unsigned)(((long)bn * g.ldb + 4 * k4) * 4), b_row64 = (unsigned)((long)64 * g.ldb * 4);
+  const unsigned b_kb = (unsigned)k_begin * 4u, b_step = TK * 4u;
+  const int b_lds = (k4 >> 1) * PLANE + bn * 16 + (k4 & 1) * 8;      // + 1024 for row + 64, + HALFB for lo
+  const int fb = kq * PLANE + l15 * 16;                              // + 256 per 16 columns
+  f32x4 acc[R][8];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[r][c][i] = 0.f;
+#define RG_LOAD_A(AH, AL, j_)                                                                                      \
+  {                                                                                                                \
+    const unsigned past = ((j_) < nb) ? 0u : 0xFFFFFFF0u;                                                          \
+    const unsigned ka = a_src + a_kb + (unsigned)(j_) * a_step;                                                    \
+    _Pragma("unroll") for (int r = 0; r < R; ++r) {                                                                \
+      AH[r] = __builtin_bit_cast(bf16x8, bld128<0>(rAh, (ka + r * (16 * TK * 2)) | past));                         \
+      AL[r] = __builtin_bit_cast(bf16x8, bld128<0>(rAl, (ka + r * (16 * TK * 2)) | past));                         \
+    }                                                                                                              \
+  }
+#define RG_LOAD_W(Q, j_)                                                                                           \
+  {                                                                                                                \
+    const unsigned past = ((j_) < nb) ? 0u : 0xFFFFFFF0u;                                                          \
+    const unsigned kb = b_off + b_kb + (unsigned)(j_) * b_step;                                                    \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) Q[i] = bld128<NT>(rB, (kb + i * b_row64) | past);                \
+  }
+#define RG_STAGE_W(Q, buf_)                                                                                        \
+  {                                                                                                                \
+    char* d = smem + (buf_) * BUF + b_lds;                                                                         \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                  \
+      split_store4(Q[i], reinterpret_cast<__bf16*>(d + i * 1024), reinterpret_cast<__bf16*>(d + HALFB + i * 1024)); \
+  }
+#define RG_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0);
+// timing ablations (scripts/build_variant.py -DRG_NO_*; results wrong): which part of a block the MFMAs wait for
+#ifdef RG_NO_A
+#define RG_A_ON 0
+#else
+#define RG_A_ON 1
+#endif
+#ifdef RG_NO_W
+#define RG_W_ON 0
+#else
+#define RG_W_ON 1
+#endif
+#ifdef RG_NO_STAGE
+#define RG_STAGE_ON 0
+#else
+#define RG_STAGE_ON 1
+#endif
+#ifdef RG_NO_BAR
+#define RG_SYNC_L()
+#else
+#define RG_SYNC_L() __syncthreads()
+#endif
+// Block j (position JB of three in the unrolled loop) in eight steps of 16 columns.  Step c: the W fragments of step c + 2 are read into a
+// ring of three (those of the next block's first two steps from buffer BN, complete since the barrier that ended block j - 1), ONE of the
+// block's loads is issued -- the 2 R fragments of X for block j + 2, the two pieces of W for block j + 4 -- and the step's 3 R MFMAs run
+// (small terms first).  W of block j + 2 (requested during block j - 2) is split into buffer BS in step 4.  X is requested TWO blocks ahead
+// because register loads retire in order: a fragment of X (an L2 hit) cannot be used before every older piece of W (HBM) has arrived.
+// 0x008 MFMA, 0x020 VMEM read, 0x100 LDS read, 0x200 LDS write, 0x002 VALU
+#define RG_BLOCK(JB, AHC, ALC, AHN, ALN, QS, QL, j_, BC, BN, BS)                                                   \
+  {                                                                                                                \
+    const unsigned pastA = ((j_) + 2 < nb) ? 0u : 0xFFFFFFF0u, pastW = ((j_) + 4 < nb) ? 0u : 0xFFFFFFF0u;          \
+    const unsigned ka = a_src + a_kb + (unsigned)((j_) + 2) * a_step;                                              \
+    const unsigned kb = b_off + b_kb + (unsigned)((j_) + 4) * b_step;                                              \
+    _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                                                \
+      {                                                                                                            \
+        const int c2 = (c + 2) & 7, s2 = (8 * (JB) + c + 2) % 3;                                                   \
+        const char* sp = smem + ((c + 2 < 8) ? (BC) : (BN)) * BUF + fb + c2 * 256;                                 \
+        fh[s2] = *reinterpret_cast<const bf16x8*>(sp);                                                             \
+        fl[s2] = *reinterpret_cast<const bf16x8*>(sp + HALFB);                                                     \
+      }                                                                                                            \
+      if (c < 2 * R) {                                                                                             \
+        if (RG_A_ON) {                                                                                             \
+          if (c & 1) ALN[c >> 1] = __builtin_bit_cast(bf16x8, bld128<0>(rAl, (ka + (c >> 1) * (16 * TK * 2)) | pastA)); \
+          else AHN[c >> 1] = __builtin_bit_cast(bf16x8, bld128<0>(rAh, (ka + (c >> 1) * (16 * TK * 2)) | pastA));  \
+        }                                                                                                          \
+      } else if (RG_W_ON && c - 2 * R < 2) {                                                                       \
+        QL[c - 2 * R] = bld128<NT>(rB, (kb + (c - 2 * R) * b_row64) | pastW);                                      \
+      }                                                                                                            \
+      if (c == 4 && RG_STAGE_ON) RG_STAGE_W(QS, BS);                                                               \
+      const int s0 = (8 * (JB) + c) % 3;                                                                           \
+      _Pragma("unroll") for (int r = 0; r < R; ++r) acc[r][c] = MFMA16_BF16(ALC[r], fh[s0], acc[r][c]);            \
+      _Pragma("unroll") for (int r = 0; r < R; ++r) acc[r][c] = MFMA16_BF16(AHC[r], fl[s0], acc[r][c]);            \
+      _Pragma("unroll") for (int r = 0; r < R; ++r) acc[r][c] = MFMA16_BF16(AHC[r], fh[s0], acc[r][c]);            \
+      RG_SGB(0x008, 1) RG_SGB(0x100, 1) RG_SGB(0x008, 1) RG_SGB(0x100, 1) RG_SGB(0x008, 1) RG_SGB(0x020, 1)        \
+      if (c == 4) { RG_SGB(0x008, 1) RG_SGB(0x002, 12) RG_SGB(0x008, 1) RG_SGB(0x002, 12) RG_SGB(0x008, 1) RG_SGB(0x002, 12) \
+                    RG_SGB(0x008, 1) RG_SGB(0x200, 2) RG_SGB(0x008, 1) RG_SGB(0x200, 2) }                          \
+      RG_SGB(0x008, 3 * R)                                                                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                                           \
+    }                                                                                                              \
+    RG_SYNC_L();                                                                                                   \
+  }
+  static_assert(R >= 2, "step c issues load c of the block's 2 R + 2: R = 1 would leave steps without one and is not instantiated");
+  bf16x8 ah0[R], al0[R], ah1[R], al1[R], ah2[R], al2[R], fh[3], fl[3];
+  u32x4 q0[2], q1[2], q2[2];
+  RG_LOAD_W(q0, 0);
+  RG_LOAD_W(q1, 1);
+  RG_LOAD_A(ah0, al0, 0);
+  RG_LOAD_A(ah1, al1, 1);
+#if defined(RG_NO_A)
+  RG_LOAD_A(ah2, al2, 2);
+#endif
+  RG_LOAD_W(q2, 2);
+  RG_STAGE_W(q0, 0);
+  RG_LOAD_W(q0, 3);
+  RG_STAGE_W(q1, 1);
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    fh[c] = *reinterpret_cast<const bf16x8*>(smem + fb + c * 256);
+    fl[c] = *reinterpret_cast<const bf16x8*>(smem + fb + c * 256 + HALFB);
+  }
+  for (int j = 0; j < nb; j += 3) {            // a block past the slice multiplies zeros (its loads are out of range)
+    RG_BLOCK(0, ah0, al0, ah2, al2, q2, q1, j, 0, 1, 2);
+    RG_BLOCK(1, ah1, al1, ah0, al0, q0, q2, j + 1, 1, 2, 0);
+    RG_BLOCK(2, ah2, al2, ah1, al1, q1, q0, j + 2, 2, 0, 1);
+  }
+  // D of a 16x16 MFMA: column lane & 15, rows 4 (lane >> 4) + i
+  const unsigned rowsz = (unsigned)g.ldc * 4u;
+  const __amdgpu_buffer_rsrc_t rC = fx_rsrc(g.C + (long)z * g.slab_stride, (long)g.M * g.ldc * 4);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int n = n0 + 16 * c + l15;
+    const unsigned oob = (n < g.N) ? 0u : 0xFFFFFFF0u;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int mm = m0 + 16 * r + 4 * kq + i;
+        bst32f(acc[r][c][i], rC, ((unsigned)mm * rowsz + (unsigned)n * 4u) | oob);       // rows >= M fall outside the slab
+      }
+  }
+}
+
 // ---- operand splitting ----------------------------------------------------------------------------------
 // hi/lo K-BLOCKED [Cp/32][Rp][32] from x [R, C]: element (r, c) at ((c/32)*Rp + r)*32 + c%32; columns C..Cp-1 are
 // written as zeros (Cp = C rounded up to 32); rows R..Rp-1 are never written (the caller allocates them as zeros)
@@ -996,12 +1172,15 @@ static int fwd_bf16x3_impl(float* Y, const void* xhi, const void* xlo, const flo
     if (tune.mt == 2) {                                   // A/B: the first design, both operands staged through registers
       if (mt == 3) hipLaunchKernelGGL((fx_fwd_bf16x3_mt_kernel<3>), dim3((unsigned)nb), dim3(512), 0, stream, g);
       else hipLaunchKernelGGL((fx_fwd_bf16x3_mt_kernel<2>), dim3((unsigned)nb), dim3(512), 0, stream, g);
-    } else if (mt == 3) {
-      if (nt) hipLaunchKernelGGL((fx_fwd_bf16x3_dma_kernel<3, 2>), dim3((unsigned)nb), dim3(512), 0, stream, g);
-      else hipLaunchKernelGGL((fx_fwd_bf16x3_dma_kernel<3, 0>), dim3((unsigned)nb), dim3(512), 0, stream, g);
-    } else {
-      if (nt) hipLaunchKernelGGL((fx_fwd_bf16x3_dma_kernel<2, 2>), dim3((unsigned)nb), dim3(512), 0, stream, g);
+    } else if (tune.mt == 3) {                            // A/B: the second design, X by LDS-DMA
+      if (mt == 3) hipLaunchKernelGGL((fx_fwd_bf16x3_dma_kernel<3, 0>), dim3((unsigned)nb), dim3(512), 0, stream, g);
       else hipLaunchKernelGGL((fx_fwd_bf16x3_dma_kernel<2, 0>), dim3((unsigned)nb), dim3(512), 0, stream, g);
+    } else if (mt == 3) {                                 // X fragments straight into registers
+      if (nt) hipLaunchKernelGGL((fx_fwd_bf16x3_reg_kernel<3, 2>), dim3((unsigned)nb), dim3(512), 0, stream, g);
+      else hipLaunchKernelGGL((fx_fwd_bf16x3_reg_kernel<3, 0>), dim3((unsigned)nb), dim3(512), 0, stream, g);
+    } else {
+      if (nt) hipLaunchKernelGGL((fx_fwd_bf16x3_reg_kernel<2, 2>), dim3((unsigned)nb), dim3(512), 0, stream, g);
+      else hipLaunchKernelGGL((fx_fwd_bf16x3_reg_kernel<2, 0>), dim3((unsigned)nb), dim3(512), 0, stream, g);
     }
   } else if (kn) {
     hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<true, XEPI_STORE, 0, 4, true>), dim3((unsigned)nblk), dim3(512), 0, stream, g);
