@@ -749,9 +749,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // the triplet shape against 396 / 565 shipped: with one wave per SIMD every load instruction's issue stalls the MFMA stream behind it --
 // timing ablations: no X loads 293 us, no W loads 335, no barrier 354, MFMAs alone 271 on zeros and 335 on random operands.)
 #define MFMA16_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
-template <int R, int NT>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void fx_fwd_bf16x3_reg_kernel(XGemmArgs g) {
-  constexpr int ROWS = 128 * R;                 // batch rows per workgroup: 8 waves x 16 R
+template <int R, int WV, int NT>
+__global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(2, 2))) void fx_fwd_bf16x3_reg_kernel(XGemmArgs g) {
+  constexpr int ROWS = 16 * R * WV;             // batch rows per workgroup: WV waves x 16 R (WV = 4: two workgroups per CU)
+  constexpr int LW = 16 / WV;                   // 16-byte pieces of W per thread and block
   constexpr int PLANE = 2048 + 64;              // one 8-k chunk of all 128 columns (16 B each) + a 16-bank shift per chunk: the split's 8-byte
                                                 // stores of 4 columns x 4 chunks (32 lanes) land on 64 distinct banks
   constexpr int HALFB = 4 * PLANE, BUF = 2 * HALFB;
@@ -773,11 +774,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // X fragment of row block r of block j: row m0 + 16 r + l15, 16-byte chunk kq of the row's 64 bytes
   const unsigned a_src = (unsigned)(((long)(m0 + l15) * TK + 8 * kq) * 2);
   const unsigned a_step = (unsigned)g.a_rp * (TK * 2u), a_kb = (unsigned)(k_begin / TK) * a_step;
-  // W: 8 lanes x 16 B = the 128 bytes a row contributes to a block; thread t loads rows t / 8 and t / 8 + 64
+  // W: 8 lanes x 16 B = the 128 bytes a row contributes to a block; thread t loads rows t / 8 + 8 WV i
   const int bn = tid >> 3, k4 = tid & 7;
-  const unsigned b_off = (unsigned)(((long)bn * g.ldb + 4 * k4) * 4), b_row64 = (unsigned)((long)64 * g.ldb * 4);
+  const unsigned b_off = (unsigned)(((long)bn * g.ldb + 4 * k4) * 4), b_rows = (unsigned)((long)(8 * WV) * g.ldb * 4);
   const unsigned b_kb = (unsigned)k_begin * 4u, b_step = TK * 4u;
-  const int b_lds = (k4 >> 1) * PLANE + bn * 16 + (k4 & 1) * 8;      // + 1024 for row + 64, + HALFB for lo
+  const int b_lds = (k4 >> 1) * PLANE + bn * 16 + (k4 & 1) * 8;      // + 128 WV per 8 WV rows, + HALFB for lo
   const int fb = kq * PLANE + l15 * 16;                              // + 256 per 16 columns
   f32x4 acc[R][8];
 #pragma unroll
@@ -799,13 +800,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   {                                                                                                                \
     const unsigned past = ((j_) < nb) ? 0u : 0xFFFFFFF0u;                                                          \
     const unsigned kb = b_off + b_kb + (unsigned)(j_) * b_step;                                                    \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) Q[i] = bld128<NT>(rB, (kb + i * b_row64) | past);                \
+    _Pragma("unroll") for (int i = 0; i < LW; ++i) Q[i] = bld128<NT>(rB, (kb + i * b_rows) | past);                \
   }
 #define RG_STAGE_W(Q, buf_)                                                                                        \
   {                                                                                                                \
     char* d = smem + (buf_) * BUF + b_lds;                                                                         \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                  \
-      split_store4(Q[i], reinterpret_cast<__bf16*>(d + i * 1024), reinterpret_cast<__bf16*>(d + HALFB + i * 1024)); \
+    _Pragma("unroll") for (int i = 0; i < LW; ++i)                                                                 \
+      split_store4(Q[i], reinterpret_cast<__bf16*>(d + i * 128 * WV), reinterpret_cast<__bf16*>(d + HALFB + i * 128 * WV)); \
   }
 #define RG_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0);
 // timing ablations (scripts/build_variant.py -DRG_NO_*; results wrong): which part of a block the MFMAs wait for
@@ -852,8 +853,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           if (c & 1) ALN[c >> 1] = __builtin_bit_cast(bf16x8, bld128<0>(rAl, (ka + (c >> 1) * (16 * TK * 2)) | pastA)); \
           else AHN[c >> 1] = __builtin_bit_cast(bf16x8, bld128<0>(rAh, (ka + (c >> 1) * (16 * TK * 2)) | pastA));  \
         }                                                                                                          \
-      } else if (RG_W_ON && c - 2 * R < 2) {                                                                       \
-        QL[c - 2 * R] = bld128<NT>(rB, (kb + (c - 2 * R) * b_row64) | pastW);                                      \
+      } else if (RG_W_ON && c - 2 * R < LW) {                                                                      \
+        QL[c - 2 * R] = bld128<NT>(rB, (kb + (c - 2 * R) * b_rows) | pastW);                                       \
       }                                                                                                            \
       if (c == 4 && RG_STAGE_ON) RG_STAGE_W(QS, BS);                                                               \
       const int s0 = (8 * (JB) + c) % 3;                                                                           \
@@ -861,16 +862,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       _Pragma("unroll") for (int r = 0; r < R; ++r) acc[r][c] = MFMA16_BF16(AHC[r], fl[s0], acc[r][c]);            \
       _Pragma("unroll") for (int r = 0; r < R; ++r) acc[r][c] = MFMA16_BF16(AHC[r], fh[s0], acc[r][c]);            \
       RG_SGB(0x008, 1) RG_SGB(0x100, 1) RG_SGB(0x008, 1) RG_SGB(0x100, 1) RG_SGB(0x008, 1) RG_SGB(0x020, 1)        \
-      if (c == 4) { RG_SGB(0x008, 1) RG_SGB(0x002, 12) RG_SGB(0x008, 1) RG_SGB(0x002, 12) RG_SGB(0x008, 1) RG_SGB(0x002, 12) \
-                    RG_SGB(0x008, 1) RG_SGB(0x200, 2) RG_SGB(0x008, 1) RG_SGB(0x200, 2) }                          \
+      if (c == 4) { RG_SGB(0x008, 1) RG_SGB(0x002, 6 * LW) RG_SGB(0x008, 1) RG_SGB(0x002, 6 * LW) RG_SGB(0x008, 1) RG_SGB(0x002, 6 * LW) \
+                    RG_SGB(0x008, 1) RG_SGB(0x200, LW) RG_SGB(0x008, 1) RG_SGB(0x200, LW) }                        \
       RG_SGB(0x008, 3 * R)                                                                                         \
       __builtin_amdgcn_sched_barrier(0);                                                                           \
     }                                                                                                              \
     RG_SYNC_L();                                                                                                   \
   }
-  static_assert(R >= 2, "step c issues load c of the block's 2 R + 2: R = 1 would leave steps without one and is not instantiated");
+  static_assert(2 * R + LW <= 8, "step c issues load c of the block's 2 R + LW");
   bf16x8 ah0[R], al0[R], ah1[R], al1[R], ah2[R], al2[R], fh[3], fl[3];
-  u32x4 q0[2], q1[2], q2[2];
+  u32x4 q0[LW], q1[LW], q2[LW];
   RG_LOAD_W(q0, 0);
   RG_LOAD_W(q1, 1);
   RG_LOAD_A(ah0, al0, 0);
@@ -1176,12 +1177,18 @@ static int fwd_bf16x3_impl(float* Y, const void* xhi, const void* xlo, const flo
       if (mt == 3) hipLaunchKernelGGL((fx_fwd_bf16x3_dma_kernel<3, 0>), dim3((unsigned)nb), dim3(512), 0, stream, g);
       else hipLaunchKernelGGL((fx_fwd_bf16x3_dma_kernel<2, 0>), dim3((unsigned)nb), dim3(512), 0, stream, g);
     } else if (mt == 3) {                                 // X fragments straight into registers
-      if (nt) hipLaunchKernelGGL((fx_fwd_bf16x3_reg_kernel<3, 2>), dim3((unsigned)nb), dim3(512), 0, stream, g);
-      else hipLaunchKernelGGL((fx_fwd_bf16x3_reg_kernel<3, 0>), dim3((unsigned)nb), dim3(512), 0, stream, g);
+      if (nt) hipLaunchKernelGGL((fx_fwd_bf16x3_reg_kernel<3, 8, 2>), dim3((unsigned)nb), dim3(512), 0, stream, g);
+      else hipLaunchKernelGGL((fx_fwd_bf16x3_reg_kernel<3, 8, 0>), dim3((unsigned)nb), dim3(512), 0, stream, g);
     } else {
-      if (nt) hipLaunchKernelGGL((fx_fwd_bf16x3_reg_kernel<2, 2>), dim3((unsigned)nb), dim3(512), 0, stream, g);
-      else hipLaunchKernelGGL((fx_fwd_bf16x3_reg_kernel<2, 0>), dim3((unsigned)nb), dim3(512), 0, stream, g);
+      if (nt) hipLaunchKernelGGL((fx_fwd_bf16x3_reg_kernel<2, 8, 2>), dim3((unsigned)nb), dim3(512), 0, stream, g);
+      else hipLaunchKernelGGL((fx_fwd_bf16x3_reg_kernel<2, 8, 0>), dim3((unsigned)nb), dim3(512), 0, stream, g);
     }
+  } else if (!kn && wn == 4 && tune.mt != 1 && (M <= 64 || tune.mt == 4)) {
+    // at most 64 rows: the register-fragment kernel with four waves of 16 rows, two workgroups per CU (4.5-5.1 TB/s of W where the
+    // 128-row tile below streams 4.2-4.5); 65..128 rows: the two measure the same (both sit on the package power limit), FX_FWD_MT=4 is the A/B
+    if (M > 64) hipLaunchKernelGGL((fx_fwd_bf16x3_reg_kernel<2, 4, 0>), dim3((unsigned)nblk), dim3(256), 0, stream, g);
+    else if (nt) hipLaunchKernelGGL((fx_fwd_bf16x3_reg_kernel<1, 4, 2>), dim3((unsigned)nblk), dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((fx_fwd_bf16x3_reg_kernel<1, 4, 0>), dim3((unsigned)nblk), dim3(256), 0, stream, g);
   } else if (kn) {
     hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<true, XEPI_STORE, 0, 4, true>), dim3((unsigned)nblk), dim3(512), 0, stream, g);
   } else if (wn == 4) {

@@ -35,7 +35,7 @@ def _env_int(name: str, default: int) -> int:
 # once at import, and handed to the library as explicit arguments of its *_ex entry points -- libfxhip itself reads no
 # environment variables.  FX_ADAM_XCD: 0 linear tile order, 1 auto (default), 2 always XCD-partitioned.
 TUNE = {
-    "fwd_splitk": _env_int("FX_SPLITK", 0), "fwd_wn": _env_int("FX_FWD_WN", 0), "fwd_no_mt": {0: 1, 2: 2, 3: 3}.get(_env_int("FX_FWD_MT", 1), 0),   # FX_FWD_MT (batches of more than 128 rows): 1 = stacked-rows kernel, X fragments straight into registers (default); 0 = one workgroup per M tile; 2 = the first stacked-rows kernel (operands staged through registers); 3 = the second (X by LDS-DMA)
+    "fwd_splitk": _env_int("FX_SPLITK", 0), "fwd_wn": _env_int("FX_FWD_WN", 0), "fwd_no_mt": {0: 1, 2: 2, 3: 3, 4: 4}.get(_env_int("FX_FWD_MT", 1), 0),   # FX_FWD_MT (batches of more than 128 rows): 1 = stacked-rows kernel, X fragments straight into registers (default); 0 = one workgroup per M tile; 2 = the first stacked-rows kernel (operands staged through registers); 3 = the second (X by LDS-DMA)
     "fwd_nt": _env_int("FX_NT_FWD", 0), "adam_order": {0: 1, 1: 0, 2: 2}.get(_env_int("FX_ADAM_XCD", 1), 0),
     "adam_wn": _env_int("FX_ADAM_WN", 0), "adam_plain": int(_env_int("FX_NT_ADAM", 1) == 0),
     "fused_runs": _env_int("FX_FUSED_RUNS", 0),   # runs (= partial-sum slabs) per row block; 0 = the library's choice

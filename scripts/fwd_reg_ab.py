@@ -12,7 +12,7 @@ def timeit(fn, n=20):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-shapes = ((384, 7500, 30000), (384, 7500, 30000), (256, 7500, 30000), (200, 5001, 10003), (500, 3000, 20000), (1024, 5000, 20000), (384, 40000, 5000))
+shapes = ((384, 7500, 30000), (384, 7500, 30000), (256, 7500, 30000), (200, 5001, 10003), (500, 3000, 20000), (1024, 5000, 20000), (384, 40000, 5000), (128, 20000, 5000), (128, 5000, 20000), (128, 10000, 20000), (100, 20001, 5003), (64, 10000, 20000), (32, 10000, 20000), (32, 5000, 20000))
 import os
 for it, (M, N, K) in enumerate(shapes[:int(os.environ.get("FX_AB_ROWS", len(shapes)))]):
     X = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev) * 0.01; b = torch.randn(N, device=dev)
@@ -20,7 +20,7 @@ for it, (M, N, K) in enumerate(shapes[:int(os.environ.get("FX_AB_ROWS", len(shap
     Y = torch.empty(M, N, device=dev); ws = ops.Workspace(dev)
     s = ops.new_split_kb(M, K, dev); ops.split_bf16(ops.IMMEDIATE, s[0], s[1], X)
     out = {}
-    for mode in (3, 0):
+    for mode in ((3, 0) if M > 128 else (0, 4)):
         ops.TUNE["fwd_no_mt"] = mode
         Y.fill_(float("nan"))
         t = timeit(lambda: ops.linear_fwd_bf16x3(ops.IMMEDIATE, Y, s[0], s[1], W, b, ws))

@@ -501,10 +501,12 @@ def test_dw_adam_xcd_tile_order_is_bit_identical(n_out, k_in, B):
 # split-bf16 (bf16x3) wide-layer kernels
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,N,K", [(128, 5000, 20000), (128, 300, 1000), (384, 130, 2500), (26, 70, 100), (8, 16, 64),
-                                   # the multi-M-tile kernel (LDS-DMA; K-steps in fours, surplus steps multiply zeros): 2 and 3 M tiles,
-                                   # ragged rows / columns, 1 .. 5 K-steps per slice, more than one row group, a K that is no multiple of 4
+                                   # the stacked-rows kernel (X fragments in registers; K blocks in threes, surplus blocks multiply zeros): 2 and
+                                   # 3 M tiles, ragged rows / columns, 1 .. 5 blocks per slice, more than one row group, a K that is no multiple of 4
                                    (200, 300, 1000), (256, 129, 96), (300, 257, 4099), (500, 130, 2500), (384, 64, 32),
-                                   (384, 200, 64), (129, 128, 160), (384, 1500, 6000)])
+                                   (384, 200, 64), (129, 128, 160), (384, 1500, 6000),
+                                   # its four-wave form for at most 64 rows
+                                   (64, 257, 4099), (33, 5000, 20000), (1, 300, 1000), (48, 129, 96), (64, 1500, 6000), (17, 128, 32)])
 def test_linear_fwd_bf16x3_vs_fp64(M, N, K):
     from flexynesis_amd import ops
     dev = _dev()
