@@ -12,6 +12,7 @@
 //   fx_split_bf16 / fx_split_bf16_t   fp32 [R,C] -> (hi, lo) bf16 [R,Cp] or transposed [C,Rp], zero padded
 //   fx_linear_fwd_bf16x3              Y[M,N] = X[M,K] . W[N,K]^T  X pre-split (re-read by every column
 //                                     tile, from L2), W fp32 streamed ONCE from HBM and split in registers
+//                                     (more than 128 or at most 64 batch rows: fx_fwd_bf16x3_reg_kernel below)
 //   fx_linear_dw_adam_bf16x3          W[N,K] -= Adam(clip * dY^T X): both operands pre-split + transposed
 //                                     (dYT [N,Bp], XT [K,Bp]); W/m/v streamed once (24 B/param)
 //

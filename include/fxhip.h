@@ -88,7 +88,9 @@ long fx_linear_fwd_bf16x3_workspace_bytes(int M, int N, int K);
 int fx_linear_fwd_bf16x3(float* Y, const void* xhi, const void* xlo, const float* W, const float* bias, int M, int N, int K,
                          long ldx, long ldw, long ldy, void* workspace, long workspace_bytes, fx_stream_t stream);
 /* fx_linear_fwd_bf16x3 with explicit tuning (A/B experiments; same contraction): splitk 0 = auto, wave_cols 0|4 = 128x128
- * tile / 2 = 128x64, no_mt 1 = one workgroup per 128-row M tile even for M > 128 (2 = the first multi-M-tile kernel, both operands staged through registers), nt 1 = non-temporal W loads.  The library
+ * tile / 2 = 128x64, no_mt 0 = stacked rows (M > 128) and M <= 64 on the register-fragment kernel, 1 = one workgroup per 128-row M tile for every M,
+ * 2 = the first multi-M-tile kernel (both operands staged through registers), 3 = the second (X by LDS-DMA), 4 = the register-fragment kernel also
+ * for 65..128 rows; nt 1 = non-temporal W loads.  The library
  * reads no environment variables: callers that want A/B switches pass them here. */
 int fx_linear_fwd_bf16x3_ex(float* Y, const void* xhi, const void* xlo, const float* W, const float* bias, int M, int N, int K,
                             long ldx, long ldw, long ldy, void* workspace, long workspace_bytes, int splitk, int wave_cols,
