@@ -55,6 +55,7 @@ PROTOTYPES = {
     "fx_reduce_group": (I, [P, P, P, P, P, P, I, P]),
     "fx_heads_fwd": (I, [P, I, P, L, I, I, I, F, P, P]),
     "fx_heads_bwd": (I, [P, I, P, L, P, L, I, I, I, F, P, P]),
+    "fx_heads_step_scratch_floats": (L, [I, I, I]),
     "fx_heads_step": (I, [P, I, P, P, P, P, P, P, L, P, L, I, I, I, F, P, P, I, I, P, P, P, P, P, P]),
     "fx_split_bf16": (I, [P, P, P, I, I, L, L, P]),
     "fx_split_bf16_t": (I, [P, P, P, I, I, L, L, P]),

@@ -19,6 +19,7 @@ constexpr int HB = 128;   // max rows
 constexpr int HS = 32;    // max supervisor hidden width
 constexpr int HC = 32;    // max head outputs
 constexpr int HL = 128;   // max latent width
+constexpr int HEADS_SHADOW = 4 * HB * HS + 2 * HS + 32;   // floats per head: the weight-gradient role's y1, a1, out, dout, statistics, loss (fx_heads_step)
 
 struct FxHeadDesc {       // mirrors include/fxhip.h: fx_head_desc
   const float* W1; const float* b1; const float* gamma; const float* beta; float* rmean; float* rvar;
@@ -590,6 +591,7 @@ struct HeadsStepArgs {
   int n_terms, weighted;
   const float* term_loss[16]; const float* term_logvar[16]; float* term_dlogvar[16];
   float* total_out; float* epoch_acc;
+  float* shadow;                           // [n_heads][HEADS_SHADOW]: where the weight-gradient role keeps ITS copies of the saved tensors
 };
 
 union __attribute__((aligned(16))) HeadsStepLds {
@@ -608,16 +610,26 @@ __global__ __launch_bounds__(256) void fx_heads_step_kernel(HeadsStepArgs sa) {
   const HeadsArgs& a = sa.ha;
   const int hi = blockIdx.x >> 1;
   const bool chain_role = (blockIdx.x & 1) == 0;       // 0: the critical chain; 1: the head's weight gradients
-  const FxHeadDesc& h = a.h[hi];
+  // Both roles run the head's forward and its loss (the weight-gradient role needs y1 / a1 / dout and cannot wait for another
+  // workgroup).  Every SHARED output -- the saved tensors y1, a1, save_mean, save_invstd, out, the output gradient dout, the loss value,
+  // the running statistics -- is stored by the chain role ONLY; the weight-gradient role stores and re-reads private copies in its
+  // shadow block (two writers of one array were what the Cox race of round 4 needed).
+  FxHeadDesc h = a.h[hi];
+  float* loss_slot = sa.loss[hi];
+  if (!chain_role) {
+    float* sh = sa.shadow + (long)hi * HEADS_SHADOW;
+    h.y1 = sh; h.a1 = sh + HB * HS; h.out = sh + 2 * HB * HS; h.dout = sh + 3 * HB * HS;
+    h.save_mean = sh + 4 * HB * HS; h.save_invstd = sh + 4 * HB * HS + HS; loss_slot = sh + 4 * HB * HS + 2 * HS;
+  }
   const int t = threadIdx.x, r = t & 127, hf = t >> 7, col = t & 31, rg = t >> 5;
   const int B = a.B, Ld = a.L, S = h.S, C = h.C;
   heads_fwd_body(a, h, U.f, chain_role);
   __syncthreads();                                   // out [B, C] is visible to the whole workgroup
   // ================= loss value + gradient at the head output =================
   float* dout = const_cast<float*>(h.dout);
-  if (sa.kind[hi] == 0) loss_mse_body(sa.loss[hi], dout, h.out, sa.y[hi], B, C, C, sa.logvar[hi], 1.0f, sm);
-  else if (sa.kind[hi] == 1) loss_ce_body(sa.loss[hi], dout, h.out, sa.y[hi], B, C, C, C, sa.logvar[hi], 1.0f, sm);
-  else loss_cox_body<HB, 1>(sa.loss[hi], dout, h.out, sa.dur[hi], sa.y[hi], B, C, C, sa.logvar[hi], 1.0f, ckey, cidx, cscan, dred);
+  if (sa.kind[hi] == 0) loss_mse_body(loss_slot, dout, h.out, sa.y[hi], B, C, C, sa.logvar[hi], 1.0f, sm);
+  else if (sa.kind[hi] == 1) loss_ce_body(loss_slot, dout, h.out, sa.y[hi], B, C, C, C, sa.logvar[hi], 1.0f, sm);
+  else loss_cox_body<HB, 1>(loss_slot, dout, h.out, sa.dur[hi], sa.y[hi], B, C, C, sa.logvar[hi], 1.0f, ckey, cidx, cscan, dred);
   __syncthreads();
   // ================= backward: parameter gradients of this head and its share of the embedding gradient =================
   HeadsBwdLds& L = U.b;
@@ -861,6 +873,11 @@ int fx_heads_bwd(const void* heads_, int n_heads, const float* x, long ldx, floa
   return fx_check_launch("fx_heads_bwd");
 }
 
+// floats of fx_heads_step's scratch: the per-head shares of dx + the arrival counter (as fx_heads_bwd), then one shadow block per head
+long fx_heads_step_scratch_floats(int n_heads, int B, int L) {
+  return (long)n_heads * B * L + 4 + (long)n_heads * HEADS_SHADOW;
+}
+
 // All heads of a training step in one launch: forward, loss, backward, summed embedding gradient, total loss (see
 // fx_heads_step_kernel).  kinds[i]: 0 masked MSE, 1 masked softmax-CE, 2 Cox; labels[i] [B] (Cox: events), durations[i] (Cox
 // only), logvars[i] / losses[i] the head's uncertainty weight (NULL: unweighted) and loss slot; heads[i].dout receives the
@@ -875,7 +892,8 @@ int fx_heads_step(const void* heads_, int n_heads, const int* kinds, const float
   FX_REQUIRE(B > 1 && kinds && labels && losses, "fx_heads_step: train mode needs B > 1 and labels / loss slots");
   FX_REQUIRE(n_terms >= 0 && n_terms <= 16 && (n_terms == 0 || (term_losses && total_out)), "fx_heads_step: bad loss terms (n=%d)", n_terms);
   FX_REQUIRE(!weighted || n_terms == 0 || term_logvars, "fx_heads_step: weighted total needs log_vars");
-  FX_REQUIRE(n_heads == 1 || !dx || dx_scratch, "fx_heads_step: several heads need the dx scratch (shares + arrival counter)");
+  FX_REQUIRE(dx_scratch && (((uintptr_t)dx_scratch) & 3) == 0,
+             "fx_heads_step: needs its scratch (fx_heads_step_scratch_floats(n_heads, B, L) floats, zero-filled once)");
   HeadsStepArgs s{};
   HeadsArgs& a = s.ha;
   for (int i = 0; i < n_heads; ++i) {
@@ -893,10 +911,10 @@ int fx_heads_step(const void* heads_, int n_heads, const int* kinds, const float
   a.n_heads = n_heads; a.x = x; a.ldx = ldx; a.dx = dx; a.lddx = lddx; a.dx_accumulate = dx_accumulate;
   a.B = B; a.L = L; a.train = 1; a.drop_p = drop_p; a.ctrl = ctrl;
   if (n_heads > 1) {
-    FX_REQUIRE((((uintptr_t)dx_scratch) & 3) == 0, "fx_heads_step: scratch must be 4-byte aligned");
     a.dx_part = (float*)dx_scratch;
     a.dx_count = (unsigned*)((float*)dx_scratch + (long)n_heads * B * L);    // zero on first use (caller zero-fills once)
   }
+  s.shadow = (float*)dx_scratch + (long)n_heads * B * L + 4;
   s.n_terms = n_terms; s.weighted = weighted; s.total_out = total_out; s.epoch_acc = epoch_acc;
   for (int i = 0; i < n_terms; ++i) {
     s.term_loss[i] = term_losses[i];

@@ -147,7 +147,7 @@ __device__ __forceinline__ void loss_cox_body(float* loss_out, float* __restrict
   // chain role and the weight-gradient role compute the same numbers and both store them), so a "zero everything, then scatter"
   // sequence lets one workgroup's zeros land between the other's final store and its read-back -- seen as run-to-run differences
   // of the Cox head's weight gradients once the two workgroups ran skewed (beside a wide product).
-#ifdef FX_COX_TWO_PHASE          // (the round-3 form, kept for scripts/build_variant.py: the regression test must fail on it)
+#ifdef FX_COX_TWO_PHASE          // (the round-3 form, kept for scripts/build_variant.py: it raced while two workgroups stored dout; one writer since round 5)
   for (int i = threadIdx.x; i < B; i += blockDim.x) dout[(long)i * ldd] = 0.f;
   __syncthreads();
   if (ok)

@@ -1190,9 +1190,7 @@ class StepPlan:
             labels.append(self.y[v])
             lvs.append(self._logvar(v))
             losses.append(self.loss_vec[names.index(v):names.index(v) + 1])
-        scratch = None
-        if len(self._head_descs) > 1 and demb is not None:
-            scratch = self.buf["heads/dx_scratch"] = ops.heads_bwd_scratch(len(self._head_descs), B, emb.shape[1], self.dev)
+        scratch = self.buf["heads/dx_scratch"] = ops.heads_bwd_scratch(len(self._head_descs), B, emb.shape[1], self.dev)
         weighted = self.train and spec.weighted
         tl = [self.loss_vec[i:i + 1] for i in range(len(names))] if with_total else []
         tv = [st.ep("log_vars." + n).view(-1) for n in names] if (with_total and weighted) else []

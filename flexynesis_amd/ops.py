@@ -981,8 +981,9 @@ def fusion_fwd_pair(rec, embs, ecats, parts2, biases2, Ws, bs, width=None):
 
 
 def heads_bwd_scratch(n_heads: int, B: int, L: int, device) -> torch.Tensor:
-    """Zero-filled scratch for fx_heads_bwd's per-head dx workgroups (shares + arrival counter)."""
-    return torch.zeros(n_heads * B * L + 4, dtype=torch.float32, device=device)
+    """Zero-filled scratch for fx_heads_bwd's per-head dx workgroups (shares + arrival counter) and fx_heads_step (the same + one
+    shadow block per head for the weight-gradient role's copies of the saved tensors)."""
+    return torch.zeros(int(lib.fx_heads_step_scratch_floats(int(n_heads), int(B), int(L))), dtype=torch.float32, device=device)
 
 
 def heads_bwd(rec, descs, x, dx, B, L, drop_p, dx_accumulate=False, scratch=None):
@@ -1005,8 +1006,8 @@ def heads_step(rec, descs, kinds, labels, durations, logvars, losses, x, dx, B, 
     _chk2d(x, "heads_step.x")
     arr = _head_array(rec, descs)
     n = len(descs)
-    if scratch is not None and scratch.numel() < n * int(B) * int(L) + 1:
-        raise FxError("heads_step: scratch too small")
+    if scratch is None or scratch.numel() < int(lib.fx_heads_step_scratch_floats(n, int(B), int(L))):
+        raise FxError("heads_step: needs heads_bwd_scratch(n_heads, B, L)")
 
     def parr(ts):
         return (C.c_void_p * max(len(ts), 1))(*[_ptr(t) for t in ts])

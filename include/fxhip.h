@@ -257,7 +257,10 @@ int fx_heads_bwd(const fx_head_desc* heads, int n_heads, const float* x, long ld
  * (parameter gradients; dx (+)= the heads' embedding gradients added in head order) and the uncertainty-weighted total over
  * ALL n_terms named losses of the model (direct_pred.py:192-223; terms written by earlier launches -- triplet, MMD -- are read
  * from their slots; term_dlogvars / epoch_acc as fx_total_loss).  Replaces fx_heads_fwd -> per-head loss kernels ->
- * fx_total_loss -> fx_heads_bwd.  heads[i].dout receives the output gradient; dx_scratch as fx_heads_bwd (needed for > 1 head). */
+ * fx_total_loss -> fx_heads_bwd.  heads[i].dout receives the output gradient.  dx_scratch (REQUIRED): fx_heads_step_scratch_floats(n_heads,
+ * B, L) floats, zero-filled once by the caller -- the shares of dx + arrival counter as fx_heads_bwd, then one block per head in which the
+ * head's second workgroup (the weight-gradient role) keeps its own copies of the saved tensors: every shared output has ONE writer. */
+long fx_heads_step_scratch_floats(int n_heads, int B, int L);
 int fx_heads_step(const fx_head_desc* heads, int n_heads, const int* kinds, const float* const* labels,
                   const float* const* durations, const float* const* logvars, float* const* losses, const float* x, long ldx,
                   float* dx, long lddx, int dx_accumulate, int B, int L, float drop_p, const float* ctrl, void* dx_scratch,
