@@ -98,7 +98,11 @@ def _live_traffic(want_prefix, args):
                "--config", args.config, "--batch", str(args.batch), "--precision", args.precision, "--steps", "4", "--warmup", "1", "--no-graph",
                "--no-cpu-baseline", "--sweep-trials-per-gpu", "0", "--no-other", "--repeats", "0", "--no-pmc"]
         try:
-            env = dict(os.environ, TMPDIR="/tmp")
+            # (the child is a plain single-process run: a launcher's rendezvous variables must not reach it)
+            env = {k: v for k, v in os.environ.items()
+                   if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT")
+                   and not k.startswith("TORCHELASTIC_")}
+            env["TMPDIR"] = "/tmp"
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120, check=True)
             path = None
             for root, _, files in os.walk(d):
