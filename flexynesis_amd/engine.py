@@ -137,6 +137,186 @@ class PlacementPool:
 POOL = PlacementPool()
 
 
+class PartitionArena:
+    """Where W and (m, v) of every wide weight live so that the dominant kernel streams them at the FAST rate, by construction.
+
+    What rounds 2-5 called the placement lottery is this (profiles/r05_partitions.txt): the GPU's memory consists of a few PARTITIONS,
+    contiguous physical ranges tens of GB long, each of which delivers ~4.9 TB/s to the fused kernel's access pattern whatever lies in it;
+    arrays in two different partitions are streamed at 6.1 TB/s together.  A fresh process allocates from one partition, so W, m and v
+    of a weight usually share it (the "slow placement"); the "fast" ones were arrays that happened to straddle a boundary or to land
+    on different sides of one.  Two arrays are in different partitions exactly when fx_placement_probe over the PAIR runs fast.
+
+    The arena is built once per process and device, at the first wide weight: pool A is allocated where the process stands; spacer
+    blocks are allocated (and kept) in steps until a test array behind them rates fast against pool A -- the allocator has crossed a
+    boundary --, pool B is allocated there, the spacers go back to the driver.  Every wide weight then takes W from pool A and m, v
+    from pool B (a third / two thirds of the kernel's traffic).  No per-weight search, nothing to rate per shape, HPO trials included.
+    Falls back to ParamStore's search (returns None) when disabled (FX_PARTITION_ARENA=0), when the device has no room for the
+    spacers, when no boundary is found, or when a pool is exhausted."""
+
+    GRAN = 1 << 21                      # sub-allocation granularity (bytes)
+    REF = (5000, 20000)                 # shape of the arrays the boundary search rates
+    FAST_TBS = 5.6                      # pair rate that means "two partitions" (one: 4.9-5.0, two: 6.0-6.1)
+    _arenas: Dict[int, "PartitionArena"] = {}
+    _glock = threading.Lock()
+
+    def __init__(self, device):
+        self.device = device
+        self.lock = threading.Lock()
+        self.pools: List[Optional[torch.Tensor]] = [None, None]       # uint8 tensors
+        self.free: List[List[Tuple[int, int]]] = [[], []]            # per pool: (offset, bytes) free ranges, sorted
+        self.events: List[Optional[torch.cuda.Event]] = [None, None]  # the last hand-back per pool
+        self.info: dict = {}
+        self.ok = False
+
+    @classmethod
+    def get(cls, device) -> Optional["PartitionArena"]:
+        if os.environ.get("FX_PARTITION_ARENA", "1") == "0" or ops.capturing():
+            return None
+        with cls._glock:
+            a = cls._arenas.get(device.index)
+            if a is None:
+                a = cls._arenas[device.index] = PartitionArena(device)
+                try:
+                    a._build()
+                except Exception as e:             # (out of memory while stepping, a runtime error of the probe: the legacy path takes over)
+                    a.info["error"] = repr(e)[:200]
+                    a.pools = [None, None]
+                    a.ok = False
+                    torch.cuda.empty_cache()
+            return a if a.ok else None
+
+    @classmethod
+    def reset(cls, device=None):
+        with cls._glock:
+            if device is None:
+                cls._arenas.clear()
+            else:
+                cls._arenas.pop(device.index, None)
+
+    def _ref_view(self, buf: torch.Tensor, off: int = 0) -> torch.Tensor:
+        r, c = self.REF
+        return buf[off:off + r * c * 4].view(torch.float32).view(r, c)
+
+    def _pair(self, a: torch.Tensor, b: torch.Tensor) -> float:
+        r, c = self.REF
+        return 16.0 * r * c / ops.placement_probe_us(a, b, None, launches=2) / 1e6
+
+    def _build(self):
+        import time
+        t0 = time.perf_counter()
+        dev = self.device
+        gb = 1 << 30
+        a_bytes = int(float(os.environ.get("FX_ARENA_A_GB", "8")) * gb)
+        b_bytes = int(float(os.environ.get("FX_ARENA_B_GB", "16")) * gb)
+        step = int(float(os.environ.get("FX_ARENA_STEP_GB", "8")) * gb)
+        max_spacer = int(float(os.environ.get("FX_ARENA_MAX_SPACER_GB", "160")) * gb)
+        ref_bytes = self.REF[0] * self.REF[1] * 4
+        with torch.cuda.device(dev):
+            free_b, _total = torch.cuda.mem_get_info(dev)
+            budget = min(max_spacer, int(free_b * 0.7) - a_bytes - b_bytes)
+            if budget < 2 * step:
+                self.info["skipped"] = f"{free_b / gb:.0f} GB free: no room to look for a partition boundary"
+                return
+            pool_a = torch.empty(a_bytes, dtype=torch.uint8, device=dev)
+            ref = self._ref_view(pool_a)
+            spacers, spent, rates, found = [], 0, [], None
+            while spent + step + ref_bytes <= budget:
+                spacers.append(torch.empty(step, dtype=torch.uint8, device=dev))
+                test = torch.empty(ref_bytes, dtype=torch.uint8, device=dev)
+                spent += step + ref_bytes
+                r = self._pair(ref, self._ref_view(test))
+                rates.append(round(r, 2))
+                spacers.append(test)
+                if r >= self.FAST_TBS:
+                    found = True
+                    break
+            self.info.update(spacer_GB=round(spent / gb, 1), pair_TBps_while_stepping=rates)
+            if not found:
+                del spacers, pool_a
+                torch.cuda.empty_cache()
+                self.info["skipped"] = "no partition boundary within the spacer budget"
+                return
+            pool_b = torch.empty(b_bytes, dtype=torch.uint8, device=dev)
+            ends = [self._pair(ref, self._ref_view(pool_b, 0)), self._pair(ref, self._ref_view(pool_b, (b_bytes - ref_bytes) // self.GRAN * self.GRAN)),
+                    self._pair(self._ref_view(pool_a, (a_bytes - ref_bytes) // self.GRAN * self.GRAN), self._ref_view(pool_b, 0))]
+            self.info["pool_pair_TBps"] = [round(x, 2) for x in ends]
+            del spacers, test
+            torch.cuda.empty_cache()                       # the spacers go back to the driver; the pools stay where they are
+            if min(ends) < self.FAST_TBS:
+                del pool_a, pool_b
+                torch.cuda.empty_cache()
+                self.info["skipped"] = "pool B does not lie behind the boundary over its whole length"
+                return
+            self.pools = [pool_a, pool_b]
+            self.free = [[(0, a_bytes)], [(0, b_bytes)]]
+            self.ok = True
+            self.info.update(pool_GB=[a_bytes / gb, b_bytes / gb], build_s=round(time.perf_counter() - t0, 3))
+
+    def _alloc(self, part: int, nbytes: int) -> Optional[Tuple[int, int]]:
+        size = (nbytes + self.GRAN - 1) // self.GRAN * self.GRAN
+        fl = self.free[part]
+        for i, (off, sz) in enumerate(fl):
+            if sz >= size:
+                if sz == size:
+                    fl.pop(i)
+                else:
+                    fl[i] = (off + size, sz - size)
+                return off, size
+        return None
+
+    def _release(self, part: int, off: int, size: int):
+        fl = self.free[part]
+        fl.append((off, size))
+        fl.sort()
+        merged = []
+        for o, z in fl:
+            if merged and merged[-1][0] + merged[-1][1] == o:
+                merged[-1] = (merged[-1][0], merged[-1][1] + z)
+            else:
+                merged.append((o, z))
+        fl[:] = merged
+
+    def take3(self, need_elems: int):
+        """(W, m, v) as flat fp32 views of need_elems elements -- W from pool A, m and v from pool B -- zero-filled, and the token that
+        gives them back; or None when a pool has no room."""
+        nbytes = need_elems * 4
+        with self.lock:
+            w = self._alloc(0, nbytes)
+            m = self._alloc(1, nbytes) if w else None
+            v = self._alloc(1, nbytes) if m else None
+            if not (w and m and v):
+                for part, r in ((0, w), (1, m), (1, v)):
+                    if r:
+                        self._release(part, *r)
+                return None
+            evs = [e for e in self.events if e is not None]
+        for e in evs:
+            torch.cuda.current_stream(self.device).wait_event(e)
+        token = [(0, w), (1, m), (1, v)]
+        views = []
+        for part, (off, size) in token:
+            t = self.pools[part][off:off + nbytes].view(torch.float32)
+            t.zero_()
+            views.append(t)
+        return views, token
+
+    def give(self, token):
+        if not self.ok:
+            return
+        ev = None
+        if not ops.capturing():
+            try:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+            except Exception:
+                ev = None
+        with self.lock:
+            for part, (off, size) in token:
+                self._release(part, off, size)
+                if ev is not None:
+                    self.events[part] = ev
+
+
 def search_arrays(device, out: int, fin: int, want: int, tries: int, seed: int = 20240):
     """Up to ``want`` flat arrays of out x pad32(fin) floats that stream the dW + Adam traffic pattern at >= PLACE_GOOD_TBS, found among
     at most 8 x tries candidates allocated behind spacers of varying size.  Returns ([(array, TB/s)], info); when the fast group is
@@ -396,6 +576,24 @@ class ParamStore:
         t0 = time.perf_counter()
         info = {}
         with torch.cuda.device(self.device):
+            # (FX_PLACEMENT_TRIES=1 in the environment is the A/B "take what the allocator gives"; a short fit's thread-local tries = 1 only
+            # switches the per-weight SEARCH off -- the arena costs a trial nothing)
+            arena = PartitionArena.get(self.device) if (eligible and os.environ.get("FX_PLACEMENT_TRIES") != "1") else None
+            if arena is not None:
+                taken = arena.take3(need)
+                if taken is not None:
+                    flats, token = taken
+                    views = []
+                    for name, flat in zip(("W", "M", "V"), flats):
+                        buf = flat.view(out, ld)
+                        self.big[key]["_" + name] = buf
+                        self.big[key][name] = buf[:, :fin]
+                        views.append(buf[:, :fin])
+                    self.big[key]["_arena"] = (arena, token)
+                    self.placement[key] = dict(arena=True, kept_us=round(ops.placement_probe_us(*views), 1),
+                                               search_s=round(time.perf_counter() - t0, 3), **{k: v for k, v in arena.info.items() if k in ("build_s", "spacer_GB")})
+                    return
+                info["arena"] = "pool exhausted"
             if eligible:
                 got = POOL.take(self.device, (out, fin), 3)
                 info["from_pool"] = len(got)
@@ -427,6 +625,9 @@ class ParamStore:
             arrs = d.pop("_arrays", None)
             if arrs:
                 POOL.give(self.device, arrs[0], arrs[1])
+            ar = d.pop("_arena", None)
+            if ar:
+                ar[0].give(ar[1])
         self.big = {}
 
     def __del__(self):
