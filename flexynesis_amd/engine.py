@@ -162,9 +162,10 @@ class PartitionArena:
     def __init__(self, device):
         self.device = device
         self.lock = threading.Lock()
-        self.pools: List[Optional[torch.Tensor]] = [None, None]       # uint8 tensors
-        self.free: List[List[Tuple[int, int]]] = [[], []]            # per pool: (offset, bytes) free ranges, sorted
-        self.events: List[Optional[torch.cuda.Event]] = [None, None]  # the last hand-back per pool
+        self.chunks: List[torch.Tensor] = []                         # uint8 tensors: chunk 0 is pool A, the rest make up pool B
+        self.kind: List[int] = []                                    # 0: pool A (W), 1: pool B (m, v)
+        self.free: List[List[Tuple[int, int]]] = []                  # per chunk: (offset, bytes) free ranges, sorted
+        self.event: Optional[torch.cuda.Event] = None                # the last hand-back
         self.info: dict = {}
         self.ok = False
 
@@ -180,7 +181,7 @@ class PartitionArena:
                     a._build()
                 except Exception as e:             # (out of memory while stepping, a runtime error of the probe: the legacy path takes over)
                     a.info["error"] = repr(e)[:200]
-                    a.pools = [None, None]
+                    a.chunks, a.kind, a.free = [], [], []
                     a.ok = False
                     torch.cuda.empty_cache()
             return a if a.ok else None
@@ -208,9 +209,11 @@ class PartitionArena:
         gb = 1 << 30
         a_bytes = int(float(os.environ.get("FX_ARENA_A_GB", "8")) * gb)
         b_bytes = int(float(os.environ.get("FX_ARENA_B_GB", "16")) * gb)
+        chunk = int(float(os.environ.get("FX_ARENA_CHUNK_GB", "4")) * gb)
         step = int(float(os.environ.get("FX_ARENA_STEP_GB", "8")) * gb)
         max_spacer = int(float(os.environ.get("FX_ARENA_MAX_SPACER_GB", "160")) * gb)
         ref_bytes = self.REF[0] * self.REF[1] * 4
+        last = lambda n: (n - ref_bytes) // self.GRAN * self.GRAN
         with torch.cuda.device(dev):
             free_b, _total = torch.cuda.mem_get_info(dev)
             budget = min(max_spacer, int(free_b * 0.7) - a_bytes - b_bytes)
@@ -218,54 +221,55 @@ class PartitionArena:
                 self.info["skipped"] = f"{free_b / gb:.0f} GB free: no room to look for a partition boundary"
                 return
             pool_a = torch.empty(a_bytes, dtype=torch.uint8, device=dev)
-            ref = self._ref_view(pool_a)
-            spacers, spent, rates, found = [], 0, [], None
-            while spent + step + ref_bytes <= budget:
-                spacers.append(torch.empty(step, dtype=torch.uint8, device=dev))
-                test = torch.empty(ref_bytes, dtype=torch.uint8, device=dev)
-                spent += step + ref_bytes
-                r = self._pair(ref, self._ref_view(test))
+            a0, a1 = self._ref_view(pool_a), self._ref_view(pool_a, last(a_bytes))
+            self.info["pool_A_ends_TBps"] = round(self._pair(a0, a1), 2)       # (slow: the pool lies in one partition)
+            spacers, spent, rates, good = [], 0, [], []
+            # candidates of pool B, one chunk at a time: a chunk is kept when BOTH its ends rate fast against BOTH ends of pool A (it lies in
+            # other partitions than pool A over its whole length); a chunk that does not stays allocated as a spacer, with a further spacer
+            # behind it, so that the next candidate comes from further along
+            while sum(c.numel() for c in good) < b_bytes and spent + chunk <= budget:
+                cand = torch.empty(chunk, dtype=torch.uint8, device=dev)
+                c0, c1 = self._ref_view(cand), self._ref_view(cand, last(chunk))
+                r = min(self._pair(a0, c0), self._pair(a0, c1), self._pair(a1, c0), self._pair(a1, c1))
                 rates.append(round(r, 2))
-                spacers.append(test)
                 if r >= self.FAST_TBS:
-                    found = True
-                    break
-            self.info.update(spacer_GB=round(spent / gb, 1), pair_TBps_while_stepping=rates)
-            if not found:
-                del spacers, pool_a
+                    good.append(cand)
+                else:
+                    spacers.append(cand)
+                    spent += chunk
+                    if spent + step <= budget:
+                        spacers.append(torch.empty(step, dtype=torch.uint8, device=dev))
+                        spent += step
+            self.info.update(spacer_GB=round(spent / gb, 1), candidate_TBps=rates)
+            del spacers
+            if sum(c.numel() for c in good) < min(b_bytes, 2 * chunk):
+                del good, pool_a, a0, a1
                 torch.cuda.empty_cache()
                 self.info["skipped"] = "no partition boundary within the spacer budget"
                 return
-            pool_b = torch.empty(b_bytes, dtype=torch.uint8, device=dev)
-            ends = [self._pair(ref, self._ref_view(pool_b, 0)), self._pair(ref, self._ref_view(pool_b, (b_bytes - ref_bytes) // self.GRAN * self.GRAN)),
-                    self._pair(self._ref_view(pool_a, (a_bytes - ref_bytes) // self.GRAN * self.GRAN), self._ref_view(pool_b, 0))]
-            self.info["pool_pair_TBps"] = [round(x, 2) for x in ends]
-            del spacers, test
             torch.cuda.empty_cache()                       # the spacers go back to the driver; the pools stay where they are
-            if min(ends) < self.FAST_TBS:
-                del pool_a, pool_b
-                torch.cuda.empty_cache()
-                self.info["skipped"] = "pool B does not lie behind the boundary over its whole length"
-                return
-            self.pools = [pool_a, pool_b]
-            self.free = [[(0, a_bytes)], [(0, b_bytes)]]
+            self.chunks = [pool_a] + good
+            self.kind = [0] + [1] * len(good)
+            self.free = [[(0, c.numel())] for c in self.chunks]
             self.ok = True
-            self.info.update(pool_GB=[a_bytes / gb, b_bytes / gb], build_s=round(time.perf_counter() - t0, 3))
+            self.info.update(pool_GB=[a_bytes / gb, sum(c.numel() for c in good) / gb], build_s=round(time.perf_counter() - t0, 3))
 
-    def _alloc(self, part: int, nbytes: int) -> Optional[Tuple[int, int]]:
+    def _alloc(self, kind: int, nbytes: int) -> Optional[Tuple[int, int, int]]:
         size = (nbytes + self.GRAN - 1) // self.GRAN * self.GRAN
-        fl = self.free[part]
-        for i, (off, sz) in enumerate(fl):
-            if sz >= size:
-                if sz == size:
-                    fl.pop(i)
-                else:
-                    fl[i] = (off + size, sz - size)
-                return off, size
+        for ci, fl in enumerate(self.free):
+            if self.kind[ci] != kind:
+                continue
+            for i, (off, sz) in enumerate(fl):
+                if sz >= size:
+                    if sz == size:
+                        fl.pop(i)
+                    else:
+                        fl[i] = (off + size, sz - size)
+                    return ci, off, size
         return None
 
-    def _release(self, part: int, off: int, size: int):
-        fl = self.free[part]
+    def _release(self, ci: int, off: int, size: int):
+        fl = self.free[ci]
         fl.append((off, size))
         fl.sort()
         merged = []
@@ -276,26 +280,29 @@ class PartitionArena:
                 merged.append((o, z))
         fl[:] = merged
 
+    def free_bytes(self) -> Tuple[int, int]:
+        with self.lock:
+            return tuple(sum(z for ci, fl in enumerate(self.free) if self.kind[ci] == k for _, z in fl) for k in (0, 1))
+
     def take3(self, need_elems: int):
         """(W, m, v) as flat fp32 views of need_elems elements -- W from pool A, m and v from pool B -- zero-filled, and the token that
         gives them back; or None when a pool has no room."""
         nbytes = need_elems * 4
         with self.lock:
-            w = self._alloc(0, nbytes)
-            m = self._alloc(1, nbytes) if w else None
-            v = self._alloc(1, nbytes) if m else None
-            if not (w and m and v):
-                for part, r in ((0, w), (1, m), (1, v)):
-                    if r:
-                        self._release(part, *r)
-                return None
-            evs = [e for e in self.events if e is not None]
-        for e in evs:
-            torch.cuda.current_stream(self.device).wait_event(e)
-        token = [(0, w), (1, m), (1, v)]
+            token = []
+            for kind in (0, 1, 1):
+                r = self._alloc(kind, nbytes)
+                if r is None:
+                    for t in token:
+                        self._release(*t)
+                    return None
+                token.append(r)
+            ev = self.event
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
         views = []
-        for part, (off, size) in token:
-            t = self.pools[part][off:off + nbytes].view(torch.float32)
+        for ci, off, size in token:
+            t = self.chunks[ci][off:off + nbytes].view(torch.float32)
             t.zero_()
             views.append(t)
         return views, token
@@ -311,10 +318,10 @@ class PartitionArena:
             except Exception:
                 ev = None
         with self.lock:
-            for part, (off, size) in token:
-                self._release(part, off, size)
-                if ev is not None:
-                    self.events[part] = ev
+            for t in token:
+                self._release(*t)
+            if ev is not None:
+                self.event = ev
 
 
 def search_arrays(device, out: int, fin: int, want: int, tries: int, seed: int = 20240):

@@ -288,6 +288,7 @@ def test_placement_probe_leaves_contents_alone_and_store_search_is_transparent(m
         ops.placement_probe_us(torch.zeros(8, 6, device=dev), torch.zeros(8, 6, device=dev), torch.zeros(8, 6, device=dev))   # k_in % 4
     spec = ArchSpec("DirectPred", [("gex", 20000)], 64, 0.25, 16, [("y", "numerical", 1)], None, None, True)
     monkeypatch.delenv("FX_PLACEMENT_TRIES", raising=False)
+    monkeypatch.setenv("FX_PARTITION_ARENA", "0")        # this test is about the per-weight search and the pool behind the arena (its fallback)
     states = []
     for tries in (1, 4):
         with placement_tries(tries):
@@ -331,3 +332,54 @@ def test_placement_probe_leaves_contents_alone_and_store_search_is_transparent(m
     del st2, other
     gc.collect()
     POOL.clear(dev)
+
+
+def test_partition_arena_serves_every_shape_at_the_fast_rate(monkeypatch):
+    """engine.PartitionArena: W of a wide weight from one pool, m and v from a pool behind a partition boundary (profiles/r05_partitions.txt):
+    the fused kernel's traffic pattern runs at the two-partition rate for any shape, with no search -- also for a short fit (tries = 1) --,
+    the model is the same as through the allocator, and a dropped store gives its ranges back."""
+    import gc
+    from flexynesis_amd import ops
+    from flexynesis_amd.arch import ArchSpec
+    from flexynesis_amd.engine import ParamStore, PartitionArena, placement_tries
+    dev = _dev()
+    monkeypatch.delenv("FX_PLACEMENT_TRIES", raising=False)
+    monkeypatch.delenv("FX_PARTITION_ARENA", raising=False)
+    ar = PartitionArena.get(dev)
+    if ar is None:
+        pytest.skip(f"no arena on this device: {PartitionArena._arenas[dev.index].info}")
+    assert ar.info["pool_A_ends_TBps"] < PartitionArena.FAST_TBS <= min(r for r in ar.info["candidate_TBps"] if r >= PartitionArena.FAST_TBS)
+    gc.collect()
+    free0 = ar.free_bytes()
+    key = "encoders.0.layer_1.weight"
+    spec = ArchSpec("DirectPred", [("gex", 20000)], 64, 0.25, 16, [("y", "numerical", 1)], None, None, True)
+    odd = ArchSpec("DirectPred", [("gex", 19873)], 61, 0.444, 13, [("y", "numerical", 1)], None, None, True)
+    stores = []
+    for sp in (spec, odd):
+        with placement_tries(1):                        # what fit() sets for a short fit: no per-weight search -- the arena serves it all the same
+            st = ParamStore(sp, dev, materialize_big_grads=False)
+        info = st.placement[key]
+        out, fin = st.eshapes[key]
+        assert info["arena"] is True and info["search_s"] < 5.0
+        assert 24.0 * out * fin / (info["kept_us"] * 1e-6) >= 5.5e12, info           # one partition: 4.9-5.0 TB/s; two: 5.9-6.1
+        big = st.big[key]
+        a0, a1 = ar.chunks[0].data_ptr(), ar.chunks[0].data_ptr() + ar.chunks[0].numel()
+        assert a0 <= big["_W"].data_ptr() < a1 and not (a0 <= big["_M"].data_ptr() < a1) and not (a0 <= big["_V"].data_ptr() < a1)
+        assert big["_W"].data_ptr() % 16 == 0 and not bool(big["_M"].any()) and not bool(big["_V"].any())
+        stores.append(st)
+    assert ar.free_bytes()[0] < free0[0] and ar.free_bytes()[1] < free0[1]
+    st = stores[0]
+    st.reset_parameters(seed=5)
+    sd = st.state_dict()
+    monkeypatch.setenv("FX_PARTITION_ARENA", "0")
+    with placement_tries(1):
+        ref = ParamStore(spec, dev, materialize_big_grads=False)
+    monkeypatch.delenv("FX_PARTITION_ARENA")
+    assert ref.placement.get(key) is None
+    ref.reset_parameters(seed=5)
+    for k, v in ref.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    assert ar.take3(64 << 30) is None                    # more than a pool holds: the caller falls back to the allocator
+    del st, stores, ref, big
+    gc.collect()
+    assert ar.free_bytes() == free0                      # every range came back and merged
