@@ -301,7 +301,7 @@ def main():
         t0 = time.perf_counter()
         st = ParamStore(spec, dev, materialize_big_grads=False)          # this rank's placement of the headline weights (search on)
         mine = {"rank": rank, "device": torch.cuda.get_device_name(dev), "store_build_s": round(time.perf_counter() - t0, 3),
-                "placement": {k: {kk: v.get(kk) for kk in ("probed", "kept_TBps", "kept_us", "search_s")} for k, v in st.placement.items()}}
+                "placement": {k: {kk: v.get(kk) for kk in ("arena", "probed", "kept_TBps", "kept_us", "search_s", "build_s", "spacer_GB")} for k, v in st.placement.items()}}
         del st
         with _stdout_to_stderr():
             try:
@@ -474,6 +474,12 @@ def main():
     # everything the legs below need from the headline objects has been read: release them (graphs first, at a known point)
     pipe.close()
     placement = dict(store.placement)
+    try:                                  # how this process's partition arena was built (engine.PartitionArena), or why it was not
+        from flexynesis_amd.engine import PartitionArena
+        _ar = PartitionArena._arenas.get(dev.index)
+        placement_arena = dict(_ar.info) if _ar is not None else None
+    except Exception:
+        placement_arena = None
     del pipe, store, cohort
     torch.cuda.empty_cache()
     sweep = None
@@ -551,7 +557,7 @@ def main():
                        "schedule_hbm_frac_of_8TBs": round(bytes_moved / (ms_per_step * 1e-3) / 8e12, 4),
                        # wide weights: probe times (us per pass of the dW + Adam traffic pattern over ONE array) of the candidate placements
                        # ParamStore tried at allocation, the three it kept and their time together (FX_PLACEMENT_TRIES=1: first)
-                       "placement": placement,
+                       "placement": placement, "placement_arena": placement_arena,
                        "loss_finite": finite, "last_losses": {k: round(v, 6) for k, v in losses.items()}},
             "roofline": roof, "cpu_baseline": cpu, "repeat_stats": repeat_stats, "other": other, "sweep": sweep,
         }
