@@ -562,11 +562,12 @@ def trial_splits(n: int, val_size: float, seed: int, use_cv: bool = False, n_spl
 
 
 def _short_fit_placement(fn):
-    """HPO trials are short fits (a few dozen steps) that do not earn back a search over placements of their wide weights (each
-    rejected candidate costs ~6 ms and a trip of its blocks back to the driver; a rating does not carry over to the next trial's
-    shapes: profiles/r05_placement_pool.txt): their ParamStores take rated arrays of their shape from the process-level pool when
-    an earlier model of the same shape left some (the folds of a cross-validated trial), else the first placement
-    (engine.placement_tries(1); FX_PLACEMENT_TRIES_TRIAL=<n> searches, FX_PLACEMENT_TRIES overrides everything)."""
+    """HPO trials are short fits (a few dozen steps) that do not earn back a per-weight search over placements (each rejected
+    candidate costs ~6 ms and a trip of its blocks back to the driver).  Their wide weights come from the process's partition arena
+    like everyone's (engine.PartitionArena: W and m, v on two sides of a memory-partition boundary, nothing to search); where there is
+    no arena, from the process-level pool when an earlier model of the same shape left rated arrays (the folds of a cross-validated
+    trial), else the first placement (engine.placement_tries(1); FX_PLACEMENT_TRIES_TRIAL=<n> searches, FX_PLACEMENT_TRIES overrides
+    everything)."""
     import functools
 
     @functools.wraps(fn)
