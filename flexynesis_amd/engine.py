@@ -248,8 +248,14 @@ class PartitionArena:
                 self.info["skipped"] = "no partition boundary within the spacer budget"
                 return
             torch.cuda.empty_cache()                       # the spacers go back to the driver; the pools stay where they are
+            # pool B's chunks may themselves lie in two partitions (the stepping often passes more than one boundary): those that rate
+            # fast against the first one form class 2 -- m is then taken from class 1 and v from class 2, three partitions for nothing
+            # (the real kernel: 456-460 us against 463-469 with two, profiles/r05_partitions.txt item 4)
+            g0 = self._ref_view(good[0])
+            cls = [1] + [2 if self._pair(g0, self._ref_view(c)) >= self.FAST_TBS else 1 for c in good[1:]]
+            self.info["pool_B_classes"] = cls
             self.chunks = [pool_a] + good
-            self.kind = [0] + [1] * len(good)
+            self.kind = [0] + cls
             self.free = [[(0, c.numel())] for c in self.chunks]
             self.ok = True
             self.info.update(pool_GB=[a_bytes / gb, sum(c.numel() for c in good) / gb], build_s=round(time.perf_counter() - t0, 3))
@@ -282,7 +288,7 @@ class PartitionArena:
 
     def free_bytes(self) -> Tuple[int, int]:
         with self.lock:
-            return tuple(sum(z for ci, fl in enumerate(self.free) if self.kind[ci] == k for _, z in fl) for k in (0, 1))
+            return tuple(sum(z for ci, fl in enumerate(self.free) if (self.kind[ci] > 0) == bool(k) for _, z in fl) for k in (0, 1))
 
     def take3(self, need_elems: int):
         """(W, m, v) as flat fp32 views of need_elems elements -- W from pool A, m and v from pool B -- zero-filled, and the token that
@@ -290,8 +296,12 @@ class PartitionArena:
         nbytes = need_elems * 4
         with self.lock:
             token = []
-            for kind in (0, 1, 1):
-                r = self._alloc(kind, nbytes)
+            for kinds in ((0,), (1, 2), (2, 1)):          # W | m | v; m and v share a class when the other has no room (or does not exist)
+                r = None
+                for kind in kinds:
+                    r = self._alloc(kind, nbytes)
+                    if r is not None:
+                        break
                 if r is None:
                     for t in token:
                         self._release(*t)
