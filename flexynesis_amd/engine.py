@@ -227,13 +227,20 @@ class PartitionArena:
             # candidates of pool B, one chunk at a time: a chunk is kept when BOTH its ends rate fast against BOTH ends of pool A (it lies in
             # other partitions than pool A over its whole length); a chunk that does not stays allocated as a spacer, with a further spacer
             # behind it, so that the next candidate comes from further along
-            while sum(c.numel() for c in good) < b_bytes and spent + chunk <= budget:
+            # FX_ARENA_PARTITIONS=3 (A/B, not the default: the third partition can lie > 100 GB = 2 s of allocations away) keeps stepping
+            # until half of pool B lies in a partition other than pool A's AND the first chunk's
+            want3 = os.environ.get("FX_ARENA_PARTITIONS", "2") == "3"
+            n2 = 0
+            while spent + chunk <= budget and (sum(c.numel() for c in good) < b_bytes or (want3 and 2 * n2 * chunk < b_bytes)):
                 cand = torch.empty(chunk, dtype=torch.uint8, device=dev)
                 c0, c1 = self._ref_view(cand), self._ref_view(cand, last(chunk))
                 r = min(self._pair(a0, c0), self._pair(a0, c1), self._pair(a1, c0), self._pair(a1, c1))
                 rates.append(round(r, 2))
-                if r >= self.FAST_TBS:
+                other = bool(good) and self._pair(self._ref_view(good[0]), c0) >= self.FAST_TBS
+                full = sum(c.numel() for c in good) >= b_bytes
+                if r >= self.FAST_TBS and (not full or other):
                     good.append(cand)
+                    n2 += int(other)
                 else:
                     spacers.append(cand)
                     spent += chunk
