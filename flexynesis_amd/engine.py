@@ -211,12 +211,12 @@ class PartitionArena:
         b_bytes = int(float(os.environ.get("FX_ARENA_B_GB", "16")) * gb)
         chunk = int(float(os.environ.get("FX_ARENA_CHUNK_GB", "4")) * gb)
         step = int(float(os.environ.get("FX_ARENA_STEP_GB", "8")) * gb)
-        max_spacer = int(float(os.environ.get("FX_ARENA_MAX_SPACER_GB", "160")) * gb)
+        max_spacer = int(float(os.environ.get("FX_ARENA_MAX_SPACER_GB", "112")) * gb)    # (boundaries seen so far: 0-64 GB along)
         ref_bytes = self.REF[0] * self.REF[1] * 4
         last = lambda n: (n - ref_bytes) // self.GRAN * self.GRAN
         with torch.cuda.device(dev):
             free_b, _total = torch.cuda.mem_get_info(dev)
-            budget = min(max_spacer, int(free_b * 0.7) - a_bytes - b_bytes)
+            budget = min(max_spacer, int(free_b * 0.45) - a_bytes - b_bytes)      # (two processes may be doing this on one GPU)
             if budget < 2 * step:
                 self.info["skipped"] = f"{free_b / gb:.0f} GB free: no room to look for a partition boundary"
                 return
