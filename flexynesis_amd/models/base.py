@@ -569,8 +569,9 @@ class FxModel(_Base):
                     pr = torch.empty_like(o)
                     ops.softmax_rows(ops.IMMEDIATE, pr, o)
                     o = pr
-                preds[v].extend(o.cpu().numpy())
-        return {v: np.array(a) for v, a in preds.items()}
+                preds[v].append(o if dataset.variable_types[v] == "categorical" else o.clone())   # (the plan's buffer is overwritten by the next batch)
+        # one read-back at the end: a .cpu() per 64-row batch was a host synchronisation per batch
+        return {v: (torch.cat(a, 0).cpu().numpy() if a else np.array([])) for v, a in preds.items()}
 
     def transform(self, dataset):
         """Latent embeddings as a DataFrame E0..E{L-1} indexed by sample (reference direct_pred.py:353-415)."""
@@ -579,8 +580,8 @@ class FxModel(_Base):
         chunks = []
         for _, dat in self._eval_batches(dataset, 64):
             plan = self._run_eval(dat)
-            chunks.append(plan.embeddings.detach().cpu().clone())
-        emb = torch.cat(chunks, 0).numpy()
+            chunks.append(plan.embeddings.detach().clone())          # (on the device: one read-back at the end)
+        emb = torch.cat(chunks, 0).cpu().numpy()
         return pd.DataFrame(emb, index=list(dataset.samples), columns=[f"E{i}" for i in range(emb.shape[1])])
 
     # -- attributions (reference models/direct_pred.py:418-590, called by the CLI at __main__.py:1385-1400) ---------------
