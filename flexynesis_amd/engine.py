@@ -220,7 +220,28 @@ class PartitionArena:
             if budget < 2 * step:
                 self.info["skipped"] = f"{free_b / gb:.0f} GB free: no room to look for a partition boundary"
                 return
+            # Allocation is what the build costs, and its price differs 60-fold between boxes (4 ms per GB on most, 250 on one: 96 GB of
+            # pools + spacers took 23.7 s there): every further allocation is priced at the rate measured so far and the build stops
+            # (-> the bounded search) when FX_ARENA_BUDGET_S (5) would be exceeded.
+            budget_s = float(os.environ.get("FX_ARENA_BUDGET_S", "5"))
+            torch.cuda.synchronize(dev)
+            ta = time.perf_counter()
             pool_a = torch.empty(a_bytes, dtype=torch.uint8, device=dev)
+            pool_a[::1 << 21].zero_()
+            torch.cuda.synchronize(dev)
+            alloc_bytes, alloc_s = a_bytes, max(time.perf_counter() - ta, 1e-4)
+            self.info["alloc_ms_per_GB"] = round(1e3 * alloc_s / (a_bytes / gb), 1)
+
+            def affordable(nbytes):
+                return (time.perf_counter() - t0) + nbytes * (alloc_s / alloc_bytes) <= budget_s
+
+            def timed_empty(nbytes):
+                nonlocal alloc_bytes, alloc_s
+                t1 = time.perf_counter()
+                buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                alloc_bytes += nbytes
+                alloc_s += time.perf_counter() - t1
+                return buf
             a0, a1 = self._ref_view(pool_a), self._ref_view(pool_a, last(a_bytes))
             self.info["pool_A_ends_TBps"] = round(self._pair(a0, a1), 2)       # (slow: the pool lies in one partition)
             spacers, spent, rates, good = [], 0, [], []
@@ -231,8 +252,9 @@ class PartitionArena:
             # until half of pool B lies in a partition other than pool A's AND the first chunk's
             want3 = os.environ.get("FX_ARENA_PARTITIONS", "2") == "3"
             n2 = 0
-            while spent + chunk <= budget and (sum(c.numel() for c in good) < b_bytes or (want3 and 2 * n2 * chunk < b_bytes)):
-                cand = torch.empty(chunk, dtype=torch.uint8, device=dev)
+            while (spent + chunk <= budget and affordable(chunk)
+                   and (sum(c.numel() for c in good) < b_bytes or (want3 and 2 * n2 * chunk < b_bytes))):
+                cand = timed_empty(chunk)
                 c0, c1 = self._ref_view(cand), self._ref_view(cand, last(chunk))
                 r = min(self._pair(a0, c0), self._pair(a0, c1), self._pair(a1, c0), self._pair(a1, c1))
                 rates.append(round(r, 2))
@@ -244,15 +266,16 @@ class PartitionArena:
                 else:
                     spacers.append(cand)
                     spent += chunk
-                    if spent + step <= budget:
-                        spacers.append(torch.empty(step, dtype=torch.uint8, device=dev))
+                    if spent + step <= budget and affordable(step + chunk):
+                        spacers.append(timed_empty(step))
                         spent += step
             self.info.update(spacer_GB=round(spent / gb, 1), candidate_TBps=rates)
             del spacers
             if sum(c.numel() for c in good) < min(b_bytes, 2 * chunk):
                 del good, pool_a, a0, a1
                 torch.cuda.empty_cache()
-                self.info["skipped"] = "no partition boundary within the spacer budget"
+                self.info["skipped"] = "no partition boundary within the spacer / time budget"
+                self.info["build_s"] = round(time.perf_counter() - t0, 3)
                 return
             torch.cuda.empty_cache()                       # the spacers go back to the driver; the pools stay where they are
             # pool B's chunks may themselves lie in two partitions (the stepping often passes more than one boundary): those that rate
