@@ -383,3 +383,30 @@ def test_partition_arena_serves_every_shape_at_the_fast_rate(monkeypatch):
     del st, stores, ref, big
     gc.collect()
     assert ar.free_bytes() == free0                      # every range came back and merged
+
+
+def test_partition_arena_gives_up_within_its_time_budget(monkeypatch):
+    """A build that cannot afford its allocations (FX_ARENA_BUDGET_S) leaves the arena off and ParamStore on the bounded search; the next
+    process-level build (reset) works again."""
+    import gc
+    from flexynesis_amd.arch import ArchSpec
+    from flexynesis_amd.engine import ParamStore, PartitionArena, placement_tries
+    dev = _dev()
+    monkeypatch.delenv("FX_PLACEMENT_TRIES", raising=False)
+    monkeypatch.delenv("FX_PARTITION_ARENA", raising=False)
+    gc.collect()
+    PartitionArena.reset(dev)
+    monkeypatch.setenv("FX_ARENA_BUDGET_S", "0.000001")
+    assert PartitionArena.get(dev) is None
+    info = PartitionArena._arenas[dev.index].info
+    assert "skipped" in info and info["build_s"] < 5.0, info
+    spec = ArchSpec("DirectPred", [("gex", 20000)], 64, 0.25, 16, [("y", "numerical", 1)], None, None, True)
+    with placement_tries(1):
+        st = ParamStore(spec, dev, materialize_big_grads=False)
+    assert st.placement.get("encoders.0.layer_1.weight") is None          # first placement, as a short fit asks for
+    st.reset_parameters(seed=1)
+    assert bool(torch.isfinite(st.p("encoders.0.layer_1.weight")).all())
+    del st
+    gc.collect()
+    monkeypatch.delenv("FX_ARENA_BUDGET_S")
+    PartitionArena.reset(dev)                                              # later tests build their arena afresh
