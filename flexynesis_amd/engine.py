@@ -1305,7 +1305,17 @@ class StepPlan:
         if gx is None:
             R = x.shape[0]
             gx = self._new(f"gram_x_full/{x.data_ptr()}", R, R)
-            ops.gemm(rec, ops.GEMM_NT, gx, x, x, None, self.ws)
+            sp = self._split_cache.get(("fwd", x.data_ptr())) if self.precision == "bf16x3" else None
+            if sp is not None and (R * R) % 4 == 0 and os.environ.get("FX_GRAM_KB", "1") != "0":
+                # the K-blocked split of x exists already (the wide forward made it): partial sums on the bf16 MFMA + one ordered reduce,
+                # as the engine loop's batch assembly does -- 16 instead of 25 us per modality on the level-1 forward tape's chain
+                F = x.shape[1]
+                k = ops.gram_kb_slices(F)
+                slabs = self._new(f"gram_x_slabs1/{x.data_ptr()}", k, R * R)
+                ops.gram_kb_group(rec, [sp], [slabs], [F], R)
+                ops.reduce_group(rec, [(gx, slabs, k, None)])
+            else:
+                ops.gemm(rec, ops.GEMM_NT, gx, x, x, None, self.ws)
             self._gram_x[("full", x.data_ptr())] = gx
         return gx
 
