@@ -3,6 +3,7 @@
 2-omics x 20k-feature cohorts (BASELINE.json configs[1]) on N MI355X GPUs of one node.
 
     python bench.py --gpus 1 --steps 50 --warmup 5
+    python bench.py --gpus N ...      (no launcher: starts the N ranks itself under torch.distributed.run on 127.0.0.1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -147,6 +148,8 @@ def parse():
     ap.add_argument("--dry", action="store_true", help="multi-GPU day-one check instead of the benchmark: cohort broadcast, ONE one-epoch "
                     "trial per rank, all_gather of the records, winner broadcast -- prints the seconds of every phase and each rank's "
                     "placement of the cfg2 weights (one JSON line from rank 0)")
+    ap.add_argument("--n1-sweep", type=float, default=0.0, help="the N = 1 sweep leg's aggregate samples/s to quote `sweep_scaling` against "
+                    "(0 = the round's committed N = 1 line under profiles/)")
     ap.add_argument("--no-pmc", action="store_true", help="do not re-run this script under rocprofv3 --pmc for roofline.traffic")
     ap.add_argument("--settle", type=int, default=40, help="untimed hipGraph replays before the --warmup steps (the first windows after "
                     "the captures run 3-5 %% slower while the clocks settle; reported as config.untimed_settle_steps)")
@@ -260,6 +263,21 @@ def _dropin_leg(dev, kind, steps, warmup, B=128):
     return rec
 
 
+def _self_launch(n):
+    """Re-exec this command under torch.distributed.run, one process per GPU (rendezvous on 127.0.0.1, a free port)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max((os.cpu_count() or n) // n, 1)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -269,9 +287,13 @@ def main():
         local = 0
         os.environ.setdefault("FX_BENCH_BACKEND", "gloo")
     backend = os.environ.get("FX_BENCH_BACKEND", "nccl")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # plain `python bench.py --gpus N` (the form the driver uses at N = 1): start the N ranks ourselves, exactly as an external
+        # `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...` would,
+        # forward the arguments, let rank 0's one JSON line through, propagate the return code
+        sys.exit(_self_launch(a.gpus))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        sys.exit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_pg = world > 1 or bool(os.environ.get("FX_BENCH_FORCE_PG"))   # the env switch exercises the RCCL path on one GPU
@@ -482,6 +504,14 @@ def main():
         placement_arena = None
     del pipe, store, cohort
     torch.cuda.empty_cache()
+    # every rank's device and partition arena (N > 1: gathered over the process group the timed region used)
+    mine = {"rank": rank, "local_rank": local, "device": torch.cuda.get_device_name(dev), "backend": backend if use_pg else None,
+            "placement_arena": placement_arena}
+    rank_info = [mine]
+    if use_pg:
+        rank_info = [None] * world
+        with _stdout_to_stderr():
+            dist.all_gather_object(rank_info, mine)
     sweep = None
     if a.sweep_trials_per_gpu > 0:
         try:
@@ -561,6 +591,25 @@ def main():
                        "loss_finite": finite, "last_losses": {k: round(v, 6) for k, v in losses.items()}},
             "roofline": roof, "cpu_baseline": cpu, "repeat_stats": repeat_stats, "other": other, "sweep": sweep,
         }
+        if use_pg:
+            # north_star's N-GPU figure is the SHARDED SWEEP's aggregate (`value` above is N independent fits: weak scaling by
+            # construction); `sweep_scaling` = that aggregate over the N = 1 sweep leg's (--n1-sweep, or this round's committed line)
+            n1, n1_src = a.n1_sweep, "--n1-sweep"
+            if not n1:
+                for fn in ("r06_bench_line.json", "r05_bench_line.json"):
+                    try:
+                        n1 = float(json.load(open(os.path.join(ROOT, "profiles", fn)))["sweep"]["aggregate_samples_per_s"])
+                        n1_src = f"profiles/{fn} (N = 1, another box)"
+                        break
+                    except Exception:
+                        n1 = 0.0
+            agg = (sweep or {}).get("aggregate_samples_per_s")
+            out["sweep_scaling"] = {"n_gpus": world, "aggregate_samples_per_s": agg, "n1_aggregate_samples_per_s": n1 or None,
+                                    "n1_source": n1_src if n1 else None, "ratio": round(agg / n1, 3) if agg and n1 else None,
+                                    "busy_over_wall": (sweep or {}).get("busy_over_wall"), "tail_imbalance": (sweep or {}).get("tail_imbalance")}
+            out["rccl_ranks_seen"] = len([r for r in rank_info if r]) if backend != "gloo" else 0
+            out["ranks_seen"] = len([r for r in rank_info if r])
+            out["ranks"] = rank_info
         print(json.dumps(out), flush=True)
     if use_pg:
         with _stdout_to_stderr():

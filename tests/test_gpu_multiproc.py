@@ -133,3 +133,36 @@ def test_bench_two_ranks_on_one_gpu_end_to_end():
     sw = out["sweep"]
     assert sw["n_gpus"] == 2 and sw["trials"] == 4 and sw["trials_ok"] == 4 and len(sw["rank_busy_s"]) == 2
     assert np.isfinite(sw["best_val_loss"]) and sw["winner_state_tensors"] > 10
+
+
+def test_bench_self_launch_without_a_launcher():
+    """Plain ``python bench.py --gpus 2`` (no torch.distributed.run in front: the form the driver uses at N = 1): bench.py starts its
+    two ranks itself, rank 0 prints the one JSON line, the return code is the launcher's; the N > 1 line carries `sweep_scaling`
+    (the sharded sweep's aggregate over the N = 1 leg's) and every rank's device / arena."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(FX_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--features", "2000",
+           "--sweep-trials-per-gpu", "2", "--repeats", "0", "--no-other", "--n1-sweep", "1000"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["loss_finite"]
+    sc = out["sweep_scaling"]
+    assert sc["n_gpus"] == 2 and sc["aggregate_samples_per_s"] == out["sweep"]["aggregate_samples_per_s"] > 0
+    assert sc["n1_aggregate_samples_per_s"] == 1000 and abs(sc["ratio"] - sc["aggregate_samples_per_s"] / 1000) < 1e-2
+    assert out["ranks_seen"] == 2 and [r["rank"] for r in out["ranks"]] == [0, 1]
+
+
+def test_bench_dry_self_launch():
+    """``python bench.py --gpus 2 --dry`` without a launcher: the day-one check of every collective, one JSON line, rc 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(FX_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry", "--features", "2000"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["dry"] and out["n_gpus"] == 2 and out["trials_ok"] == 2 and len(out["ranks"]) == 2 and not out["error"]
