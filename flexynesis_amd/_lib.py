@@ -86,6 +86,18 @@ PROTOTYPES = {
     "fx_randperm_scratch_bytes": (L, [L]),
     "fx_randperm": (I, [P, P, L, U64, U64, P, L, P]),
     "fx_triplet_sample": (I, [P, P, P, L, P, P, P, P, P, I, U64, U64, P, P]),
+    "fx_lease_queue_create": (P, []),
+    "fx_lease_queue_destroy": (None, [P]),
+    "fx_lease_wrap": (P, [P, P, C.c_longlong, I, I, C.c_longlong]),
+    "fx_lease_discard": (None, [P]),
+    "fx_lease_drain": (I, [P, P, I]),
+    "fx_lease_outstanding": (C.c_longlong, [P]),
+    "fx_graph_begin": (I, [P, I]),
+    "fx_graph_end": (I, [P, P, P]),
+    "fx_graph_abort": (I, [P]),
+    "fx_graph_launch": (I, [P, P]),
+    "fx_graph_destroy": (I, [P]),
+    "fx_graph_capturing": (I, [P]),
     "fx_mse_masked": (I, [P, P, P, P, I, L, L, P, F, P]),
     "fx_ce_masked": (I, [P, P, P, P, I, I, L, L, P, F, P]),
     "fx_cox_ph": (I, [P, P, P, P, P, I, L, L, P, F, P]),
@@ -176,7 +188,11 @@ def _load():
             "(or __graft_entry__.build()).  flexynesis_amd has no CPU/PyTorch fallback path.")
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
-        fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:         # header / library mismatch (an older libfxhip.so beside newer Python, FXHIP_LIB): fail loudly
+            raise ImportError(f"{LIB_PATH} does not export {name}: ABI mismatch between this Python package and the library "
+                              "(include/fxhip.h declares it) -- rebuild with `python -m flexynesis_amd.csrc.build --force`") from None
         fn.restype = res
         fn.argtypes = args
     return lib

@@ -66,14 +66,27 @@ class placement_tries:
         return False
 
 
+def _wait_events(device, events, unsynced=False):
+    """Order the caller's current stream behind the streams that last used a range (the events its previous owner recorded when it
+    let go); a range released while nothing could be recorded (during a hipGraph capture) costs one device synchronisation."""
+    if unsynced:
+        torch.cuda.synchronize(device)
+        return
+    st = torch.cuda.current_stream(device)
+    for ev in events:
+        st.wait_event(ev)
+
+
 class PlacementPool:
     """Rated arrays for wide weights, kept for the life of the process (per device and SHAPE).  ``take`` hands out fast arrays of exactly
-    the shape asked for, ``give`` takes them back -- only arrays rated at least ParamStore.PLACE_GOOD_TBS are kept, at most
+    the shape asked for; an array comes back by itself when the LAST view of the memory has gone (ops.LEASES: the ParamStore that took it,
+    every nn.Parameter .data and state_dict tensor that aliased it) -- only arrays rated at least ParamStore.PLACE_GOOD_TBS are kept, at most
     FX_PLACEMENT_POOL_GB (default 64) per device; the rest go back to the allocator.  A rating does NOT travel to another shape: the
     first half of a fast [10000, 20000] array, used as [5000, 20000], probes at 4.7-4.9 TB/s, slower than most fresh arrays of that shape
     (profiles/r05_placement_pool.txt) -- so the pool serves series of models of ONE shape: the k folds of a cross-validated trial, the
     lr x freeze x fold grid of the FineTuner (45 fits of one model), repeated fits in one process.  Thread-safe (trials in flight on
-    several host threads); an array handed back carries an event of the stream that last used it, and the taker's stream waits for it."""
+    several host threads); an array handed back carries the events of the streams that last used it, and the taker's stream waits for
+    them."""
 
     def __init__(self):
         self._lock = threading.Lock()
@@ -84,6 +97,7 @@ class PlacementPool:
         return int(float(os.environ.get("FX_PLACEMENT_POOL_GB", "64")) * (1 << 30))
 
     def take(self, device, shape: Tuple[int, int], count: int):
+        ops.LEASES.drain()
         out = []
         with self._lock:
             free = self._free.get(device.index, [])
@@ -96,21 +110,15 @@ class PlacementPool:
             free[:] = rest
             self.stats["taken"] += len(out)
         for e in out:
-            if e[2] is not None:
-                torch.cuda.current_stream(device).wait_event(e[2])
+            _wait_events(device, e[2], e[4])
         return [(e[0], e[1]) for e in out]
 
-    def give(self, device, shape: Tuple[int, int], arrays):
+    def give(self, device, shape: Tuple[int, int], arrays, events=(), unsynced: bool = False):
+        """``arrays``: [(flat array, TB/s or None)] that NOTHING views any more (ParamStore hands its arrays back through their leases)."""
         good = float(os.environ.get("FX_PLACEMENT_GOOD_TBS", ParamStore.PLACE_GOOD_TBS))
         keep = [(flat, tbs) for flat, tbs in arrays if tbs is not None and tbs >= good]
-        if not keep or ops.capturing():       # (a store collected while a hipGraph capture is in progress: nothing may be recorded now)
+        if not keep:
             return
-        ev = None
-        try:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(device))
-        except Exception:
-            ev = None
         with self._lock:
             free = self._free.setdefault(device.index, [])
             held = sum(e[0].numel() * 4 for e in free)
@@ -118,11 +126,12 @@ class PlacementPool:
                 if held + flat.numel() * 4 > self._cap_bytes():
                     self.stats["dropped"] += 1
                     continue
-                free.append((flat, tbs, ev, tuple(shape)))
+                free.append((flat, tbs, list(events), tuple(shape), bool(unsynced)))
                 held += flat.numel() * 4
                 self.stats["given"] += 1
 
     def held(self, device) -> List[Tuple[Tuple[int, int], float]]:
+        ops.LEASES.drain()
         with self._lock:
             return [(e[3], e[1]) for e in self._free.get(device.index, [])]
 
@@ -165,7 +174,8 @@ class PartitionArena:
         self.chunks: List[torch.Tensor] = []                         # uint8 tensors: chunk 0 is pool A, the rest make up pool B
         self.kind: List[int] = []                                    # 0: pool A (W), 1: pool B (m, v)
         self.free: List[List[Tuple[int, int]]] = []                  # per chunk: (offset, bytes) free ranges, sorted
-        self.event: Optional[torch.cuda.Event] = None                # the last hand-back
+        self.pending: List[list] = []                                # [chunk, offset, bytes, events, unsynced] of ranges that came back: whoever
+        #                                                              takes memory overlapping one waits for ITS events (one entry per hand-back)
         self.info: dict = {}
         self.ok = False
 
@@ -317,51 +327,107 @@ class PartitionArena:
         fl[:] = merged
 
     def free_bytes(self) -> Tuple[int, int]:
+        ops.LEASES.drain()
         with self.lock:
             return tuple(sum(z for ci, fl in enumerate(self.free) if (self.kind[ci] > 0) == bool(k) for _, z in fl) for k in (0, 1))
 
+    def _events_for(self, ci: int, off: int, size: int):
+        """(events, unsynced) of the hand-backs whose ranges overlap [off, off + size) of chunk ci; entries whose events have all
+        completed are dropped on the way (called under the lock)."""
+        evs, unsynced, keep = [], False, []
+        for e in self.pending:
+            done = not e[4] and all(ev.query() for ev in e[3])
+            if done:
+                continue
+            if e[0] == ci and e[1] < off + size and off < e[1] + e[2]:
+                evs.extend(e[3])
+                unsynced = unsynced or e[4]
+                if e[1] >= off and e[1] + e[2] <= off + size:
+                    continue                       # wholly inside what is being handed out: the taker's stream now orders it
+            keep.append(e)
+        self.pending = keep
+        return evs, unsynced
+
     def take3(self, need_elems: int):
-        """(W, m, v) as flat fp32 views of need_elems elements -- W from pool A, m and v from pool B -- zero-filled, and the token that
-        gives them back; or None when a pool has no room."""
+        """(W, m, v) as flat fp32 tensors of need_elems elements -- W from pool A, m and v from pool B -- zero-filled, each a LEASE
+        (ops.LEASES) on its range: the range returns to its pool when the last view of that tensor's storage has gone, wherever
+        that happens, and the next taker waits for the events recorded by ``ParamStore.release_big`` on the streams that used it.
+        Returns (tensors, lease ids), or None when a pool has no room."""
+        import gc
         nbytes = need_elems * 4
-        with self.lock:
-            token = []
-            for kinds in ((0,), (1, 2), (2, 1)):          # W | m | v; m and v share a class when the other has no room (or does not exist)
-                r = None
-                for kind in kinds:
-                    r = self._alloc(kind, nbytes)
-                    if r is not None:
+        for attempt in (0, 1):
+            ops.LEASES.drain()
+            with self.lock:
+                token = []
+                for kinds in ((0,), (1, 2), (2, 1)):          # W | m | v; m and v share a class when the other has no room (or does not exist)
+                    r = None
+                    for kind in kinds:
+                        r = self._alloc(kind, nbytes)
+                        if r is not None:
+                            break
+                    if r is None:
+                        for t in token:
+                            self._release(*t)
+                        token = None
                         break
-                if r is None:
-                    for t in token:
-                        self._release(*t)
-                    return None
-                token.append(r)
-            ev = self.event
-        if ev is not None:
-            torch.cuda.current_stream(self.device).wait_event(ev)
-        views = []
+                    token.append(r)
+                waits = [self._events_for(*t) for t in token] if token else None
+            if token is not None:
+                break
+            if attempt == 0 and not ops.capturing():
+                gc.collect()                   # ranges of dropped models that sit in reference cycles come back now
+        if token is None:
+            return None
+        for evs, unsynced in waits:
+            _wait_events(self.device, evs, unsynced)
+        views, ids = [], []
         for ci, off, size in token:
-            t = self.chunks[ci][off:off + nbytes].view(torch.float32)
+            t, lid = ops.LEASES.wrap(self.chunks[ci].data_ptr() + off, need_elems, self.device,
+                                     (lambda evs, unsynced, r=(ci, off, size), keep=self.chunks[ci]: self._returned(r, evs, unsynced)))
+            # (``keep``: the lease does not own the pool's memory -- the chunk must outlive every view of it, also across reset())
             t.zero_()
             views.append(t)
-        return views, token
+            ids.append(lid)
+        return views, ids
 
-    def give(self, token):
-        if not self.ok:
-            return
-        ev = None
-        if not ops.capturing():
-            try:
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(self.device))
-            except Exception:
-                ev = None
+    def _returned(self, r, events, unsynced):
+        """A lease's storage has gone (ops.LEASES.drain): the range is free again, with the events its last owner recorded."""
         with self.lock:
-            for t in token:
-                self._release(*t)
-            if ev is not None:
-                self.event = ev
+            if not self.ok or r[0] >= len(self.free):
+                return
+            self._release(*r)
+            if events or unsynced:
+                self.pending.append([r[0], r[1], r[2], list(events), bool(unsynced)])
+
+
+def _cuda_device(device=None) -> torch.device:
+    device = torch.device("cuda" if device is None else device)
+    return torch.device("cuda", torch.cuda.current_device()) if device.index is None else device
+
+
+def placement_memory(device=None) -> dict:
+    """What this process holds on ``device`` for the placement of wide weights, outside torch's per-tensor accounting: the partition
+    arena's pools (resident for the life of the process unless released) and the rated arrays of the placement pool."""
+    dev = _cuda_device(device)
+    ar = PartitionArena._arenas.get(dev.index)
+    res = sum(c.numel() for c in ar.chunks) if (ar is not None and ar.ok) else 0
+    free = sum(ar.free_bytes()) if (ar is not None and ar.ok) else 0
+    pooled = sum(int(np.prod(shp)) * 4 for shp, _ in POOL.held(dev))
+    return {"arena_resident_bytes": int(res), "arena_free_bytes": int(free), "pool_bytes": int(pooled),
+            "arena_build_spacer_GB": (ar.info.get("spacer_GB") if ar is not None else None)}
+
+
+def release_placement_memory(device=None):
+    """Give the partition arena's pools and the placement pool's arrays of ``device`` (default: every device) back to the allocator
+    and the driver -- for a process that is done training and wants its 24 GB back, or that shares the GPU.  Ranges still viewed by
+    live models stay valid (their leases keep the pool's memory alive) and are freed with them; the next wide weight builds a new
+    arena."""
+    dev = None if device is None else _cuda_device(device)
+    ops.LEASES.drain()
+    PartitionArena.reset(dev)
+    POOL.clear(dev)
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()
 
 
 def search_arrays(device, out: int, fin: int, want: int, tries: int, seed: int = 20240):
@@ -519,6 +585,8 @@ class ParamStore:
         self.nbt: Dict[str, int] = {k: 0 for k in self.nbt_keys}
         # wide weights
         self.big: Dict[str, Dict[str, Optional[torch.Tensor]]] = {}
+        self._streams: Dict[int, "torch.cuda.Stream"] = {}
+        self.note_stream()
         # Rows are padded to a multiple of 32 floats: with an arbitrary feature count the rows of W / m / v start at
         # arbitrary offsets inside a 128-byte line, every 512-byte row segment of the dW+Adam kernel then straddles a
         # fifth line (reads) and partial lines (writes) -- the decoders' [20000, 5000] weights took 510-630 us per launch
@@ -629,14 +697,14 @@ class ParamStore:
             if arena is not None:
                 taken = arena.take3(need)
                 if taken is not None:
-                    flats, token = taken
+                    flats, lease_ids = taken
                     views = []
                     for name, flat in zip(("W", "M", "V"), flats):
                         buf = flat.view(out, ld)
                         self.big[key]["_" + name] = buf
                         self.big[key][name] = buf[:, :fin]
                         views.append(buf[:, :fin])
-                    self.big[key]["_arena"] = (arena, token)
+                    self.big[key]["_leases"] = list(lease_ids)
                     self.placement[key] = dict(arena=True, kept_us=round(ops.placement_probe_us(*views), 1),
                                                search_s=round(time.perf_counter() - t0, 3), **{k: v for k, v in arena.info.items() if k in ("build_s", "spacer_GB")})
                     return
@@ -651,35 +719,63 @@ class ParamStore:
             while len(got) < 3:
                 got.append((torch.zeros(need, dtype=torch.float32, device=self.device), None))
             views = []
+            lease_ids = []
             for name, (flat, tbs) in zip(("W", "M", "V"), got):
-                buf = flat[:need].view(out, ld)
+                if tbs is not None:
+                    # a rated array: used through a lease, so that it returns to the process-level pool exactly when the last view
+                    # of it (this store, an nn.Parameter's .data, a state_dict tensor) has gone
+                    dev = self.device
+                    lt, lid = ops.LEASES.wrap(flat.data_ptr(), need, dev,
+                                              (lambda evs, unsynced, a=flat, r=tbs: POOL.give(dev, (out, fin), [(a, r)], evs, unsynced)))
+                    lease_ids.append(lid)
+                    buf = lt.view(out, ld)
+                else:
+                    buf = flat[:need].view(out, ld)
                 if info.get("from_pool"):
                     buf.zero_()
                 self.big[key]["_" + name] = buf
                 self.big[key][name] = buf[:, :fin]
                 views.append(buf[:, :fin])
-            self.big[key]["_arrays"] = ((out, fin), got)
+            self.big[key]["_leases"] = lease_ids
             if eligible and (info.get("from_pool") or info.get("probed")):
                 info["kept_TBps"] = [None if r is None else round(r, 2) for _, r in got]
                 info["kept_us"] = round(ops.placement_probe_us(*views), 1)
                 info["search_s"] = round(time.perf_counter() - t0, 3)
                 self.placement[key] = info
 
+    def note_stream(self, stream=None):
+        """Remember a stream that launches work on this store's arrays (plans call it when they are built): ``release_big`` records
+        one event on each, and whoever is given the memory next waits for them."""
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        self._streams[st.cuda_stream] = st
+
     def release_big(self):
-        """Hand the rated arrays of the wide weights to the process-level pool (the next model of this process takes them instead of
-        whatever the allocator would give it).  Called when the store is dropped; the store is unusable afterwards."""
-        for k, d in list(self.big.items()):
-            arrs = d.pop("_arrays", None)
-            if arrs:
-                POOL.give(self.device, arrs[0], arrs[1])
-            ar = d.pop("_arena", None)
-            if ar:
-                ar[0].give(ar[1])
+        """Let go of the wide weights' arrays; the store is unusable afterwards.  Arena ranges and rated arrays are LEASES
+        (ops.LEASES): the memory itself returns to its pool when the last view of it has gone -- parameters of a model that has been
+        closed or moved keep their values for as long as they exist -- and carries the events recorded here, one per stream that
+        ran this store's plans, for the next taker to wait on.  Called by fit() / FxModel.close() at a known point, or when the
+        store is dropped."""
+        ids = [lid for d in self.big.values() for lid in (d.pop("_leases", None) or [])]
+        if ids:
+            events, unsynced = [], False
+            if ops.capturing():            # (a store collected while a hipGraph capture is in progress: nothing may be recorded now)
+                unsynced = True
+            else:
+                try:
+                    for st in self._streams.values():
+                        ev = torch.cuda.Event()
+                        ev.record(st)
+                        events.append(ev)
+                except Exception:
+                    unsynced = True
+            for lid in ids:
+                ops.LEASES.add_events(lid, events, unsynced)
         self.big = {}
 
     def __del__(self):
         try:
-            self.release_big()
+            if self.big:
+                self.release_big()
         except Exception:
             pass
 
@@ -789,6 +885,7 @@ class StepPlan:
                  fuse_heads: bool = True, frozen: Tuple[str, ...] = (), fuse_next_fwd: bool = False,
                  attribution: bool = False, clip_norm: float = CLIP_MAX_NORM, forward_alone: bool = False):
         self.store, self.spec, self.B, self.train = store, store.spec, int(B), train
+        store.note_stream()                     # (the stream this plan's launches will be ordered on: ParamStore.release_big)
         # the forward tape may be run on its own and must leave every loss (the total included) behind: the level-1 path, whose
         # caller reads the loss between ``forward()`` and ``backward()``.  Otherwise loss bookkeeping may ride in the backward tape.
         self.forward_alone = bool(forward_alone)
@@ -2318,6 +2415,7 @@ class StepPlan:
         second use captures it into a hipGraph and later uses replay that -- ~50 eager launches per step become three graph
         launches."""
         tape = getattr(self, "t_" + name)
+        self.store.note_stream()
         if not getattr(self, "tape_graphs", False):
             tape.run()
             return
@@ -2328,7 +2426,7 @@ class StepPlan:
         g = graphs.get(name)
         if g is None and n >= 1 and not ops.capturing():
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
+            g = ops.new_graph()
             with ops.graph_capture(g):
                 tape.run()
             graphs[name] = g
@@ -2384,7 +2482,7 @@ class StepPlan:
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
             self.bump_nbt()
-        g = torch.cuda.CUDAGraph()
+        g = ops.new_graph()
         with ops.graph_capture(g):
             self._step_for_capture(lr, gather)
         self.graph = g
@@ -2435,7 +2533,7 @@ class StepPlan:
         g = self.__dict__.get("_eval_graph")
         if use_graph and g is None and n >= 1 and not ops.capturing():
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
+            g = ops.new_graph()
             with ops.graph_capture(g):
                 self.t_gather.run()
                 self.t_fwd.run()
@@ -2574,7 +2672,7 @@ class PipelinedStep:
         """Capture both parities of the step into hipGraphs (no work is executed)."""
         torch.cuda.synchronize()
         for k in (0, 1):
-            g = torch.cuda.CUDAGraph()
+            g = ops.new_graph()
             with ops.graph_capture(g):
                 self._issue(k, lr)
             self.graphs[k] = g

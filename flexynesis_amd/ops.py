@@ -197,14 +197,56 @@ def retire_graph(g):
     object dies on return; during a capture it is parked until the capture is over."""
     if g is not None and _CAPTURING[0] > 0:
         _GRAVEYARD.append(g)
+    elif isinstance(g, FxGraph):
+        g.close()                      # (the library's own graphs: destroyed here, deterministically)
+
+
+class FxGraph:
+    """A hipGraphExec captured and replayed through libfxhip's own entry points (fx_graph_begin / _end / _launch / _destroy:
+    csrc/fx_runtime.hip) -- the default backend of ``graph_capture``.  Same surface as the part of torch.cuda.CUDAGraph the engine
+    uses: ``replay()`` on the current stream; released explicitly (``close``, via ``retire_graph``) or with the object."""
+
+    def __init__(self):
+        self._exec = None
+        self.n_nodes = 0
+
+    def replay(self):
+        rc = lib.fx_graph_launch(self._exec, _stream())
+        if rc != 0:
+            raise FxError(f"fx_graph_launch failed (rc={rc}): {_lib.last_error()}")
+
+    def close(self):
+        x, self._exec = self._exec, None
+        if x is not None:
+            lib.fx_graph_destroy(x)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+GRAPH_BACKEND = os.environ.get("FX_GRAPH_BACKEND", "fx")       # "fx": the library's own capture; "torch": torch.cuda.CUDAGraph (A/B)
+
+
+def new_graph():
+    """The graph object to hand to ``graph_capture`` (backend: FX_GRAPH_BACKEND, default the library's own)."""
+    return FxGraph() if GRAPH_BACKEND != "torch" else torch.cuda.CUDAGraph()
 
 
 class graph_capture:
-    """``with ops.graph_capture(g): ...`` = ``torch.cuda.graph(g, stream=capture_stream())`` with Python's cyclic garbage
-    collector switched off for the duration and graph releases deferred to its end (see above)."""
+    """``with ops.graph_capture(g): ...`` captures what the block launches into ``g`` (from ``new_graph()``).
+
+    FxGraph: the block runs on the capture stream of the shared pool, ordered behind the caller's stream, between fx_graph_begin
+    (relaxed mode: the engine owns every buffer the captured launches touch and allocates nothing inside) and fx_graph_end.
+    torch.cuda.CUDAGraph (FX_GRAPH_BACKEND=torch): ``torch.cuda.graph(g, stream=capture_stream())``.
+    Either way Python's cyclic collector is off for the duration and graph releases are deferred to the end (see above)."""
 
     def __init__(self, g):
-        self._ctx = torch.cuda.graph(g, stream=capture_stream())
+        self._g = g
+        self._fx = isinstance(g, FxGraph)
+        self._ctx = None if self._fx else torch.cuda.graph(g, stream=capture_stream())
         self._gc = False
 
     def __enter__(self):
@@ -212,7 +254,18 @@ class graph_capture:
         if in_flight_thread():
             raise FxError("hipGraph capture on a thread that runs fits concurrently with others (trials.run_units(in_flight > 1)): "
                           "a capture is process-wide on ROCm; launch eagerly there (fit(use_graph=False))")
-        self._ctx.__enter__()              # (torch collects garbage and empties the cache before capture_begin)
+        if self._fx:
+            self._cs = capture_stream()
+            self._caller = torch.cuda.current_stream()
+            self._cs.wait_stream(self._caller)
+            self._sctx = torch.cuda.stream(self._cs)
+            self._sctx.__enter__()
+            rc = lib.fx_graph_begin(self._cs.cuda_stream, 2)
+            if rc != 0:
+                self._sctx.__exit__(None, None, None)
+                raise FxError(f"fx_graph_begin failed (rc={rc}): {_lib.last_error()}")
+        else:
+            self._ctx.__enter__()              # (torch collects garbage and empties the cache before capture_begin)
         self._gc = gc.isenabled()
         gc.disable()
         _CAPTURING[0] += 1
@@ -221,13 +274,99 @@ class graph_capture:
     def __exit__(self, *exc):
         import gc
         try:
-            return self._ctx.__exit__(*exc)
+            if not self._fx:
+                return self._ctx.__exit__(*exc)
+            try:
+                if exc and exc[0] is not None:
+                    lib.fx_graph_abort(self._cs.cuda_stream)
+                else:
+                    x, n = C.c_void_p(), C.c_int(0)
+                    rc = lib.fx_graph_end(self._cs.cuda_stream, C.byref(x), C.byref(n))
+                    if rc != 0 or not x.value:
+                        raise FxError(f"fx_graph_end failed (rc={rc}): {_lib.last_error()}")
+                    self._g._exec, self._g.n_nodes = x.value, int(n.value)
+            finally:
+                self._sctx.__exit__(None, None, None)
+                self._caller.wait_stream(self._cs)
+            return False
         finally:
             _CAPTURING[0] -= 1
             if _CAPTURING[0] == 0:
                 _GRAVEYARD.clear()         # parked graphs die now: the device synchronisation of their destructor is legal again
             if self._gc:
                 gc.enable()
+
+
+# ---- memory leases (csrc/fx_runtime.hip) ------------------------------------------------------------------------------------
+class LeaseRegistry:
+    """Ranges of long-lived device memory (the partition arena's pools, rated arrays of the placement pool) handed out as torch
+    tensors whose STORAGE reports back when its last view has gone.  ``wrap`` imports a DLPack tensor made by fx_lease_wrap: when
+    torch drops the storage -- the ParamStore, every nn.Parameter .data, every state_dict tensor that viewed it are gone -- the
+    library's deleter queues the lease id; ``drain`` (called by the owners before they allocate) runs ``on_release(events)`` for
+    every queued id, with the HIP events recorded when the owning store let go (``add_events``): the next taker's stream waits for
+    them.  A range is therefore never reused while anything can still read or write it (a model's parameters survived
+    their ParamStore as views of memory the next trial was given)."""
+
+    def __init__(self):
+        import threading
+        self._q = lib.fx_lease_queue_create()
+        self._lock = threading.Lock()
+        self._next = 1
+        self._live: dict = {}           # id -> [on_release, events, unsynced]
+        C.pythonapi.PyCapsule_New.restype = C.py_object
+        C.pythonapi.PyCapsule_New.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
+
+    _NAME = b"dltensor"
+
+    def wrap(self, ptr: int, n: int, device, on_release):
+        """(flat fp32 tensor of n elements at ptr on ``device``, lease id)."""
+        device = torch.device(device)
+        with self._lock:
+            lid = self._next
+            self._next += 1
+            self._live[lid] = [on_release, [], False]
+        m = lib.fx_lease_wrap(self._q, ptr, n, 10 if device.type == "cuda" else 1, device.index or 0, lid)
+        if not m:
+            with self._lock:
+                self._live.pop(lid, None)
+            raise FxError(f"fx_lease_wrap failed: {_lib.last_error()}")
+        try:
+            cap = C.pythonapi.PyCapsule_New(m, self._NAME, None)
+            t = torch.utils.dlpack.from_dlpack(cap)
+        except Exception:
+            with self._lock:
+                self._live.pop(lid, None)
+            lib.fx_lease_discard(m)
+            self.drain()
+            raise
+        return t, lid
+
+    def add_events(self, lid: int, events, unsynced: bool = False):
+        with self._lock:
+            e = self._live.get(lid)
+            if e is not None:
+                e[1].extend(events)
+                e[2] = e[2] or unsynced
+
+    def drain(self) -> int:
+        ids = (C.c_longlong * 64)()
+        done = 0
+        while True:
+            n = lib.fx_lease_drain(self._q, ids, 64)
+            if n <= 0:
+                return done
+            for i in range(n):
+                with self._lock:
+                    e = self._live.pop(int(ids[i]), None)
+                if e is not None and e[0] is not None:
+                    e[0](e[1], e[2])
+                done += 1
+
+    def outstanding(self) -> int:
+        return int(lib.fx_lease_outstanding(self._q))
+
+
+LEASES = LeaseRegistry()
 
 
 class ImmediateRecorder:

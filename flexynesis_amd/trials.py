@@ -249,6 +249,11 @@ def run_units(n: int, unit_fn: Callable[[int], Tuple[float, int, Optional[dict]]
     dev = torch.device(device)
     if int(in_flight) > 1 and unit_bytes and dev.type == "cuda":
         free_b = torch.cuda.mem_get_info(dev)[0]
+        try:      # memory this process already holds for wide weights (engine.PartitionArena's pools) is invisible to the driver's figure
+            from .engine import placement_memory
+            free_b += placement_memory(dev)["arena_free_bytes"]
+        except Exception:
+            pass
         fit_n = max(int(0.8 * free_b // max(float(unit_bytes), 1.0)), 1)
         if fit_n < int(in_flight):
             warnings.warn(f"run_units: {in_flight} units in flight need ~{in_flight * unit_bytes / 2**30:.1f} GiB, {free_b / 2**30:.1f} GiB "

@@ -474,6 +474,27 @@ int fx_triplet_sample(long* pos, long* neg, const long* anchors, long n, const l
                       const long* counts, const long* rank_in_group, int n_groups, unsigned long long seed,
                       unsigned long long offset, int* err_flag, fx_stream_t stream);
 
+/* ---- host-side runtime (csrc/fx_runtime.hip): memory leases and the library's own hipGraph capture / replay -----------------
+ * Leases: the engine sub-allocates the W / m / v arrays of every wide weight (reference: nn.Linear parameters of modules.py:26-41
+ * and torch.optim.Adam's state, direct_pred.py:143) from long-lived pools; a range goes back to its pool when the LAST view of it
+ * has gone.  fx_lease_wrap returns a DLPack DLManagedTensor* (1-D fp32, n elements at ptr; device_type 10 = ROCm, 1 = host) whose
+ * deleter -- called by the importing framework from any thread -- pushes `id` onto the queue; fx_lease_drain pops released ids. */
+void* fx_lease_queue_create(void);
+void fx_lease_queue_destroy(void* queue);
+void* fx_lease_wrap(void* queue, void* ptr, long long n, int device_type, int device_id, long long id);
+void fx_lease_discard(void* managed);
+int fx_lease_drain(void* queue, long long* ids, int max_ids);
+long long fx_lease_outstanding(void* queue);
+/* Graphs: everything launched on `stream` (and on streams forked from it through event waits) between fx_graph_begin and
+ * fx_graph_end becomes one hipGraphExec (mode: 0 global, 1 thread-local, 2 relaxed); fx_graph_launch replays it on a stream.
+ * Replaces torch.cuda.CUDAGraph around the reference's training_step / validation_step loop (main.py:212-225) on the engine's path. */
+int fx_graph_begin(fx_stream_t stream, int mode);
+int fx_graph_end(fx_stream_t stream, void** exec_out, int* n_nodes);
+int fx_graph_abort(fx_stream_t stream);
+int fx_graph_launch(void* exec, fx_stream_t stream);
+int fx_graph_destroy(void* exec);
+int fx_graph_capturing(fx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

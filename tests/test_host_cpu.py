@@ -661,3 +661,34 @@ def test_library_has_no_packed_fp32_valu_ops():
             bad = [ln for ln in dis.splitlines() if "v_pk_" in ln and "_f32" in ln]
             assert not bad, bad[:3]
         assert n_kernels > 50
+
+
+def test_lease_returns_when_the_last_view_has_gone():
+    """ops.LEASES (csrc/fx_runtime.hip): a range of long-lived memory handed out as a torch tensor comes back exactly when the LAST view
+    of that tensor's storage is gone -- not when the object that took it is dropped (parameters that outlived their
+    ParamStore as views of memory the next trial was given) -- with the events its owner attached.  Host memory here (DLPack device
+    type 1); the GPU tests run the same path on arena ranges."""
+    import gc
+    from flexynesis_amd import ops
+    base = torch.arange(64, dtype=torch.float32)
+    back = []
+    before = ops.LEASES.outstanding()
+    t, lid = ops.LEASES.wrap(base.data_ptr() + 16 * 4, 32, "cpu", lambda evs, unsynced: back.append((list(evs), unsynced)))
+    assert t.shape == (32,) and t.dtype == torch.float32 and t.data_ptr() == base.data_ptr() + 64
+    assert torch.equal(t, base[16:48]) and ops.LEASES.outstanding() == before + 1
+    w = t.view(4, 8)[:, :6]                  # what ParamStore hands out: a strided view (the "W" of a padded buffer)
+    p = torch.nn.Parameter(torch.empty(0))
+    p.data = w                               # ... and what a model's nn.Parameter keeps
+    sd = {"w": p.detach()}                   # ... and a state_dict tensor
+    t.mul_(2.0)
+    assert float(base[16]) == 32.0           # the lease IS the memory, not a copy
+    ops.LEASES.add_events(lid, ["ev0"], False)
+    del t, w
+    gc.collect()
+    assert ops.LEASES.drain() == 0 and not back          # the parameter and the state_dict still view it
+    del p
+    assert ops.LEASES.drain() == 0 and not back
+    del sd
+    assert ops.LEASES.drain() == 1 and back == [(["ev0"], False)]
+    assert ops.LEASES.outstanding() == before
+    assert ops.LEASES.drain() == 0 and len(back) == 1    # exactly once
