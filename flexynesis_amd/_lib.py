@@ -70,6 +70,8 @@ PROTOTYPES = {
     "fx_reduce_slabs": (I, [P, P, P, I, I, L, I, L, P]),
     "fx_reduce_slabs_par": (I, [P, P, P, I, I, L, I, L, P]),
     "fx_placement_probe": (I, [P, P, P, I, I, L, P]),
+    "fx_placement_probe_oop": (I, [P, P, P, P, P, P, I, I, L, P]),
+    "fx_linear_dw_adam_fwd_bf16x3_oop": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, L, L, L, P, P, P, L, I, P, L, I, P]),
     "fx_linear_bwd_x_bf16x3": (I, [P, P, P, P, I, I, I, L, L, L, P, L, P]),
     "fx_bn_act_fwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, L, L, I, I, I, F, U64, U64, P, P]),
     "fx_bn_act_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, L, L, L, L, I, I, F, I, P]),

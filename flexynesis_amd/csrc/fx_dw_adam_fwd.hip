@@ -58,6 +58,7 @@ __device__ unsigned long long ft_stamp[1024 * 8];      // [workgroup][k]: wall c
 
 struct DwAdamFwdArgs {
   float* W; float* m; float* v;
+  float* Wd; float* md; float* vd;          // where the updated W / m / v go: == W / m / v (in place) or twins in another memory partition (out of place)
   const __bf16* Ah; const __bf16* Al;       // dY^T [M, lda]
   const __bf16* Bh; const __bf16* Bl;       // X^T  [N, ldb]
   const __bf16* Xh; const __bf16* Xl;       // next batch, K-blocked [kblocks][128][32]
@@ -122,7 +123,9 @@ __device__ __forceinline__ void ft_store32(float v, __amdgpu_buffer_rsrc_t r, un
 
 // MT = M-tiles of the next batch (rows / 128); UNITS = 16-byte W / m / v units per thread in flight in the Adam phase
 // (4 for MT = 1; 2 for MT > 1, whose MT accumulator sets need the registers).
-template <int NT, int MT, int UNITS>
+// NP = products per contraction: 3 = split bf16 (hi hi + hi lo + lo hi: fp32-grade, the parity mode), 1 = plain bf16 (hi hi only: the
+// `lo` halves are neither loaded nor produced -- the throughput mode, torch's "medium" matmul precision of the reference, main.py:24).
+template <int NT, int MT, int UNITS, int NP = 3>
 __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g) {
   // LDS map (bf16 elements unless noted), 64 KB:
   //   phase 1 (dW K-loop)   stage s at s*12288: A hi [64][32] | A lo | B hi [128][32] | B lo          (2 x 24 KB)
@@ -168,6 +171,8 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
   const long wbytes = ((long)(rows_valid - 1) * g.ldw + g.N) * 4;
   const __amdgpu_buffer_rsrc_t rP = ft_rsrc(g.W + (long)m0 * g.ldw, wbytes), rM = ft_rsrc(g.m + (long)m0 * g.ldw, wbytes),
                                rV = ft_rsrc(g.v + (long)m0 * g.ldw, wbytes);
+  const __amdgpu_buffer_rsrc_t rPd = ft_rsrc(g.Wd + (long)m0 * g.ldw, wbytes), rMd = ft_rsrc(g.md + (long)m0 * g.ldw, wbytes),
+                               rVd = ft_rsrc(g.vd + (long)m0 * g.ldw, wbytes);
   const long abytes = (long)rows_valid * g.lda * 2;
   const __amdgpu_buffer_rsrc_t rAh = ft_rsrc(g.Ah + (long)m0 * g.lda, abytes), rAl = ft_rsrc(g.Al + (long)m0 * g.lda, abytes);
   const __amdgpu_buffer_rsrc_t rBh = ft_rsrc(g.Bh, (long)g.N * g.ldb * 2), rBl = ft_rsrc(g.Bl, (long)g.N * g.ldb * 2);
@@ -231,9 +236,9 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
     __bf16* sb = smem + (stage) * 12288;                                                                  \
     const unsigned ko = (unsigned)(kt) * (FT_K * 2u);                                                     \
     if (w < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rAh, LDS_PTR(sb + (w & 3) * 512), 16, a_src + ko, 0, 0, 0);        \
-    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rAl, LDS_PTR(sb + 2048 + (w & 3) * 512), 16, a_src + ko, 0, 0, 0);       \
+    else if (NP == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rAl, LDS_PTR(sb + 2048 + (w & 3) * 512), 16, a_src + ko, 0, 0, 0);       \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rBh, LDS_PTR(sb + 4096 + w * 512), 16, b_src + ko, 0, 0, 0);                  \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rBl, LDS_PTR(sb + 8192 + w * 512), 16, b_src + ko, 0, 0, 0);                  \
+    if (NP == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rBl, LDS_PTR(sb + 8192 + w * 512), 16, b_src + ko, 0, 0, 0);     \
   }
     FT_TICK(0);
     FT_GLDS_K(0, 0);
@@ -246,11 +251,13 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const bf16x8 ah = *reinterpret_cast<const bf16x8*>(sb + ft_swz(fa_d, 2 * ks + kh));
-        const bf16x8 al = *reinterpret_cast<const bf16x8*>(sb + 2048 + ft_swz(fa_d, 2 * ks + kh));
         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(sb + 4096 + ft_swz(fb_d, 2 * ks + kh));
-        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(sb + 8192 + ft_swz(fb_d, 2 * ks + kh));
-        acc = FT_MFMA(al, bh, acc);
-        acc = FT_MFMA(ah, bl, acc);
+        if (NP == 3) {
+          const bf16x8 al = *reinterpret_cast<const bf16x8*>(sb + 2048 + ft_swz(fa_d, 2 * ks + kh));
+          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(sb + 8192 + ft_swz(fb_d, 2 * ks + kh));
+          acc = FT_MFMA(al, bh, acc);
+          acc = FT_MFMA(ah, bl, acc);
+        }
         acc = FT_MFMA(ah, bh, acc);
       }
       FT_TICK(2);
@@ -299,15 +306,15 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
           mo[j] = mj;
           vo[j] = vj;
           h[j] = (__bf16)po[j];
-          l[j] = (__bf16)(po[j] - (float)h[j]);
+          if (NP == 3) l[j] = (__bf16)(po[j] - (float)h[j]);
         }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, po), rP, off[i], 0, NT);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mo), rM, off[i], 0, NT);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vo), rV, off[i], 0, NT);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, po), rPd, off[i], 0, NT);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mo), rMd, off[i], 0, NT);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vo), rVd, off[i], 0, NT);
         // columns 4 c4 .. 4 c4 + 3 of the tile: K-step block c4 >> 3, 16-byte chunk (c4 & 7) >> 1, half (c4 & 1)
         const int wo = (c4 >> 3) * 2048 + ft_swz(row, (c4 & 7) >> 1) + ((c4 & 1) << 2);
         *reinterpret_cast<bf16x4*>(wn_hi + wo) = h;
-        *reinterpret_cast<bf16x4*>(wn_lo + wo) = l;
+        if (NP == 3) *reinterpret_cast<bf16x4*>(wn_lo + wo) = l;
       }
       FT_TICK(7);
     }
@@ -321,7 +328,7 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
     __bf16* xb = smem + (stage) * 8192;                                                                   \
     const unsigned xo = (unsigned)(n0 / FT_K + ((q) & 3)) * (128u * MT * FT_K * 2u) + (unsigned)((q) >> 2) * (128u * FT_K * 2u) + x_src; \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rXh, LDS_PTR(xb + w * 512), 16, xo, 0, 0, 0);                \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rXl, LDS_PTR(xb + 4096 + w * 512), 16, xo, 0, 0, 0);         \
+    if (NP == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rXl, LDS_PTR(xb + 4096 + w * 512), 16, xo, 0, 0, 0);         \
   }
     FT_GLDS_X(0, 0);
 #pragma unroll
@@ -337,11 +344,13 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const bf16x8 ah = *reinterpret_cast<const bf16x8*>(xb + ft_swz(fa_f, 2 * ks + kh));
-        const bf16x8 al = *reinterpret_cast<const bf16x8*>(xb + 4096 + ft_swz(fa_f, 2 * ks + kh));
         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wh + ft_swz(fb_f, 2 * ks + kh));
-        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wl + ft_swz(fb_f, 2 * ks + kh));
-        yacc[m] = FT_MFMA(al, bh, yacc[m]);
-        yacc[m] = FT_MFMA(ah, bl, yacc[m]);
+        if (NP == 3) {
+          const bf16x8 al = *reinterpret_cast<const bf16x8*>(xb + 4096 + ft_swz(fa_f, 2 * ks + kh));
+          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wl + ft_swz(fb_f, 2 * ks + kh));
+          yacc[m] = FT_MFMA(al, bh, yacc[m]);
+          yacc[m] = FT_MFMA(ah, bl, yacc[m]);
+        }
         yacc[m] = FT_MFMA(ah, bh, yacc[m]);
       }
       FT_TICK(10);
@@ -433,13 +442,19 @@ int fx_linear_dw_adam_fwd_bf16x3_slabs_ex(int n_out, int k_in, int batch_padded,
 // ... with the default flags and a batch of <= 128 rows
 int fx_linear_dw_adam_fwd_bf16x3_slabs(int n_out, int k_in) { return fx_linear_dw_adam_fwd_bf16x3_slabs_ex(n_out, k_in, 128, 0); }
 
-int fx_linear_dw_adam_fwd_bf16x3(float* W, float* adam_m, float* adam_v, const void* dyT_hi, const void* dyT_lo,
-                                 const void* xT_hi, const void* xT_lo, int batch_padded, int n_out, int k_in, long lddy,
-                                 long ldx, long ldw, const float* ctrl, const void* xn_hi, const void* xn_lo,
-                                 long xn_rows_padded, int next_rows, float* y_slabs, long y_slabs_bytes, int flags,
-                                 hipStream_t stream) {
-  FX_REQUIRE(W && adam_m && adam_v && dyT_hi && dyT_lo && xT_hi && xT_lo && ctrl && xn_hi && xn_lo && y_slabs,
+static int dw_adam_fwd_impl(float* W, float* adam_m, float* adam_v, float* W_dst, float* m_dst, float* v_dst, const void* dyT_hi,
+                            const void* dyT_lo, const void* xT_hi, const void* xT_lo, int batch_padded, int n_out, int k_in, long lddy,
+                            long ldx, long ldw, const float* ctrl, const void* xn_hi, const void* xn_lo,
+                            long xn_rows_padded, int next_rows, float* y_slabs, long y_slabs_bytes, int flags,
+                            hipStream_t stream) {
+  FX_REQUIRE(W && adam_m && adam_v && W_dst && m_dst && v_dst && dyT_hi && xT_hi && ctrl && xn_hi && y_slabs,
              "fx_linear_dw_adam_fwd_bf16x3: null pointer");
+  // the three `lo` operands come together or not at all: without them the contractions are plain bf16 (one product, fp32 accumulate)
+  const bool plain = dyT_lo == nullptr;
+  FX_REQUIRE((xT_lo == nullptr) == plain && (xn_lo == nullptr) == plain,
+             "fx_linear_dw_adam_fwd_bf16x3: dyT_lo, xT_lo and xn_lo must be all given (split bf16) or all NULL (plain bf16)");
+  FX_REQUIRE(((W_dst == W) == (m_dst == adam_m)) && ((W_dst == W) == (v_dst == adam_v)) && ft_aligned16(W_dst) && ft_aligned16(m_dst) && ft_aligned16(v_dst),
+             "fx_linear_dw_adam_fwd_bf16x3: the destinations are W / m / v themselves (in place) or three other 16-byte aligned arrays");
   FX_REQUIRE(batch_padded > 0 && batch_padded % FT_K == 0, "fx_linear_dw_adam_fwd_bf16x3: padded batch %d must be a multiple of %d",
              batch_padded, FT_K);
   FX_REQUIRE(n_out > 0 && k_in > 0 && ldw >= k_in && ldw % 4 == 0 && k_in % 4 == 0 && ft_aligned16(W) && ft_aligned16(adam_m) &&
@@ -456,6 +471,7 @@ int fx_linear_dw_adam_fwd_bf16x3(float* W, float* adam_m, float* adam_v, const v
              "fx_linear_dw_adam_fwd_bf16x3: operand row block exceeds 4 GiB");
   DwAdamFwdArgs g{};
   g.W = W; g.m = adam_m; g.v = adam_v;
+  g.Wd = W_dst; g.md = m_dst; g.vd = v_dst;
   g.Ah = (const __bf16*)dyT_hi; g.Al = (const __bf16*)dyT_lo;
   g.Bh = (const __bf16*)xT_hi; g.Bl = (const __bf16*)xT_lo;
   g.Xh = (const __bf16*)xn_hi; g.Xl = (const __bf16*)xn_lo;
@@ -494,12 +510,36 @@ int fx_linear_dw_adam_fwd_bf16x3(float* W, float* adam_m, float* adam_v, const v
   FX_REQUIRE(nblk < (1L << 31), "fx_linear_dw_adam_fwd_bf16x3: grid too large");
   const dim3 grid((unsigned)nblk), blk(FT_T);
   const int mt = (int)(xn_rows_padded / 128);
-#define FT_LAUNCH(NTV, MTV, UV) hipLaunchKernelGGL((fx_dw_adam_fwd_kernel<NTV, MTV, UV>), grid, blk, 0, stream, g)
-  if (mt == 1) { if (nt) FT_LAUNCH(2, 1, 4); else FT_LAUNCH(0, 1, 4); }
-  else if (mt == 2) { if (nt) FT_LAUNCH(2, 2, 2); else FT_LAUNCH(0, 2, 2); }
-  else { if (nt) FT_LAUNCH(2, 3, 2); else FT_LAUNCH(0, 3, 2); }
+#define FT_LAUNCH(NTV, MTV, UV) { if (plain) hipLaunchKernelGGL((fx_dw_adam_fwd_kernel<NTV, MTV, UV, 1>), grid, blk, 0, stream, g); \
+                                 else hipLaunchKernelGGL((fx_dw_adam_fwd_kernel<NTV, MTV, UV, 3>), grid, blk, 0, stream, g); }
+  if (mt == 1) { if (nt) FT_LAUNCH(2, 1, 4) else FT_LAUNCH(0, 1, 4) }
+  else if (mt == 2) { if (nt) FT_LAUNCH(2, 2, 2) else FT_LAUNCH(0, 2, 2) }
+  else { if (nt) FT_LAUNCH(2, 3, 2) else FT_LAUNCH(0, 3, 2) }
 #undef FT_LAUNCH
   return fx_check_launch("fx_linear_dw_adam_fwd_bf16x3");
+}
+
+int fx_linear_dw_adam_fwd_bf16x3(float* W, float* adam_m, float* adam_v, const void* dyT_hi, const void* dyT_lo,
+                                 const void* xT_hi, const void* xT_lo, int batch_padded, int n_out, int k_in, long lddy,
+                                 long ldx, long ldw, const float* ctrl, const void* xn_hi, const void* xn_lo,
+                                 long xn_rows_padded, int next_rows, float* y_slabs, long y_slabs_bytes, int flags,
+                                 hipStream_t stream) {
+  return dw_adam_fwd_impl(W, adam_m, adam_v, W, adam_m, adam_v, dyT_hi, dyT_lo, xT_hi, xT_lo, batch_padded, n_out, k_in, lddy, ldx, ldw,
+                          ctrl, xn_hi, xn_lo, xn_rows_padded, next_rows, y_slabs, y_slabs_bytes, flags, stream);
+}
+
+// The same step OUT OF PLACE: W / m / v are only read, the updated values go to W_dst / m_dst / v_dst (same shape and pitch), which
+// the caller has placed in OTHER memory partitions than the sources -- every partition then sees only reads or only writes during the
+// launch -- and swaps with the sources for the next step (profiles/r06_outofplace.txt).
+int fx_linear_dw_adam_fwd_bf16x3_oop(float* W_dst, float* m_dst, float* v_dst, const float* W, const float* adam_m, const float* adam_v,
+                                     const void* dyT_hi, const void* dyT_lo, const void* xT_hi, const void* xT_lo, int batch_padded,
+                                     int n_out, int k_in, long lddy, long ldx, long ldw, const float* ctrl, const void* xn_hi,
+                                     const void* xn_lo, long xn_rows_padded, int next_rows, float* y_slabs, long y_slabs_bytes,
+                                     int flags, hipStream_t stream) {
+  FX_REQUIRE(W_dst != W && m_dst != adam_m && v_dst != adam_v, "fx_linear_dw_adam_fwd_bf16x3_oop: destinations must differ from the sources");
+  return dw_adam_fwd_impl(const_cast<float*>(W), const_cast<float*>(adam_m), const_cast<float*>(adam_v), W_dst, m_dst, v_dst, dyT_hi,
+                          dyT_lo, xT_hi, xT_lo, batch_padded, n_out, k_in, lddy, ldx, ldw, ctrl, xn_hi, xn_lo, xn_rows_padded,
+                          next_rows, y_slabs, y_slabs_bytes, flags, stream);
 }
 
 // ---- placement probe -----------------------------------------------------------------------------------------------------------
@@ -509,6 +549,7 @@ int fx_linear_dw_adam_fwd_bf16x3(float* W, float* adam_m, float* adam_v, const v
 // allocation history of the process (scripts/adamprobe.hip `r placement`, profiles/r04_placement.txt) -- what rounds 2-4 had
 // taken for two kinds of box.  The host allocates a few candidates, probes each and keeps the fastest (engine.ParamStore).
 __global__ __launch_bounds__(512, 2) void fx_placement_probe_kernel(float* __restrict__ W, float* __restrict__ M, float* __restrict__ V,
+                                                                    float* __restrict__ Wd, float* __restrict__ Md, float* __restrict__ Vd,
                                                                     int H, int F, long ld, int S, int n_hi) {
   __shared__ char pad[65536];                                      // the fused kernel's LDS footprint: two workgroups per CU
   if (threadIdx.x == 9999) pad[threadIdx.x] = 1;
@@ -534,9 +575,9 @@ __global__ __launch_bounds__(512, 2) void fx_placement_probe_kernel(float* __res
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (off[i] < 0) continue;
-      __builtin_nontemporal_store(p[i], (f32x4*)W + off[i]);
-      if (M) __builtin_nontemporal_store(m[i], (f32x4*)M + off[i]);
-      if (V) __builtin_nontemporal_store(v[i], (f32x4*)V + off[i]);
+      __builtin_nontemporal_store(p[i], (f32x4*)Wd + off[i]);
+      if (M) __builtin_nontemporal_store(m[i], (f32x4*)Md + off[i]);
+      if (V) __builtin_nontemporal_store(v[i], (f32x4*)Vd + off[i]);
     }
   }
 }
@@ -597,8 +638,25 @@ int fx_placement_probe(float* W, float* m, float* v, int n_out, int k_in, long l
   const int tiles_m = (n_out + 63) / 64, tiles_n = (k_in + 127) / 128;
   const FtPlan pl = ft_plan(tiles_m, tiles_n, FT_G);
   const int grid = (tiles_m - pl.n_hi) * pl.S_lo + pl.n_hi * (pl.S_lo + 1);
-  hipLaunchKernelGGL(fx_placement_probe_kernel, dim3(grid), dim3(512), 0, stream, W, m, v, n_out, k_in, ldw, pl.S_lo, pl.n_hi);
+  hipLaunchKernelGGL(fx_placement_probe_kernel, dim3(grid), dim3(512), 0, stream, W, m, v, W, m, v, n_out, k_in, ldw, pl.S_lo, pl.n_hi);
   return fx_check_launch("fx_placement_probe");
+}
+
+// The out-of-place twin: W / m / v are read, the same values are written to W_dst / m_dst / v_dst (same shape and pitch; m, v and their
+// destinations may be NULL together) -- rates a (source partitions, destination partitions) layout for fx_linear_dw_adam_fwd_bf16x3_oop.
+int fx_placement_probe_oop(float* W_dst, float* m_dst, float* v_dst, const float* W, const float* m, const float* v, int n_out, int k_in,
+                           long ldw, hipStream_t stream) {
+  FX_REQUIRE(W && W_dst && n_out > 0 && k_in > 0 && ldw >= k_in && (m == nullptr) == (m_dst == nullptr) && (v == nullptr) == (v_dst == nullptr),
+             "fx_placement_probe_oop: bad args");
+  FX_REQUIRE(k_in % 4 == 0 && ldw % 4 == 0 &&
+                 ((((uintptr_t)W) | ((uintptr_t)m) | ((uintptr_t)v) | ((uintptr_t)W_dst) | ((uintptr_t)m_dst) | ((uintptr_t)v_dst)) & 15) == 0,
+             "fx_placement_probe_oop: k_in and ldw must be multiples of 4 and the bases 16-byte aligned");
+  const int tiles_m = (n_out + 63) / 64, tiles_n = (k_in + 127) / 128;
+  const FtPlan pl = ft_plan(tiles_m, tiles_n, FT_G);
+  const int grid = (tiles_m - pl.n_hi) * pl.S_lo + pl.n_hi * (pl.S_lo + 1);
+  hipLaunchKernelGGL(fx_placement_probe_kernel, dim3(grid), dim3(512), 0, stream, const_cast<float*>(W), const_cast<float*>(m),
+                     const_cast<float*>(v), W_dst, m_dst, v_dst, n_out, k_in, ldw, pl.S_lo, pl.n_hi);
+  return fx_check_launch("fx_placement_probe_oop");
 }
 
 // The same sum for MANY slabs of a SMALL output (N, ldy, slab_stride multiples of 4, 16-byte aligned bases): 8 lanes per four outputs, each

@@ -130,6 +130,18 @@ int fx_linear_dw_adam_fwd_bf16x3(float* W, float* adam_m, float* adam_v, const v
                                  long ldx, long ldw, const float* ctrl, const void* xn_hi, const void* xn_lo,
                                  long xn_rows_padded, int next_rows, float* y_slabs, long y_slabs_bytes, int flags,
                                  fx_stream_t stream);
+/* Plain-bf16 throughput mode of the wide kernels (the reference trains under torch.set_float32_matmul_precision("medium"),
+ * main.py:24): pass NULL for every `lo` operand of fx_linear_fwd_bf16x3* / fx_linear_bwd_x_bf16x3 / fx_linear_dw_adam_bf16x3* /
+ * fx_linear_dw_adam_fwd_bf16x3* and the contraction is hi . hi only (one bf16 MFMA product, fp32 accumulate; W is rounded to bf16
+ * in-kernel), a third of the matrix work; master weights, Adam moments and everything narrow stay fp32.  The `lo` operands of one
+ * call come together or not at all.
+ * The fused step OUT OF PLACE: W / m / v are only read, the updated values go to W_dst / m_dst / v_dst (same shape and pitch) in
+ * other memory partitions; the caller swaps sources and destinations for the next step. */
+int fx_linear_dw_adam_fwd_bf16x3_oop(float* W_dst, float* m_dst, float* v_dst, const float* W, const float* adam_m,
+                                     const float* adam_v, const void* dyT_hi, const void* dyT_lo, const void* xT_hi,
+                                     const void* xT_lo, int batch_padded, int n_out, int k_in, long lddy, long ldx, long ldw,
+                                     const float* ctrl, const void* xn_hi, const void* xn_lo, long xn_rows_padded, int next_rows,
+                                     float* y_slabs, long y_slabs_bytes, int flags, fx_stream_t stream);
 /* Y[M,N] = sum_z slabs[z][M][N] (+ bias[N]), summed in slab order (deterministic) */
 int fx_reduce_slabs(float* Y, const float* slabs, const float* bias, int M, int N, long ldy, int n_slabs, long slab_stride,
                     fx_stream_t stream);
@@ -143,6 +155,10 @@ int fx_reduce_slabs_par(float* Y, const float* slabs, const float* bias, int M, 
  *      161-168 us for one array on its own: m = v = NULL): the host allocates candidate arrays one by one, times this with HIP events and
  *      keeps the fast ones (flexynesis_amd.engine.ParamStore, FX_PLACEMENT_TRIES). */
 int fx_placement_probe(float* W, float* m, float* v, int n_out, int k_in, long ldw, fx_stream_t stream);
+/* its out-of-place twin: reads W / m / v, writes the same values to W_dst / m_dst / v_dst (m, v and their destinations may be NULL
+ * together): rates a (source partitions, destination partitions) layout for fx_linear_dw_adam_fwd_bf16x3_oop */
+int fx_placement_probe_oop(float* W_dst, float* m_dst, float* v_dst, const float* W, const float* m, const float* v, int n_out,
+                           int k_in, long ldw, fx_stream_t stream);
 
 /* ---- launch-fusion variants (same reference ops, fewer passes): GEMMs that leave their split-K partial sums in
  *      slabs [splitk][M][N] for a consumer that reduces them in its own pass; Gram-norm Hadamard sum straight
