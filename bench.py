@@ -153,8 +153,9 @@ def parse():
     ap.add_argument("--no-pmc", action="store_true", help="do not re-run this script under rocprofv3 --pmc for roofline.traffic")
     ap.add_argument("--settle", type=int, default=40, help="untimed hipGraph replays before the --warmup steps (the first windows after "
                     "the captures run 3-5 %% slower while the clocks settle; reported as config.untimed_settle_steps)")
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "f32"],
-                    help="wide-layer contraction: split-bf16 MFMA with fp32 accumulate (default) or exact fp32 MFMA")
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "f32", "bf16"],
+                    help="wide-layer contraction: split-bf16 MFMA with fp32 accumulate (default: the parity mode), exact fp32 MFMA, or "
+                         "plain bf16 (one product: the labelled THROUGHPUT mode, looser documented tolerance)")
     return ap.parse_args()
 
 
@@ -353,7 +354,7 @@ def main():
     torch.manual_seed(1000 + rank)
     store = ParamStore(spec, dev, materialize_big_grads=False)
     pipe = PipelinedStep(store, B, cohort=cohort, n_batches=n_batches, seed=17 + rank, precision=a.precision)
-    dominant = "fx_linear_dw_adam_bf16x3" if a.precision == "bf16x3" else "fx_linear_dw_adam_f32"
+    dominant = "fx_linear_dw_adam_bf16x3" if a.precision in ("bf16x3", "bf16") else "fx_linear_dw_adam_f32"
     if pipe.plans[0]._next_fwd:
         dominant = "fx_linear_dw_adam_fwd_bf16x3"       # the same optimiser step + the next step's wide forward
     gen = ops.DeviceRng(4321 + rank)
@@ -536,7 +537,9 @@ def main():
         with _stdout_to_stderr():
             for name, (cfgname, prec) in (("cfg1", ("cfg1", "bf16x3")), ("cfg3", ("cfg3", "bf16x3")), ("cfg4", ("cfg4", "bf16x3")),
                                           ("cfg2_f32", ("cfg2", "f32")), ("cfg2_early_fusion", ("cfg2_early", "bf16x3")),
-                                          ("cfg2_odd", ("cfg2_odd", "bf16x3"))):
+                                          ("cfg2_odd", ("cfg2_odd", "bf16x3")),
+                                          # the plain-bf16 throughput mode (one MFMA product instead of three)
+                                          ("cfg2_bf16", ("cfg2", "bf16")), ("cfg3_bf16", ("cfg3", "bf16")), ("cfg4_bf16", ("cfg4", "bf16"))):
                 try:
                     rec, p_, s_, _ = _engine_leg(cfgname, B, dev, prec, 20, 5, a.lr)
                     p_.close()
@@ -573,8 +576,9 @@ def main():
             else f"training samples/sec ({a.config})",
             "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16x3 (fp32 split into 2 bf16 terms, 3 bf16-MFMA products, fp32 accumulate; fp32 master weights/Adam)"
-            if a.precision == "bf16x3" else "f32", "data": "synthetic",
+            "dtype": {"bf16x3": "bf16x3 (fp32 split into 2 bf16 terms, 3 bf16-MFMA products, fp32 accumulate; fp32 master weights/Adam)",
+                      "bf16": "bf16 (operands rounded to bf16, 1 bf16-MFMA product, fp32 accumulate; fp32 master weights/Adam) -- throughput mode",
+                      "f32": "f32"}[a.precision], "data": "synthetic",
             "config": {"workload": f"{a.config}: {cfg['model']} {len(cfg['layers'])} omics x "
                                    f"{cfg['layers'][0][1]} features, N={cfg['n_samples']}, B={B}, latent 64, "
                                    f"hidden_dim_factor 0.25, lr {a.lr}, clip 1.0 + Adam, "

@@ -91,6 +91,7 @@ __device__ __forceinline__ void bst32f(float v, __amdgpu_buffer_rsrc_t r, unsign
 }
 
 // split 4 fp32 (as raw u32x4) into 4 hi + 4 lo bf16 and store them 8 bytes each
+template <bool LO = true>
 __device__ __forceinline__ void split_store4(const u32x4 raw, __bf16* hi_dst, __bf16* lo_dst) {
   // NB: bit_cast the WHOLE vector; __builtin_bit_cast(float, raw[j]) on a vector element is miscompiled by
   // hipcc 7.2 (every j reads element 0 and the load is narrowed to one dword).
@@ -100,10 +101,10 @@ __device__ __forceinline__ void split_store4(const u32x4 raw, __bf16* hi_dst, __
   for (int j = 0; j < 4; ++j) {
     const float v = f[j];
     h[j] = (__bf16)v;
-    l[j] = (__bf16)(v - (float)h[j]);
+    if (LO) l[j] = (__bf16)(v - (float)h[j]);
   }
   *reinterpret_cast<bf16x4*>(hi_dst) = h;
-  *reinterpret_cast<bf16x4*>(lo_dst) = l;
+  if (LO) *reinterpret_cast<bf16x4*>(lo_dst) = l;
 }
 
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
@@ -113,7 +114,9 @@ __device__ __forceinline__ void split_store4(const u32x4 raw, __bf16* hi_dst, __
 // dX = dY . W through a wide layer (W [out=K, in=N]).  Each thread then loads the 8 consecutive k of ONE column n as
 // eight coalesced dword loads (64 lanes = 256 contiguous bytes of a W row) and owns exactly one 16-byte k-chunk of
 // the [n][k] LDS tile, so the MFMA side is unchanged and no LDS transpose is needed.
-template <bool B_F32, int EPI, int NT, int WN, bool B_KN = false>
+// NP = products per contraction: 3 = split bf16 (hi hi + hi lo + lo hi), 1 = plain bf16 (hi hi only; the `lo` operands are neither
+// loaded nor produced: the throughput mode, selected by the host when the caller passes NULL for them).
+template <bool B_F32, int EPI, int NT, int WN, bool B_KN = false, int NP = 3>
 __global__ __launch_bounds__(128 * WN) void fx_gemm_bf16x3_kernel(XGemmArgs g) {
   static_assert(!B_KN || (B_F32 && WN == 4), "B_KN needs the fp32 B operand and the 128x128 tile");
   constexpr int TN = 32 * WN, T = 128 * WN;
@@ -219,10 +222,10 @@ __global__ __launch_bounds__(128 * WN) void fx_gemm_bf16x3_kernel(XGemmArgs g) {
     const unsigned ka = a_kb + (unsigned)(kt) * a_step;                \
     const unsigned kb = b_kb + (unsigned)(kt) * b_step;                \
     P##_ah0 = bld128(rAh, a_off0 + ka);                                \
-    P##_al0 = bld128(rAl, a_off0 + ka);                                \
+    if (NP == 3) P##_al0 = bld128(rAl, a_off0 + ka);                   \
     if (A2) {                                                          \
       P##_ah1 = bld128(rAh, a_off1 + ka);                              \
-      P##_al1 = bld128(rAl, a_off1 + ka);                              \
+      if (NP == 3) P##_al1 = bld128(rAl, a_off1 + ka);                 \
     }                                                                  \
     if (B_KN) {                                                        \
       P##_b0 = u32x4{bld32u(rB0, b_off0 + kb), bld32u(rB0, b_off0 + kb + b_row), bld32u(rB0, b_off0 + kb + 2 * b_row),      \
@@ -231,26 +234,26 @@ __global__ __launch_bounds__(128 * WN) void fx_gemm_bf16x3_kernel(XGemmArgs g) {
                      bld32u(rB0, b_off1 + kb + 3 * b_row)};            \
     } else {                                                           \
       P##_b0 = bld128<B_F32 ? NT : 0>(rB0, b_off0 + kb);               \
-      P##_b1 = bld128<B_F32 ? NT : 0>(B_F32 ? rB0 : rB1, b_off1 + kb); \
+      if (B_F32 || NP == 3) P##_b1 = bld128<B_F32 ? NT : 0>(B_F32 ? rB0 : rB1, b_off1 + kb); \
     }                                                                  \
   }
 #define STASH_STAGE(P, buf)                                            \
   {                                                                    \
     __bf16* base = smem + (buf) * STAGE_ELEMS;                         \
     *reinterpret_cast<u32x4*>(base + a_lds0) = P##_ah0;                \
-    *reinterpret_cast<u32x4*>(base + TM * TK + a_lds0) = P##_al0;      \
+    if (NP == 3) *reinterpret_cast<u32x4*>(base + TM * TK + a_lds0) = P##_al0;      \
     if (A2) {                                                          \
       *reinterpret_cast<u32x4*>(base + a_lds1) = P##_ah1;              \
-      *reinterpret_cast<u32x4*>(base + TM * TK + a_lds1) = P##_al1;    \
+      if (NP == 3) *reinterpret_cast<u32x4*>(base + TM * TK + a_lds1) = P##_al1;    \
     }                                                                  \
     __bf16* bh = base + 2 * TM * TK;                                   \
     __bf16* bl = bh + TN * TK;                                         \
     if (B_F32) {                                                       \
-      split_store4(P##_b0, bh + b_lds0, bl + b_lds0);                  \
-      split_store4(P##_b1, bh + b_lds1, bl + b_lds1);                  \
+      split_store4<NP == 3>(P##_b0, bh + b_lds0, bl + b_lds0);         \
+      split_store4<NP == 3>(P##_b1, bh + b_lds1, bl + b_lds1);         \
     } else {                                                           \
       *reinterpret_cast<u32x4*>(bh + b_lds0) = P##_b0;                 \
-      *reinterpret_cast<u32x4*>(bl + b_lds1) = P##_b1;                 \
+      if (NP == 3) *reinterpret_cast<u32x4*>(bl + b_lds1) = P##_b1;    \
     }                                                                  \
   }
 
@@ -271,24 +274,28 @@ __global__ __launch_bounds__(128 * WN) void fx_gemm_bf16x3_kernel(XGemmArgs g) {
     const __bf16* Bl = Bh + TN * TK;                                                         \
     {                                                                                        \
       const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(Ah + fa0);                         \
-      const bf16x8 al0 = *reinterpret_cast<const bf16x8*>(Al + fa0);                         \
       const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(Ah + fa0b);                        \
-      const bf16x8 al1 = *reinterpret_cast<const bf16x8*>(Al + fa0b);                        \
       const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Bh + fb0);                          \
-      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Bl + fb0);                          \
-      acc0 = MFMA_BF16(al0, bh, acc0); acc1 = MFMA_BF16(al1, bh, acc1);                      \
-      acc0 = MFMA_BF16(ah0, bl, acc0); acc1 = MFMA_BF16(ah1, bl, acc1);                      \
+      if (NP == 3) {                                                                         \
+        const bf16x8 al0 = *reinterpret_cast<const bf16x8*>(Al + fa0);                       \
+        const bf16x8 al1 = *reinterpret_cast<const bf16x8*>(Al + fa0b);                      \
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Bl + fb0);                        \
+        acc0 = MFMA_BF16(al0, bh, acc0); acc1 = MFMA_BF16(al1, bh, acc1);                    \
+        acc0 = MFMA_BF16(ah0, bl, acc0); acc1 = MFMA_BF16(ah1, bl, acc1);                    \
+      }                                                                                      \
       acc0 = MFMA_BF16(ah0, bh, acc0); acc1 = MFMA_BF16(ah1, bh, acc1);                      \
     }                                                                                        \
     {                                                                                        \
       const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(Ah + fa1);                         \
-      const bf16x8 al0 = *reinterpret_cast<const bf16x8*>(Al + fa1);                         \
       const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(Ah + fa1b);                        \
-      const bf16x8 al1 = *reinterpret_cast<const bf16x8*>(Al + fa1b);                        \
       const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Bh + fb1);                          \
-      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Bl + fb1);                          \
-      acc0 = MFMA_BF16(al0, bh, acc0); acc1 = MFMA_BF16(al1, bh, acc1);                      \
-      acc0 = MFMA_BF16(ah0, bl, acc0); acc1 = MFMA_BF16(ah1, bl, acc1);                      \
+      if (NP == 3) {                                                                         \
+        const bf16x8 al0 = *reinterpret_cast<const bf16x8*>(Al + fa1);                       \
+        const bf16x8 al1 = *reinterpret_cast<const bf16x8*>(Al + fa1b);                      \
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Bl + fb1);                        \
+        acc0 = MFMA_BF16(al0, bh, acc0); acc1 = MFMA_BF16(al1, bh, acc1);                    \
+        acc0 = MFMA_BF16(ah0, bl, acc0); acc1 = MFMA_BF16(ah1, bl, acc1);                    \
+      }                                                                                      \
       acc0 = MFMA_BF16(ah0, bh, acc0); acc1 = MFMA_BF16(ah1, bh, acc1);                      \
     }                                                                                        \
   }
@@ -750,7 +757,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // the triplet shape against 396 / 565 shipped: with one wave per SIMD every load instruction's issue stalls the MFMA stream behind it --
 // timing ablations: no X loads 293 us, no W loads 335, no barrier 354, MFMAs alone 271 on zeros and 335 on random operands.)
 #define MFMA16_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
-template <int R, int WV, int NT>
+template <int R, int WV, int NT, int NP = 3>
 __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(2, 2))) void fx_fwd_bf16x3_reg_kernel(XGemmArgs g) {
   constexpr int ROWS = 16 * R * WV;             // batch rows per workgroup: WV waves x 16 R (WV = 4: two workgroups per CU)
   constexpr int LW = 16 / WV;                   // 16-byte pieces of W per thread and block
@@ -794,7 +801,7 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const unsigned ka = a_src + a_kb + (unsigned)(j_) * a_step;                                                    \
     _Pragma("unroll") for (int r = 0; r < R; ++r) {                                                                \
       AH[r] = __builtin_bit_cast(bf16x8, bld128<0>(rAh, (ka + r * (16 * TK * 2)) | past));                         \
-      AL[r] = __builtin_bit_cast(bf16x8, bld128<0>(rAl, (ka + r * (16 * TK * 2)) | past));                         \
+      if (NP == 3) AL[r] = __builtin_bit_cast(bf16x8, bld128<0>(rAl, (ka + r * (16 * TK * 2)) | past));            \
     }                                                                                                              \
   }
 #define RG_LOAD_W(Q, j_)                                                                                           \
@@ -807,7 +814,7 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(2, 2)))
   {                                                                                                                \
     char* d = smem + (buf_) * BUF + b_lds;                                                                         \
     _Pragma("unroll") for (int i = 0; i < LW; ++i)                                                                 \
-      split_store4(Q[i], reinterpret_cast<__bf16*>(d + i * 128 * WV), reinterpret_cast<__bf16*>(d + HALFB + i * 128 * WV)); \
+      split_store4<NP == 3>(Q[i], reinterpret_cast<__bf16*>(d + i * 128 * WV), reinterpret_cast<__bf16*>(d + HALFB + i * 128 * WV)); \
   }
 #define RG_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0);
 // timing ablations (scripts/build_variant.py -DRG_NO_*; results wrong): which part of a block the MFMAs wait for
@@ -847,11 +854,11 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const int c2 = (c + 2) & 7, s2 = (8 * (JB) + c + 2) % 3;                                                   \
         const char* sp = smem + ((c + 2 < 8) ? (BC) : (BN)) * BUF + fb + c2 * 256;                                 \
         fh[s2] = *reinterpret_cast<const bf16x8*>(sp);                                                             \
-        fl[s2] = *reinterpret_cast<const bf16x8*>(sp + HALFB);                                                     \
+        if (NP == 3) fl[s2] = *reinterpret_cast<const bf16x8*>(sp + HALFB);                                        \
       }                                                                                                            \
       if (c < 2 * R) {                                                                                             \
         if (RG_A_ON) {                                                                                             \
-          if (c & 1) ALN[c >> 1] = __builtin_bit_cast(bf16x8, bld128<0>(rAl, (ka + (c >> 1) * (16 * TK * 2)) | pastA)); \
+          if (c & 1) { if (NP == 3) ALN[c >> 1] = __builtin_bit_cast(bf16x8, bld128<0>(rAl, (ka + (c >> 1) * (16 * TK * 2)) | pastA)); } \
           else AHN[c >> 1] = __builtin_bit_cast(bf16x8, bld128<0>(rAh, (ka + (c >> 1) * (16 * TK * 2)) | pastA));  \
         }                                                                                                          \
       } else if (RG_W_ON && c - 2 * R < LW) {                                                                      \
@@ -859,13 +866,17 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(2, 2)))
       }                                                                                                            \
       if (c == 4 && RG_STAGE_ON) RG_STAGE_W(QS, BS);                                                               \
       const int s0 = (8 * (JB) + c) % 3;                                                                           \
-      _Pragma("unroll") for (int r = 0; r < R; ++r) acc[r][c] = MFMA16_BF16(ALC[r], fh[s0], acc[r][c]);            \
-      _Pragma("unroll") for (int r = 0; r < R; ++r) acc[r][c] = MFMA16_BF16(AHC[r], fl[s0], acc[r][c]);            \
+      if (NP == 3) {                                                                                               \
+        _Pragma("unroll") for (int r = 0; r < R; ++r) acc[r][c] = MFMA16_BF16(ALC[r], fh[s0], acc[r][c]);          \
+        _Pragma("unroll") for (int r = 0; r < R; ++r) acc[r][c] = MFMA16_BF16(AHC[r], fl[s0], acc[r][c]);          \
+      }                                                                                                            \
       _Pragma("unroll") for (int r = 0; r < R; ++r) acc[r][c] = MFMA16_BF16(AHC[r], fh[s0], acc[r][c]);            \
-      RG_SGB(0x008, 1) RG_SGB(0x100, 1) RG_SGB(0x008, 1) RG_SGB(0x100, 1) RG_SGB(0x008, 1) RG_SGB(0x020, 1)        \
-      if (c == 4) { RG_SGB(0x008, 1) RG_SGB(0x002, 6 * LW) RG_SGB(0x008, 1) RG_SGB(0x002, 6 * LW) RG_SGB(0x008, 1) RG_SGB(0x002, 6 * LW) \
-                    RG_SGB(0x008, 1) RG_SGB(0x200, LW) RG_SGB(0x008, 1) RG_SGB(0x200, LW) }                        \
-      RG_SGB(0x008, 3 * R)                                                                                         \
+      if (NP == 3) {                                                                                               \
+        RG_SGB(0x008, 1) RG_SGB(0x100, 1) RG_SGB(0x008, 1) RG_SGB(0x100, 1) RG_SGB(0x008, 1) RG_SGB(0x020, 1)      \
+        if (c == 4) { RG_SGB(0x008, 1) RG_SGB(0x002, 6 * LW) RG_SGB(0x008, 1) RG_SGB(0x002, 6 * LW) RG_SGB(0x008, 1) RG_SGB(0x002, 6 * LW) \
+                      RG_SGB(0x008, 1) RG_SGB(0x200, LW) RG_SGB(0x008, 1) RG_SGB(0x200, LW) }                      \
+        RG_SGB(0x008, 3 * R)                                                                                       \
+      }                                                                                                            \
       __builtin_amdgcn_sched_barrier(0);                                                                           \
     }                                                                                                              \
     RG_SYNC_L();                                                                                                   \
@@ -888,7 +899,7 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     fh[c] = *reinterpret_cast<const bf16x8*>(smem + fb + c * 256);
-    fl[c] = *reinterpret_cast<const bf16x8*>(smem + fb + c * 256 + HALFB);
+    if (NP == 3) fl[c] = *reinterpret_cast<const bf16x8*>(smem + fb + c * 256 + HALFB);
   }
   for (int j = 0; j < nb; j += 3) {            // a block past the slice multiplies zeros (its loads are out of range)
     RG_BLOCK(0, ah0, al0, ah2, al2, q2, q1, j, 0, 1, 2);
@@ -1144,11 +1155,13 @@ int fx_linear_bwd_x_bf16x3(float* dX, const void* dyhi, const void* dylo, const 
 static int fwd_bf16x3_impl(float* Y, const void* xhi, const void* xlo, const float* W, const float* bias, int M, int N,
                            int K, long ldx, long ldw, long ldy, void* workspace, long workspace_bytes, bool reduce,
                            hipStream_t stream, bool kn, FwdTune tune) {
-  FX_REQUIRE(xhi && xlo && W && M > 0 && N > 0 && K > 0, "fx_linear_fwd_bf16x3: bad args");
+  FX_REQUIRE(xhi && W && M > 0 && N > 0 && K > 0, "fx_linear_fwd_bf16x3: bad args");
+  const bool plain = xlo == nullptr;        // no `lo` operand: plain bf16 (one product); W is rounded to bf16 in-kernel
   const int Kp = (K + TK - 1) / TK * TK;
   FX_REQUIRE(ldx >= M && ldx % 128 == 0 && aligned16(xhi) && aligned16(xlo),
              "fx_linear_fwd_bf16x3: X must be a K-blocked split with rows padded to a multiple of 128 (got %ld for M=%d)", ldx, M);
-  const int wn = kn ? 4 : fwd_wn(tune), tn = 32 * wn;
+  FX_REQUIRE(!(plain && (tune.mt == 2 || tune.mt == 3)), "fx_linear_fwd_bf16x3: the A/B kernels (no_mt 2 / 3) need the lo operand");
+  const int wn = (kn || plain) ? 4 : fwd_wn(tune), tn = 32 * wn;
   const int s = pick_splitk_x(M, N, Kp, wn, tune);
   // W is addressed per N tile (or per K slice when stored [K, N]) through a rebased descriptor: only that block must
   // stay below 4 GiB, not the weight
@@ -1178,22 +1191,28 @@ static int fwd_bf16x3_impl(float* Y, const void* xhi, const void* xlo, const flo
       if (mt == 3) hipLaunchKernelGGL((fx_fwd_bf16x3_dma_kernel<3, 0>), dim3((unsigned)nb), dim3(512), 0, stream, g);
       else hipLaunchKernelGGL((fx_fwd_bf16x3_dma_kernel<2, 0>), dim3((unsigned)nb), dim3(512), 0, stream, g);
     } else if (mt == 3) {                                 // X fragments straight into registers
-      if (nt) hipLaunchKernelGGL((fx_fwd_bf16x3_reg_kernel<3, 8, 2>), dim3((unsigned)nb), dim3(512), 0, stream, g);
+      if (plain) hipLaunchKernelGGL((fx_fwd_bf16x3_reg_kernel<3, 8, 0, 1>), dim3((unsigned)nb), dim3(512), 0, stream, g);
+      else if (nt) hipLaunchKernelGGL((fx_fwd_bf16x3_reg_kernel<3, 8, 2>), dim3((unsigned)nb), dim3(512), 0, stream, g);
       else hipLaunchKernelGGL((fx_fwd_bf16x3_reg_kernel<3, 8, 0>), dim3((unsigned)nb), dim3(512), 0, stream, g);
     } else {
-      if (nt) hipLaunchKernelGGL((fx_fwd_bf16x3_reg_kernel<2, 8, 2>), dim3((unsigned)nb), dim3(512), 0, stream, g);
+      if (plain) hipLaunchKernelGGL((fx_fwd_bf16x3_reg_kernel<2, 8, 0, 1>), dim3((unsigned)nb), dim3(512), 0, stream, g);
+      else if (nt) hipLaunchKernelGGL((fx_fwd_bf16x3_reg_kernel<2, 8, 2>), dim3((unsigned)nb), dim3(512), 0, stream, g);
       else hipLaunchKernelGGL((fx_fwd_bf16x3_reg_kernel<2, 8, 0>), dim3((unsigned)nb), dim3(512), 0, stream, g);
     }
   } else if (!kn && wn == 4 && tune.mt != 1 && (M <= 64 || tune.mt == 4)) {
     // at most 64 rows: the register-fragment kernel with four waves of 16 rows, two workgroups per CU (4.5-5.1 TB/s of W where the
     // 128-row tile below streams 4.2-4.5); 65..128 rows: the two measure the same (both sit on the package power limit), FX_FWD_MT=4 is the A/B
-    if (M > 64) hipLaunchKernelGGL((fx_fwd_bf16x3_reg_kernel<2, 4, 0>), dim3((unsigned)nblk), dim3(256), 0, stream, g);
+    if (M > 64 && plain) hipLaunchKernelGGL((fx_fwd_bf16x3_reg_kernel<2, 4, 0, 1>), dim3((unsigned)nblk), dim3(256), 0, stream, g);
+    else if (M > 64) hipLaunchKernelGGL((fx_fwd_bf16x3_reg_kernel<2, 4, 0>), dim3((unsigned)nblk), dim3(256), 0, stream, g);
+    else if (plain) hipLaunchKernelGGL((fx_fwd_bf16x3_reg_kernel<1, 4, 0, 1>), dim3((unsigned)nblk), dim3(256), 0, stream, g);
     else if (nt) hipLaunchKernelGGL((fx_fwd_bf16x3_reg_kernel<1, 4, 2>), dim3((unsigned)nblk), dim3(256), 0, stream, g);
     else hipLaunchKernelGGL((fx_fwd_bf16x3_reg_kernel<1, 4, 0>), dim3((unsigned)nblk), dim3(256), 0, stream, g);
   } else if (kn) {
-    hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<true, XEPI_STORE, 0, 4, true>), dim3((unsigned)nblk), dim3(512), 0, stream, g);
+    if (plain) hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<true, XEPI_STORE, 0, 4, true, 1>), dim3((unsigned)nblk), dim3(512), 0, stream, g);
+    else hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<true, XEPI_STORE, 0, 4, true>), dim3((unsigned)nblk), dim3(512), 0, stream, g);
   } else if (wn == 4) {
-    if (nt) hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<true, XEPI_STORE, 2, 4>), dim3((unsigned)nblk), dim3(512), 0, stream, g);
+    if (plain) hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<true, XEPI_STORE, 0, 4, false, 1>), dim3((unsigned)nblk), dim3(512), 0, stream, g);
+    else if (nt) hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<true, XEPI_STORE, 2, 4>), dim3((unsigned)nblk), dim3(512), 0, stream, g);
     else hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<true, XEPI_STORE, 0, 4>), dim3((unsigned)nblk), dim3(512), 0, stream, g);
   } else {
     if (nt) hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<true, XEPI_STORE, 2, 2>), dim3((unsigned)nblk), dim3(256), 0, stream, g);
@@ -1211,7 +1230,9 @@ static int dw_adam_bf16x3_impl(float* W, float* adam_m, float* adam_v, const voi
                                const void* xT_hi, const void* xT_lo, int batch_padded, int n_out, int k_in, long lddy,
                                long ldx, long ldw, const float* ctrl, int tile_order, int wave_cols, int plain_loads,
                                hipStream_t stream) {
-  FX_REQUIRE(W && adam_m && adam_v && dyT_hi && dyT_lo && xT_hi && xT_lo && ctrl, "fx_linear_dw_adam_bf16x3: null pointer");
+  FX_REQUIRE(W && adam_m && adam_v && dyT_hi && xT_hi && ctrl, "fx_linear_dw_adam_bf16x3: null pointer");
+  const bool plain = dyT_lo == nullptr;       // no `lo` operands: plain bf16 (one product)
+  FX_REQUIRE((xT_lo == nullptr) == plain, "fx_linear_dw_adam_bf16x3: dyT_lo and xT_lo must be both given (split bf16) or both NULL (plain bf16)");
   FX_REQUIRE(batch_padded > 0 && batch_padded % TK == 0, "fx_linear_dw_adam_bf16x3: padded batch %d must be a multiple of %d",
              batch_padded, TK);
   FX_REQUIRE(lddy % 8 == 0 && ldx % 8 == 0 && aligned16(dyT_hi) && aligned16(dyT_lo) && aligned16(xT_hi) && aligned16(xT_lo),
@@ -1229,7 +1250,7 @@ static int dw_adam_bf16x3_impl(float* W, float* adam_m, float* adam_v, const voi
   g.splitk = 1; g.kchunk = batch_padded;
   g.n_fast = n_out > k_in;
   g.adam_m = adam_m; g.adam_v = adam_v; g.ctrl = ctrl;
-  const int wn = wave_cols == 2 ? 2 : 4, tn = 32 * wn;
+  const int wn = (wave_cols == 2 && !plain) ? 2 : 4, tn = 32 * wn;
   long nblk = (long)((n_out + TM - 1) / TM) * ((k_in + tn - 1) / tn);
   if (tile_order != 1) {
     const int tiles_m = (n_out + TM - 1) / TM, tiles_n = (k_in + tn - 1) / tn;
@@ -1248,7 +1269,10 @@ static int dw_adam_bf16x3_impl(float* W, float* adam_m, float* adam_v, const voi
     }
   }
   FX_REQUIRE(nblk < (1L << 31), "fx_linear_dw_adam_bf16x3: grid too large");
-  if (wn == 4) {
+  if (plain) {
+    if (!plain_loads) hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<false, XEPI_ADAM, 2, 4, false, 1>), dim3((unsigned)nblk), dim3(512), 0, stream, g);
+    else hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<false, XEPI_ADAM, 0, 4, false, 1>), dim3((unsigned)nblk), dim3(512), 0, stream, g);
+  } else if (wn == 4) {
     if (!plain_loads) hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<false, XEPI_ADAM, 2, 4>), dim3((unsigned)nblk), dim3(512), 0, stream, g);
     else hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<false, XEPI_ADAM, 0, 4>), dim3((unsigned)nblk), dim3(512), 0, stream, g);
   } else {

@@ -926,9 +926,14 @@ class StepPlan:
         self._gram_x: Dict[int, tuple] = {}
         self._jobs: Dict[str, tuple] = {}
         self._slot_o = 0
-        if precision not in ("f32", "bf16x3"):
-            raise ValueError(f"precision must be 'f32' or 'bf16x3', got {precision!r}")
-        self.precision = precision
+        if precision not in ("f32", "bf16x3", "bf16"):
+            raise ValueError(f"precision must be 'f32', 'bf16x3' or 'bf16', got {precision!r}")
+        # "bf16": the THROUGHPUT mode -- the wide kernels' contractions in plain bf16 (hi . hi, fp32 accumulate: torch's "medium"
+        # matmul precision, which the reference itself trains under, main.py:24) instead of three split products; same kernels, same
+        # schedule, same operand buffers (the tapes pass NULL for the `lo` halves); master weights, Adam moments, the Gram norm and
+        # everything narrow stay as in "bf16x3".  Looser, documented tolerance; every parity gate runs bf16x3.
+        self.plain_bf16 = precision == "bf16"
+        self.precision = "bf16x3" if self.plain_bf16 else precision
         self._split_cache: Dict[tuple, tuple] = {}
         self.cohort = cohort
         self.n_batches = int(n_batches)
@@ -962,7 +967,7 @@ class StepPlan:
             self.y[spec.surv_time_var] = torch.zeros(self.B, **f)
         self._rng_ctr = 0
         self.big_jobs: List[Tuple[str, torch.Tensor, torch.Tensor]] = []   # (weight key, dY, X) for fused dW+Adam
-        self.t_gather, self.t_fwd, self.t_bwd, self.t_opt = TapeRecorder(), TapeRecorder(), TapeRecorder(), TapeRecorder()
+        self.t_gather, self.t_fwd, self.t_bwd, self.t_opt = self._tape(), self._tape(), self._tape(), self._tape()
         # Next-step forward fused into the optimiser kernel (fx_linear_dw_adam_fwd_bf16x3): this plan's wide forward is
         # then only the ordered reduce of partial sums that the PREVIOUS step's dW+Adam launch left behind (it had this
         # plan's batch, assembled one step ahead, and the freshly updated weight tile in registers).  Needs a partner plan
@@ -971,11 +976,11 @@ class StepPlan:
         self.fuse_next = bool(fuse_next_fwd) and self.fused and precision == "bf16x3" and cohort is not None
         self._next_fwd: Dict[str, tuple] = {}
         self.path: Dict[str, bool] = {}       # which of the fused schedules this plan records (tests / bench: "did the fast path engage")
-        self.t_boot = TapeRecorder()
+        self.t_boot = self._tape()
         # attribution (eval plans): input-gradient tapes d head_output / d X for IntegratedGradients / GradientShap
         self.attribution = bool(attribution) and not train
         self.t_attr_head: Dict[str, TapeRecorder] = {}
-        self.t_attr_common = TapeRecorder()
+        self.t_attr_common = self._tape()
         self.attr_dout: Dict[str, torch.Tensor] = {}
         self.dX: List[torch.Tensor] = []
         self._build()
@@ -1200,6 +1205,9 @@ class StepPlan:
         self._weight_grad(rec, prefix + ".hidden_layers.0.weight", dh, x)
         if dx is not None:
             ops.linear_bwd_x(rec, dx, dh, st.ep(prefix + ".hidden_layers.0.weight"), self.ws, accumulate=dx_accumulate)
+
+    def _tape(self) -> TapeRecorder:
+        return TapeRecorder(products=1 if self.plain_bf16 else 3)
 
     def _lin_fwd(self, rec, y, x, wkey, bkey, want_slabs=False, raw_slabs=False, gram_after=False):
         """nn.Linear forward; wide weights take the split-bf16 MFMA path when precision == 'bf16x3'.
@@ -1728,7 +1736,7 @@ class StepPlan:
             return
         if set(self._next_fwd) != set(nxt._next_fwd):
             raise RuntimeError("link_next: the two plans fuse different layers")
-        self.t_opt = TapeRecorder()
+        self.t_opt = self._tape()
         self._build_optimizer(nxt)
 
     def set_clip(self, max_norm: Optional[float]):
@@ -1744,7 +1752,7 @@ class StepPlan:
         if self.frozen and clip:
             raise ValueError("frozen parameter groups train without gradient clipping")
         self.clip, self.clip_norm = clip, norm
-        self.t_opt = TapeRecorder()
+        self.t_opt = self._tape()
         self._build_optimizer()
         self.graph = None
         self.__dict__.get("_tape_graph", {}).pop("opt", None)
@@ -1827,7 +1835,7 @@ class StepPlan:
         spec, st, B = self.spec, self.store, self.B
         demb = self._new("attr/demb", B, L)
         for (v, kind, C) in spec.variables:
-            ra = self.t_attr_head[v] = TapeRecorder()
+            ra = self.t_attr_head[v] = self._tape()
             pre = "MLPs." + v
             S = st.eshapes[pre + ".layer_1.weight"][0]
             do = self.attr_dout[v] = self._new(f"attr/dout.{v}", B, C)
@@ -1862,7 +1870,7 @@ class StepPlan:
         spec, st, B, n = self.spec, self.store, self.B, len(enc)
         dz = self._new("attr/dz", B, L)
         for (v, kind, C) in spec.variables:
-            ra = self.t_attr_head[v] = TapeRecorder()
+            ra = self.t_attr_head[v] = self._tape()
             pre = "MLPs." + v
             S = st.eshapes[pre + ".layer_1.weight"][0]
             do = self.attr_dout[v] = self._new(f"attr/dout.{v}", B, C)
@@ -1901,7 +1909,7 @@ class StepPlan:
         nodes, C = int(g["nodes"]), int(g["embedding_dim"])
         demb = self._new("attr/demb", B, L)
         for (v, kind, Cv) in spec.variables:
-            ra = self.t_attr_head[v] = TapeRecorder()
+            ra = self.t_attr_head[v] = self._tape()
             pre = "MLPs." + v
             S = st.eshapes[pre + ".layer_1.weight"][0]
             do = self.attr_dout[v] = self._new(f"attr/dout.{v}", B, Cv)

@@ -371,6 +371,7 @@ LEASES = LeaseRegistry()
 
 class ImmediateRecorder:
     """Launch each op immediately on the current stream."""
+    products = 3
 
     def emit(self, name: str, *args):
         rc = getattr(lib, name)(*args, _stream())
@@ -406,10 +407,13 @@ class TapeRecorder:
     graph branches: the narrow per-modality chains overlap each other and the other modality's HBM-bound
     wide-layer kernel instead of queueing behind it."""
 
-    def __init__(self):
+    def __init__(self, products: int = 3):
         self.segments: List[List[List[tuple]]] = [[[]]]
         self._cur = 0
         self.keepalive: List[object] = []
+        # 3: the wide kernels recorded on this tape contract in split bf16 (hi hi + hi lo + lo hi); 1: plain bf16 -- their `lo`
+        # operands are passed as NULL, which the library reads as "one product" (include/fxhip.h)
+        self.products = int(products)
 
     @property
     def calls(self):
@@ -681,6 +685,11 @@ def _chk_kb(hi, lo, R, K, what):
         raise FxError(f"{what}: hi/lo must be contiguous K-blocked bf16 {want} (ops.new_split_kb), got {tuple(hi.shape)}")
 
 
+def _lo(rec, t):
+    """The `lo` operand of a wide kernel: its address, or NULL on a plain-bf16 tape (TapeRecorder.products == 1)."""
+    return None if getattr(rec, "products", 3) == 1 else t.data_ptr()
+
+
 def split_bf16(rec, hi, lo, x):
     """hi/lo K-blocked (new_split_kb(R, C)) <- x [R, C]  (x ~= hi + lo)."""
     _chk2d(x, "split_bf16.x")
@@ -712,11 +721,11 @@ def linear_fwd_bf16x3(rec, y, xhi, xlo, W, b, ws):
     if t["fwd_splitk"] or t["fwd_wn"] or t["fwd_no_mt"] or t["fwd_nt"]:
         need = max(need, max(t["fwd_splitk"], 1) * M * N * 4)
         ws.reserve(need)
-        rec.emit("fx_linear_fwd_bf16x3_ex", y.data_ptr(), xhi.data_ptr(), xlo.data_ptr(), W.data_ptr(), _ptr(b), M, N, K,
+        rec.emit("fx_linear_fwd_bf16x3_ex", y.data_ptr(), xhi.data_ptr(), _lo(rec, xlo), W.data_ptr(), _ptr(b), M, N, K,
                  xhi.shape[1], _ld(W), _ld(y), ws.buf.data_ptr(), ws.nbytes, t["fwd_splitk"], t["fwd_wn"], t["fwd_no_mt"], t["fwd_nt"])
         return
     ws.reserve(need)
-    rec.emit("fx_linear_fwd_bf16x3", y.data_ptr(), xhi.data_ptr(), xlo.data_ptr(), W.data_ptr(), _ptr(b), M, N, K,
+    rec.emit("fx_linear_fwd_bf16x3", y.data_ptr(), xhi.data_ptr(), _lo(rec, xlo), W.data_ptr(), _ptr(b), M, N, K,
              xhi.shape[1], _ld(W), _ld(y), ws.buf.data_ptr(), ws.nbytes)
 
 
@@ -730,7 +739,7 @@ def linear_bwd_x_bf16x3(rec, dx, dyhi, dylo, W, ws: Workspace):
         raise FxError("linear_bwd_x_bf16x3: shape mismatch")
     _chk_kb(dyhi, dylo, M, K, "linear_bwd_x_bf16x3")
     ws.reserve(int(lib.fx_linear_fwd_bf16x3_workspace_bytes(M, N, K)))
-    rec.emit("fx_linear_bwd_x_bf16x3", dx.data_ptr(), dyhi.data_ptr(), dylo.data_ptr(), W.data_ptr(), M, N, K, dyhi.shape[1],
+    rec.emit("fx_linear_bwd_x_bf16x3", dx.data_ptr(), dyhi.data_ptr(), _lo(rec, dylo), W.data_ptr(), M, N, K, dyhi.shape[1],
              _ld(W), _ld(dx), ws.buf.data_ptr(), ws.nbytes)
 
 
@@ -747,12 +756,12 @@ def linear_dw_adam_bf16x3(rec, W, m, v, dyT_hi, dyT_lo, xT_hi, xT_lo, ctrl, tile
         raise FxError("linear_dw_adam_bf16x3: W/m/v must share a leading dimension")
     order = TUNE["adam_order"] if tile_order is None else int(tile_order)
     if order or TUNE["adam_wn"] or TUNE["adam_plain"]:
-        rec.emit("fx_linear_dw_adam_bf16x3_ex", W.data_ptr(), m.data_ptr(), v.data_ptr(), dyT_hi.data_ptr(), dyT_lo.data_ptr(),
-                 xT_hi.data_ptr(), xT_lo.data_ptr(), Bp, N, K, _ld(dyT_hi), _ld(xT_hi), _ld(W), ctrl.data_ptr(), order,
+        rec.emit("fx_linear_dw_adam_bf16x3_ex", W.data_ptr(), m.data_ptr(), v.data_ptr(), dyT_hi.data_ptr(), _lo(rec, dyT_lo),
+                 xT_hi.data_ptr(), _lo(rec, xT_lo), Bp, N, K, _ld(dyT_hi), _ld(xT_hi), _ld(W), ctrl.data_ptr(), order,
                  TUNE["adam_wn"], TUNE["adam_plain"])
         return
-    rec.emit("fx_linear_dw_adam_bf16x3", W.data_ptr(), m.data_ptr(), v.data_ptr(), dyT_hi.data_ptr(), dyT_lo.data_ptr(),
-             xT_hi.data_ptr(), xT_lo.data_ptr(), Bp, N, K, _ld(dyT_hi), _ld(xT_hi), _ld(W), ctrl.data_ptr())
+    rec.emit("fx_linear_dw_adam_bf16x3", W.data_ptr(), m.data_ptr(), v.data_ptr(), dyT_hi.data_ptr(), _lo(rec, dyT_lo),
+             xT_hi.data_ptr(), _lo(rec, xT_lo), Bp, N, K, _ld(dyT_hi), _ld(xT_hi), _ld(W), ctrl.data_ptr())
 
 
 def _fused_flags(nt=True, mapping=0) -> int:
@@ -781,9 +790,9 @@ def linear_dw_adam_fwd_bf16x3(rec, W, m, v, dyT_hi, dyT_lo, xT_hi, xT_lo, ctrl, 
     S = dw_adam_fwd_slabs(N, K, Bp, mapping)
     if y_slabs.dtype != torch.float32 or not y_slabs.is_contiguous() or y_slabs.numel() < S * next_rows * N:
         raise FxError(f"linear_dw_adam_fwd_bf16x3: y_slabs must hold {S} x {next_rows} x {N} fp32")
-    rec.emit("fx_linear_dw_adam_fwd_bf16x3", W.data_ptr(), m.data_ptr(), v.data_ptr(), dyT_hi.data_ptr(), dyT_lo.data_ptr(),
-             xT_hi.data_ptr(), xT_lo.data_ptr(), Bp, N, K, _ld(dyT_hi), _ld(xT_hi), _ld(W), ctrl.data_ptr(), xn_hi.data_ptr(),
-             xn_lo.data_ptr(), xn_hi.shape[1], int(next_rows), y_slabs.data_ptr(), y_slabs.numel() * 4,
+    rec.emit("fx_linear_dw_adam_fwd_bf16x3", W.data_ptr(), m.data_ptr(), v.data_ptr(), dyT_hi.data_ptr(), _lo(rec, dyT_lo),
+             xT_hi.data_ptr(), _lo(rec, xT_lo), Bp, N, K, _ld(dyT_hi), _ld(xT_hi), _ld(W), ctrl.data_ptr(), xn_hi.data_ptr(),
+             _lo(rec, xn_lo), xn_hi.shape[1], int(next_rows), y_slabs.data_ptr(), y_slabs.numel() * 4,
              _fused_flags(nt, mapping))
 
 
@@ -849,7 +858,7 @@ def linear_fwd_bf16x3_slabs(rec, slabs, xhi, xlo, W, M):
     _chk_kb(xhi, xlo, M, K, "linear_fwd_bf16x3_slabs")
     if slabs.numel() < s * M * N:
         raise FxError("linear_fwd_bf16x3_slabs: bad buffer shapes")
-    rec.emit("fx_linear_fwd_bf16x3_slabs", slabs.data_ptr(), slabs.numel() * 4, xhi.data_ptr(), xlo.data_ptr(),
+    rec.emit("fx_linear_fwd_bf16x3_slabs", slabs.data_ptr(), slabs.numel() * 4, xhi.data_ptr(), _lo(rec, xlo),
              W.data_ptr(), M, N, K, xhi.shape[1], _ld(W))
     return s
 

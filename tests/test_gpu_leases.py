@@ -96,7 +96,7 @@ def test_wide_parameters_survive_to_and_close_while_other_models_come_and_go(mon
     same("after close() + a third model")
     third.close()
     m.close()
-    del third, m, want
+    del third, m, want, opt                               # (an optimiser holds its model's Parameters, and they view the range)
     gc.collect()
     ar = PartitionArena._arenas.get(DEV.index)
     if ar is not None and ar.ok:

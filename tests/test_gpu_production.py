@@ -663,3 +663,160 @@ def test_integration_md_ctypes_binding_runs_as_written():
     ref.backward()
     assert abs(float(loss) - float(ref.detach())) <= 1e-5 * abs(float(ref.detach())) + 1e-7
     assert torch.allclose(grad.cpu().double(), o.grad, rtol=1e-4, atol=1e-7)
+
+
+# ---- the plain-bf16 THROUGHPUT mode (precision="bf16"): a labelled second mode beside the split-bf16 parity mode ---------------------
+# Documented tolerance: (a) the kernels compute exactly "operands rounded to bf16, products exact, fp32
+# accumulation" -- checked against fp64 contractions of the ROUNDED operands at the split-bf16 kernels' own tolerances; (b) a training
+# step's named losses stay within 5e-3 relative of the fp32 oracle (measured ~1e-3: bf16 carries 8 significant bits, a contraction over
+# K = 5000 .. 20000 averages the roundings); (c) a free-running 5-step trajectory stays inside the band the reference itself shows
+# between torch's "medium" (what main.py:24 sets) and "highest" matmul precision: 2.7e-2 relative.
+BF16_STEP_RTOL = 5e-3
+BF16_TRAJ_RTOL = 2.7e-2
+
+
+def test_bf16_mode_kernels_are_exact_products_of_rounded_operands():
+    from flexynesis_amd import ops
+    dev = _dev()
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    n_out, k_in, K = 2048, 4096, 128
+    rnd = lambda t: t.bfloat16().double()
+    # -- forward: y = bf16(x) . bf16(W)^T, and its data gradient dx = bf16(dy) . bf16(W)
+    x = torch.randn(K, k_in, generator=g, device=dev)
+    W = torch.randn(n_out, k_in, generator=g, device=dev) * 0.02
+    b = torch.randn(n_out, generator=g, device=dev)
+    y = torch.empty(K, n_out, device=dev)
+    sp = ops.new_split_kb(K, k_in, dev)
+    ops.split_bf16(ops.IMMEDIATE, sp[0], sp[1], x)
+    ws = ops.Workspace(dev)
+    for products, op_x, op_w in ((1, rnd(x), rnd(W)), (3, x.double(), W.double())):
+        rec = ops.TapeRecorder(products=products)
+        ops.linear_fwd_bf16x3(rec, y, sp[0], sp[1], W, b, ws)
+        rec.run()
+        ref = op_x @ op_w.t() + b.double()
+        err = float((y.double() - ref).abs().max() / ref.abs().max())
+        assert err <= 2e-5, (products, err)
+    plain_vs_full = float((rnd(x) @ rnd(W).t() - x.double() @ W.double().t()).abs().max() / (x.double() @ W.double().t()).abs().max())
+    assert plain_vs_full > 1e-4                                    # (the two modes really differ: the check above tells them apart)
+    dy = torch.randn(K, n_out, generator=g, device=dev) * 1e-3
+    dsp = ops.new_split_kb(K, n_out, dev)
+    ops.split_bf16(ops.IMMEDIATE, dsp[0], dsp[1], dy)
+    dx = torch.empty(K, k_in, device=dev)
+    rec = ops.TapeRecorder(products=1)
+    ops.linear_bwd_x_bf16x3(rec, dx, dsp[0], dsp[1], W, ws)
+    rec.run()
+    ref = rnd(dy) @ rnd(W)
+    assert float((dx.double() - ref).abs().max() / ref.abs().max()) <= 2e-5
+    # -- dW + clip + Adam (+ the next step's forward): dW = bf16(dy)^T . bf16(x); the next forward multiplies bf16(W_new)
+    ldw = ops.pad32(k_in)
+    m = torch.randn(n_out, ldw, generator=g, device=dev) * 1e-4
+    v = torch.rand(n_out, ldw, generator=g, device=dev) * 1e-7
+    Wp = torch.zeros(n_out, ldw, device=dev)
+    Wp[:, :k_in] = W
+    ctrl = torch.zeros(64, device=dev)
+    lr, coef, t = 1e-3, 0.37, 5
+    dyt, xt = ops.new_split(n_out, K, dev), ops.new_split(k_in, K, dev)
+    ops.split_bf16_t(ops.IMMEDIATE, dyt[0], dyt[1], dy)
+    ops.split_bf16_t(ops.IMMEDIATE, xt[0], xt[1], x)
+    gr = (rnd(dy).t() @ rnd(x)) * coef
+    m_ref = 0.9 * m[:, :k_in].double() + 0.1 * gr
+    v_ref = 0.999 * v[:, :k_in].double() + 0.001 * gr * gr
+    W_ref = W.double() - (lr / (1 - 0.9 ** t)) * m_ref / (v_ref.sqrt() / math.sqrt(1 - 0.999 ** t) + 1e-8)
+    xn = torch.randn(K, k_in, generator=g, device=dev)
+    nsp = ops.new_split_kb(K, k_in, dev)
+    ops.split_bf16(ops.IMMEDIATE, nsp[0], nsp[1], xn)
+    for fused in (False, True):
+        W1, m1, v1 = Wp.clone(), m.clone(), v.clone()
+        ctrl.zero_()
+        ctrl[0] = 4.0
+        ops.step_begin(ops.IMMEDIATE, ctrl, lr)           # t = 5
+        ctrl[4] = coef
+        rec = ops.TapeRecorder(products=1)
+        if fused:
+            S = ops.dw_adam_fwd_slabs(n_out, k_in, 128)
+            slabs = torch.empty(S, K, n_out, device=dev)
+            ops.linear_dw_adam_fwd_bf16x3(rec, W1[:, :k_in], m1[:, :k_in], v1[:, :k_in], dyt[0], dyt[1], xt[0], xt[1], ctrl, nsp[0], nsp[1],
+                                          K, slabs)
+        else:
+            ops.linear_dw_adam_bf16x3(rec, W1[:, :k_in], m1[:, :k_in], v1[:, :k_in], dyt[0], dyt[1], xt[0], xt[1], ctrl)
+        rec.run()
+        torch.cuda.synchronize()
+        gscale = float(gr.abs().max())
+        assert float((m1[:, :k_in].double() - m_ref).abs().max()) <= 0.1 * 3e-5 * gscale + 1e-9, fused
+        rel = float((W1[:, :k_in].double() - W_ref).norm() / (W_ref - W.double()).norm())
+        assert rel <= 1e-4, (fused, rel)
+        if fused:
+            yn = slabs.sum(0).double()
+            ref = rnd(xn) @ rnd(W1[:, :k_in]).t()
+            assert float((yn - ref).abs().max() / ref.abs().max()) <= 2e-5
+
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg3"])
+def test_train_step_bf16_mode_within_documented_band(name):
+    """precision="bf16" on the schedule bench.py times (PipelinedStep, hipGraph replay), free-running for 5 steps from the oracle's
+    initial state on the oracle's batches and draws: every step's named losses within BF16_STEP_RTOL of the fp32 oracle's step from
+    ITS OWN trajectory while both are close (step 0 exactly comparable), the 5-step trajectory within BF16_TRAJ_RTOL -- and the same
+    run in the parity mode (bf16x3) within 1e-4, so the band is about the mode and not about the harness."""
+    from flexynesis_amd import ops
+    from flexynesis_amd.data import DeviceCohort
+    from flexynesis_amd.engine import ParamStore, PipelinedStep
+    from oracle import restate as O
+    cfg, dev, B, N, nb = FULL[name], _dev(), 128, 768, 6
+    layers = cfg["layers"]
+    aspec = _arch(cfg)
+    ospec = _oracle_spec(aspec)
+    dat, ann = O.synthetic_cohort(layers, N, seed=78)
+    cohort = DeviceCohort(dat, ann, dev)
+    gen = torch.Generator().manual_seed(5)
+    table = torch.randperm(N, generator=gen)[: nb * B]
+    lr, steps = 1e-3, 5
+    runs = {}
+    draws_log = None
+    for precision in ("bf16", "bf16x3"):
+        store = ParamStore(aspec, dev, materialize_big_grads=False)
+        store.load_state(O.init_state(ospec, seed=9))
+        pipe = PipelinedStep(store, B, cohort=cohort, n_batches=nb, seed=3, supplied_draws=True, precision=precision)
+        assert pipe.plans[0].plain_bf16 == (precision == "bf16")
+        pipe.idx.copy_(table.to(dev))
+        pipe.prime()
+        if draws_log is None:
+            dgen = torch.Generator().manual_seed(17)
+            shapes = {dn: t.shape for dn, t in pipe.pending.draws.items()}
+            draws_log = []
+            for _ in range(steps):
+                d = {}
+                for dn, shp in shapes.items():
+                    normal = dn == "eps" or dn.startswith("prior.")
+                    d[dn] = torch.randn(shp, generator=dgen) if normal else (torch.rand(shp, generator=dgen) < 0.9).float()
+                draws_log.append(d)
+        got = []
+        for step in range(steps):
+            pipe.pending.set_draws({k: v.to(dev) for k, v in draws_log[step].items()})
+            if pipe.graphs[0] is not None:
+                pipe.replay()
+            else:
+                pipe.step(lr)
+                pipe.capture(lr)
+            got.append(pipe.losses())
+        runs[precision] = got
+        y_keys = list(pipe.pending.y)
+        pipe.close()
+        del pipe, store
+    st, opt = O.init_state(ospec, seed=9), {}
+    ref = []
+    for step in range(steps):
+        rows = table[step * B:(step + 1) * B]
+        batch = {"x": [dat[n][rows] for n, _ in layers], "y": {k: ann[k][rows] for k in y_keys}}
+        st, opt, info = O.train_step(ospec, st, opt, batch, draws_log[step], lr)
+        ref.append({k: float(v.reshape(-1)[0]) for k, v in info["losses"].items()})
+    worst = {"bf16": 0.0, "bf16x3": 0.0}
+    for precision, tol_step, tol_traj in (("bf16x3", 1e-4, 1e-4), ("bf16", BF16_STEP_RTOL, BF16_TRAJ_RTOL)):
+        for step in range(steps):
+            for k, r in ref[step].items():
+                rel = abs(runs[precision][step][k] - r) / max(abs(r), 1e-6)
+                worst[precision] = max(worst[precision], rel)
+                tol = tol_step if step == 0 else tol_traj
+                assert rel <= tol + 1e-6, f"{name} {precision} step {step} loss {k}: {runs[precision][step][k]} vs {r} (rel {rel:.2e} > {tol})"
+    print(f"[bf16 band] {name}: worst relative loss deviation over {steps} free-running steps: bf16 {worst['bf16']:.2e}, bf16x3 {worst['bf16x3']:.2e}")
+    assert worst["bf16"] > worst["bf16x3"]            # (the throughput mode IS the less exact one; it ran)
