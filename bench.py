@@ -501,6 +501,13 @@ def main():
         from flexynesis_amd.engine import PartitionArena
         _ar = PartitionArena._arenas.get(dev.index)
         placement_arena = dict(_ar.info) if _ar is not None else None
+        if placement_arena is not None:
+            # what the arena costs: resident for the life of the process (pools), transient while it was built (spacers, back with the driver)
+            from flexynesis_amd.engine import placement_memory
+            pm = placement_memory(dev)
+            placement_arena["resident_GB"] = round(pm["arena_resident_bytes"] / 2 ** 30, 2)
+            placement_arena["transient_spacer_GB"] = pm["arena_build_spacer_GB"]
+            placement_arena["placement_pool_GB"] = round(pm["pool_bytes"] / 2 ** 30, 2)
     except Exception:
         placement_arena = None
     del pipe, store, cohort

@@ -64,6 +64,7 @@ def objective(self, params, current_step, total_steps, full_train=False):
         model_kwargs["input_layers"] = self.input_layers
         model_kwargs["output_layers"] = self.output_layers
     cls = engine_class(self.model_class)
+    _models.base.resolve_device(self.device_type)                      # "cpu" / "mps": refused here, loudly (a failed fit would only report +inf)
     common = dict(batch_variables=self.batch_variables, surv_event_var=self.surv_event_var, surv_time_var=self.surv_time_var,
                   use_loss_weighting=self.use_loss_weighting, seed=_seed(current_step), device=self.device_type)
     if full_train:                                                      # main.py:247-262: all samples, no validation, no early stopping

@@ -331,6 +331,54 @@ class PartitionArena:
         with self.lock:
             return tuple(sum(z for ci, fl in enumerate(self.free) if (self.kind[ci] > 0) == bool(k) for _, z in fl) for k in (0, 1))
 
+    def _grow(self, want_a: bool, nbytes: int) -> bool:
+        """One more chunk for pool A (``want_a``) or pool B, at least ``nbytes`` long: a weight larger than what is free in a pool (early
+        fusion at hidden_dim_factor 2: 12.8 GB per array against the 8 GB pool A is built with) used to fall back to the allocator's
+        first placement -- the slow one.  The new chunk joins the pool whose partition it lies in: both of its ends are rated against
+        both ends of pool A's first chunk (fast pair = other partition: pool B; slow = pool A's).  A chunk that lies across a boundary
+        is given back.  Bounded by FX_ARENA_GROW_GB (default 64) of growth per device and by a third of what is free now.
+        In practice this grows pool A: a fresh allocation comes from where the process stands, i.e. pool A's partition (a chunk that
+        does is kept for pool A whichever pool asked); the partition of pool B lay up to 100 GB of spacers away when the arena was
+        built, so a model whose m / v outgrow pool B needs FX_ARENA_B_GB set before the first wide weight -- or takes the bounded
+        per-weight search, as before."""
+        gb = 1 << 30
+        size = max((nbytes + self.GRAN - 1) // self.GRAN * self.GRAN, int(float(os.environ.get("FX_ARENA_CHUNK_GB", "4")) * gb))
+        cap = int(float(os.environ.get("FX_ARENA_GROW_GB", "64")) * gb)
+        ref_bytes = self.REF[0] * self.REF[1] * 4
+        if ops.capturing() or size < 2 * ref_bytes:
+            return False
+        with torch.cuda.device(self.device):
+            for _ in range(1):
+                free_b = torch.cuda.mem_get_info(self.device)[0]
+                with self.lock:
+                    grown = self.info.get("grown_GB", 0.0) * gb
+                if grown + size > cap or size > free_b // 3:
+                    return False
+                try:
+                    cand = torch.empty(size, dtype=torch.uint8, device=self.device)
+                except torch.OutOfMemoryError:
+                    return False
+                last = (size - ref_bytes) // self.GRAN * self.GRAN
+                a = self.chunks[0]
+                a0, a1 = self._ref_view(a), self._ref_view(a, (a.numel() - ref_bytes) // self.GRAN * self.GRAN)
+                c0, c1 = self._ref_view(cand), self._ref_view(cand, last)
+                rates = [self._pair(a0, c0), self._pair(a0, c1), self._pair(a1, c0), self._pair(a1, c1)]
+                in_b, in_a = min(rates) >= self.FAST_TBS, max(rates) < self.FAST_TBS
+                if not (in_a or in_b):
+                    del cand, c0, c1
+                    torch.cuda.empty_cache()
+                    continue
+                kind = 0 if in_a else 1
+                with self.lock:
+                    self.chunks.append(cand)
+                    self.kind.append(kind)
+                    self.free.append([(0, size)])
+                    self.info["grown_GB"] = round((grown + size) / gb, 1)
+                    self.info.setdefault("grown", []).append(["A" if kind == 0 else "B", round(size / gb, 1), round(min(rates), 2), round(max(rates), 2)])
+                if (kind == 0) == want_a:
+                    return True
+        return False
+
     def _events_for(self, ci: int, off: int, size: int):
         """(events, unsynced) of the hand-backs whose ranges overlap [off, off + size) of chunk ci; entries whose events have all
         completed are dropped on the way (called under the lock)."""
@@ -355,8 +403,9 @@ class PartitionArena:
         Returns (tensors, lease ids), or None when a pool has no room."""
         import gc
         nbytes = need_elems * 4
-        for attempt in (0, 1):
+        for attempt in (0, 1, 2, 3):
             ops.LEASES.drain()
+            short_a = None
             with self.lock:
                 token = []
                 for kinds in ((0,), (1, 2), (2, 1)):          # W | m | v; m and v share a class when the other has no room (or does not exist)
@@ -366,6 +415,7 @@ class PartitionArena:
                         if r is not None:
                             break
                     if r is None:
+                        short_a = kinds == (0,)
                         for t in token:
                             self._release(*t)
                         token = None
@@ -376,6 +426,8 @@ class PartitionArena:
                 break
             if attempt == 0 and not ops.capturing():
                 gc.collect()                   # ranges of dropped models that sit in reference cycles come back now
+            elif attempt == 3 or not self._grow(bool(short_a), nbytes):     # one more chunk for the pool that ran short (W, then m / v)
+                break
         if token is None:
             return None
         for evs, unsynced in waits:
@@ -2131,8 +2183,11 @@ class StepPlan:
         heads_aside = bool(self.train and vae_par and nd > 1 and not self.forward_alone
                            and os.environ.get("FX_VAE_HEADS_BRANCH", "1") != "0")
         self._losses_in_bwd = heads_aside        # (losses() between forward() and backward() would read a stale MMD term / total)
+        # FX_VAE_HEADS_BRANCH=2 (round 6, A/B): the heads on a graph branch of their OWN next to the decoder branches -- the schedule that
+        # made torch's CUDAGraph layer segfault in round 4; with the library's own capture (ops.FxGraph) it can be measured again
+        heads_branch = bool(heads_aside and self.branches and os.environ.get("FX_VAE_HEADS_BRANCH", "1") == "2")
         deferred_mmd = []
-        with rf.parallel(nd if vae_par else 1) as par:      # one graph branch per decoder
+        with rf.parallel((nd + 1 if heads_branch else nd) if vae_par else 1) as par:      # one graph branch per decoder (+ the heads')
             for i in range(nd):
                 if vae_par:
                     self._enter_branch(par, i)
@@ -2201,8 +2256,11 @@ class StepPlan:
                 if mmd_late and i == nd - 1:
                     for term in deferred_mmd:
                         term(rf)
-                if heads_aside and i == 0:
+                if heads_aside and i == 0 and not heads_branch:
                     self._svae_heads(rf, z, dz)
+            if heads_branch:
+                self._enter_branch(par, nd)
+                self._svae_heads(rf, z, dz)
         self._branch = 0
         if not heads_aside:
             self._svae_heads(rf, z, dz)

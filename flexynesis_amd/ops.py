@@ -828,6 +828,31 @@ def placement_probe_us(W, m=None, v=None, launches: int = 3) -> float:
     return best
 
 
+def placement_probe_oop_us(dst, src, launches: int = 3) -> float:
+    """Microseconds per pass of the OUT-OF-PLACE twin of the fused kernel's traffic pattern: ``src`` = (W, m, v) are read, the same
+    values are written to ``dst`` = (W', m', v') (m, v and their destinations may be None together).  Rates a (source partitions,
+    destination partitions) layout for fx_linear_dw_adam_fwd_bf16x3_oop (include/fxhip.h: fx_placement_probe_oop)."""
+    W, m, v = src
+    Wd, md, vd = dst
+    for t in (W, m, v, Wd, md, vd):
+        if t is not None:
+            _chk2d(t, "placement_probe_oop")
+            if t.shape != W.shape or _ld(t) != _ld(W):
+                raise FxError("placement_probe_oop: all arrays must share shape and leading dimension")
+    n_out, k_in = W.shape
+    args = (Wd.data_ptr(), _ptr(md), _ptr(vd), W.data_ptr(), _ptr(m), _ptr(v), n_out, k_in, _ld(W))
+    IMMEDIATE.emit("fx_placement_probe_oop", *args)
+    best = float("inf")
+    for _ in range(max(1, launches)):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        IMMEDIATE.emit("fx_placement_probe_oop", *args)
+        e1.record()
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3)
+    return best
+
+
 def reduce_slabs_par(rec, y, slabs, bias, n_slabs):
     """reduce_slabs for many slabs of a small output: partial sums over contiguous ranges of slabs, combined in range order."""
     _chk2d(y, "reduce_slabs_par.y")

@@ -16,7 +16,7 @@ for (H, ld) in shapes:
     if ar is not None:
         (w, m, v), tok = ar.take3(H * ld)
         a_rate = 24.0 * H * ld / ops.placement_probe_us(w.view(H, ld), m.view(H, ld), v.view(H, ld)) / 1e6
-        keep.append(tok)
+        keep.append((w, m, v))            # (the ranges stay leased while these tensors live)
     else:
         a_rate = float("nan")
     seps = []

@@ -169,3 +169,45 @@ def test_handed_back_ranges_wait_for_their_previous_owners_streams(monkeypatch):
         assert ar.free_bytes() == total
     finally:
         PartitionArena.reset(DEV)                                  # the next test builds the default-sized arena again
+
+
+def test_arena_pools_grow_instead_of_falling_back(monkeypatch):
+    """A pool that runs short takes one more chunk in ITS partition (rated against pool A's ends) instead of sending the weight to the
+    allocator's first placement (weights larger than pool A silently took the slow path)."""
+    from flexynesis_amd.arch import ArchSpec
+    from flexynesis_amd.engine import ParamStore, PartitionArena, placement_memory, placement_tries
+    monkeypatch.delenv("FX_PLACEMENT_TRIES", raising=False)
+    monkeypatch.delenv("FX_PARTITION_ARENA", raising=False)
+    monkeypatch.setenv("FX_ARENA_A_GB", "1")
+    monkeypatch.setenv("FX_ARENA_B_GB", "5")
+    monkeypatch.setenv("FX_ARENA_CHUNK_GB", "1")
+    gc.collect()
+    PartitionArena.reset(DEV)
+    ar = PartitionArena.get(DEV)
+    if ar is None:
+        PartitionArena.reset(DEV)
+        pytest.skip("no arena on this device")
+    try:
+        spec = ArchSpec("DirectPred", [("gex", 20000)], 64, 0.25, 16, [("y", "numerical", 1)], None, None, True)
+        stores = []
+        for i in range(5):                                # 5 x 400 MB of W against a 1 GB pool A (it grows); 10 x 400 MB of m, v fit pool B
+            with placement_tries(1):
+                st = ParamStore(spec, DEV, materialize_big_grads=False)
+            info = st.placement.get(KEY)
+            assert info is not None and info.get("arena") is True, (i, info, ar.info)
+            assert 24.0 * 5000 * 20000 / (info["kept_us"] * 1e-6) >= 5.5e12, (i, info)        # still the two-partition rate
+            stores.append(st)
+        grown = ar.info.get("grown")
+        assert grown and {g[0] for g in grown} == {"A"} and all(g[3] < PartitionArena.FAST_TBS for g in grown), ar.info
+        a0 = ar.chunks[0].data_ptr()
+        kinds_of = lambda t: [k for c, k in zip(ar.chunks, ar.kind) if c.data_ptr() <= t.data_ptr() < c.data_ptr() + c.numel()]
+        for st in stores:
+            big = st.big[KEY]
+            assert kinds_of(big["_W"]) == [0] and kinds_of(big["_M"])[0] > 0 and kinds_of(big["_V"])[0] > 0
+        pm = placement_memory(DEV)
+        assert pm["arena_resident_bytes"] == sum(c.numel() for c in ar.chunks) > 3 * (1 << 30)
+        del stores, st, big
+        gc.collect()
+        assert placement_memory(DEV)["arena_free_bytes"] == pm["arena_resident_bytes"]
+    finally:
+        PartitionArena.reset(DEV)
