@@ -27,7 +27,8 @@ import numpy as np
 import torch
 
 from . import models as _models
-from .fit import fine_tune, full_train, run_trial
+from .fit import fine_tune, run_trial
+from .fit import full_train as _full_train
 
 
 def engine_class(model_class):
@@ -68,7 +69,7 @@ def objective(self, params, current_step, total_steps, full_train=False):
     common = dict(batch_variables=self.batch_variables, surv_event_var=self.surv_event_var, surv_time_var=self.surv_time_var,
                   use_loss_weighting=self.use_loss_weighting, seed=_seed(current_step), device=self.device_type)
     if full_train:                                                      # main.py:247-262: all samples, no validation, no early stopping
-        model, _ = full_train(cls, params, self.dataset, self.target_variables, **common, **model_kwargs)
+        model, _ = _full_train(cls, params, self.dataset, self.target_variables, **common, **model_kwargs)
         return model
     patience = int(self.early_stop_patience) if int(self.early_stop_patience) > 0 else 0     # main.py:207-209
     val, epochs, model, info = run_trial(cls, params, self.dataset, self.target_variables, val_size=self.val_size,
