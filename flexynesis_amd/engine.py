@@ -1025,7 +1025,7 @@ class StepPlan:
         # plan's batch, assembled one step ahead, and the freshly updated weight tile in registers).  Needs a partner plan
         # (PipelinedStep links the two); t_boot computes the partial sums stand-alone for the first step / after any
         # weight change made outside the pipeline.
-        self.fuse_next = bool(fuse_next_fwd) and self.fused and precision == "bf16x3" and cohort is not None
+        self.fuse_next = bool(fuse_next_fwd) and self.fused and self.precision == "bf16x3" and cohort is not None
         self._next_fwd: Dict[str, tuple] = {}
         self.path: Dict[str, bool] = {}       # which of the fused schedules this plan records (tests / bench: "did the fast path engage")
         self.t_boot = self._tape()

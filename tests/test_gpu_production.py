@@ -778,6 +778,8 @@ def test_train_step_bf16_mode_within_documented_band(name):
         store.load_state(O.init_state(ospec, seed=9))
         pipe = PipelinedStep(store, B, cohort=cohort, n_batches=nb, seed=3, supplied_draws=True, precision=precision)
         assert pipe.plans[0].plain_bf16 == (precision == "bf16")
+        if name == "cfg2":           # the SAME schedule in both modes: the next step's wide forward rides on the dW + Adam launches
+            assert sorted(pipe.plans[0]._next_fwd) == sorted(store.big_keys) and pipe.n_launches() == 14
         pipe.idx.copy_(table.to(dev))
         pipe.prime()
         if draws_log is None:
