@@ -350,6 +350,29 @@ class FxModel(_Base):
         self.__dict__["_fx_optimizer"] = opt
         return out
 
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        """``assign=True`` REPLACES the Parameter objects (torch >= 2.1): the engine's arenas, the cached parameter walk and the optimiser's
+        references would go on using the old ones -- the binding is dropped and rebuilt lazily from the new parameters."""
+        out = super().load_state_dict(state_dict, strict=strict, assign=assign)
+        if assign:
+            opt = self.__dict__.get("_fx_optimizer")
+            self._reset_runtime()
+            self.__dict__["_fx_optimizer"] = opt
+        return out
+
+    def _check_param_cache(self):
+        """Parameters registered / replaced behind the model's back (register_parameter, ParameterDict edits, torch.__future__'s
+        overwrite-on-conversion): the cached walk is compared with a fresh one whenever a plan is BUILT (not per step) and dropped,
+        together with the binding, when they differ."""
+        c = self.__dict__.get("_fx_param_cache")
+        if c is None:
+            return
+        fresh = list(self.named_parameters())
+        if len(fresh) != len(c) or any(a[1] is not b[1] for a, b in zip(fresh, c)):
+            opt = self.__dict__.get("_fx_optimizer")
+            self._reset_runtime()
+            self.__dict__["_fx_optimizer"] = opt
+
     def __deepcopy__(self, memo):
         cls = self.__class__
         new = cls.__new__(cls)
@@ -392,6 +415,8 @@ class FxModel(_Base):
                 seen[k] = tag
         key = (int(B), bool(train), bool(fused))
         if key not in self._plans:
+            self._check_param_cache()
+            store = self._bind()
             self._plans[key] = StepPlan(store, B, train=train, fused=fused, supplied_draws=False,
                                         seed=self._seed + len(self._plans), forward_alone=True)
             # Training plans of the level-1 path (driven tape by tape from an external loop) replay their tapes as hipGraphs

@@ -219,3 +219,43 @@ def test_arena_pools_grow_instead_of_falling_back(monkeypatch):
         assert placement_memory(DEV)["arena_free_bytes"] == pm["arena_resident_bytes"]
     finally:
         PartitionArena.reset(DEV)
+
+
+def test_assigned_state_dict_and_new_parameters_rebind_the_engine():
+    """``load_state_dict(assign=True)`` replaces the Parameter OBJECTS: the engine must compute with the new ones (the cached
+    parameter walk / the arena binding kept the old tensors)."""
+    import flexynesis_amd.models as M
+    from test_gpu_api import _synthetic_ds
+    ds = _synthetic_ds(n=128)
+    cfg = {"latent_dim": 16, "hidden_dim_factor": 0.5, "lr": 3e-3, "supervisor_hidden_dim": 8, "epochs": 1, "batch_size": 32}
+    torch.manual_seed(1)
+    a = M.DirectPred(cfg, ds, ["y", "c"], device_type="cuda")
+    a.to(DEV)
+    torch.manual_seed(2)
+    b = M.DirectPred(cfg, ds, ["y", "c"], device_type="cuda")
+    b.to(DEV)
+    pa, pb = a.predict(ds), b.predict(ds)                       # (both bound now; their cached walks exist)
+    assert not (pa["y"] == pb["y"]).all()
+    sd_b = {k: v.detach().clone() for k, v in b.state_dict().items()}
+    a.load_state_dict(sd_b, assign=True)
+    assert a._store is None                                      # the binding went with the old Parameter objects
+    pa2 = a.predict(ds)
+    for k in pb:
+        assert (pa2[k] == pb[k]).all(), k                        # a now IS b
+    # a parameter swapped behind the model's back is noticed when the next plan is built
+    a.train()
+    opt = a.configure_optimizers()
+    idx = torch.arange(32)
+    batch = ({k: v[idx].to(DEV) for k, v in ds.dat.items()}, {k: ds.ann[k][idx].to(DEV) for k in ("y", "c")}, None)
+    a.training_step(batch, 0, log=False)
+    name, old = next(iter(a.named_parameters()))
+    mod = a
+    for part in name.split(".")[:-1]:
+        mod = getattr(mod, part)
+    mod.register_parameter(name.split(".")[-1], torch.nn.Parameter(old.detach().clone() * 0 + 0.123))
+    a.eval()
+    a._plans.clear()                                             # (a plan is built again: that is where the walk is checked)
+    a.predict(ds)
+    assert dict(a._param_items())[name] is dict(a.named_parameters())[name]
+    assert float(a._store.p(name).flatten()[0]) == pytest.approx(0.123)
+    del opt
