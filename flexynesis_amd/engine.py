@@ -2291,6 +2291,25 @@ class StepPlan:
         # Hadamard sum, transposed operand splits, bias gradient).  Decoder 0 reads its weight FIRST and prepares afterwards, the
         # others prepare first: every branch's narrow work runs under another branch's weight read.  (As extra branches the
         # preparation cost more in fork / join edges than it hid: 2.93 vs 2.89 ms.)
+        # PARTIAL JOIN (round 6, FX_VAE_PARTIAL_JOIN=0: A/B): the latent / encoder backward needs the decoders' shares of dz only, not
+        # what the optimiser tape needs of decoder 0's FC_output (Gram norm share, transposed splits, bias gradient) nor the loss
+        # bookkeeping, which follow decoder 0's dz share in ITS branch (~90 us of narrow launches, profiles/r05_timeline_cfg3.txt:
+        # 626 -> 717 us).  So the chain continues INSIDE the last decoder's branch -- the last one issued, hence the one that may wait
+        # for events of the others (TapeRecorder.record_event) -- as soon as every earlier branch has produced its share, and the
+        # branches join behind it: decoder 0's tail runs beside the latent / encoder backward instead of in front of it.
+        late = bool(vae_par and nd > 1 and lat_fused and self.branches and os.environ.get("FX_VAE_PARTIAL_JOIN", "1") != "0")
+        self.path["partial_join"] = late
+        dz_evs = []
+
+        def latent_chain():
+            if lat_fused:
+                n_all = 1 + nd + sum(dz_ns)                  # heads, MMD terms, decoder 0's partial sums, decoder 1's, ...
+                if L % 4 == 0 and n_all >= 16:
+                    ops.reduce_slabs_par(rb, dz_sum, dzs, None, n_all)
+                else:
+                    ops.reduce_slabs(rb, dz_sum, dzs, None, n_all)
+            self._svae_bwd_latent(rb, enc, hs, mcat, vcat, dz, dhs, eps_used, n, nd, L, B, dz_complete=lat_fused)
+
         with rb.parallel(nd if vae_par else 1) as par:
             for i in range(nd):
                 p = f"decoders.{i}"
@@ -2307,19 +2326,22 @@ class StepPlan:
                 if lat_fused:
                     o = 1 + nd + sum(dz_ns[:i])
                     ops.gemm_slabs(rb, ops.GEMM_NN, dzs[o:o + dz_ns[i]], dh, st.ep(p + ".hidden_layers.0.weight"), B, L)
+                if late and i < nd - 1:
+                    ev = torch.cuda.Event()
+                    rb.record_event(ev)                      # this decoder's share of dz is complete
+                    dz_evs.append(ev)
                 if not prep_first:
                     self._weight_grad(rb, p + ".FC_output.weight", logits[i], hd[i])
                     ops.colsum(rb, st.eg(p + ".FC_output.bias"), logits[i])
                 if heads_aside and i == 0:
                     bookkeeping(rb)
+                if late and i == nd - 1:
+                    for ev in dz_evs:
+                        rb.wait_event(ev)
+                    latent_chain()
         self._branch = 0
-        if lat_fused:
-            n_all = 1 + nd + sum(dz_ns)                  # heads, MMD terms, decoder 0's partial sums, decoder 1's, ...
-            if L % 4 == 0 and n_all >= 16:
-                ops.reduce_slabs_par(rb, dz_sum, dzs, None, n_all)
-            else:
-                ops.reduce_slabs(rb, dz_sum, dzs, None, n_all)
-        self._svae_bwd_latent(rb, enc, hs, mcat, vcat, dz, dhs, eps_used, n, nd, L, B, dz_complete=lat_fused)
+        if not late:
+            latent_chain()
 
     def _svae_heads(self, rec, z, dz):
         """The supervisor heads of a VAE plan: losses and, when training, their backward with dz's first share (the total needs the
