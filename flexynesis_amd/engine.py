@@ -42,6 +42,12 @@ CLIP_MAX_NORM = 1.0      # gradient_clip_val=1.0, reference main.py:216
 TRIPLET_MARGIN = 1.0
 
 
+def default_precision() -> str:
+    """Contraction mode of the wide layers for plans built without an explicit ``precision``: FX_PRECISION = bf16x3 (default: the parity
+    mode, split bf16 with three products), bf16 (the throughput mode: one product) or f32 (exact-fp32 MFMA)."""
+    return os.environ.get("FX_PRECISION", "bf16x3")
+
+
 def _align4(n: int) -> int:
     return (n + 3) // 4 * 4
 
@@ -933,7 +939,7 @@ class StepPlan:
     @ops.device_guard
     def __init__(self, store: ParamStore, B: int, train: bool = True, fused: bool = True, clip: bool = True,
                  supplied_draws: bool = False, seed: int = 0, cohort=None, n_batches: int = 0,
-                 epoch_acc: bool = False, precision: str = "bf16x3", branches: bool = True, share: "StepPlan" = None,
+                 epoch_acc: bool = False, precision: Optional[str] = None, branches: bool = True, share: "StepPlan" = None,
                  fuse_heads: bool = True, frozen: Tuple[str, ...] = (), fuse_next_fwd: bool = False,
                  attribution: bool = False, clip_norm: float = CLIP_MAX_NORM, forward_alone: bool = False):
         self.store, self.spec, self.B, self.train = store, store.spec, int(B), train
@@ -978,6 +984,8 @@ class StepPlan:
         self._gram_x: Dict[int, tuple] = {}
         self._jobs: Dict[str, tuple] = {}
         self._slot_o = 0
+        if precision is None:                   # the process-wide default: FX_PRECISION (f32 | bf16x3 | bf16), else the parity mode
+            precision = default_precision()
         if precision not in ("f32", "bf16x3", "bf16"):
             raise ValueError(f"precision must be 'f32', 'bf16x3' or 'bf16', got {precision!r}")
         # "bf16": the THROUGHPUT mode -- the wide kernels' contractions in plain bf16 (hi . hi, fp32 accumulate: torch's "medium"
@@ -2656,7 +2664,7 @@ class PipelinedStep:
     This is the DataLoader-prefetch of the reference's loop (main.py:289-298, num_workers) moved onto the GPU."""
 
     def __init__(self, store: ParamStore, B: int, *, cohort, n_batches: int, seed: int = 0,
-                 precision: str = "bf16x3", epoch_acc: bool = True, clip: bool = True, frozen: Tuple[str, ...] = (),
+                 precision: Optional[str] = None, epoch_acc: bool = True, clip: bool = True, frozen: Tuple[str, ...] = (),
                  fuse_next_fwd: Optional[bool] = None, supplied_draws: bool = False):
         if fuse_next_fwd is None:            # FX_FUSE_NEXT_FWD=0: A/B switch (separate forward kernel, 28 B/param/step)
             fuse_next_fwd = os.environ.get("FX_FUSE_NEXT_FWD", "1") != "0"

@@ -153,7 +153,8 @@ def _eval_loss(model, store, cohort, idx_rows: torch.Tensor, batch_size: int, pa
 def fit(model, dataset, train_idx: Sequence[int], val_idx: Optional[Sequence[int]] = None, *, batch_size: int,
         epochs: int, lr: float, patience: int = 0, seed: int = 0, use_graph: bool = True, device=None,
         verbose: bool = False, clip: bool = True, frozen: Sequence[str] = (), drop_last: bool = True,
-        fresh_optimizer: bool = False, supplied: Optional[dict] = None, prof: Optional[dict] = None) -> FitResult:
+        fresh_optimizer: bool = False, supplied: Optional[dict] = None, prof: Optional[dict] = None,
+        precision: Optional[str] = None) -> FitResult:
     """Train ``model`` on ``dataset[train_idx]`` and validate on ``dataset[val_idx]`` once per epoch.
     For MultiTripletNetwork the indices address the valid (non-NaN main label) anchors, like the reference's
     ``TripletMultiOmicDataset`` (data.py:1102-1104).
@@ -166,7 +167,8 @@ def fit(model, dataset, train_idx: Sequence[int], val_idx: Optional[Sequence[int
     {name: tensor}} replaces the device shuffle and the in-kernel Philox draws by recorded ones; optional "triplets":
     fn(epoch, batch) -> (positive rows, negative rows) replaces the device triplet sampler, "val_draws" / "val_triplets":
     fn(epoch, chunk) the same for the validation batches (epoch == number of epochs run addresses the final validation).
-    The schedule (pipelined batch assembly, hipGraph replay, fused kernels) is the production one."""
+    The schedule (pipelined batch assembly, hipGraph replay, fused kernels) is the production one.
+    ``precision``: None = the process default (FX_PRECISION, else "bf16x3", the parity mode); "bf16" = the plain-bf16 throughput mode."""
     if use_graph and ops.in_flight_thread():
         # a fit running beside others on this GPU (trials.run_units(in_flight > 1)) must not capture: a hipGraph capture is
         # process-wide on ROCm and the neighbours synchronise and launch all the time.  Same launches, issued eagerly.
@@ -179,7 +181,7 @@ def fit(model, dataset, train_idx: Sequence[int], val_idx: Optional[Sequence[int
     with torch.cuda.device(store.device):
         return _fit(model, store, dataset, train_idx, val_idx, batch_size=batch_size, epochs=epochs, lr=lr, patience=patience,
                     seed=seed, use_graph=use_graph, verbose=verbose, clip=clip, frozen=frozen, drop_last=drop_last,
-                    fresh_optimizer=fresh_optimizer, supplied=supplied, prof=prof)
+                    fresh_optimizer=fresh_optimizer, supplied=supplied, prof=prof, precision=precision)
 
 
 class _OwnedPlans(dict):
@@ -232,7 +234,7 @@ def _fit(model, store, dataset, train_idx, val_idx, **kw) -> FitResult:
 
 
 def _fit_impl(model, store, dataset, train_idx, val_idx, *, batch_size, epochs, lr, patience, seed, use_graph, verbose, clip, frozen,
-              drop_last, fresh_optimizer, supplied=None, prof=None, owned=None) -> FitResult:
+              drop_last, fresh_optimizer, supplied=None, prof=None, owned=None, precision=None) -> FitResult:
     dev = store.device
     ph = _Phases(prof, dev)
     if fresh_optimizer:
@@ -256,6 +258,8 @@ def _fit_impl(model, store, dataset, train_idx, val_idx, *, batch_size, epochs, 
         raise ValueError(f"batch_size {B} exceeds the training split ({tr.numel()} samples) with drop_last=True")
     frozen = tuple(frozen)
     plan_kw = dict(clip=bool(clip), frozen=frozen)
+    if precision is not None:           # "bf16": the plain-bf16 throughput mode (training plans; validation plans follow FX_PRECISION)
+        plan_kw["precision"] = precision
     if supplied is not None and (tail or (trip and "triplets" not in supplied)):
         raise ValueError("supplied permutations / draws cover full batches only (and the triplet network needs its triplets)")
     ph.lap("setup")
