@@ -350,16 +350,6 @@ class FxModel(_Base):
         self.__dict__["_fx_optimizer"] = opt
         return out
 
-    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
-        """``assign=True`` REPLACES the Parameter objects (torch >= 2.1): the engine's arenas, the cached parameter walk and the optimiser's
-        references would go on using the old ones (ADVICE r5) -- the binding is dropped and rebuilt lazily from the new parameters."""
-        out = super().load_state_dict(state_dict, strict=strict, assign=assign)
-        if assign:
-            opt = self.__dict__.get("_fx_optimizer")
-            self._reset_runtime()
-            self.__dict__["_fx_optimizer"] = opt
-        return out
-
     def _check_param_cache(self):
         """Parameters registered / replaced behind the model's back (register_parameter, ParameterDict edits, torch.__future__'s
         overwrite-on-conversion): the cached walk is compared with a fresh one whenever a plan is BUILT (not per step) and dropped,
@@ -724,7 +714,13 @@ class FxModel(_Base):
         return df_imp
 
     def load_state_dict(self, state_dict, strict=True, **kw):
+        """``assign=True`` REPLACES the Parameter objects (torch >= 2.1): the engine's arenas, the cached parameter walk and the optimiser's
+        references would go on using the old ones (ADVICE r5) -- the binding is dropped and rebuilt lazily from the new parameters."""
         out = super().load_state_dict(state_dict, strict=strict, **kw)
+        if kw.get("assign"):
+            opt = self.__dict__.get("_fx_optimizer")
+            self._reset_runtime()
+            self.__dict__["_fx_optimizer"] = opt
         if self._store is not None:
             for k, b in self.named_buffers():
                 if k.endswith("num_batches_tracked"):
