@@ -209,15 +209,27 @@ class FxGraph:
     def __init__(self):
         self._exec = None
         self.n_nodes = 0
+        self._streams = {}            # streams this graph has been launched on (cuda_stream -> torch stream)
 
     def replay(self):
-        rc = lib.fx_graph_launch(self._exec, _stream())
+        st = torch.cuda.current_stream()
+        rc = lib.fx_graph_launch(self._exec, st.cuda_stream)
         if rc != 0:
             raise FxError(f"fx_graph_launch failed (rc={rc}): {_lib.last_error()}")
+        self._streams[st.cuda_stream] = st
 
     def close(self):
+        """Destroy the executable graph.  hipGraphExecDestroy does not wait for launches of it that are still in flight (torch's
+        ~CUDAGraph synchronised the whole DEVICE for that reason -- the call that is illegal during another capture): the streams this
+        graph was launched on are waited for first -- stream synchronisations, legal beside a relaxed-mode capture on another stream."""
         x, self._exec = self._exec, None
         if x is not None:
+            try:
+                for st in self._streams.values():
+                    st.synchronize()
+            except Exception:
+                pass
+            self._streams = {}
             lib.fx_graph_destroy(x)
 
     def __del__(self):
