@@ -1836,11 +1836,21 @@ class StepPlan:
                     self._mlp_fwd(rf, f"encoders.{i}", self.X[i], ecat[:, i * L:(i + 1) * L], R, self.passes,
                                   [f"encoders.{i}{t}" for t in tags])
             self._branch = 0
+            # Stacked-rows plans (the triplet network): the next batch's assembly (PipelinedStep: three gathers + three X X^T products,
+            # ~0.4 ms of work) used to fork behind the whole forward tape and its tail ended AFTER the Gram norm's last Hadamard sum,
+            # i.e. on the critical path in front of the clip (profiles/r06_timeline_cfg4.txt: 1966 vs 1915 us).  It now depends on the
+            # join of the wide forwards and is issued behind the fusion layer -- 110 us earlier, still not beside a wide forward
+            # (FX_FORK_AFTER_WIDE=0: the old fork point).
+            early = self.train and os.environ.get("FX_FORK_AFTER_WIDE", "1" if self.passes > 1 else "0") == "1"
+            if early:
+                rf.mark("fork_assembly")
             if n > 1:
                 emb = self._new("emb", R, L)
                 self._small_fwd(rf, emb, ecat, "fusion_block.weight", "fusion_block.bias")
             else:
                 emb = ecat
+            if early:
+                rf.mark("fork_issue_1")
         self.embeddings = emb[:B]
         demb = self._new("demb", R, L)
         if trip:
