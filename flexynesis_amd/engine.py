@@ -1836,12 +1836,12 @@ class StepPlan:
                     self._mlp_fwd(rf, f"encoders.{i}", self.X[i], ecat[:, i * L:(i + 1) * L], R, self.passes,
                                   [f"encoders.{i}{t}" for t in tags])
             self._branch = 0
-            # Stacked-rows plans (the triplet network): the next batch's assembly (PipelinedStep: three gathers + three X X^T products,
-            # ~0.4 ms of work) used to fork behind the whole forward tape and its tail ended AFTER the Gram norm's last Hadamard sum,
-            # i.e. on the critical path in front of the clip (profiles/r06_timeline_cfg4.txt: 1966 vs 1915 us).  It now depends on the
-            # join of the wide forwards and is issued behind the fusion layer -- 110 us earlier, still not beside a wide forward
-            # (FX_FORK_AFTER_WIDE=0: the old fork point).
-            early = self.train and os.environ.get("FX_FORK_AFTER_WIDE", "1" if self.passes > 1 else "0") == "1"
+            # FX_FORK_AFTER_WIDE=1 (A/B, round 6; off): the next batch's assembly (PipelinedStep: for the triplet network three gathers +
+            # three X X^T products, ~0.4 ms of work) forks behind the wide forwards' join instead of behind the whole forward tape,
+            # 110 us earlier -- its tail used to end after the Gram norm's last Hadamard sum (profiles/r06_timeline_cfg4.txt: 1966 vs
+            # 1915 us).  Measured SLOWER: 5.31-5.35 vs 5.19-5.21 ms (bf16 mode 4.19 vs 4.11): beside the triplet / heads / fusion-backward
+            # launches the assembly slows the critical chain by more than its tail cost (profiles/r06_cfg4_fork.txt).
+            early = self.train and os.environ.get("FX_FORK_AFTER_WIDE", "0") == "1"
             if early:
                 rf.mark("fork_assembly")
             if n > 1:
