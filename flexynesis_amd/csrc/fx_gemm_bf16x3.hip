@@ -122,7 +122,12 @@ __global__ __launch_bounds__(128 * WN) void fx_gemm_bf16x3_kernel(XGemmArgs g) {
   constexpr int TN = 32 * WN, T = 128 * WN;
   constexpr int STAGE_ELEMS = 2 * TM * TK + 2 * TN * TK;
   constexpr bool A2 = (T == 256);  // two A chunks per array per thread (else one)
-  __shared__ __attribute__((aligned(16))) __bf16 smem[2 * STAGE_ELEMS];
+  // WN = 8 (128 x 256 tile, 1024 threads, one workgroup per CU: the activation tile is re-read from the L2 once per 32 KB of W instead of
+  // once per 16 KB): only the first 512 threads fetch A -- the others issue the same instructions with an out-of-range offset (no
+  // memory traffic: the descriptor's range check answers) and stash into a scratch slot of their own (no branch around a load or a
+  // store: see the note above the K loop)
+  constexpr bool AHALF = (T == 1024);
+  __shared__ __attribute__((aligned(16))) __bf16 smem[2 * STAGE_ELEMS + (AHALF ? 1024 : 0)];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid & 1, wc = wid >> 1;
   const int tiles_m = (g.M + TM - 1) / TM;
@@ -187,7 +192,11 @@ __global__ __launch_bounds__(128 * WN) void fx_gemm_bf16x3_kernel(XGemmArgs g) {
   const long a_ld = g.a_rp ? TK : g.lda;
   const unsigned a_off0 = (unsigned)(((long)(m0 + a_row0) * a_ld + 8 * a_c) * 2);
   const unsigned a_off1 = (unsigned)(((long)(m0 + a_row1) * a_ld + 8 * a_c) * 2);
+  const bool a_on = !AHALF || tid < 512;
+  const unsigned a_oob = a_on ? 0u : 0xFFFFFFF0u;
   const int a_lds0 = swz(a_row0, a_c), a_lds1 = swz(a_row1, a_c);
+  // (stash destinations relative to a stage's base; the idle half's slots lie behind both stages, 16 bytes per lane, hi and lo planes)
+  const int a_dump = 2 * STAGE_ELEMS + (tid & 63) * 8;
   unsigned b_off0, b_off1;
   int b_lds0, b_lds1;
   if (B_KN) {   // thread (n = tid & 127, kq = tid >> 7): W[k0 + 8 kq + j][n0 + n], j = 0..7  -> LDS chunk kq of row n
@@ -221,8 +230,8 @@ __global__ __launch_bounds__(128 * WN) void fx_gemm_bf16x3_kernel(XGemmArgs g) {
   {                                                                    \
     const unsigned ka = a_kb + (unsigned)(kt) * a_step;                \
     const unsigned kb = b_kb + (unsigned)(kt) * b_step;                \
-    P##_ah0 = bld128(rAh, a_off0 + ka);                                \
-    if (NP == 3) P##_al0 = bld128(rAl, a_off0 + ka);                   \
+    P##_ah0 = bld128(rAh, (a_off0 + ka) | a_oob);                      \
+    if (NP == 3) P##_al0 = bld128(rAl, (a_off0 + ka) | a_oob);         \
     if (A2) {                                                          \
       P##_ah1 = bld128(rAh, a_off1 + ka);                              \
       if (NP == 3) P##_al1 = bld128(rAl, a_off1 + ka);                 \
@@ -240,8 +249,8 @@ __global__ __launch_bounds__(128 * WN) void fx_gemm_bf16x3_kernel(XGemmArgs g) {
 #define STASH_STAGE(P, buf)                                            \
   {                                                                    \
     __bf16* base = smem + (buf) * STAGE_ELEMS;                         \
-    *reinterpret_cast<u32x4*>(base + a_lds0) = P##_ah0;                \
-    if (NP == 3) *reinterpret_cast<u32x4*>(base + TM * TK + a_lds0) = P##_al0;      \
+    *reinterpret_cast<u32x4*>(a_on ? base + a_lds0 : smem + a_dump) = P##_ah0;                \
+    if (NP == 3) *reinterpret_cast<u32x4*>(a_on ? base + TM * TK + a_lds0 : smem + a_dump + 512) = P##_al0;      \
     if (A2) {                                                          \
       *reinterpret_cast<u32x4*>(base + a_lds1) = P##_ah1;              \
       if (NP == 3) *reinterpret_cast<u32x4*>(base + TM * TK + a_lds1) = P##_al1;    \
@@ -1018,7 +1027,7 @@ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0;
 // Tuning knobs of the wide kernels.  They are ARGUMENTS of the *_ex entry points (0 = the shipped choice); the library
 // itself reads no environment variable and keeps no mutable state (include/fxhip.h).
 struct FwdTune { int splitk, wn, mt, nt; };      // forced split-K (0 auto) | 2 or 4 wave columns (0 -> 4) | 1 = no multi-M-tile kernel | non-temporal W loads
-static inline int fwd_wn(const FwdTune& t) { return t.wn == 2 ? 2 : 4; }
+static inline int fwd_wn(const FwdTune& t) { return t.wn == 2 ? 2 : (t.wn == 8 ? 8 : 4); }
 
 // split-K so that the grid fills the chip about once: 256 CUs x (3 workgroups of 256 threads | 2 of 512)
 // M > 128 takes fx_fwd_bf16x3_mt_kernel: MT M-tiles per workgroup, one workgroup (64 KB LDS, ~190 VGPRs) per CU
@@ -1038,7 +1047,7 @@ static int pick_splitk_x(int M, int N, int K, int wn, const FwdTune& t) {
   }
   const int tn = 32 * wn;
   const long tiles = (long)((M + TM - 1) / TM) * ((N + tn - 1) / tn);
-  const long slots = wn == 2 ? 768 : 512;
+  const long slots = wn == 2 ? 768 : (wn == 8 ? 256 : 512);
   if (tiles >= slots / 2 || K <= 8 * TK) return 1;
   int s = (int)(slots / tiles);
   const int maxs = (K + 8 * TK - 1) / (8 * TK);  // keep >= 8 K-steps per slice
@@ -1161,7 +1170,9 @@ static int fwd_bf16x3_impl(float* Y, const void* xhi, const void* xlo, const flo
   FX_REQUIRE(ldx >= M && ldx % 128 == 0 && aligned16(xhi) && aligned16(xlo),
              "fx_linear_fwd_bf16x3: X must be a K-blocked split with rows padded to a multiple of 128 (got %ld for M=%d)", ldx, M);
   FX_REQUIRE(!(plain && (tune.mt == 2 || tune.mt == 3)), "fx_linear_fwd_bf16x3: the A/B kernels (no_mt 2 / 3) need the lo operand");
-  const int wn = (kn || plain) ? 4 : fwd_wn(tune), tn = 32 * wn;
+  // wave_cols 8: the 128 x 256 tile (at most 128 rows, row-major W); plain bf16 otherwise always takes the 128 x 128 tile
+  const int wn_t = fwd_wn(tune);
+  const int wn = (wn_t == 8 && !kn && M <= TM) ? 8 : ((kn || plain) ? 4 : (wn_t == 8 ? 4 : wn_t)), tn = 32 * wn;
   const int s = pick_splitk_x(M, N, Kp, wn, tune);
   // W is addressed per N tile (or per K slice when stored [K, N]) through a rebased descriptor: only that block must
   // stay below 4 GiB, not the weight
@@ -1207,6 +1218,9 @@ static int fwd_bf16x3_impl(float* Y, const void* xhi, const void* xlo, const flo
     else if (plain) hipLaunchKernelGGL((fx_fwd_bf16x3_reg_kernel<1, 4, 0, 1>), dim3((unsigned)nblk), dim3(256), 0, stream, g);
     else if (nt) hipLaunchKernelGGL((fx_fwd_bf16x3_reg_kernel<1, 4, 2>), dim3((unsigned)nblk), dim3(256), 0, stream, g);
     else hipLaunchKernelGGL((fx_fwd_bf16x3_reg_kernel<1, 4, 0>), dim3((unsigned)nblk), dim3(256), 0, stream, g);
+  } else if (wn == 8) {
+    if (plain) hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<true, XEPI_STORE, 0, 8, false, 1>), dim3((unsigned)nblk), dim3(1024), 0, stream, g);
+    else hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<true, XEPI_STORE, 0, 8, false, 3>), dim3((unsigned)nblk), dim3(1024), 0, stream, g);
   } else if (kn) {
     if (plain) hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<true, XEPI_STORE, 0, 4, true, 1>), dim3((unsigned)nblk), dim3(512), 0, stream, g);
     else hipLaunchKernelGGL((fx_gemm_bf16x3_kernel<true, XEPI_STORE, 0, 4, true>), dim3((unsigned)nblk), dim3(512), 0, stream, g);

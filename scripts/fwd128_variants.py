@@ -8,7 +8,7 @@ sys.path.insert(0, ".")
 from flexynesis_amd import ops
 dev = torch.device("cuda:0")
 ws = ops.Workspace(dev)
-for (M, K, N) in ((128, 5000, 20000), (128, 20000, 5000), (64, 20000, 5000)):
+for (M, K, N) in ((128, 5000, 20000), (128, 20000, 5000), (100, 20000, 5000)):
     x = torch.randn(M, K, device=dev)
     W = torch.randn(N, K, device=dev) * 0.01
     b = torch.zeros(N, device=dev)
@@ -17,17 +17,17 @@ for (M, K, N) in ((128, 5000, 20000), (128, 20000, 5000), (64, 20000, 5000)):
     ops.split_bf16(ops.IMMEDIATE, sp[0], sp[1], x)
     ref = None
     for products in (3, 1):
-        for no_mt in (0, 4):
-            for splitk in (0, 1, 2, 4, 6):
+        for no_mt, wc in ((0, 0), (4, 0), (0, 8)):
+            for splitk in (0, 2, 3, 4, 6):
                 rec = ops.TapeRecorder(products=products)
                 need = max(splitk, 1) * M * N * 4 if splitk else int(ops.lib.fx_linear_fwd_bf16x3_workspace_bytes(M, N, K))
                 ws.reserve(max(need, 8 * M * N * 4))
                 rec.emit("fx_linear_fwd_bf16x3_ex", y.data_ptr(), sp[0].data_ptr(), ops._lo(rec, sp[1]), W.data_ptr(), b.data_ptr(), M, N, K,
-                         sp[0].shape[1], W.stride(0), y.stride(0), ws.buf.data_ptr(), ws.nbytes, splitk, 0, no_mt, 0)
+                         sp[0].shape[1], W.stride(0), y.stride(0), ws.buf.data_ptr(), ws.nbytes, splitk, wc, no_mt, 0)
                 try:
                     rec.run(); torch.cuda.synchronize()
                 except Exception as e:
-                    print(f"[{M} x {K}] -> {N} products {products} no_mt {no_mt} splitk {splitk}: {e}")
+                    print(f"[{M} x {K}] -> {N} products {products} no_mt {no_mt} wave_cols {wc} splitk {splitk}: {e}")
                     continue
                 if products == 3 and ref is None:
                     ref = y.clone()
@@ -40,5 +40,5 @@ for (M, K, N) in ((128, 5000, 20000), (128, 20000, 5000), (64, 20000, 5000)):
                     rec.run()
                 e1.record(); e1.synchronize()
                 us = e0.elapsed_time(e1) * 1e3 / 50
-                print(f"[{M} x {K}] -> {N}  products {products}  kernel {'reg-fragment' if no_mt == 4 else '128x128 tile '}  splitk {splitk or 'auto'}: "
+                print(f"[{M} x {K}] -> {N}  products {products}  kernel {'reg-fragment' if no_mt == 4 else ('128x256 tile ' if wc == 8 else '128x128 tile ')}  splitk {splitk or 'auto'}: "
                       f"{us:7.1f} us (incl. slab reduce)  W at {4.0 * N * K / us / 1e6:5.2f} TB/s   max dev vs bf16x3 {err:.1e}", flush=True)

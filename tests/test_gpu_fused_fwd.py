@@ -410,3 +410,35 @@ def test_partition_arena_gives_up_within_its_time_budget(monkeypatch):
     gc.collect()
     monkeypatch.delenv("FX_ARENA_BUDGET_S")
     PartitionArena.reset(dev)                                              # later tests build their arena afresh
+
+
+@pytest.mark.parametrize("M,K,N", [(128, 5000, 20000), (100, 4100, 1000), (37, 2080, 300)])
+def test_forward_tile_variants_compute_the_same_contraction(M, K, N):
+    """fx_linear_fwd_bf16x3_ex's kernel choices -- the 128 x 128 tile, the register-fragment kernel (no_mt 4) and round 6's 128 x 256
+    tile (wave_cols 8: the activation tile crosses L2 -> LDS once per 32 KB of W instead of once per 16 KB) -- against an fp64
+    contraction, in the parity mode and (hi operands only) in the plain-bf16 mode; equal split-K -> bit-identical sums."""
+    from flexynesis_amd import ops
+    dev = _dev()
+    g = torch.Generator(device=dev)
+    g.manual_seed(M + N)
+    x = torch.randn(M, K, generator=g, device=dev)
+    W = torch.randn(N, K, generator=g, device=dev) * 0.02
+    b = torch.randn(N, generator=g, device=dev)
+    sp = ops.new_split_kb(M, K, dev)
+    ops.split_bf16(ops.IMMEDIATE, sp[0], sp[1], x)
+    ws = ops.Workspace(dev)
+    ws.reserve(8 * M * N * 4)
+    for products, ref in ((3, x.double() @ W.double().t() + b.double()),
+                          (1, x.bfloat16().double() @ W.bfloat16().double().t() + b.double())):
+        outs = {}
+        for name, (wc, no_mt) in {"128x128": (0, 0), "128x256": (8, 0), "reg": (0, 4)}.items():
+            y = torch.full((M, N), float("nan"), device=dev)
+            rec = ops.TapeRecorder(products=products)
+            rec.emit("fx_linear_fwd_bf16x3_ex", y.data_ptr(), sp[0].data_ptr(), ops._lo(rec, sp[1]), W.data_ptr(), b.data_ptr(), M, N, K,
+                     sp[0].shape[1], W.stride(0), y.stride(0), ws.buf.data_ptr(), ws.nbytes, 2, wc, no_mt, 0)
+            rec.run()
+            torch.cuda.synchronize()
+            err = float((y.double() - ref).abs().max() / ref.abs().max())
+            assert err <= 2e-5, (products, name, err)
+            outs[name] = y
+        assert torch.equal(outs["128x128"], outs["128x256"]), products      # same K slices, same summation order within a slice
