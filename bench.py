@@ -58,7 +58,7 @@ def _spec_of(cfg):
     from flexynesis_amd.arch import ArchSpec
     return ArchSpec(cfg["model"], cfg["layers"], cfg.get("latent", 64), cfg.get("factor", 0.25), cfg.get("sup", 16), cfg["variables"],
                     cfg["surv"][0], cfg["surv"][1], True)
-PMC_FILE = "r04_pmc_traffic_cfg2.json"      # rocprofv3 --pmc passes of this command, this round, this kernel (scripts/profile_round.sh)
+PMC_FILE = "r06_pmc_traffic_cfg2.json"      # rocprofv3 --pmc passes of this command, this round, this kernel (scripts/profile_round.sh)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
