@@ -2204,8 +2204,16 @@ class StepPlan:
         # FX_VAE_HEADS_BRANCH=2 (round 6, A/B): the heads on a graph branch of their OWN next to the decoder branches -- the schedule that
         # made torch's CUDAGraph layer segfault in round 4; with the library's own capture (ops.FxGraph) it can be measured again
         heads_branch = bool(heads_aside and self.branches and os.environ.get("FX_VAE_HEADS_BRANCH", "1") == "2")
+        # FX_VAE_MMD_BRANCH (round 6; =0: A/B): every decoder's MMD term (prior draw, kernel rows, dz share: they need z only) on ONE graph
+        # branch of their own that starts with the decoder branches -- on a chip that is idle but for the decoders' narrow hidden layers --
+        # instead of inside the decoder branches, where a later decoder's term stood in front of its FC_output product (the product started
+        # 35 us after decoder 0's had ended: profiles/r06_timeline_cfg3.txt, 192 -> 222 us) and decoder 0's deferred term was the last
+        # launch of the forward tape (17 + 5 us in front of the first data-gradient product)
+        mmd_branch = bool(heads_aside and self.branches and not heads_branch and os.environ.get("FX_VAE_MMD_BRANCH", "1") != "0")
+        self.path["mmd_branch"] = mmd_branch
         deferred_mmd = []
-        with rf.parallel((nd + 1 if heads_branch else nd) if vae_par else 1) as par:      # one graph branch per decoder (+ the heads')
+        n_fbr = nd + (1 if (heads_branch or mmd_branch) else 0)
+        with rf.parallel(n_fbr if vae_par else 1) as par:      # one graph branch per decoder (+ the heads' or the MMD terms')
             for i in range(nd):
                 if vae_par:
                     self._enter_branch(par, i)
@@ -2233,7 +2241,9 @@ class StepPlan:
                 # front of it and the second product started 50 us late, profiles/r05_timeline_cfg3.txt), then its own MMD term under
                 # decoder 0's product; decoder 0's term goes to the END of the last branch, behind the reconstruction epilogue.
                 mmd_late = heads_aside and os.environ.get("FX_VAE_MMD_LATE", "1") != "0"
-                if heads_aside and i == 0:
+                if mmd_branch:
+                    deferred_mmd.append(mmd_term)
+                elif heads_aside and i == 0:
                     deferred_mmd.append(mmd_term)
                 elif not mmd_late:
                     mmd_term(rf)
@@ -2245,7 +2255,7 @@ class StepPlan:
                 if self.train and vae_par and i > 0 and os.environ.get("FX_VAE_PREP_X", "1") != "0":
                     # (beside decoder 0's FC_output product; decoder 0 itself heads the critical chain and prepares in the backward)
                     self._weight_grad_prep_x(rf, p + ".FC_output.weight", h)
-                if mmd_late and i > 0:
+                if mmd_late and i > 0 and not mmd_branch:
                     mmd_term(rf)
                 lg = self._new(p + "/logits", B, F)
                 logits.append(lg)
@@ -2271,7 +2281,7 @@ class StepPlan:
                     ops.recon_sigmoid(rf, rp, lg if self.train else None, self.xhat[i] if self.xhat else None, lg, self.Xt[dec[i]], lv_mmd,
                                       1.0 / nd)
                 rec_parts.append((rp, nblk))
-                if mmd_late and i == nd - 1:
+                if mmd_late and i == nd - 1 and not mmd_branch:
                     for term in deferred_mmd:
                         term(rf)
                 if heads_aside and i == 0 and not heads_branch:
@@ -2279,6 +2289,10 @@ class StepPlan:
             if heads_branch:
                 self._enter_branch(par, nd)
                 self._svae_heads(rf, z, dz)
+            if mmd_branch:
+                self._enter_branch(par, nd)
+                for term in deferred_mmd:
+                    term(rf)
         self._branch = 0
         if not heads_aside:
             self._svae_heads(rf, z, dz)

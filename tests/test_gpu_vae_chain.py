@@ -179,7 +179,7 @@ def test_mmd_rows_ex_matches_the_first_kernel(P, B, L):
     assert torch.equal(rs2, rs1)
 
 
-SWITCHES = ("FX_RECON_EPILOGUE", "FX_VAE_LATENT_FUSED", "FX_VAE_HEADS_BRANCH", "FX_VAE_FUSION_PAIR", "FX_VAE_PARTIAL_JOIN")
+SWITCHES = ("FX_RECON_EPILOGUE", "FX_VAE_LATENT_FUSED", "FX_VAE_HEADS_BRANCH", "FX_VAE_FUSION_PAIR", "FX_VAE_PARTIAL_JOIN", "FX_VAE_MMD_BRANCH")
 
 
 def _svae_steps(monkeypatch, off, model="supervised_vae", use_graph=False):
@@ -217,6 +217,18 @@ def _svae_steps(monkeypatch, off, model="supervised_vae", use_graph=False):
         plan.train_step(1e-3)
         losses.append((dict(plan.losses()), float(store.ctrl[5])))
     return names, losses, store.state_dict()
+
+
+@pytest.mark.parametrize("model", ["supervised_vae", "CrossModalPred"])
+def test_vae_mmd_branch_is_a_pure_schedule_change(monkeypatch, model):
+    """Round 6: the decoders' MMD terms on one graph branch of their own (FX_VAE_MMD_BRANCH) instead of inside the decoder branches: the same
+    launches on the same operands, each dz share in its own slab -- bit-identical steps."""
+    n1, l1, sd1 = _svae_steps(monkeypatch, (), model)
+    n0, l0, sd0 = _svae_steps(monkeypatch, ("FX_VAE_MMD_BRANCH",), model)
+    assert sorted(n1) == sorted(n0)
+    assert l1 == l0
+    for k in sd1:
+        assert torch.equal(sd1[k], sd0[k]), k
 
 
 @pytest.mark.parametrize("model", ["supervised_vae", "CrossModalPred"])
