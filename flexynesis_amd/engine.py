@@ -2204,12 +2204,13 @@ class StepPlan:
         # FX_VAE_HEADS_BRANCH=2 (round 6, A/B): the heads on a graph branch of their OWN next to the decoder branches -- the schedule that
         # made torch's CUDAGraph layer segfault in round 4; with the library's own capture (ops.FxGraph) it can be measured again
         heads_branch = bool(heads_aside and self.branches and os.environ.get("FX_VAE_HEADS_BRANCH", "1") == "2")
-        # FX_VAE_MMD_BRANCH (round 6; =0: A/B): every decoder's MMD term (prior draw, kernel rows, dz share: they need z only) on ONE graph
-        # branch of their own that starts with the decoder branches -- on a chip that is idle but for the decoders' narrow hidden layers --
-        # instead of inside the decoder branches, where a later decoder's term stood in front of its FC_output product (the product started
-        # 35 us after decoder 0's had ended: profiles/r06_timeline_cfg3.txt, 192 -> 222 us) and decoder 0's deferred term was the last
-        # launch of the forward tape (17 + 5 us in front of the first data-gradient product)
-        mmd_branch = bool(heads_aside and self.branches and not heads_branch and os.environ.get("FX_VAE_MMD_BRANCH", "1") != "0")
+        # FX_VAE_MMD_BRANCH=1 (round 6, A/B; off): every decoder's MMD term (prior draw, kernel rows, dz share: they need z only) on ONE
+        # graph branch of their own that starts with the decoder branches, instead of inside the decoder branches -- where a later
+        # decoder's term stands in front of its FC_output product (which starts 30 us after decoder 0's has ended:
+        # profiles/r06_timeline_cfg3.txt) and decoder 0's deferred term is the last launch of the forward tape.  Measured SLOWER: 2.500
+        # vs 2.470 ms (bf16 mode 2.395 vs 2.348; profiles/r06_mmd_branch.txt) -- like the heads branch, a further fork / join and two
+        # more narrow kernels beside decoder 0's product cost more than the gaps they close.
+        mmd_branch = bool(heads_aside and self.branches and not heads_branch and os.environ.get("FX_VAE_MMD_BRANCH", "0") == "1")
         self.path["mmd_branch"] = mmd_branch
         deferred_mmd = []
         n_fbr = nd + (1 if (heads_branch or mmd_branch) else 0)
