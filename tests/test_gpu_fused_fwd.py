@@ -441,4 +441,5 @@ def test_forward_tile_variants_compute_the_same_contraction(M, K, N):
             err = float((y.double() - ref).abs().max() / ref.abs().max())
             assert err <= 2e-5, (products, name, err)
             outs[name] = y
-        assert torch.equal(outs["128x128"], outs["128x256"]), products      # same K slices, same summation order within a slice
+        if M > 64:      # (at most 64 rows: "128x128" is served by the register-fragment kernel, whose 16 x 16 x 32 MFMAs sum in another order)
+            assert torch.equal(outs["128x128"], outs["128x256"]), products  # same K slices, same summation order within a slice
