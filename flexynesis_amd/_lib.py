@@ -37,6 +37,8 @@ PROTOTYPES = {
     "fx_gemm_splitk": (I, [I, I, I]),
     "fx_gemm_f32_slabs": (I, [I, P, P, P, I, I, I, L, L, P]),
     "fx_linear_fwd_bf16x3_splitk": (I, [I, I, I]),
+    "fx_linear_fwd_bf16x3_splitk_ex": (I, [I, I, I, I]),
+    "fx_linear_fwd_bf16x3_slabs_ex": (I, [P, L, P, P, P, I, I, I, L, L, I, P]),
     "fx_linear_fwd_bf16x3_slabs": (I, [P, L, P, P, P, I, I, I, L, L, P]),
     "fx_bn_act_fwd_slabs": (I, [P, P, P, I, L, P, P, P, P, P, P, P, P, I, I, L, L, I, I, I, F, U64, U64, P, P]),
     "fx_gram_hadamard_blocks": (I, [L]),

@@ -1149,6 +1149,21 @@ int fx_linear_fwd_bf16x3_slabs(float* slabs, long slabs_bytes, const void* xhi, 
   return fwd_bf16x3_impl(nullptr, xhi, xlo, W, nullptr, M, N, K, ldx, ldw, N, slabs, slabs_bytes, false, stream);
 }
 
+// ... with the output tile chosen by the caller: wave_cols 0 | 4 = 128 x 128, 8 = 128 x 256 (M <= 128: the activation tile crosses L2 -> LDS
+// once per 32 KB of W instead of once per 16 KB; same K slices and summation order, i.e. the same slabs bit for bit at equal split-K)
+int fx_linear_fwd_bf16x3_splitk_ex(int M, int N, int K, int wave_cols) {
+  FwdTune t{};
+  t.wn = wave_cols;
+  const int wn = (fwd_wn(t) == 8 && M <= TM) ? 8 : 4;
+  return pick_splitk_x(M, N, (K + TK - 1) / TK * TK, wn, t);
+}
+int fx_linear_fwd_bf16x3_slabs_ex(float* slabs, long slabs_bytes, const void* xhi, const void* xlo, const float* W, int M,
+                                  int N, int K, long ldx, long ldw, int wave_cols, hipStream_t stream) {
+  FwdTune t{};
+  t.wn = wave_cols;
+  return fwd_bf16x3_impl(nullptr, xhi, xlo, W, nullptr, M, N, K, ldx, ldw, N, slabs, slabs_bytes, false, stream, false, t);
+}
+
 // dX[M,N] = dY[M,K] . W[K,N]   (W = the layer's weight [out=K, in=N] as stored): the data gradient through a WIDE
 // layer (autograd's mm in Linear backward, e.g. the supervised_vae / CrossModalPred decoders' FC_output).  dY given
 // as a K-blocked split (fx_split_bf16 with rows_padded = lddy_rows).  Workspace: fx_linear_fwd_bf16x3_workspace_bytes.

@@ -886,17 +886,22 @@ def gemm_slabs(rec, layout, slabs, A, Bm, M, N):
     return s
 
 
-def linear_fwd_bf16x3_slabs(rec, slabs, xhi, xlo, W, M):
+def fwd_slabs_splitk(M: int, N: int, K: int, wave_cols: int = 0) -> int:
+    """Slabs linear_fwd_bf16x3_slabs writes for this shape and output tile (wave_cols 8 = the 128 x 256 tile)."""
+    return int(lib.fx_linear_fwd_bf16x3_splitk_ex(int(M), int(N), int(K), int(wave_cols)))
+
+
+def linear_fwd_bf16x3_slabs(rec, slabs, xhi, xlo, W, M, wave_cols: int = 0):
     """Wide forward contraction, partial sums left in ``slabs`` [splitk, M, N]; returns splitk."""
     _chk2d(W, "linear_fwd_bf16x3_slabs.W")
     N, K = W.shape
     M = int(M)
-    s = int(lib.fx_linear_fwd_bf16x3_splitk(M, N, K))
+    s = fwd_slabs_splitk(M, N, K, wave_cols)
     _chk_kb(xhi, xlo, M, K, "linear_fwd_bf16x3_slabs")
     if slabs.numel() < s * M * N:
         raise FxError("linear_fwd_bf16x3_slabs: bad buffer shapes")
-    rec.emit("fx_linear_fwd_bf16x3_slabs", slabs.data_ptr(), slabs.numel() * 4, xhi.data_ptr(), _lo(rec, xlo),
-             W.data_ptr(), M, N, K, xhi.shape[1], _ld(W))
+    rec.emit("fx_linear_fwd_bf16x3_slabs_ex", slabs.data_ptr(), slabs.numel() * 4, xhi.data_ptr(), _lo(rec, xlo),
+             W.data_ptr(), M, N, K, xhi.shape[1], _ld(W), int(wave_cols))
     return s
 
 

@@ -167,6 +167,11 @@ int fx_gemm_splitk(int M, int N, int K);
 int fx_gemm_f32_slabs(int layout, float* slabs, const float* A, const float* B, int M, int N, int K, long lda, long ldb,
                       fx_stream_t stream);
 int fx_linear_fwd_bf16x3_splitk(int M, int N, int K);
+/* the slab-producing forward with the output tile chosen by the caller: wave_cols 0 | 4 = 128 x 128, 8 = 128 x 256 (at most 128 rows);
+ * fx_linear_fwd_bf16x3_splitk_ex gives the number of slabs that choice writes */
+int fx_linear_fwd_bf16x3_splitk_ex(int M, int N, int K, int wave_cols);
+int fx_linear_fwd_bf16x3_slabs_ex(float* slabs, long slabs_bytes, const void* xhi, const void* xlo, const float* W, int M, int N,
+                                  int K, long ldx, long ldw, int wave_cols, fx_stream_t stream);
 int fx_linear_fwd_bf16x3_slabs(float* slabs, long slabs_bytes, const void* xhi, const void* xlo, const float* W, int M,
                                int N, int K, long ldx, long ldw, fx_stream_t stream);
 int fx_bn_act_fwd_slabs(float* out, float* x_out, const float* slabs, int nslabs, long slab_stride, const float* lin_bias,
