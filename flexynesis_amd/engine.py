@@ -1305,9 +1305,10 @@ class StepPlan:
                 rec.wait_event(self._last_wide_ev)
             if raw_slabs or (want_slabs and os.environ.get("FX_BN_SLABS_UNFUSED", "0") == "1"):      # (BN: no gain with the stand-alone forward)
                 M, N = y.shape
-                # FX_FWD_TILE256 (round 6): a tall weight behind at most 128 rows (the VAE decoders' FC_output) takes the 128 x 256 output
-                # tile -- half the activation re-reads from the L2 per byte of W; bit-identical slabs (profiles/r06_fwd128_variants.txt)
-                wc = 8 if (M <= 128 and N >= 4096 and os.environ.get("FX_FWD_TILE256", "1") != "0") else 0
+                # FX_FWD_TILE256=1 (round 6, A/B; off): a tall weight behind at most 128 rows (the VAE decoders' FC_output) on the 128 x 256
+                # output tile -- half the activation re-reads from the L2 per byte of W, bit-identical slabs; 3-9 % faster stand-alone
+                # (profiles/r06_fwd128_variants.txt), nothing inside the cfg3 step (2.511 vs 2.505 ms: profiles/r06_tile256.txt)
+                wc = 8 if (M <= 128 and N >= 4096 and os.environ.get("FX_FWD_TILE256", "0") == "1") else 0
                 ns = ops.fwd_slabs_splitk(M, N, x.shape[1], wc)
                 sbuf = self._new(f"slabs/{wkey}", ns, M * N)
                 ops.linear_fwd_bf16x3_slabs(rec, sbuf, sp[0], sp[1], st.ep(wkey), M, wave_cols=wc)
