@@ -56,6 +56,16 @@ __device__ unsigned long long ft_stamp[1024 * 8];      // [workgroup][k]: wall c
 #define FT_STAMP(it)
 #endif
 
+// -DFT_ABL=n (scripts/build_variant.py, never the shipped library; RESULTS ARE WRONG): energy / time ablations of the two GEMM phases --
+// 3: no MFMAs (the fragment reads go with them; the operand LDS-DMA stays), 5: no operand LDS-DMA (MFMAs + fragment reads on stale LDS),
+// 4: neither (transposes + Adam stream only), 6: MFMAs without their `lo` fragment reads (ah / bh used for all three products).
+// scripts/fused_energy_ablation.py, profiles/r06_fused_energy_ablation.txt
+#ifndef FT_ABL
+#define FT_ABL 0
+#endif
+#define FT_DMA_ON (FT_ABL != 5 && FT_ABL != 4)
+#define FT_MFMA_ON (FT_ABL != 3 && FT_ABL != 4)
+
 struct DwAdamFwdArgs {
   float* W; float* m; float* v;
   float* Wd; float* md; float* vd;          // where the updated W / m / v go: == W / m / v (in place) or twins in another memory partition (out of place)
@@ -235,10 +245,11 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
   {                                                                                                       \
     __bf16* sb = smem + (stage) * 12288;                                                                  \
     const unsigned ko = (unsigned)(kt) * (FT_K * 2u);                                                     \
+    if (!FT_DMA_ON) {} else                                                                               \
     if (w < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rAh, LDS_PTR(sb + (w & 3) * 512), 16, a_src + ko, 0, 0, 0);        \
     else if (NP == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rAl, LDS_PTR(sb + 2048 + (w & 3) * 512), 16, a_src + ko, 0, 0, 0);       \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rBh, LDS_PTR(sb + 4096 + w * 512), 16, b_src + ko, 0, 0, 0);                  \
-    if (NP == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rBl, LDS_PTR(sb + 8192 + w * 512), 16, b_src + ko, 0, 0, 0);     \
+    if (FT_DMA_ON) __builtin_amdgcn_raw_ptr_buffer_load_lds(rBh, LDS_PTR(sb + 4096 + w * 512), 16, b_src + ko, 0, 0, 0);   \
+    if (NP == 3 && FT_DMA_ON) __builtin_amdgcn_raw_ptr_buffer_load_lds(rBl, LDS_PTR(sb + 8192 + w * 512), 16, b_src + ko, 0, 0, 0);     \
   }
     FT_TICK(0);
     FT_GLDS_K(0, 0);
@@ -250,11 +261,12 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
       const __bf16* sb = smem + (kt & 1) * 12288;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
+        if (!FT_MFMA_ON) continue;
         const bf16x8 ah = *reinterpret_cast<const bf16x8*>(sb + ft_swz(fa_d, 2 * ks + kh));
         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(sb + 4096 + ft_swz(fb_d, 2 * ks + kh));
         if (NP == 3) {
-          const bf16x8 al = *reinterpret_cast<const bf16x8*>(sb + 2048 + ft_swz(fa_d, 2 * ks + kh));
-          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(sb + 8192 + ft_swz(fb_d, 2 * ks + kh));
+          const bf16x8 al = FT_ABL == 6 ? ah : *reinterpret_cast<const bf16x8*>(sb + 2048 + ft_swz(fa_d, 2 * ks + kh));
+          const bf16x8 bl = FT_ABL == 6 ? bh : *reinterpret_cast<const bf16x8*>(sb + 8192 + ft_swz(fb_d, 2 * ks + kh));
           acc = FT_MFMA(al, bh, acc);
           acc = FT_MFMA(ah, bl, acc);
         }
@@ -327,8 +339,8 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
   {                                                                                                       \
     __bf16* xb = smem + (stage) * 8192;                                                                   \
     const unsigned xo = (unsigned)(n0 / FT_K + ((q) & 3)) * (128u * MT * FT_K * 2u) + (unsigned)((q) >> 2) * (128u * FT_K * 2u) + x_src; \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rXh, LDS_PTR(xb + w * 512), 16, xo, 0, 0, 0);                \
-    if (NP == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rXl, LDS_PTR(xb + 4096 + w * 512), 16, xo, 0, 0, 0);         \
+    if (FT_DMA_ON) __builtin_amdgcn_raw_ptr_buffer_load_lds(rXh, LDS_PTR(xb + w * 512), 16, xo, 0, 0, 0); \
+    if (NP == 3 && FT_DMA_ON) __builtin_amdgcn_raw_ptr_buffer_load_lds(rXl, LDS_PTR(xb + 4096 + w * 512), 16, xo, 0, 0, 0);         \
   }
     FT_GLDS_X(0, 0);
 #pragma unroll
@@ -343,11 +355,12 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
       const __bf16* wl = smem + 24576 + kb * 2048;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
+        if (!FT_MFMA_ON) continue;
         const bf16x8 ah = *reinterpret_cast<const bf16x8*>(xb + ft_swz(fa_f, 2 * ks + kh));
         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wh + ft_swz(fb_f, 2 * ks + kh));
         if (NP == 3) {
-          const bf16x8 al = *reinterpret_cast<const bf16x8*>(xb + 4096 + ft_swz(fa_f, 2 * ks + kh));
-          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wl + ft_swz(fb_f, 2 * ks + kh));
+          const bf16x8 al = FT_ABL == 6 ? ah : *reinterpret_cast<const bf16x8*>(xb + 4096 + ft_swz(fa_f, 2 * ks + kh));
+          const bf16x8 bl = FT_ABL == 6 ? bh : *reinterpret_cast<const bf16x8*>(wl + ft_swz(fb_f, 2 * ks + kh));
           yacc[m] = FT_MFMA(al, bh, yacc[m]);
           yacc[m] = FT_MFMA(ah, bl, yacc[m]);
         }
