@@ -58,7 +58,8 @@ __device__ unsigned long long ft_stamp[1024 * 8];      // [workgroup][k]: wall c
 
 // -DFT_ABL=n (scripts/build_variant.py, never the shipped library; RESULTS ARE WRONG): energy / time ablations of the two GEMM phases --
 // 3: no MFMAs (the fragment reads go with them; the operand LDS-DMA stays), 5: no operand LDS-DMA (MFMAs + fragment reads on stale LDS),
-// 4: neither (transposes + Adam stream only), 6: MFMAs without their `lo` fragment reads (ah / bh used for all three products).
+// 4: neither (transposes + Adam stream only), 6: MFMAs without their `lo` fragment reads (ah / bh used for all three products),
+// 7: the three products in an order in which consecutive MFMAs share an operand (al bh, ah bh, ah bl) -- correct results, another summation order.
 // scripts/fused_energy_ablation.py, profiles/r06_fused_energy_ablation.txt
 #ifndef FT_ABL
 #define FT_ABL 0
@@ -268,6 +269,7 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
           const bf16x8 al = FT_ABL == 6 ? ah : *reinterpret_cast<const bf16x8*>(sb + 2048 + ft_swz(fa_d, 2 * ks + kh));
           const bf16x8 bl = FT_ABL == 6 ? bh : *reinterpret_cast<const bf16x8*>(sb + 8192 + ft_swz(fb_d, 2 * ks + kh));
           acc = FT_MFMA(al, bh, acc);
+          if (FT_ABL == 7) { acc = FT_MFMA(ah, bh, acc); acc = FT_MFMA(ah, bl, acc); continue; }   // operand-sharing order (experiment)
           acc = FT_MFMA(ah, bl, acc);
         }
         acc = FT_MFMA(ah, bh, acc);
@@ -362,6 +364,7 @@ __global__ __launch_bounds__(FT_T, 2) void fx_dw_adam_fwd_kernel(DwAdamFwdArgs g
           const bf16x8 al = FT_ABL == 6 ? ah : *reinterpret_cast<const bf16x8*>(xb + 4096 + ft_swz(fa_f, 2 * ks + kh));
           const bf16x8 bl = FT_ABL == 6 ? bh : *reinterpret_cast<const bf16x8*>(wl + ft_swz(fb_f, 2 * ks + kh));
           yacc[m] = FT_MFMA(al, bh, yacc[m]);
+          if (FT_ABL == 7) { yacc[m] = FT_MFMA(ah, bh, yacc[m]); yacc[m] = FT_MFMA(ah, bl, yacc[m]); continue; }
           yacc[m] = FT_MFMA(ah, bl, yacc[m]);
         }
         yacc[m] = FT_MFMA(ah, bh, yacc[m]);

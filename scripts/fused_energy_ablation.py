@@ -58,6 +58,8 @@ print(us, sum(ws) / max(len(ws), 1), samples[4][1] if len(samples) > 4 else "?")
 rows = []
 for name, lib, products, what in (("shipped", None, 3, "everything (parity mode: three products)"),
                                   ("abl6", "abl6", 3, "MFMAs without the `lo` fragment reads"),
+                                  ("abl7", "abl7", 3, "products ordered so that consecutive MFMAs share an operand (correct results)"),
+                                  ("shipped", None, 3, "everything, again"),
                                   ("abl3", "abl3", 3, "no MFMAs / fragment reads; operand LDS-DMA stays"),
                                   ("abl5", "abl5", 3, "no operand LDS-DMA; MFMAs + fragment reads on stale LDS"),
                                   ("abl4", "abl4", 3, "no GEMM work: LDS transposes + W / m / v stream"),
