@@ -216,6 +216,14 @@ def gnn_conv_keys(prefix: str, conv: str):
         return prefix + ".lin_l.weight", prefix + ".lin_l.bias", prefix + ".lin_r.weight"
     if conv == "GCN":
         return prefix + ".lin.weight", prefix + ".bias", None
+    if conv == "GAT":
+        # The reference lists GATConv in flexGCN's table (modules.py:221-226) but cannot run it: flexGCN.forward feeds every conv the
+        # batched node features [B, nodes, C] with one shared edge_index (modules.py:251-262, a "static graph" in torch_geometric's
+        # terms), which GraphConv / SAGEConv / GCNConv broadcast over and GATConv refuses (its forward asserts ``x.dim() == 2``:
+        # "Static graphs not supported in 'GATConv'"); accordingly the CLI does not offer it (__main__.py:536-540).  There is no
+        # reference behaviour to reproduce, so the engine refuses at construction instead of at the first forward.
+        raise ValueError("gnn_conv_type 'GAT': torch_geometric's GATConv does not accept the batched [B, nodes, C] node features that "
+                         f"the reference's flexGCN feeds its convolutions (static graphs unsupported). Choose one of: {list(GNN_CONVS)}")
     raise ValueError(f"Unknown convolution type {conv!r}. Choose one of: {list(GNN_CONVS)}")
 
 

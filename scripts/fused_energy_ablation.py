@@ -64,6 +64,9 @@ for name, lib, products, what in (("shipped", None, 3, "everything (parity mode:
                                   ("abl5", "abl5", 3, "no operand LDS-DMA; MFMAs + fragment reads on stale LDS"),
                                   ("abl4", "abl4", 3, "no GEMM work: LDS transposes + W / m / v stream"),
                                   ("plain", None, 1, "plain-bf16 mode (one product), shipped build")):
+    only = os.environ.get("ABL_ONLY")            # e.g. ABL_ONLY=shipped,abl7: just these rows (in the table's order)
+    if only and name not in only.split(","):
+        continue
     env = dict(os.environ)
     if lib:
         env["FXHIP_LIB"] = os.path.join(ROOT, "build_tmp", f"libfxhip_{lib}.so")

@@ -272,6 +272,18 @@ def test_kfold_indices_are_a_partition_with_sklearn_fold_sizes():
     assert kfold_indices(23, 5, seed=3) == folds and kfold_indices(23, 5, seed=4) != folds
 
 
+def test_gat_is_refused_at_construction_with_the_reason():
+    """flexGCN's table lists GATConv (reference modules.py:221-226) but its forward hands every conv the batched
+    [B, nodes, C] tensor (modules.py:251-262), which torch_geometric's GATConv rejects ("Static graphs not supported"), and the
+    CLI offers GC / GCN / SAGE only (__main__.py:536-540): the engine refuses the choice up front and says why."""
+    from flexynesis_amd.arch import GNN_CONVS, gnn_conv_keys
+    assert GNN_CONVS == ("GC", "SAGE", "GCN")
+    with pytest.raises(ValueError, match="GATConv does not accept the batched"):
+        gnn_conv_keys("encoders.0.convs.0", "GAT")
+    with pytest.raises(ValueError, match="Unknown convolution type"):
+        gnn_conv_keys("encoders.0.convs.0", "GIN")
+
+
 @pytest.mark.parametrize("conv", ["GC", "SAGE", "GCN"])
 def test_graph_operator_matches_oracle_edge_weights(conv):
     """flexynesis_amd/graph.py (host side of the GNN path) against the oracle's restatement of the torch_geometric
