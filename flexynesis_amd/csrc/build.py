@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["fx_gemm.hip", "fx_gemm_bf16x3.hip", "fx_dw_adam_fwd.hip", "fx_norm_act.hip", "fx_fused_small.hip", "fx_heads.hip", "fx_small_linear.hip", "fx_enc_tail.hip", "fx_assembly.hip",
            "fx_block_bwd.hip", "fx_losses.hip", "fx_optim.hip", "fx_ingest.hip", "fx_gnn.hip", "fx_sampling.hip", "fx_runtime.hip"]
-HEADERS = ["fx_common.h", "fx_reduce.h", "fx_small.h", "fx_loss_dev.h"]
+HEADERS = ["fx_common.h", "fx_reduce.h", "fx_small.h", "fx_loss_dev.h", "fx_chain_prof.h"]
 # packed fp32 VALU ops are off: a v_pk_fma_f32 whose low source register was written by the preceding VALU instructions drops
 # that term in lanes 48..63 when another wave on the SIMD streams ds_read_b128 results into back-to-back MFMAs (measured:
 # scripts/pkfma_hazard_probe.hip) -- i.e. whenever a small fp32 kernel shares a CU with one of the

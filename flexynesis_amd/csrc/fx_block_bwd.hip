@@ -19,6 +19,7 @@
 // (v_mfma_f32_16x16x4_f32, one 16 x 16 block family per wave): 50 -> 27 us at cfg2 for two modalities, same arithmetic
 // error against fp64 (1.6e-7 rms, scripts/block_bwd_error.py).
 #include "fx_common.h"
+#include "fx_chain_prof.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -168,6 +169,8 @@ __device__ __forceinline__ void bb_body(const BlockBwdArgs& a, int blk) {
   const int cc = min(c, a.C - 1);                    // clamped column: loads are unconditional, stores predicated
   const bool cok = c < a.C;
   const int r0 = ry * BB_RPT;
+  const int cpw = blockIdx.y * gridDim.x + blockIdx.x;
+  CP_TICK(cpw, 0);
   // ---- this thread's 16 rows of x and of the block output
   float xv[BB_RPT], ov[BB_RPT];
 #pragma unroll
@@ -183,10 +186,12 @@ __device__ __forceinline__ void bb_body(const BlockBwdArgs& a, int blk) {
     ov[i] = (rok && cok) ? ov[i] : 0.f;
     T[cx][r0 + i] = ov[i];
   }
+  CP_TICK(cpw, 1);
   // ---- da = sum_k dE_k . W_k (this thread: 16 rows x its column), and the small Linears' weight/bias gradients
   f32x4 dacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   bb_upstream(a.dE[0], a.ldE[0], a.W[0], a.gW[0], a.gb[0], a.L[0], B, a.C, c0, cc, dEs, T, Wt, dacc, a.accumulate, blk);
   if (a.n_up > 1) bb_upstream(a.dE[1], a.ldE[1], a.W[1], a.gW[1], a.gb[1], a.L[1], B, a.C, c0, cc, dEs, T, Wt, dacc, a.accumulate, blk);
+  CP_TICK(cpw, 2);
   // da from the MFMA result layout to this thread's (column cx, rows r0 ..) through the dE stage (dead now)
   float da[BB_RPT];
   {
@@ -200,6 +205,7 @@ __device__ __forceinline__ void bb_body(const BlockBwdArgs& a, int blk) {
 #pragma unroll
     for (int i = 0; i < BB_RPT; ++i) da[i] = dEs[(r0 + i) * 33 + cx];
   }
+  CP_TICK(cpw, 3);
   // ---- gate (ReLU + dropout in one test on the saved output) and BatchNorm backward (fx_bn_bwd_kernel's expressions)
   const float gate_scale = 1.0f / (1.0f - a.drop_p);
   float s1 = 0.f, s2 = 0.f;
@@ -231,6 +237,20 @@ __device__ __forceinline__ void bb_body(const BlockBwdArgs& a, int blk) {
     sb += d;
   }
   const float sum_dx = bb_colsum(sb, red, cx, ry);     // (its barriers also order the last reads of T above)
+  CP_TICK(cpw, 4);
+  // ---- the X X^T entries the norm share multiplies (rows 16 w + 4 kq + i, columns 16 bj + l15 of this lane's result blocks) are
+  // REQUESTED here, in front of every store of the epilogue: read inside the product loop they were eight dependent L2 round trips
+  // (8.5 of the launch's ~20 us, scripts/chain_profile.py); clamped addresses, the predicates stay on the use
+  // (in two halves of 16 registers: all 32 at once cost the second workgroup of a CU its registers)
+  float gxv[8][4];
+#define BB_GRAM_REQ(b0)                                                                                                      \
+  {                                                                                                                          \
+    const int lane_ = t & 63, w_ = t >> 6, l15_ = lane_ & 15, kq_ = lane_ >> 4;                                              \
+    _Pragma("unroll") for (int bj = (b0); bj < (b0) + 4; ++bj)                                                               \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                          \
+        gxv[bj][i] = a.gram_x[(long)min(16 * w_ + 4 * kq_ + i, B - 1) * B + min(16 * bj + l15_, B - 1)];                     \
+  }
+  if (a.gram_x) BB_GRAM_REQ(0)
   if (cok && ry == 0) {
     a.dgamma[c] = a.accumulate ? a.dgamma[c] + sum_dy_xh : sum_dy_xh;
     a.dbeta[c] = a.accumulate ? a.dbeta[c] + sum_dy : sum_dy;
@@ -245,6 +265,7 @@ __device__ __forceinline__ void bb_body(const BlockBwdArgs& a, int blk) {
 #pragma unroll
   for (int i = 0; i < BB_RPT; ++i) T[cx][r0 + i] = da[i];
   __syncthreads();
+  CP_TICK(cpw, 5);
   if (a.dyT_hi) {      // thread: column t >> 4, rows (t & 15) * 8 .. +8  -> one 16-byte store per array
     const int col = t >> 4, rb = (t & 15) * 8;
     if (c0 + col < a.C && rb < ((B + 31) & ~31)) {       // rows B .. round32(B) - 1 are written as zeros; nothing beyond (a pass of stacked rows owns only its columns)
@@ -259,6 +280,7 @@ __device__ __forceinline__ void bb_body(const BlockBwdArgs& a, int blk) {
       *reinterpret_cast<bf16x8*>(a.dyT_lo + (long)(c0 + col) * a.ldt + rb) = lo;
     }
   }
+  CP_TICK(cpw, 6);
   if (a.gram_x) {      // <dY_blk dY_blk^T, X X^T>: wave w owns rows 16 w .. 16 w + 15 of the B x B product (8 blocks of 16 x 16)
     const int lane = t & 63, w = t >> 6, l15 = lane & 15, kq = lane >> 4;
     f32x4 av[BB_COLS / 16];
@@ -267,7 +289,8 @@ __device__ __forceinline__ void bb_body(const BlockBwdArgs& a, int blk) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) av[q][e] = T[16 * q + 4 * kq + e][16 * w + l15];
     double acc = 0.0;
-#pragma unroll 2
+    BB_GRAM_REQ(4)
+#pragma unroll
     for (int bj = 0; bj < 8; ++bj) {
       f32x4 p = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -283,7 +306,7 @@ __device__ __forceinline__ void bb_body(const BlockBwdArgs& a, int blk) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int ii = 16 * w + 4 * kq + i;
-          if (ii < B) acc += (double)p[i] * (double)a.gram_x[(long)ii * B + j];
+          if (ii < B) acc += (double)p[i] * (double)gxv[bj][i];
         }
       }
     }
@@ -297,9 +320,10 @@ __device__ __forceinline__ void bb_body(const BlockBwdArgs& a, int blk) {
       a.slots[blk] = tot;
     }
   }
+  CP_TICK(cpw, 7);
 }
 
-__global__ __launch_bounds__(BB_T) void fx_block_bwd_kernel(BlockBwdArgs a) { bb_body(a, blockIdx.x); }
+__global__ __launch_bounds__(BB_T, 4) void fx_block_bwd_kernel(BlockBwdArgs a) { bb_body(a, blockIdx.x); }
 
 // Several encoder tails (one per modality) in one launch: grid (column blocks of the widest, modalities).  The modalities'
 // backward chains are independent until the optimiser; as two launches on two hipGraph branches they paid a fork and a join
@@ -308,7 +332,7 @@ __global__ __launch_bounds__(BB_T) void fx_block_bwd_kernel(BlockBwdArgs a) { bb
 struct BlockBwdGroup {
   BlockBwdArgs a[BB_MAX_GROUP];
 };
-__global__ __launch_bounds__(BB_T) void fx_block_bwd_group_kernel(BlockBwdGroup g) {
+__global__ __launch_bounds__(BB_T, 4) void fx_block_bwd_group_kernel(BlockBwdGroup g) {
   const int blk = blockIdx.x;
   // (a runtime index into the kernel-argument array would put the argument blocks in scratch: one call per constant index)
   switch (blockIdx.y) {
@@ -323,11 +347,13 @@ __global__ __launch_bounds__(BB_T) void fx_block_bwd_group_kernel(BlockBwdGroup 
 struct BlockBwdGroup2 {
   BlockBwdArgs a[2];
 };
-__global__ __launch_bounds__(BB_T) void fx_block_bwd_group2_kernel(BlockBwdGroup2 g) {
+__global__ __launch_bounds__(BB_T, 4) void fx_block_bwd_group2_kernel(BlockBwdGroup2 g) {
   const int blk = blockIdx.x;
   if (blockIdx.y == 0) { if (blk * BB_COLS < g.a[0].C) bb_body(g.a[0], blk); }
   else { if (blk * BB_COLS < g.a[1].C) bb_body(g.a[1], blk); }
 }
+
+CP_READER(fx_debug_chain_stamps_bb)
 
 extern "C" {
 

@@ -13,7 +13,7 @@
 //                     rows: ordered slab sum + bias -> x (saved for the backward), two-pass batch statistics, affine,
 //                     activation, dropout (Philox: one counter block per 4 consecutive columns, the stream of
 //                     fx_bn_act_fwd) -> out (saved), and the block's share of every following small Linear:
-//                     part_k[blk][r, l] = sum_{c in block} out[r, c] W_k[l, c]  (plain fp32 FMA from LDS tiles).
+//                     part_k[blk][r, l] = sum_{c in block} out[r, c] W_k[l, c]  (exact-fp32 matrix pipe, operands from LDS).
 //   fx_fusion_fwd     grid (row blocks).  One workgroup owns 4 rows: ecat[r, :] = for every modality the ordered sum of
 //                     its column blocks' partial products + layer_out bias (four threads share the slab range of an
 //                     output and combine in a fixed order), then emb[r, :] = ecat[r, :] W_f^T + b_f from an LDS copy of
@@ -21,6 +21,7 @@
 //
 // Deterministic: fixed summation orders, no atomics.
 #include "fx_common.h"
+#include "fx_chain_prof.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -60,8 +61,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t et_rsrc(const void* p, long by
 __device__ __forceinline__ f32x4 et_ld4(__amdgpu_buffer_rsrc_t r, unsigned off) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
 }
+#ifndef ET_ST_AUX
+#define ET_ST_AUX 0          // cache policy bits of the x / out / partial-product stores (A/B: 16 = sc1 write-through)
+#endif
 __device__ __forceinline__ void et_st4(f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned off) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, ET_ST_AUX);
 }
 
 // Sum over the 32 row groups of a column: lanes of a wave hold (cq = lane & 15, row group bits 0-1 = lane >> 4), the 8 waves
@@ -85,13 +89,16 @@ __device__ __forceinline__ f32x4 et_colsum(f32x4 v, float (*red)[ET_COLS + 4], i
 }
 
 __device__ __forceinline__ void et_body(const EncTailDesc& d, const EncTailArgs& a, int blk) {
-  // LDS: As [32][132] one 32-column half of the block output, k-major (column, row); Ws [32][132] the matching 32 columns
-  // of a following Linear's weight, k-major (column, output)
-  __shared__ __attribute__((aligned(16))) float As[32][ET_MAXB + 4];
-  __shared__ __attribute__((aligned(16))) float Ws[32][ET_MAXL + 4];
+  // LDS: As [128][68] the block output, row-major (row, column of the block); Ws [128][68] a following Linear's weight columns of the
+  // block, row-major (output, column): the operand fragments of the fp32 MFMA are 16-byte reads along a row (stride 68: two-way
+  // bank conflicts at worst)
+  __shared__ __attribute__((aligned(16))) float As[ET_MAXB][ET_COLS + 4];
+  __shared__ __attribute__((aligned(16))) float Ws[ET_MAXL][ET_COLS + 4];
   __shared__ __attribute__((aligned(16))) float red[ET_T / 64][ET_COLS + 4];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int cq = t & 15, rg = t >> 4;                 // columns 4 cq .. 4 cq + 3 of the block, rows rg + 32 i
+  const int cpw = blockIdx.y * gridDim.x + blockIdx.x;
+  CP_TICK(cpw, 0);
   const int B = a.B, H = d.H;
   const int c = blk * ET_COLS + 4 * cq;               // H % 4 == 0: a unit of 4 columns is inside or outside as a whole
   const unsigned cmask = (c < H) ? 0u : ET_OOB;
@@ -102,36 +109,59 @@ __device__ __forceinline__ void et_body(const EncTailDesc& d, const EncTailArgs&
   unsigned off[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) off[i] = (unsigned)(((long)(rg + 32 * i) * H + c) * 4) | cmask;   // rows >= B lie beyond the range
+  // ---- every read whose address is known at entry is REQUESTED at entry (round 6).  The kernel sits on the step's critical path with
+  // one workgroup per CU and nothing else to hide a memory round trip behind; the first version waited for the Linear bias, then for
+  // the slabs two at a time, then -- behind the statistics' barriers -- for the running statistics, the affine pair and the step
+  // counter: eight dependent round trips of 1.5-2.5 us in a 32 us launch.  Same values, same summation order; only the issue order moved.
+  // (range-checked buffer loads with an out-of-range offset instead of predicated loads: a predicated load gets an exec-mask region
+  // of its own with an s_waitcnt behind it)
+  const long hbytes = (long)H * 4;
+  const unsigned coff = (unsigned)(c * 4) | cmask;
+  const f32x4 bv = et_ld4(et_rsrc((d.slabs && d.lin_bias) ? d.lin_bias : d.x, (d.slabs && d.lin_bias) ? hbytes : 0), coff);
+  const f32x4 gm = et_ld4(et_rsrc(d.gamma, hbytes), coff), bt = et_ld4(et_rsrc(d.beta, hbytes), coff);
+  const f32x4 rm_in = et_ld4(et_rsrc(d.running_mean, hbytes), coff), rv_in = et_ld4(et_rsrc(d.running_var, hbytes), coff);
+  // (the step counter as a VECTOR load: a scalar load would be waited for on the spot, in front of everything below)
+  const float stepf = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(et_rsrc(a.ctrl ? (const void*)a.ctrl : (const void*)d.x,
+                                                                                     a.ctrl ? FXC_SIZE * 4 : 0), FXC_STEP * 4, 0, 0));
   if (d.slabs) {
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (d.lin_bias && cok) bv = *reinterpret_cast<const f32x4*>(d.lin_bias + c);
+    if (d.n_slabs <= 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xv[i] = bv;
-    // slab order = summation order of fx_reduce_slabs; all four row loads of a slab are in flight together, two slabs deep
-    int z = 0;
-    for (; z + 2 <= d.n_slabs; z += 2) {
-      const __amdgpu_buffer_rsrc_t r0 = et_rsrc(d.slabs + (long)z * d.slab_stride, xbytes),
-                                   r1 = et_rsrc(d.slabs + (long)(z + 1) * d.slab_stride, xbytes);
-      f32x4 u0[4], u1[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { u0[i] = et_ld4(r0, off[i]); u1[i] = et_ld4(r1, off[i]); }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { xv[i] += u0[i]; xv[i] += u1[i]; }
+      for (int i = 0; i < 4; ++i) xv[i] = bv;
     }
-    if (z < d.n_slabs) {
-      const __amdgpu_buffer_rsrc_t r0 = et_rsrc(d.slabs + (long)z * d.slab_stride, xbytes);
-      f32x4 u0[4];
+    // slab order = summation order of fx_reduce_slabs; up to eight slabs (all four row loads of each) are in flight together
+    for (int z0 = 0; z0 < d.n_slabs; z0 += 8) {
+      f32x4 u[8][4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) u0[i] = et_ld4(r0, off[i]);
+      for (int zi = 0; zi < 8; ++zi) {
+        const bool have = z0 + zi < d.n_slabs;               // (an absent slab reads nothing: zero-length range)
+        const __amdgpu_buffer_rsrc_t rz = et_rsrc(d.slabs + (have ? (long)(z0 + zi) * d.slab_stride : 0), have ? xbytes : 0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) xv[i] += u0[i];
+        for (int i = 0; i < 4; ++i) u[zi][i] = et_ld4(rz, off[i]);
+      }
+      if (z0 == 0) {                                         // (behind the requests: the bias is the first thing waited for)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xv[i] = bv;
+      }
+#pragma unroll
+      for (int zi = 0; zi < 8; ++zi)
+        if (z0 + zi < d.n_slabs) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) xv[i] += u[zi][i];
+        }
     }
+    // x (saved for the backward) is stored HERE only when the pre-activation is about to overwrite it; otherwise with the block
+    // output below: the memory counter retires in order, so the statistics' first wait for anything younger (the weight columns
+    // requested next) would sit out these four stores' acknowledgements
+    if (a.pre_act != ET_ACT_NONE) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) et_st4(xv[i], rx, off[i]);
+      for (int i = 0; i < 4; ++i) et_st4(xv[i], rx, off[i]);
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i) xv[i] = et_ld4(rx, off[i]);
   }
+  const bool x_late = d.slabs && a.pre_act == ET_ACT_NONE;
+  CP_TICK(cpw, 1);
   // ---- the first following Linear's weight columns are requested now (consumed after the statistics)
   // thread -> (output l = t >> 3 (+ 64), columns 8 * (t & 7) .. + 7 of the block): 2 x 16 bytes per output row
   f32x4 wv[2][2][2];                                   // [up][l half][column quad]
@@ -176,7 +206,7 @@ __device__ __forceinline__ void et_body(const EncTailDesc& d, const EncTailArgs&
       *reinterpret_cast<f32x4*>(d.save_mean + c) = mean;
       *reinterpret_cast<f32x4*>(d.save_invstd + c) = invstd;
       const float unb = B > 1 ? (float)B / (float)(B - 1) : 1.0f;
-      f32x4 rm = *reinterpret_cast<const f32x4*>(d.running_mean + c), rv = *reinterpret_cast<const f32x4*>(d.running_var + c);
+      f32x4 rm = rm_in, rv = rv_in;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         rm[j] = (1.0f - FX_BN_MOMENTUM) * rm[j] + FX_BN_MOMENTUM * mean[j];
@@ -189,25 +219,21 @@ __device__ __forceinline__ void et_body(const EncTailDesc& d, const EncTailArgs&
     mean = f32x4{0.f, 0.f, 0.f, 0.f};
     invstd = f32x4{0.f, 0.f, 0.f, 0.f};
     if (cok) {
-      mean = *reinterpret_cast<const f32x4*>(d.running_mean + c);
-      const f32x4 rv = *reinterpret_cast<const f32x4*>(d.running_var + c);
+      mean = rm_in;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) invstd[j] = 1.0f / sqrtf(rv[j] + FX_BN_EPS);
+      for (int j = 0; j < 4; ++j) invstd[j] = 1.0f / sqrtf(rv_in[j] + FX_BN_EPS);
     }
   }
-  f32x4 gm = {0.f, 0.f, 0.f, 0.f}, bt = {0.f, 0.f, 0.f, 0.f};
-  if (cok) {
-    gm = *reinterpret_cast<const f32x4*>(d.gamma + c);
-    bt = *reinterpret_cast<const f32x4*>(d.beta + c);
-  }
+  CP_TICK(cpw, 2);
   // ---- affine, activation, dropout (mask scaled first, then multiplied == F.dropout on CPU)
   const bool drop = a.train && a.drop_p > 0.f;
   const float keep = 1.0f - a.drop_p, keep_scale = 1.0f / (1.0f - a.drop_p);
-  const unsigned long long rng_off = a.ctrl ? d.offset + (((unsigned long long)a.ctrl[FXC_STEP]) << 44) : d.offset;
+  const unsigned long long rng_off = a.ctrl ? d.offset + (((unsigned long long)stepf) << 44) : d.offset;
   const __amdgpu_buffer_rsrc_t rmk = et_rsrc(d.mask, xbytes);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = rg + 32 * i;
+    if (x_late) et_st4(xv[i], rx, off[i]);
     f32x4 y;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -231,71 +257,56 @@ __device__ __forceinline__ void et_body(const EncTailDesc& d, const EncTailArgs&
     et_st4(y, ro, off[i]);
     xv[i] = y;                                          // the block output replaces x in registers
   }
-  // ---- the block's share of the following Linears: part_k[blk][r, l] = sum_c out[r, c] W_k[l, c]
-  // micro-tile (rows 4 rt .. + 3) x (outputs 4 lt .. + 3): for L <= 64 every thread has one (rt = t & 31, lt = t >> 5),
-  // for L <= 128 two (lt and lt + 16)
-  const int rt = t & 31, lt = t >> 5;
+  CP_TICK(cpw, 3);
+  // ---- the block's share of the following Linears: part_k[blk][r, l] = sum_c out[r, c] W_k[l, c] on the exact-fp32 matrix pipe
+  // (v_mfma_f32_16x16x4_f32, fp32 operands and accumulate; round 6 -- the FMA loops over k-major LDS tiles this replaces were 9 of the
+  // launch's 24 us, scripts/chain_profile.py).  The block output goes to LDS row-major once, every W_k row-major as it was fetched;
+  // operand A: lane (m = lane & 15, kq = lane >> 4) reads out[16 w + m][16 q + 4 kq .. + 3], operand B: lane (n, kq) reads
+  // W_k[16 nb + n][16 q + 4 kq .. + 3], instruction e uses element e on both sides (the contraction index is a dummy); wave w owns rows
+  // 16 w .. 16 w + 15 and every 16-output block; result: lane holds rows 16 w + 4 kq + i (i = 0..3) of output 16 nb + m.
+#pragma unroll
+  for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&As[rg + 32 * i][4 * cq]) = xv[i];
+  const int m16 = lane & 15, kq = lane >> 4;
   for (int k = 0; k < d.n_up; ++k) {
     const int Lk = d.L[k];
-    f32x4 acc[2][4];
+    if (k > 0) __syncthreads();                         // the previous Linear's fragment reads of Ws are done
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int lh = 0; lh < 2; ++lh)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[u][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < 2; ++q)
+        *reinterpret_cast<f32x4*>(&Ws[(t >> 3) + 64 * lh][8 * (t & 7) + 4 * q]) = k == 0 ? wv[0][lh][q] : wv[1][lh][q];
+    __syncthreads();
+    const int nnb = (Lk + 15) >> 4;
+    f32x4 acc[ET_MAXL / 16];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      __syncthreads();                                  // the previous users of As / Ws are done
-      if ((cq >> 3) == half) {                          // this thread's 4 columns lie in this half
+    for (int nb = 0; nb < ET_MAXL / 16; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+    for (int q = 0; q < ET_COLS / 16; ++q) {
+      const f32x4 av = *reinterpret_cast<const f32x4*>(&As[16 * w + m16][16 * q + 4 * kq]);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) As[4 * (cq & 7) + j][rg + 32 * i] = xv[i][j];
-      }
-      // W_k columns of this half: the thread holds columns 8 (t & 7) .. + 7 -> half (t & 7) >> 2
-      if (((t & 7) >> 2) == half) {
+      for (int nb = 0; nb < ET_MAXL / 16; ++nb) {
+        if (nb < nnb) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(&Ws[16 * nb + m16][16 * q + 4 * kq]);
 #pragma unroll
-        for (int lh = 0; lh < 2; ++lh)
-#pragma unroll
-          for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) Ws[8 * (t & 3) + 4 * q + j][(t >> 3) + 64 * lh] = k == 0 ? wv[0][lh][q][j] : wv[1][lh][q][j];
-      }
-      __syncthreads();
-      if (4 * lt < Lk) {
-#pragma unroll 8
-        for (int cc = 0; cc < 32; ++cc) {
-          const f32x4 av = *reinterpret_cast<const f32x4*>(&As[cc][4 * rt]);
-          const f32x4 w0 = *reinterpret_cast<const f32x4*>(&Ws[cc][4 * lt]);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc[0][i] += av[i] * w0;
-          if (Lk > 64) {
-            const f32x4 w1 = *reinterpret_cast<const f32x4*>(&Ws[cc][4 * lt + 64]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[1][i] += av[i] * w1;
-          }
+          for (int e = 0; e < 4; ++e) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], acc[nb], 0, 0, 0);
         }
       }
     }
+    CP_TICK(cpw, 4);
     float* pk = d.part[k] + (long)blk * B * Lk;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int l0 = 4 * lt + 64 * u;
-      if (l0 < Lk)
+    for (int nb = 0; nb < ET_MAXL / 16; ++nb) {
+      const int l = 16 * nb + m16;
+      if (nb < nnb && l < Lk) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int r = 4 * rt + i;
-          if (r < B) {
-            if (l0 + 3 < Lk && (Lk & 3) == 0) {
-              *reinterpret_cast<f32x4*>(pk + (long)r * Lk + l0) = acc[u][i];
-            } else {
-#pragma unroll
-              for (int j = 0; j < 4; ++j)
-                if (l0 + j < Lk) pk[(long)r * Lk + l0 + j] = acc[u][i][j];
-            }
-          }
+          const int r = 16 * w + 4 * kq + i;
+          if (r < B) pk[(long)r * Lk + l] = acc[nb][i];
         }
+      }
     }
   }
+  CP_TICK(cpw, 5);
 }
 
 __global__ __launch_bounds__(ET_T) void fx_enc_tail_fwd_kernel(EncTailArgs a) {
@@ -314,6 +325,7 @@ __global__ __launch_bounds__(ET_T) void fx_enc_tail_fwd_kernel(EncTailArgs a) {
 #define FU_SUB 8            // threads (neighbouring lanes) that split one unit's slab range
 #define FU_T 1024
 #define FU_MAXK 512
+#define FU_FLIGHT 10        // slab loads in flight per thread
 #define FU_MAX_LAYERS 8
 
 struct FusionArgs {
@@ -332,6 +344,8 @@ struct FusionArgs {
 __device__ __forceinline__ void fx_fusion_body(const FusionArgs& a, float (*es)[FU_MAXK + 4], float (*wfs)[ET_MAXL + 1]) {
   const int t = threadIdx.x, r0 = blockIdx.x * FU_ROWS;
   const int B = a.B, Kf = a.Kf, L = a.L;
+  const int cpw = 512 + blockIdx.y * gridDim.x + blockIdx.x;      // (chain profile: the fusion launch's rows of the table)
+  CP_TICK(cpw, 0);
   // ---- first W_f chunk: requested before the slab sums, stored after them.  element idx -> (l = idx / 64, k = idx % 64)
   float wreg[ET_MAXL * FU_KC / FU_T];
   if (a.Wf) {
@@ -341,6 +355,8 @@ __device__ __forceinline__ void fx_fusion_body(const FusionArgs& a, float (*es)[
       wreg[i] = a.Wf[(long)min(l, L - 1) * Kf + min(k, Kf - 1)];
     }
   }
+  float bfv = 0.f;                       // the fusion bias of this thread's output (t % L < L: valid for every thread)
+  if (a.Wf && a.bf) bfv = a.bf[t % L];
   // ---- ecat rows: unit = (row, 4 consecutive columns of one modality); its FU_SUB threads (neighbouring lanes) split the slab
   // range (4 rows x 8 sub-ranges: 32 workgroups at B = 128, ~10 slabs of 16 bytes per thread in 2-3 dependent rounds)
   const int sub = t & (FU_SUB - 1), unit0 = t / FU_SUB;
@@ -356,18 +372,23 @@ __device__ __forceinline__ void fx_fusion_body(const FusionArgs& a, float (*es)[
     const int c = c0 + pc;                                     // first of (up to) four ecat columns
     const int per = (np + FU_SUB - 1) / FU_SUB, z0 = min(np, sub * per), z1 = min(np, z0 + per);
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    if (r < B) {
+    // the layer_out bias of the unit's columns is requested with the slabs (it used to be a round trip of its own behind the sum)
+    // (unconditional, from an address that is valid either way: a predicated load is waited for on the spot;
+    // bias arrays are allocated up to a multiple of 4: zeros)
+    const f32x4 bq = *reinterpret_cast<const f32x4*>(bias ? bias + pc : part + pc);
+    if (r < B && z0 < z1) {
       const float* src = part + (long)r * pw + pc;
       const long stride = (long)B * pw;
-      int z = z0;
-      for (; z + 4 <= z1; z += 4) {
-        f32x4 v[4];
+      // up to FU_FLIGHT slabs of 16 bytes in flight per thread (79 column blocks at cfg2 = 10 per thread: one round instead of
+      // three dependent ones); addresses clamped into the thread's range, the adds predicated: same order, same sum
+      for (int z = z0; z < z1; z += FU_FLIGHT) {
+        f32x4 v[FU_FLIGHT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4*>(src + (long)(z + j) * stride);
+        for (int j = 0; j < FU_FLIGHT; ++j) v[j] = *reinterpret_cast<const f32x4*>(src + (long)min(z + j, z1 - 1) * stride);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s += v[j];
+        for (int j = 0; j < FU_FLIGHT; ++j)
+          if (z + j < z1) s += v[j];
       }
-      for (; z < z1; ++z) s += *reinterpret_cast<const f32x4*>(src + (long)z * stride);
     }
     // combine the sub-ranges in range order (fixed: deterministic)
     const int base = (t & 63) & ~(FU_SUB - 1);
@@ -380,7 +401,7 @@ __device__ __forceinline__ void fx_fusion_body(const FusionArgs& a, float (*es)[
       tot += sq;
     }
     if (sub == 0) {
-      if (bias) tot += *reinterpret_cast<const f32x4*>(bias + pc);        // (bias arrays are allocated up to a multiple of 4: zeros)
+      if (bias) tot += bq;
       if (((c | wd) & 3) == 0) {
         *reinterpret_cast<f32x4*>(&es[rr][c]) = tot;
         if (r < B && a.ecat) *reinterpret_cast<f32x4*>(a.ecat + (long)r * a.ldecat + c) = tot;
@@ -394,11 +415,12 @@ __device__ __forceinline__ void fx_fusion_body(const FusionArgs& a, float (*es)[
       }
     }
   }
+  CP_TICK(cpw, 1);
   if (!a.Wf) return;
   // ---- emb[r, l] = b_f[l] + sum_k ecat[r, k] W_f[l, k]: one output per thread, W_f in 64-column chunks through LDS
   const int rr = t / L, l = t - rr * L;
   const bool own = t < FU_ROWS * L;
-  float acc = (own && a.bf) ? a.bf[l] : 0.f;
+  float acc = bfv;
   for (int k0 = 0; k0 < Kf; k0 += FU_KC) {
     __syncthreads();                       // es complete (first pass) / the previous chunk has been consumed
 #pragma unroll
@@ -421,6 +443,7 @@ __device__ __forceinline__ void fx_fusion_body(const FusionArgs& a, float (*es)[
     }
   }
   if (own && r0 + rr < B) a.emb[(long)(r0 + rr) * a.ldemb + l] = acc;
+  CP_TICK(cpw, 2);
 }
 
 __global__ __launch_bounds__(FU_T) void fx_fusion_fwd_kernel(FusionArgs a) {
@@ -436,6 +459,8 @@ __global__ __launch_bounds__(FU_T) void fx_fusion_fwd_pair_kernel(FusionPair p) 
   __shared__ float wfs[FU_KC][ET_MAXL + 1];
   fx_fusion_body(p.a[blockIdx.y], es, wfs);
 }
+
+CP_READER(fx_debug_chain_stamps_tail)
 
 extern "C" {
 

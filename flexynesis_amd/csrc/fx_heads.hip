@@ -12,6 +12,7 @@
 // [B, L]-sized products (layer_1 forward, the embedding gradient of fx_heads_step) run on the exact-fp32 matrix pipe
 // (v_mfma_f32_16x16x4_f32) with their operands fetched straight from memory / the LDS tiles.
 #include "fx_common.h"
+#include "fx_chain_prof.h"
 #include "fx_loss_dev.h"
 
 #define FX_MAX_HEADS 8
@@ -122,7 +123,7 @@ struct HeadsFwdLds {
   Tile ys;                       // layer_1 output, then the block output (columns >= S stay zero)
   float W2s[HC * HS];            // [C][32], columns >= S zero
   float part[8][32];
-  float stat[5][32];             // mean, invstd, gamma, beta, layer_1 bias (zero padded)
+  float stat[6][32];             // mean, invstd, gamma, beta, layer_1 bias, layer_out bias (zero padded)
 };
 
 __device__ __forceinline__ void heads_fwd_body(const HeadsArgs& a, const FxHeadDesc& h, HeadsFwdLds& F, bool update_running = true) {
@@ -133,6 +134,13 @@ __device__ __forceinline__ void heads_fwd_body(const HeadsArgs& a, const FxHeadD
   const int t = threadIdx.x, r = t & 127, hf = t >> 7, col = t & 31, rg = t >> 5;
   const int S = h.S, C = h.C, B = a.B, L = a.L;
   const int s0 = hf * (HS / 2);
+  // ---- requested at entry, used several barriers later (round 6: each of these used to be a dependent round trip of the ONE workgroup
+  // the whole step waits for -- the running statistics behind the batch statistics, the step counter in front of the dropout draws,
+  // the layer_out bias in front of the last product; scripts/chain_profile.py: 14 of the launch's 30 us were this forward)
+  const int scc = min(col, S - 1);
+  const float rm0 = h.rmean[scc], rv0 = h.rvar[scc];
+  const float stepf = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ctrl ? a.ctrl : h.W1), 0, a.ctrl ? FXC_SIZE * 4 : 0, 0x00020000), FXC_STEP * 4, 0, 0));
   // ---- layer_1 on the exact-fp32 matrix pipe (v_mfma_f32_16x16x4_f32): y1[r, s] = b1[s] + sum_l x[r, l] W1[s, l].
   // Operand A: lane (m = lane & 15, kq = lane >> 4) supplies x[row m][k], operand B: lane (n = lane & 15, kq) supplies
   // W1[s = n][k]; a lane fetches four consecutive k = 16 q + 4 kq + e straight from memory (x rows and W1 rows are both
@@ -209,9 +217,11 @@ __device__ __forceinline__ void heads_fwd_body(const HeadsArgs& a, const FxHeadD
   if (t < 32) {
     const int sc = min(t, S - 1);
     const float g_ = h.gamma[sc], b_ = h.beta[sc], b1_ = h.b1[sc];
+    const float b2_ = (h.b2 ? h.b2 : h.b1)[h.b2 ? min(t, C - 1) : sc];
     stat[2][t] = t < S ? g_ : 0.f;
     stat[3][t] = t < S ? b_ : 0.f;
     stat[4][t] = t < S ? b1_ : 0.f;
+    stat[5][t] = (h.b2 && t < C) ? b2_ : 0.f;
   }
   __syncthreads();
   {
@@ -266,14 +276,13 @@ __device__ __forceinline__ void heads_fwd_body(const HeadsArgs& a, const FxHeadD
       h.save_invstd[col] = invstd;
       const float var_u = B > 1 ? var_b * ((float)B / (float)(B - 1)) : var_b;
       if (update_running) {
-        h.rmean[col] = (1.0f - FX_BN_MOMENTUM) * h.rmean[col] + FX_BN_MOMENTUM * mean;
-        h.rvar[col] = (1.0f - FX_BN_MOMENTUM) * h.rvar[col] + FX_BN_MOMENTUM * var_u;
+        h.rmean[col] = (1.0f - FX_BN_MOMENTUM) * rm0 + FX_BN_MOMENTUM * mean;
+        h.rvar[col] = (1.0f - FX_BN_MOMENTUM) * rv0 + FX_BN_MOMENTUM * var_u;
       }
     }
   } else {
-    const int sc = min(col, S - 1);
-    mean = h.rmean[sc];
-    invstd = 1.0f / sqrtf(h.rvar[sc] + FX_BN_EPS);
+    mean = rm0;
+    invstd = 1.0f / sqrtf(rv0 + FX_BN_EPS);
   }
   if (rg == 0) { stat[0][col] = mean; stat[1][col] = invstd; }
   __syncthreads();
@@ -285,7 +294,7 @@ __device__ __forceinline__ void heads_fwd_body(const HeadsArgs& a, const FxHeadD
 #pragma unroll
     for (int j = 0; j < HS / 2; ++j) mk[j] = h.mask[(long)min(r, B - 1) * S + min(s0 + j, S - 1)];
   } else if (drop) {
-    const unsigned long long rng_off = heads_step_offset(a.ctrl, h.offset);
+    const unsigned long long rng_off = a.ctrl ? h.offset + (((unsigned long long)stepf) << 44) : h.offset;    // = heads_step_offset
 #pragma unroll
     for (int jb = 0; jb < HS / 8; ++jb) {
       if (s0 + 4 * jb < S) {                 // (padded columns hold zeros whatever the mask: no draw)
@@ -319,7 +328,7 @@ __device__ __forceinline__ void heads_fwd_body(const HeadsArgs& a, const FxHeadD
   // ---- layer_out: out[r, c] = b2[c] + sum_s a1[r, s] W2[c, s]   (padded columns of a1 / W2 are zero)
   const int Ch = (C + 1) >> 1;
   for (int c = hf * Ch; c < min(C, (hf + 1) * Ch); ++c) {
-    float o = h.b2 ? h.b2[c] : 0.f;
+    float o = stat[5][c];
 #pragma unroll
     for (int s = 0; s < HS; ++s) o += ys[r][s] * W2s[c * HS + s];
     if (r < B) h.out[(long)r * C + c] = o;
@@ -623,14 +632,17 @@ __global__ __launch_bounds__(256) void fx_heads_step_kernel(HeadsStepArgs sa) {
   }
   const int t = threadIdx.x, r = t & 127, hf = t >> 7, col = t & 31, rg = t >> 5;
   const int B = a.B, Ld = a.L, S = h.S, C = h.C;
+  CP_TICK(blockIdx.x, 0);
   heads_fwd_body(a, h, U.f, chain_role);
   __syncthreads();                                   // out [B, C] is visible to the whole workgroup
+  CP_TICK(blockIdx.x, 1);
   // ================= loss value + gradient at the head output =================
   float* dout = const_cast<float*>(h.dout);
   if (sa.kind[hi] == 0) loss_mse_body(loss_slot, dout, h.out, sa.y[hi], B, C, C, sa.logvar[hi], 1.0f, sm);
   else if (sa.kind[hi] == 1) loss_ce_body(loss_slot, dout, h.out, sa.y[hi], B, C, C, C, sa.logvar[hi], 1.0f, sm);
   else loss_cox_body<HB, 1>(loss_slot, dout, h.out, sa.dur[hi], sa.y[hi], B, C, C, sa.logvar[hi], 1.0f, ckey, cidx, cscan, dred);
   __syncthreads();
+  CP_TICK(blockIdx.x, 2);
   // ================= backward: parameter gradients of this head and its share of the embedding gradient =================
   HeadsBwdLds& L = U.b;
   const float gate_scale = 1.0f / (1.0f - a.drop_p);
@@ -664,7 +676,9 @@ __global__ __launch_bounds__(256) void fx_heads_step_kernel(HeadsStepArgs sa) {
     }
   }
   float sum_dy, sum_dy_xh, sum_dx;
+  CP_TICK(blockIdx.x, 3);
   heads_bwd_prefix(L, h, B, gate_scale);
+  CP_TICK(blockIdx.x, 4);
   if (!chain_role) {
     // layer_out.weight / bias gradients (over the padded [C][32] grid; only true columns are stored)
     for (int o = t; o < C * HS; o += 256) {
@@ -683,6 +697,7 @@ __global__ __launch_bounds__(256) void fx_heads_step_kernel(HeadsStepArgs sa) {
   }
   __syncthreads();
   heads_bwd_bn(L, B, vy, sum_dy, sum_dy_xh, sum_dx);
+  CP_TICK(blockIdx.x, 5);
   if (!chain_role) {
     // ---- layer_1.weight gradient on the exact-fp32 matrix pipe: gW1[s, l] = sum_r dy1[r, s] x[r, l]
     // (A = dy1^T: lane (s = lane & 15, kq) reads R3[16 q + 4 kq + e][s block + s]; B = the x fragments requested above)
@@ -772,6 +787,7 @@ __global__ __launch_bounds__(256) void fx_heads_step_kernel(HeadsStepArgs sa) {
       }
     }
   }
+  CP_TICK(blockIdx.x, 6);
   const int Lh = (Ld + 1) >> 1, l0 = hf * Lh;      // (the meet below: a thread's rows / columns of the per-head shares)
   // ================= meet: the last workgroup adds the shares in head order and evaluates the total =================
   bool last = true;
@@ -817,7 +833,10 @@ __global__ __launch_bounds__(256) void fx_heads_step_kernel(HeadsStepArgs sa) {
     }
     sa.total_out[0] = tot;
   }
+  CP_TICK(blockIdx.x, 7);
 }
+
+CP_READER(fx_debug_chain_stamps_heads)
 
 extern "C" {
 
