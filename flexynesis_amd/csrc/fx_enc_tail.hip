@@ -13,7 +13,7 @@
 //                     rows: ordered slab sum + bias -> x (saved for the backward), two-pass batch statistics, affine,
 //                     activation, dropout (Philox: one counter block per 4 consecutive columns, the stream of
 //                     fx_bn_act_fwd) -> out (saved), and the block's share of every following small Linear:
-//                     part_k[blk][r, l] = sum_{c in block} out[r, c] W_k[l, c]  (exact-fp32 matrix pipe, operands from LDS).
+//                     part_k[blk][r, l] = sum_{c in block} out[r, c] W_k[l, c]  (plain fp32 FMA from LDS tiles).
 //   fx_fusion_fwd     grid (row blocks).  One workgroup owns 4 rows: ecat[r, :] = for every modality the ordered sum of
 //                     its column blocks' partial products + layer_out bias (four threads share the slab range of an
 //                     output and combine in a fixed order), then emb[r, :] = ecat[r, :] W_f^T + b_f from an LDS copy of
@@ -89,11 +89,10 @@ __device__ __forceinline__ f32x4 et_colsum(f32x4 v, float (*red)[ET_COLS + 4], i
 }
 
 __device__ __forceinline__ void et_body(const EncTailDesc& d, const EncTailArgs& a, int blk) {
-  // LDS: As [128][68] the block output, row-major (row, column of the block); Ws [128][68] a following Linear's weight columns of the
-  // block, row-major (output, column): the operand fragments of the fp32 MFMA are 16-byte reads along a row (stride 68: two-way
-  // bank conflicts at worst)
-  __shared__ __attribute__((aligned(16))) float As[ET_MAXB][ET_COLS + 4];
-  __shared__ __attribute__((aligned(16))) float Ws[ET_MAXL][ET_COLS + 4];
+  // LDS: As [32][132] one 32-column half of the block output, k-major (column, row); Ws [32][132] the matching 32 columns
+  // of a following Linear's weight, k-major (column, output)
+  __shared__ __attribute__((aligned(16))) float As[32][ET_MAXB + 4];
+  __shared__ __attribute__((aligned(16))) float Ws[32][ET_MAXL + 4];
   __shared__ __attribute__((aligned(16))) float red[ET_T / 64][ET_COLS + 4];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int cq = t & 15, rg = t >> 4;                 // columns 4 cq .. 4 cq + 3 of the block, rows rg + 32 i
@@ -257,53 +256,69 @@ __device__ __forceinline__ void et_body(const EncTailDesc& d, const EncTailArgs&
     et_st4(y, ro, off[i]);
     xv[i] = y;                                          // the block output replaces x in registers
   }
-  CP_TICK(cpw, 3);
-  // ---- the block's share of the following Linears: part_k[blk][r, l] = sum_c out[r, c] W_k[l, c] on the exact-fp32 matrix pipe
-  // (v_mfma_f32_16x16x4_f32, fp32 operands and accumulate; round 6 -- the FMA loops over k-major LDS tiles this replaces were 9 of the
-  // launch's 24 us, scripts/chain_profile.py).  The block output goes to LDS row-major once, every W_k row-major as it was fetched;
-  // operand A: lane (m = lane & 15, kq = lane >> 4) reads out[16 w + m][16 q + 4 kq .. + 3], operand B: lane (n, kq) reads
-  // W_k[16 nb + n][16 q + 4 kq .. + 3], instruction e uses element e on both sides (the contraction index is a dummy); wave w owns rows
-  // 16 w .. 16 w + 15 and every 16-output block; result: lane holds rows 16 w + 4 kq + i (i = 0..3) of output 16 nb + m.
-#pragma unroll
-  for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&As[rg + 32 * i][4 * cq]) = xv[i];
-  const int m16 = lane & 15, kq = lane >> 4;
+  // ---- the block's share of the following Linears: part_k[blk][r, l] = sum_c out[r, c] W_k[l, c]
+  // micro-tile (rows 4 rt .. + 3) x (outputs 4 lt .. + 3): for L <= 64 every thread has one (rt = t & 31, lt = t >> 5),
+  // for L <= 128 two (lt and lt + 16)
+  const int rt = t & 31, lt = t >> 5;
   for (int k = 0; k < d.n_up; ++k) {
     const int Lk = d.L[k];
-    if (k > 0) __syncthreads();                         // the previous Linear's fragment reads of Ws are done
+    f32x4 acc[2][4];
 #pragma unroll
-    for (int lh = 0; lh < 2; ++lh)
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int q = 0; q < 2; ++q)
-        *reinterpret_cast<f32x4*>(&Ws[(t >> 3) + 64 * lh][8 * (t & 7) + 4 * q]) = k == 0 ? wv[0][lh][q] : wv[1][lh][q];
-    __syncthreads();
-    const int nnb = (Lk + 15) >> 4;
-    f32x4 acc[ET_MAXL / 16];
+      for (int i = 0; i < 4; ++i) acc[u][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int nb = 0; nb < ET_MAXL / 16; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int half = 0; half < 2; ++half) {
+      __syncthreads();                                  // the previous users of As / Ws are done
+      if ((cq >> 3) == half) {                          // this thread's 4 columns lie in this half
 #pragma unroll
-    for (int q = 0; q < ET_COLS / 16; ++q) {
-      const f32x4 av = *reinterpret_cast<const f32x4*>(&As[16 * w + m16][16 * q + 4 * kq]);
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int nb = 0; nb < ET_MAXL / 16; ++nb) {
-        if (nb < nnb) {
-          const f32x4 bv = *reinterpret_cast<const f32x4*>(&Ws[16 * nb + m16][16 * q + 4 * kq]);
+          for (int j = 0; j < 4; ++j) As[4 * (cq & 7) + j][rg + 32 * i] = xv[i][j];
+      }
+      // W_k columns of this half: the thread holds columns 8 (t & 7) .. + 7 -> half (t & 7) >> 2
+      if (((t & 7) >> 2) == half) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], acc[nb], 0, 0, 0);
+        for (int lh = 0; lh < 2; ++lh)
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Ws[8 * (t & 3) + 4 * q + j][(t >> 3) + 64 * lh] = k == 0 ? wv[0][lh][q][j] : wv[1][lh][q][j];
+      }
+      __syncthreads();
+      if (4 * lt < Lk) {
+#pragma unroll 8
+        for (int cc = 0; cc < 32; ++cc) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(&As[cc][4 * rt]);
+          const f32x4 w0 = *reinterpret_cast<const f32x4*>(&Ws[cc][4 * lt]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[0][i] += av[i] * w0;
+          if (Lk > 64) {
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(&Ws[cc][4 * lt + 64]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[1][i] += av[i] * w1;
+          }
         }
       }
     }
-    CP_TICK(cpw, 4);
     float* pk = d.part[k] + (long)blk * B * Lk;
 #pragma unroll
-    for (int nb = 0; nb < ET_MAXL / 16; ++nb) {
-      const int l = 16 * nb + m16;
-      if (nb < nnb && l < Lk) {
+    for (int u = 0; u < 2; ++u) {
+      const int l0 = 4 * lt + 64 * u;
+      if (l0 < Lk)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int r = 16 * w + 4 * kq + i;
-          if (r < B) pk[(long)r * Lk + l] = acc[nb][i];
+          const int r = 4 * rt + i;
+          if (r < B) {
+            if (l0 + 3 < Lk && (Lk & 3) == 0) {
+              *reinterpret_cast<f32x4*>(pk + (long)r * Lk + l0) = acc[u][i];
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                if (l0 + j < Lk) pk[(long)r * Lk + l0 + j] = acc[u][i][j];
+            }
+          }
         }
-      }
     }
   }
   CP_TICK(cpw, 5);

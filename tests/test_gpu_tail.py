@@ -25,6 +25,8 @@ def _close(a, b, rtol, atol, what):
     (128, [1024, 768], [[32, 32], [32, 32]], 5, ACT_LEAKY, ACT_NONE, True),  # VAE encoders: LeakyReLU -> BN -> FC_mean, FC_var
     (37, [260], [[128]], 1, ACT_NONE, ACT_RELU, False),                      # one modality, latent 128, x given directly, odd batch
     (2, [64], [[16]], 2, ACT_NONE, ACT_RELU, True),                          # smallest train batch
+    (10, [12, 8], [[8], [8]], 1, ACT_NONE, ACT_RELU, False),                 # the fine-tune golden's widths: blocks far narrower than a tile
+    (30, [12, 8], [[8], [8]], 9, ACT_NONE, ACT_RELU, True),                  # ... and more than eight slabs (two request rounds)
 ])
 @pytest.mark.parametrize("train", [True, False])
 def test_enc_tail_fwd_vs_fp64(B, Hs, Ls, n_slabs, pre, post, use_slabs, train):
@@ -129,6 +131,37 @@ def test_fusion_fwd_vs_fp64(B, widths, blocks, L):
     ops.fusion_fwd(ops.IMMEDIATE, emb, ecat, list(zip(parts, blocks)), biases, W, b)
     torch.cuda.synchronize()
     ref = torch.cat([p.double().sum(0) + (bb.double() if bb is not None else 0.0) for p, bb in zip(parts, biases)], dim=1)
+    _close(ecat, ref, 2e-6, 2e-5, "ecat")
+    if L:
+        _close(emb, ref @ W.double().t() + b.double(), 1e-5, 1e-5, "emb")
+
+
+@pytest.mark.parametrize("B,width,blocks,L", [(10, 6, [1, 1], 6), (30, 6, [1, 1], 6), (128, 61, [78, 79], 61), (7, 17, [12], 0)])
+def test_fusion_fwd_unaligned_width_vs_fp64(B, width, blocks, L):
+    """Latent widths that are not multiples of 4 (the engine's layout: a part's row pitch = the width rounded up to 4, pad columns
+    zero, biases allocated up to the pitch) -- the fine-tune golden's latent 6 and the bench's cfg2_odd latent 61."""
+    from flexynesis_amd import ops
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(B + L + width)
+    pw = (width + 3) // 4 * 4
+    parts = []
+    for nb in blocks:
+        p_ = torch.zeros(nb, B, pw, device=dev)
+        p_[:, :, :width] = torch.randn(nb, B, width, device=dev, generator=g)
+        parts.append(p_)
+    biases = []
+    for i in range(len(blocks)):
+        bb = torch.zeros(pw, device=dev)
+        bb[:width] = torch.randn(width, device=dev, generator=g)
+        biases.append(bb if i % 2 == 0 else None)
+    Kf = width * len(blocks)
+    ecat = torch.full((B, Kf), float("nan"), device=dev)
+    W = torch.randn(L, Kf, device=dev, generator=g) / Kf ** 0.5 if L else None
+    b = torch.randn(L, device=dev, generator=g) if L else None
+    emb = torch.full((B, L), float("nan"), device=dev) if L else None
+    ops.fusion_fwd(ops.IMMEDIATE, emb, ecat, list(zip(parts, blocks)), biases, W, b, width=width)
+    torch.cuda.synchronize()
+    ref = torch.cat([p_[:, :, :width].double().sum(0) + (bb[:width].double() if bb is not None else 0.0) for p_, bb in zip(parts, biases)], dim=1)
     _close(ecat, ref, 2e-6, 2e-5, "ecat")
     if L:
         _close(emb, ref @ W.double().t() + b.double(), 1e-5, 1e-5, "emb")
