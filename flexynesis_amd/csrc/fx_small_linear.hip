@@ -27,20 +27,28 @@ struct SmallLinArgs {
 // stage a [rows x cols] block of src (row stride ld) into dst[rows][SL_KC + 1]; out-of-range elements become 0.  Addresses
 // are clamped and the loads unconditional (a predicated load costs a dependent round trip each, fx_heads.hip)
 template <int ROWS>
-__device__ __forceinline__ void sl_stage(float (*dst)[SL_KC + 1], const float* __restrict__ src, long ld, int r0, int nr,
-                                         int c0, int nc) {
-  constexpr int PER = ROWS * SL_KC / SL_T;
-  float v[PER];
+__device__ __forceinline__ void sl_stage_load(float (&v)[ROWS * SL_KC / SL_T], const float* __restrict__ src, long ld, int r0, int nr,
+                                              int c0, int nc) {
 #pragma unroll
-  for (int i = 0; i < PER; ++i) {
+  for (int i = 0; i < ROWS * SL_KC / SL_T; ++i) {
     const int idx = threadIdx.x + SL_T * i, rr = idx / SL_KC, cc = idx % SL_KC;
     v[i] = src[(long)min(r0 + rr, nr - 1) * ld + min(c0 + cc, nc - 1)];
   }
+}
+template <int ROWS>
+__device__ __forceinline__ void sl_stage_store(float (*dst)[SL_KC + 1], const float (&v)[ROWS * SL_KC / SL_T], int r0, int nr, int c0, int nc) {
 #pragma unroll
-  for (int i = 0; i < PER; ++i) {
+  for (int i = 0; i < ROWS * SL_KC / SL_T; ++i) {
     const int idx = threadIdx.x + SL_T * i, rr = idx / SL_KC, cc = idx % SL_KC;
     dst[rr][cc] = (r0 + rr < nr && c0 + cc < nc) ? v[i] : 0.f;
   }
+}
+template <int ROWS>
+__device__ __forceinline__ void sl_stage(float (*dst)[SL_KC + 1], const float* __restrict__ src, long ld, int r0, int nr,
+                                         int c0, int nc) {
+  float v[ROWS * SL_KC / SL_T];
+  sl_stage_load<ROWS>(v, src, ld, r0, nr, c0, nc);
+  sl_stage_store<ROWS>(dst, v, r0, nr, c0, nc);
 }
 
 __global__ __launch_bounds__(SL_T) void fx_small_linear_fwd_kernel(SmallLinArgs a) {
@@ -53,10 +61,17 @@ __global__ __launch_bounds__(SL_T) void fx_small_linear_fwd_kernel(SmallLinArgs 
   const float bias = (a.b && o0 + ol < a.O) ? a.b[o0 + ol] : 0.f;
 #pragma unroll
   for (int i = 0; i < SL_TR / 4; ++i) acc[i] = bias;
+  float vx[SL_TR * SL_KC / SL_T], vw[SL_TC * SL_KC / SL_T];           // (the next K chunk's loads in flight while this one is multiplied)
+  sl_stage_load<SL_TR>(vx, a.x, a.ldx, r0, a.R, 0, a.K);
+  sl_stage_load<SL_TC>(vw, a.W, a.K, o0, a.O, 0, a.K);
   for (int k0 = 0; k0 < a.K; k0 += SL_KC) {
     __syncthreads();
-    sl_stage<SL_TR>(xs, a.x, a.ldx, r0, a.R, k0, a.K);
-    sl_stage<SL_TC>(ws, a.W, a.K, o0, a.O, k0, a.K);
+    sl_stage_store<SL_TR>(xs, vx, r0, a.R, k0, a.K);
+    sl_stage_store<SL_TC>(ws, vw, o0, a.O, k0, a.K);
+    if (k0 + SL_KC < a.K) {
+      sl_stage_load<SL_TR>(vx, a.x, a.ldx, r0, a.R, k0 + SL_KC, a.K);
+      sl_stage_load<SL_TC>(vw, a.W, a.K, o0, a.O, k0 + SL_KC, a.K);
+    }
     __syncthreads();
 #pragma unroll 8
     for (int k = 0; k < SL_KC; ++k) {
@@ -127,23 +142,29 @@ __device__ __forceinline__ void sl_bwd_body(const SmallLinArgs& a, const int bid
   const int t = bid - a.tiles_dx;
   const int o0 = (t / tiles_k) * SL_TR, k0 = (t % tiles_k) * SL_TC;
   float accb = 0.f;
+  // The row chunks are a dependent chain of (load -> LDS -> multiply) in a handful of workgroups that the whole launch waits for (the
+  // stacked-rows plans have six chunks: 56 us at R = 384): the NEXT chunk's loads are in flight while this one is multiplied (round 6).
+  // Same chunks in the same order: the same sums.
+  constexpr int PERX = SL_KC * SL_KC / SL_T, PERD = SL_KC * SL_TR / SL_T;
+  float vx[PERX], vd[PERD];
+#define SL_GW_REQ(rr0)                                                                       \
+  {                                                                                          \
+    sl_stage_load<SL_KC>(vx, a.x, a.ldx, (rr0), a.R, k0, a.K);                               \
+    _Pragma("unroll") for (int i = 0; i < PERD; ++i) {                                       \
+      const int idx = threadIdx.x + SL_T * i, rr = idx / SL_TR, oo = idx % SL_TR;            \
+      vd[i] = sl_dy(a, (rr0) + rr, o0 + oo);                                                 \
+    }                                                                                        \
+  }
+  SL_GW_REQ(0)
   for (int r0 = 0; r0 < a.R; r0 += SL_KC) {
     __syncthreads();
-    sl_stage<SL_KC>(s1, a.x, a.ldx, r0, a.R, k0, a.K);                   // s1[r][k]
-    {                                                                     // s2[r][o] = dy[r0 + r, o0 + o]
-      constexpr int PER = SL_KC * SL_TR / SL_T;
-      float v[PER];
+    sl_stage_store<SL_KC>(s1, vx, r0, a.R, k0, a.K);                     // s1[r][k]
 #pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int idx = threadIdx.x + SL_T * i, rr = idx / SL_TR, oo = idx % SL_TR;
-        v[i] = sl_dy(a, r0 + rr, o0 + oo);
-      }
-#pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int idx = threadIdx.x + SL_T * i, rr = idx / SL_TR, oo = idx % SL_TR;
-        s2[rr][oo] = (r0 + rr < a.R && o0 + oo < a.O) ? v[i] : 0.f;
-      }
+    for (int i = 0; i < PERD; ++i) {                                      // s2[r][o] = dy[r0 + r, o0 + o]
+      const int idx = threadIdx.x + SL_T * i, rr = idx / SL_TR, oo = idx % SL_TR;
+      s2[rr][oo] = (r0 + rr < a.R && o0 + oo < a.O) ? vd[i] : 0.f;
     }
+    if (r0 + SL_KC < a.R) SL_GW_REQ(r0 + SL_KC)
     __syncthreads();
 #pragma unroll 8
     for (int r = 0; r < SL_KC; ++r) {
