@@ -238,11 +238,11 @@ struct GatherSplit {
 typedef float gs_f4 __attribute__((ext_vector_type(4)));
 typedef __bf16 gs_bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 gs_bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void gs_body(const GatherSplit& a, const int bx) {
+__device__ __forceinline__ void gs_body(const GatherSplit& a) {
   __shared__ float tile[32][GS_COLS + 1];
   const long* idx = a.idx;
   if (a.ctrl) idx += (long)a.ctrl[FXC_BATCH_CURSOR] * a.cursor_stride;
-  const int c0 = bx * GS_COLS, r0 = blockIdx.y * 32;
+  const int c0 = blockIdx.x * GS_COLS, r0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 lanes x 4 columns = 128 columns, 8 rows per pass
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -299,7 +299,7 @@ __device__ __forceinline__ void gs_body(const GatherSplit& a, const int bx) {
   }
 }
 
-__global__ __launch_bounds__(256) void fx_gather_split_kernel(GatherSplit a) { gs_body(a, blockIdx.x); }
+__global__ __launch_bounds__(256) void fx_gather_split_kernel(GatherSplit a) { gs_body(a); }
 
 // every modality of a batch in one launch: grid (column tiles of the widest, row blocks, modalities)
 #define GS_MAX_GROUP 4
@@ -308,18 +308,11 @@ struct GatherSplitGroup {
 };
 __global__ __launch_bounds__(256) void fx_gather_split_group_kernel(GatherSplitGroup g) {
   // (a runtime index into the kernel-argument array would put the argument blocks in scratch: one call per constant index)
-  // -DGS_CAP=n (A/B builds): at most n workgroups per (row block, layer), each walking the column tiles with stride n -- the assembly of
-  // the next batch at a lower intensity beside the step's latency-bound chain (profiles/r06_chain.txt)
-#define GS_WALK(A)                                                                                                  \
-  for (int bx = blockIdx.x; bx * GS_COLS < (((A).F + 31) / 32) * 32; bx += gridDim.x) {                             \
-    gs_body((A), bx);                                                                                               \
-    if (bx + (int)gridDim.x < ((((A).F + 31) / 32) * 32 + GS_COLS - 1) / GS_COLS) __syncthreads();                  \
-  }
   switch (blockIdx.z) {
-    case 0: GS_WALK(g.a[0]) break;
-    case 1: GS_WALK(g.a[1]) break;
-    case 2: GS_WALK(g.a[2]) break;
-    default: GS_WALK(g.a[3]) break;
+    case 0: if ((int)blockIdx.x * GS_COLS < ((g.a[0].F + 31) / 32) * 32) gs_body(g.a[0]); break;
+    case 1: if ((int)blockIdx.x * GS_COLS < ((g.a[1].F + 31) / 32) * 32) gs_body(g.a[1]); break;
+    case 2: if ((int)blockIdx.x * GS_COLS < ((g.a[2].F + 31) / 32) * 32) gs_body(g.a[2]); break;
+    default: if ((int)blockIdx.x * GS_COLS < ((g.a[3].F + 31) / 32) * 32) gs_body(g.a[3]); break;
   }
 }
 
@@ -405,9 +398,6 @@ int fx_gather_split_group(const void* descs_, int n, const long* idx, int n_rows
   }
   for (int i = n; i < GS_MAX_GROUP; ++i) g.a[i] = g.a[0];
   const int Rp = (n_rows + 31) / 32 * 32;
-#ifdef GS_CAP
-  if (max_tiles > GS_CAP) max_tiles = GS_CAP;
-#endif
   hipLaunchKernelGGL(fx_gather_split_group_kernel, dim3(max_tiles, Rp / 32, n), dim3(256), 0, stream, g);
   return fx_check_launch("fx_gather_split_group");
 }

@@ -205,8 +205,11 @@ def test_arena_pools_grow_instead_of_falling_back(monkeypatch):
         # all five stores are served), on some behind the boundary (the chunk is kept for pool B, and the store takes the bounded search)
         for g in grown:
             assert (g[0] == "A" and g[3] < PartitionArena.FAST_TBS) or (g[0] == "B" and g[2] >= PartitionArena.FAST_TBS), grown
+        # pool A as built serves the first two stores; every later store that runs short asks for ONE chunk: an "A" chunk serves the store
+        # that asked (and the next one), a "B" chunk leaves that store to the bounded search -- so the count depends on the ORDER in which the
+        # box hands out its partitions ([B, B, A]: 3 served, [A, A]: 5), and only the lower bound below holds everywhere
         n_a = sum(1 for g in grown if g[0] == "A")
-        assert served >= 2 + min(n_a * 2, 3) or served == 5, (served, grown)
+        assert served >= min(5, 2 + n_a), (served, grown)
         kinds_of = lambda t: [k for c, k in zip(ar.chunks, ar.kind) if c.data_ptr() <= t.data_ptr() < c.data_ptr() + c.numel()]
         for st in stores:
             big = st.big[KEY]
