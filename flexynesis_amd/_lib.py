@@ -46,6 +46,7 @@ PROTOTYPES = {
     "fx_gather_split": (I, [P, P, P, P, P, P, P, I, I, L, L, L, L, P, L, P]),
     "fx_block_bwd_blocks": (I, [I]),
     "fx_block_bwd": (I, [P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, P, P, P, L, P, P, I, I, L, L, I, I, F, I, P]),
+    "fx_block_bwd_ex": (I, [P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, P, P, P, L, P, P, I, I, L, L, I, I, F, I, P, P, L, I, P]),
     "fx_enc_tail_blocks": (I, [I]),
     "fx_enc_tail_fwd": (I, [P, I, I, I, I, I, F, P, P]),
     "fx_fusion_fwd": (I, [P, L, P, L, P, P, P, P, I, P, P, I, I, P]),

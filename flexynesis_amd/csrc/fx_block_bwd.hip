@@ -51,6 +51,7 @@ struct BlockBwdArgs {
   float* dgamma; float* dbeta; float* dbias;
   float* dy;               // optional [B, C] fp32 gradient at the wide Linear's output
   __bf16* dyT_hi; __bf16* dyT_lo; long ldt;     // optional transposed split [C, ldt] (ldt >= round32(B), zero padded)
+  __bf16* dyK_hi; __bf16* dyK_lo; long ldk; int krow0;   // optional K-blocked split [ceil(C / 32)][ldk rows][32] (fx_split_bf16's layout), rows krow0 ..
   const float* gram_x;     // optional [B, B] = X X^T: then slots[blockIdx] = this block's share of ||dW_wide||_F^2
   double* slots;
   int B, C; long ldx, ldo;
@@ -280,6 +281,21 @@ __device__ __forceinline__ void bb_body(const BlockBwdArgs& a, int blk) {
       *reinterpret_cast<bf16x8*>(a.dyT_lo + (long)(c0 + col) * a.ldt + rb) = lo;
     }
   }
+  if (a.dyK_hi) {      // the same values in the K-blocked layout: this workgroup's 32 columns ARE K-block blk; thread = (row t >> 2, columns 8 (t & 3) ..)
+    const int row = t >> 2, cg = (t & 3) * 8;
+    if (row < ((B + 31) & ~31)) {                      // rows B .. round32(B) - 1 as zeros, nothing beyond (as above)
+      bf16x8 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = T[cg + j][row];
+        hi[j] = (__bf16)v;
+        lo[j] = (__bf16)(v - (float)hi[j]);
+      }
+      const long o = ((long)blk * a.ldk + a.krow0 + row) * 32 + cg;
+      *reinterpret_cast<bf16x8*>(a.dyK_hi + o) = hi;
+      *reinterpret_cast<bf16x8*>(a.dyK_lo + o) = lo;
+    }
+  }
   CP_TICK(cpw, 6);
   if (a.gram_x) {      // <dY_blk dY_blk^T, X X^T>: wave w owns rows 16 w .. 16 w + 15 of the B x B product (8 blocks of 16 x 16)
     const int lane = t & 63, w = t >> 6, l15 = lane & 15, kq = lane >> 4;
@@ -364,13 +380,16 @@ static int bb_fill(BlockBwdArgs& a, const float* const* dE, const long* ldE, con
                    float* const* gb, const int* L, int n_up, const float* x, const float* out, const float* gamma,
                    const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* dbias, float* dy,
                    void* dyT_hi, void* dyT_lo, long ldt, const float* gram_x, double* slots, int B, int C, long ldx, long ldo,
-                   int pre_act, int post_act, float drop_p, int accumulate) {
+                   int pre_act, int post_act, float drop_p, int accumulate, void* dyK_hi = nullptr, void* dyK_lo = nullptr,
+                   long ldk = 0, int krow0 = 0) {
   FX_REQUIRE(dE && ldE && W && gW && gb && L && n_up >= 1 && n_up <= 2, "fx_block_bwd: 1 or 2 upstream Linears");
   FX_REQUIRE(x && out && gamma && save_mean && save_invstd && dgamma && dbeta, "fx_block_bwd: null pointer");
   FX_REQUIRE(B > 1 && B <= 128 && C > 0, "fx_block_bwd: B=%d must be in 2..128", B);
   FX_REQUIRE(!dyT_hi || (dyT_lo && ldt % 8 == 0 && ldt >= (B + 31) / 32 * 32),
              "fx_block_bwd: dyT needs hi and lo, ld %% 8 == 0, ld >= round32(B) (got %ld)", ldt);
   FX_REQUIRE(!gram_x || slots, "fx_block_bwd: gram_x needs the norm slots");
+  FX_REQUIRE(!dyK_hi || (dyK_lo && krow0 >= 0 && krow0 % 8 == 0 && ldk >= krow0 + (B + 31) / 32 * 32 && ((((uintptr_t)dyK_hi) | ((uintptr_t)dyK_lo)) & 15) == 0),
+             "fx_block_bwd: the K-blocked split needs hi and lo (16-byte aligned), row0 %% 8 == 0, rows >= row0 + round32(B) (got %ld, %d)", ldk, krow0);
   a = BlockBwdArgs{};
   for (int k = 0; k < n_up; ++k) {
     FX_REQUIRE(dE[k] && W[k] && gW[k] && L[k] > 0 && ldE[k] >= L[k], "fx_block_bwd: upstream %d: bad L=%d / ld=%ld", k, L[k],
@@ -381,6 +400,7 @@ static int bb_fill(BlockBwdArgs& a, const float* const* dE, const long* ldE, con
   a.x = x; a.out = out; a.gamma = gamma; a.save_mean = save_mean; a.save_invstd = save_invstd;
   a.dgamma = dgamma; a.dbeta = dbeta; a.dbias = dbias; a.dy = dy;
   a.dyT_hi = (__bf16*)dyT_hi; a.dyT_lo = (__bf16*)dyT_lo; a.ldt = ldt;
+  a.dyK_hi = (__bf16*)dyK_hi; a.dyK_lo = (__bf16*)dyK_lo; a.ldk = ldk; a.krow0 = krow0;
   a.gram_x = gram_x; a.slots = slots;
   a.B = B; a.C = C; a.ldx = ldx; a.ldo = ldo; a.pre_act = pre_act; a.post_act = post_act; a.drop_p = drop_p;
   a.accumulate = accumulate ? 1 : 0;
@@ -398,6 +418,20 @@ int fx_block_bwd(const float* const* dE, const long* ldE, const float* const* W,
     return rc;
   hipLaunchKernelGGL(fx_block_bwd_kernel, dim3(fx_block_bwd_blocks(C)), dim3(BB_T), 0, stream, a);
   return fx_check_launch("fx_block_bwd");
+}
+
+// fx_block_bwd + dY's K-blocked split (fx_split_bf16's layout [ceil(C / 32)][kb_rows][32], rows kb_row0 .. of it): see include/fxhip.h
+int fx_block_bwd_ex(const float* const* dE, const long* ldE, const float* const* W, float* const* gW, float* const* gb,
+                    const int* L, int n_up, const float* x, const float* out, const float* gamma, const float* save_mean,
+                    const float* save_invstd, float* dgamma, float* dbeta, float* dbias, float* dy, void* dyT_hi, void* dyT_lo,
+                    long ldt, const float* gram_x, double* slots, int B, int C, long ldx, long ldo, int pre_act, int post_act,
+                    float drop_p, int accumulate, void* dy_kb_hi, void* dy_kb_lo, long kb_rows, int kb_row0, hipStream_t stream) {
+  BlockBwdArgs a;
+  if (int rc = bb_fill(a, dE, ldE, W, gW, gb, L, n_up, x, out, gamma, save_mean, save_invstd, dgamma, dbeta, dbias, dy, dyT_hi,
+                       dyT_lo, ldt, gram_x, slots, B, C, ldx, ldo, pre_act, post_act, drop_p, accumulate, dy_kb_hi, dy_kb_lo, kb_rows, kb_row0))
+    return rc;
+  hipLaunchKernelGGL(fx_block_bwd_kernel, dim3(fx_block_bwd_blocks(C)), dim3(BB_T), 0, stream, a);
+  return fx_check_launch("fx_block_bwd_ex");
 }
 
 struct fx_block_bwd_desc_ {   // include/fxhip.h: fx_block_bwd_desc

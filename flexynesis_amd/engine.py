@@ -1115,13 +1115,21 @@ class StepPlan:
             # the wide layer's fused optimiser wants dY as a transposed split [H, rows]: each pass writes its own columns
             want_t = (self.fused and w1 in st.big and not self._is_frozen(w1) and self.precision == "bf16x3" and Bp % 32 == 0)
             dyt = ops.new_split(H, rows, self.dev) if want_t else None
+            # ... and the Gram norm's dY dY^T product (stacked rows: _weight_grad) wants dY's K-blocked split: a workgroup's 32 columns
+            # are one K-block, so each pass writes its rows of it as well (FX_BLOCK_BWD_KB=0: a launch of fx_split_bf16 over dY behind
+            # the last pass -- 47 us on the chain between the encoder tails' backward and the clip coefficient at cfg4)
+            dkb = None
+            if (want_t and self.clip and self._stacked_gram_kb_ok(rows, H) and Bp % 8 == 0
+                    and os.environ.get("FX_BLOCK_BWD_KB", "1") != "0"):
+                dkb = ops.new_split_kb(rows, H, self.dev)
             for p in range(passes):
                 sl = slice(p * Bp, (p + 1) * Bp)
                 ops.block_bwd(rec, [(dout[sl], st.ep(wk), st.eg(wk), st.eg(bias_key) if bias_key in st.eshapes else None)], y1[sl], a1[sl],
                               st.ep(prefix + ".batchnorm.weight"), sm[p], si[p], st.eg(prefix + ".batchnorm.weight"),
                               st.eg(prefix + ".batchnorm.bias"), st.eg(prefix + ".layer_1.bias"), ACT_NONE, ACT_RELU, DROPOUT_P,
-                              dy=da1[sl], dyT=(dyt[0][:, p * Bp:], dyt[1][:, p * Bp:]) if want_t else None, accumulate=p > 0)
-            self._weight_grad(rec, w1, da1, x, dyt=dyt)
+                              dy=da1[sl], dyT=(dyt[0][:, p * Bp:], dyt[1][:, p * Bp:]) if want_t else None, accumulate=p > 0,
+                              dy_kb=(dkb[0], dkb[1], p * Bp) if dkb is not None else None)
+            self._weight_grad(rec, w1, da1, x, dyt=dyt, dy_kb=dkb)
             return
         self._weight_grad(rec, prefix + ".layer_out.weight", dout, a1)
         if prefix + ".layer_out.bias" in st.eshapes:
@@ -1391,8 +1399,13 @@ class StepPlan:
     def _is_frozen(self, key: str) -> bool:
         return bool(self.frozen) and key.startswith(self.frozen)
 
-    def _weight_grad(self, rec, key, dy, x, dyt=None):
-        """dW = dY^T X: materialised, or deferred to the fused dW+clip+Adam kernel for wide layers."""
+    def _stacked_gram_kb_ok(self, R, cols) -> bool:
+        """dY dY^T of stacked rows runs on the split-bf16 forward kernel (dY's K-blocked split against dY itself): _weight_grad."""
+        return (self.precision == "bf16x3" and R > 128 and cols >= 4096 and cols % 4 == 0 and self.gram_bf16x3 and self.gram_kb_wide)
+
+    def _weight_grad(self, rec, key, dy, x, dyt=None, dy_kb=None):
+        """dW = dY^T X: materialised, or deferred to the fused dW+clip+Adam kernel for wide layers.  ``dy_kb``: dY's K-blocked split,
+        when the producer of dY wrote it (fx_block_bwd_ex)."""
         if self._is_frozen(key):
             return                                       # requires_grad=False: no gradient, not in the optimiser
         if self.fused and key in self.store.big:
@@ -1416,13 +1429,15 @@ class StepPlan:
                     gd = self._new(f"gram_dy/{key}", nd, R * R)
                     ops.gram_kb_group(rec, [sd], [gd], [dy.shape[1]], R)
                     self.buf[f"gram_dy_split/{key}"], self.buf[f"gram_dy_split_lo/{key}"] = sd
-                elif (self.precision == "bf16x3" and R > 128 and dy.shape[1] >= 4096 and dy.shape[1] % 4 == 0 and self.gram_bf16x3
-                      and self.gram_kb_wide and dy.is_contiguous()):
+                elif self._stacked_gram_kb_ok(R, dy.shape[1]) and dy.is_contiguous():
                     # stacked rows (the triplet network's 3 B = 384): dY dY^T like X X^T in _gram_x_for -- dY's K-blocked split against dY
                     # itself as the fp32 "weight" on the split-bf16 forward kernel, instead of the exact-fp32 GEMM (100 us per modality
                     # on the chain between the encoder tails' backward and the clip coefficient)
-                    sd = ops.new_split_kb(R, dy.shape[1], self.dev)
-                    ops.split_bf16(rec, sd[0], sd[1], dy)
+                    if dy_kb is not None:
+                        sd = dy_kb
+                    else:
+                        sd = ops.new_split_kb(R, dy.shape[1], self.dev)
+                        ops.split_bf16(rec, sd[0], sd[1], dy)
                     self.buf[f"gram_dy_split/{key}"], self.buf[f"gram_dy_split_lo/{key}"] = sd
                     nd = 1
                     gd = self._new(f"gram_dy/{key}", 1, R * R)

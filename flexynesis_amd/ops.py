@@ -943,9 +943,10 @@ def block_bwd_blocks(C: int) -> int:
 
 
 def block_bwd(rec, ups, x, out, gamma, save_mean, save_invstd, dgamma, dbeta, dbias, pre_act, post_act, drop_p,
-              dy=None, dyT=None, gram_x=None, slots=None, accumulate=False):
+              dy=None, dyT=None, gram_x=None, slots=None, accumulate=False, dy_kb=None):
     """Backward of "wide Linear -> BatchNorm block -> small Linears" in one launch (include/fxhip.h: fx_block_bwd).
-    ``ups`` = [(dE [B, L], W [L, C], gW [L, C], gb [L] | None), ...] (1 or 2 entries)."""
+    ``ups`` = [(dE [B, L], W [L, C], gW [L, C], gb [L] | None), ...] (1 or 2 entries).  ``dy_kb`` = (hi, lo, row0): dY also in the
+    K-blocked split layout (new_split_kb(total rows, C)), this pass's rows starting at row0 (fx_block_bwd_ex)."""
     _chk2d(x, "block_bwd.x")
     _chk2d(out, "block_bwd.out")
     B, Cc = x.shape
@@ -960,10 +961,18 @@ def block_bwd(rec, ups, x, out, gamma, save_mean, save_invstd, dgamma, dbeta, db
             PA(*[u[2].data_ptr() for u in ups]), PA(*[_ptr(u[3]) for u in ups]), IA(*[u[0].shape[1] for u in ups]))
     if hasattr(rec, "keep"):
         rec.keep(arrs)
-    rec.emit("fx_block_bwd", *[C.addressof(a_) for a_ in arrs], n, x.data_ptr(), out.data_ptr(), gamma.data_ptr(),
-             save_mean.data_ptr(), save_invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dbias), _ptr(dy),
-             _ptr(dyT[0]) if dyT else None, _ptr(dyT[1]) if dyT else None, _ld(dyT[0]) if dyT else 0, _ptr(gram_x),
-             _ptr(slots), B, Cc, _ld(x), _ld(out), int(pre_act), int(post_act), float(drop_p), int(bool(accumulate)))
+    common = [*[C.addressof(a_) for a_ in arrs], n, x.data_ptr(), out.data_ptr(), gamma.data_ptr(),
+              save_mean.data_ptr(), save_invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dbias), _ptr(dy),
+              _ptr(dyT[0]) if dyT else None, _ptr(dyT[1]) if dyT else None, _ld(dyT[0]) if dyT else 0, _ptr(gram_x),
+              _ptr(slots), B, Cc, _ld(x), _ld(out), int(pre_act), int(post_act), float(drop_p), int(bool(accumulate))]
+    if dy_kb is None:
+        rec.emit("fx_block_bwd", *common)
+    else:
+        khi, klo, row0 = dy_kb
+        if (khi.dim() != 3 or khi.shape[0] != pad32(Cc) // 32 or khi.shape[2] != 32 or klo.shape != khi.shape or khi.dtype != torch.bfloat16
+                or not khi.is_contiguous() or not klo.is_contiguous()):
+            raise FxError(f"block_bwd: dy_kb must be K-blocked bf16 [{pad32(Cc) // 32}, rows, 32] (ops.new_split_kb), got {tuple(khi.shape)}")
+        rec.emit("fx_block_bwd_ex", *common, khi.data_ptr(), klo.data_ptr(), int(khi.shape[1]), int(row0))
     return arrs
 
 

@@ -306,6 +306,16 @@ int fx_block_bwd(const float* const* dE, const long* ldE, const float* const* W,
                  long ldt, const float* gram_x, double* slots, int B, int C, long ldx, long ldo, int pre_act, int post_act,
                  float drop_p, int accumulate, fx_stream_t stream);
 
+/* fx_block_bwd that ALSO writes dY in fx_split_bf16's K-blocked layout [ceil(C / 32)][kb_rows][32] (hi, lo; rows kb_row0 .. kb_row0 +
+ * round32(B) - 1 of it): a workgroup's 32 columns are exactly one K-block, so the split the stacked-rows Gram product dY dY^T needs
+ * (triplet_encoder.py:298-330 under clip_grad_norm_, main.py:216) costs sixteen more bytes per thread here instead of a launch of
+ * fx_split_bf16 over dY behind the last pass.  dy_kb_hi NULL = fx_block_bwd. */
+int fx_block_bwd_ex(const float* const* dE, const long* ldE, const float* const* W, float* const* gW, float* const* gb,
+                    const int* L, int n_up, const float* x, const float* out, const float* gamma, const float* save_mean,
+                    const float* save_invstd, float* dgamma, float* dbeta, float* dbias, float* dy, void* dyT_hi, void* dyT_lo,
+                    long ldt, const float* gram_x, double* slots, int B, int C, long ldx, long ldo, int pre_act, int post_act,
+                    float drop_p, int accumulate, void* dy_kb_hi, void* dy_kb_lo, long kb_rows, int kb_row0, fx_stream_t stream);
+
 /* fx_block_bwd for up to 4 independent encoder tails (one per modality) in ONE launch (grid: column blocks x tails); every
  * field has the meaning of the fx_block_bwd argument of the same name.  B, the activations and drop_p are common. */
 typedef struct fx_block_bwd_desc {

@@ -977,6 +977,51 @@ def test_free_running_training_curve_tracks_oracle(model):
     assert ref[-5:].mean() < 0.8 * ref[:5].mean() and got[-5:].mean() < 0.8 * got[:5].mean()
 
 
+@pytest.mark.parametrize("Bp,passes,C", [(128, 3, 7500), (64, 3, 4100), (128, 1, 300), (96, 2, 1031)])
+def test_block_bwd_k_blocked_split_equals_split_bf16(Bp, passes, C):
+    """fx_block_bwd_ex: the K-blocked split of dY that every pass of stacked rows writes for its own rows is, bit for bit, what
+    fx_split_bf16 makes of the fp32 dY the same launches wrote (the triplet network's dY dY^T product reads it: engine._mlp_bwd),
+    pad rows and pad columns zero; every other output is untouched by the extra store."""
+    from flexynesis_amd import ops
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(Bp + C)
+    rows, L = Bp * passes, 32
+    x = torch.randn(rows, C, device=dev, generator=g)
+    out = torch.relu(torch.randn(rows, C, device=dev, generator=g))
+    gamma = torch.rand(C, device=dev, generator=g) + 0.5
+    W = torch.randn(L, C, device=dev, generator=g) / C ** 0.5
+    dE = torch.randn(rows, L, device=dev, generator=g)
+    sm = torch.randn(passes, C, device=dev, generator=g) * 0.1
+    si = torch.rand(passes, C, device=dev, generator=g) + 0.5
+    res = []
+    for with_kb in (False, True):
+        gW, gb = torch.zeros(L, C, device=dev), torch.zeros(L, device=dev)
+        dg, db, dbias = (torch.zeros(C, device=dev) for _ in range(3))
+        dy = torch.full((rows, C), float("nan"), device=dev)
+        dyT = ops.new_split(C, rows, dev)
+        kb = ops.new_split_kb(rows, C, dev)
+        for p_ in range(passes):
+            sl = slice(p_ * Bp, (p_ + 1) * Bp)
+            ops.block_bwd(ops.IMMEDIATE, [(dE[sl], W, gW, gb)], x[sl], out[sl], gamma, sm[p_], si[p_], dg, db, dbias, 0, 2, 0.1, dy=dy[sl],
+                          dyT=(dyT[0][:, p_ * Bp:], dyT[1][:, p_ * Bp:]) if Bp % 32 == 0 else None, accumulate=p_ > 0,
+                          dy_kb=(kb[0], kb[1], p_ * Bp) if with_kb else None)
+        torch.cuda.synchronize()
+        res.append((dy, gW, gb, dg, db, dbias, dyT, kb))
+    for a, b in zip(res[0][:6], res[1][:6]):
+        assert torch.equal(a, b)
+    if Bp % 32 == 0:
+        assert torch.equal(res[0][6][0].view(torch.int16), res[1][6][0].view(torch.int16)) and torch.equal(res[0][6][1].view(torch.int16), res[1][6][1].view(torch.int16))
+    ref = ops.new_split_kb(rows, C, dev)
+    ops.split_bf16(ops.IMMEDIATE, ref[0], ref[1], res[1][0])
+    torch.cuda.synchronize()
+    kb = res[1][7]
+    assert torch.equal(kb[0].view(torch.int16), ref[0].view(torch.int16)) and torch.equal(kb[1].view(torch.int16), ref[1].view(torch.int16))
+    assert float(res[0][7][0].float().abs().sum()) == 0.0          # (without dy_kb nothing is written there)
+    with pytest.raises(ops.FxError):
+        ops.block_bwd(ops.IMMEDIATE, [(dE[:Bp], W, gW, gb)], x[:Bp], out[:Bp], gamma, sm[0], si[0], dg, db, dbias, 0, 2, 0.1,
+                      dy_kb=(kb[0][:1], kb[1][:1], 0))
+
+
 @pytest.mark.parametrize("B,C,Ls,pre,post", [(128, 5000, (64,), 0, 2), (100, 700, (64, 64), 1, 0), (37, 95, (17,), 0, 2),
                                               (128, 1250, (100, 33), 1, 0)])
 def test_block_bwd_vs_autograd_fp64(B, C, Ls, pre, post):
