@@ -2733,7 +2733,12 @@ class PipelinedStep:
         # (triplet): their assembly is 0.4 ms of X X^T products that would run against the wide forwards (5.78 vs 5.75 ms).
         # (only for plans whose assembly is the grouped one -- four launches without split-K scratch, the configurations the
         # full-size parity tests and the bench run; every other plan keeps the long-tested fork behind the forward tape)
-        dep_default = "1" if (a.passes == 1 and getattr(a, "assembly_grouped", False)) else "0"
+        # NOT for the VAE family either (re-measured at the end of round 6, profiles/r06_chain.txt): with the dependency on fx_step_begin alone
+        # the runtime places the assembly's launches BEHIND the backward chain's on their hardware queue (cfg3: it ran at 728-782 us of the step,
+        # after the chain had finished at 752, and the clip coefficient waited for it); forked behind the forward tape it runs beside the first
+        # data-gradient product, which hides it: 2.513 -> 2.479 ms per step
+        vae = a.spec.model in ("supervised_vae", "CrossModalPred")
+        dep_default = "1" if (a.passes == 1 and getattr(a, "assembly_grouped", False) and not vae) else "0"
         self.fork_dep_begin = os.environ.get("FX_FORK_DEP_BEGIN", dep_default) == "1"
         self.k = 0                       # plan holding the batch of the next step
         self.done = 0                    # steps issued since prime()
